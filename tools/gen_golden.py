@@ -1,0 +1,344 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures under tests/golden/ by RUNNING the reference.
+
+Dev-only tool.  It contains no reference code: it puts /root/reference on sys.path,
+imports the reference's own modules (neural_dynamics, torchdiffeq, utils_in_learn_dynamics,
+propagation) and the module-level set-up of its three dynamics scripts, feeds them seeded
+inputs, and stores (inputs, expected outputs) as small .npz files.  Only those data files
+travel to the GPU box; the reference's Python never does.  When /root/reference is absent
+(GPU box) it exits cleanly without touching anything.
+
+Fixture families:
+  G1 rhs_*.npz        ODEFunc.forward                       neural_dynamics.py:20-39
+  G2 fixed_*.npz      odeint euler / midpoint / rk4         torchdiffeq/_impl/{solvers,fixed_grid,rk_common}.py
+  G3 dopri5_*.npz     odeint dopri5 + per-attempt step log  torchdiffeq/_impl/{dopri5,interp,misc}.py
+  G4 ndcn_*.npz       NDCN end to end (state_dict + output) neural_dynamics.py:122-160
+  G5 truth_*.npz      heat / gene / mutualistic truth       {heat,gene,mutualistic}_dynamics.py:186-232
+  G6 operators_*.npz  dense operator builders, zipf alpha   utils_in_learn_dynamics.py:80-157, propagation.py:91-103
+  G7 dgnn_*.npz       ODEBlock2(no_control, terminal)       dgnn.py:173-182 on the Planetoid topologies
+"""
+import os
+import sys
+import io
+import pickle
+import runpy
+import contextlib
+
+REF = '/root/reference'
+if not os.path.isdir(REF):
+    print('gen_golden: %s not present - nothing to do' % REF)
+    sys.exit(0)
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+sys.path.insert(0, REF)
+os.environ.setdefault('MPLBACKEND', 'Agg')
+import neural_dynamics as ref_nd            # noqa: E402  (the reference)
+import torchdiffeq as ref_ode               # noqa: E402  (the reference's vendored copy)
+import torchdiffeq._impl.dopri5 as ref_dopri5   # noqa: E402
+import utils_in_learn_dynamics as ref_u     # noqa: E402
+import propagation as ref_prop              # noqa: E402
+
+assert ref_ode.__file__.startswith(REF), ref_ode.__file__
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(1)      # deterministic summation order inside ATen
+
+
+def save(name, **arrays):
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **conv)
+    print('wrote %-34s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def csr_of(dense):
+    m = sp.csr_matrix(np.asarray(dense, dtype=np.float32))
+    m.sort_indices()
+    return dict(indptr=m.indptr.astype(np.int32), indices=m.indices.astype(np.int32),
+                data=m.data.astype(np.float32), shape=np.array(m.shape, dtype=np.int64))
+
+
+def grid_operator(S, kind='norm_lap'):
+    A = ref_u.grid_8_neighbor_graph(S)
+    if kind == 'norm_lap':
+        OM = torch.FloatTensor(ref_u.normalized_laplacian(A.numpy()))
+    elif kind == 'norm_adj':
+        OM = torch.FloatTensor(ref_u.normalized_adj(A.numpy()))
+    elif kind == 'kipf':
+        OM = torch.FloatTensor(ref_u.zipf_smoothing(A.numpy()))
+    elif kind == 'lap':
+        OM = torch.diag(A.sum(1)) - A
+    return A, OM
+
+
+def x0_blocks(S):
+    # the reference's initial image, heat_dynamics.py:178-182
+    x0 = torch.zeros(S, S)
+    x0[int(0.05 * S):int(0.25 * S), int(0.05 * S):int(0.25 * S)] = 25
+    x0[int(0.45 * S):int(0.75 * S), int(0.45 * S):int(0.75 * S)] = 20
+    x0[int(0.05 * S):int(0.25 * S), int(0.35 * S):int(0.65 * S)] = 17
+    return x0.view(-1, 1).float()
+
+
+# ----------------------------------------------------------------------------- G1
+def gen_rhs():
+    _, OM = grid_operator(20)
+    OMs = ref_u.torch_sensor_to_torch_sparse_tensor(OM)
+    for H in (1, 20, 256):
+        for flag in ('default', 'no_control', 'no_graph'):
+            for layout in ('dense', 'coo'):
+                if H == 256 and layout == 'dense':
+                    continue            # keep the fixture set small
+                torch.manual_seed(100 + H)
+                f = ref_nd.ODEFunc(H, OM if layout == 'dense' else OMs, dropout=0.0,
+                                   no_graph=(flag == 'no_graph'), no_control=(flag == 'no_control'))
+                x = torch.randn(400, H)
+                with torch.no_grad():
+                    out = f(torch.tensor(0.0), x)
+                save('rhs_grid400_H%d_%s_%s' % (H, flag, layout), x=x, W=f.wt.weight, b=f.wt.bias,
+                     out=out, **csr_of(OM))
+
+
+# ----------------------------------------------------------------------------- G2
+def make_func(H, OM, seed, **kw):
+    torch.manual_seed(seed)
+    f = ref_nd.ODEFunc(H, OM, dropout=0.0, **kw)
+    x = torch.rand(OM.shape[0], H)
+    return f, x
+
+
+def gen_fixed():
+    _, OM = grid_operator(20)
+    OMs = ref_u.torch_sensor_to_torch_sparse_tensor(OM)
+    t_eq = torch.linspace(0., 5., 21)
+    rng = np.random.RandomState(7)
+    t_ir = torch.linspace(0., 5., 200)[np.sort(rng.permutation(200)[:14])].clone()
+    t_ir[0] = 0
+    for method in ('euler', 'midpoint', 'rk4'):
+        for tname, t in (('equal', t_eq), ('irregular', t_ir)):
+            f, x = make_func(20, OMs, 11)
+            with torch.no_grad():
+                y = ref_ode.odeint(f, x, t, method=method)
+            save('fixed_%s_%s' % (method, tname), x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, **csr_of(OM))
+    # decreasing time vector (misc.py:184-187) on rk4
+    f, x = make_func(20, OMs, 11)
+    t = torch.linspace(1., 0., 6)
+    with torch.no_grad():
+        y = ref_ode.odeint(f, x, t, method='rk4')
+    save('fixed_rk4_decreasing', x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, **csr_of(OM))
+
+
+# ----------------------------------------------------------------------------- G3
+class StepLog:
+    """Records every attempted dopri5 step by wrapping (not editing) the reference's methods."""
+
+    def __init__(self):
+        self.rows = []
+        self.nfe = 0
+        self._ratio = None
+
+    @contextlib.contextmanager
+    def attach(self):
+        orig_step = ref_dopri5.Dopri5Solver._adaptive_dopri5_step
+        orig_ratio = ref_dopri5._compute_error_ratio
+        log = self
+
+        def ratio_wrap(*a, **k):
+            r = orig_ratio(*a, **k)
+            log._ratio = float(r[0])
+            return r
+
+        def step_wrap(solver, rk_state):
+            t0, dt = float(rk_state.t1), float(rk_state.dt)
+            new = orig_step(solver, rk_state)
+            accepted = float(new.t1) != t0
+            log.rows.append((t0, dt, 1.0 if accepted else 0.0, log._ratio, float(new.dt)))
+            return new
+
+        ref_dopri5.Dopri5Solver._adaptive_dopri5_step = step_wrap
+        ref_dopri5._compute_error_ratio = ratio_wrap
+        try:
+            yield self
+        finally:
+            ref_dopri5.Dopri5Solver._adaptive_dopri5_step = orig_step
+            ref_dopri5._compute_error_ratio = orig_ratio
+
+
+class CountingFunc(torch.nn.Module):
+    def __init__(self, f):
+        super().__init__()
+        self.f = f
+        self.nfe = 0
+
+    def forward(self, t, x):
+        self.nfe += 1
+        return self.f(t, x)
+
+
+def gen_dopri5():
+    _, OM = grid_operator(20)
+    OMs = ref_u.torch_sensor_to_torch_sparse_tensor(OM)
+    cases = [('loose', .01, .001, torch.linspace(0., 5., 21)),
+             ('dgnn', .1, .1, torch.linspace(0., 1.2, 16)),
+             ('tight', 1e-7, 1e-9, torch.linspace(0., 2., 6)),
+             ('twotick', .01, .001, torch.tensor([0., 5.]))]
+    for name, rtol, atol, t in cases:
+        f, x = make_func(20, OMs, 23)
+        cf = CountingFunc(f)
+        log = StepLog()
+        with torch.no_grad(), log.attach():
+            y = ref_ode.odeint(cf, x, t, rtol=rtol, atol=atol, method='dopri5')
+        save('dopri5_%s' % name, x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, rtol=rtol, atol=atol,
+             steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe, **csr_of(OM))
+    # no_control (pure SpMM+ReLU RHS) and a decreasing time vector
+    f, x = make_func(20, OMs, 29, no_control=True)
+    cf = CountingFunc(f)
+    log = StepLog()
+    t = torch.linspace(0., 3., 7)
+    with torch.no_grad(), log.attach():
+        y = ref_ode.odeint(cf, x, t, rtol=.01, atol=.001, method='dopri5')
+    save('dopri5_no_control', x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, rtol=.01, atol=.001,
+         steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe, **csr_of(OM))
+    f, x = make_func(20, OMs, 31)
+    cf = CountingFunc(f)
+    log = StepLog()
+    t = torch.linspace(2., 0., 5)
+    with torch.no_grad(), log.attach():
+        y = ref_ode.odeint(cf, x, t, rtol=.01, atol=.001, method='dopri5')
+    save('dopri5_decreasing', x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, rtol=.01, atol=.001,
+         steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe, **csr_of(OM))
+
+
+# ----------------------------------------------------------------------------- G4
+def gen_ndcn():
+    _, OM = grid_operator(20)
+    x0 = x0_blocks(20)
+    t = torch.linspace(0., 5., 21)
+    variants = {
+        'ndcn': dict(hidden_size=20, no_embed=False, no_graph=False, no_control=False),
+        'no_embed': dict(hidden_size=1, no_embed=True, no_graph=False, no_control=False),
+        'no_control': dict(hidden_size=20, no_embed=False, no_graph=False, no_control=True),
+        'no_graph': dict(hidden_size=20, no_embed=False, no_graph=True, no_control=False),
+    }
+    for name, kw in variants.items():
+        for method in ('euler', 'dopri5'):
+            torch.manual_seed(0)
+            m = ref_nd.NDCN(input_size=1, A=OM, num_classes=1, dropout=0.0, rtol=.01, atol=.001, method=method, **kw)
+            with torch.no_grad():
+                y = m(t, x0)
+            sd = {'sd__' + k.replace('.', '__'): v for k, v in m.state_dict().items()}
+            save('ndcn_%s_%s' % (name, method), x0=x0, t=t, out=y, **sd, **csr_of(OM))
+
+
+# ----------------------------------------------------------------------------- G5
+def run_script_setup(script, argv):
+    """Execute a reference driver's module-level set-up (graph, operator, truth solve, model build).
+    Its training loop sits under `if __name__ == '__main__'` and is not entered."""
+    old_argv, old_cwd = sys.argv, os.getcwd()
+    sys.argv = [script] + argv
+    os.chdir(REF)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = runpy.run_path(os.path.join(REF, script), run_name='ref_setup')
+    finally:
+        sys.argv, _ = old_argv, os.chdir(old_cwd)
+    return g
+
+
+def gen_truth():
+    for script, tag in (('heat_dynamics.py', 'heat'), ('gene_dynamics.py', 'gene'), ('mutualistic_dynamics.py', 'mutual')):
+        for sparse in (False, True):
+            argv = ['--network', 'grid', '--sampled_time', 'equal', '--baseline', 'ndcn', '--gpu', '-1',
+                    '--time_tick', '21'] + (['--sparse'] if sparse else [])
+            g = run_script_setup(script, argv)
+            A = g['A'].to_dense() if g['A'].is_sparse else g['A']
+            L = g['L'].to_dense() if g['L'].is_sparse else g['L']
+            OM = g['OM'].to_dense() if g['OM'].is_sparse else g['OM']
+            a, l, om = csr_of(A), csr_of(L), csr_of(OM)
+            save('truth_%s_%s' % (tag, 'coo' if sparse else 'dense'), x0=g['x0'], t=g['t'], traj=g['solution_numerical'],
+                 A_indptr=a['indptr'], A_indices=a['indices'], A_data=a['data'],
+                 L_indptr=l['indptr'], L_indices=l['indices'], L_data=l['data'],
+                 OM_indptr=om['indptr'], OM_indices=om['indices'], OM_data=om['data'], n=np.int64(A.shape[0]))
+
+
+# ----------------------------------------------------------------------------- G6
+def load_planetoid_adj(name):
+    """Adjacency of a Planetoid pickle, symmetrised as utils.py:183-196 does (utils.load_data itself
+    no longer runs under scipy 1.15)."""
+    with open(os.path.join(REF, 'data', name, 'ind.%s.graph' % name), 'rb') as fh:
+        graph = pickle.load(fh, encoding='latin1')
+    rows, cols = [], []
+    for r in graph:
+        for c in graph.get(r):
+            rows.append(r)
+            cols.append(c)
+    n = max(max(rows), max(cols)) + 1
+    adj = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    adj = adj + adj.T
+    adj[adj > 1] = 1
+    return adj.tocsr()
+
+
+def gen_operators():
+    A, _ = grid_operator(20)
+    a = csr_of(A)
+    arrs = dict(A_indptr=a['indptr'], A_indices=a['indices'], A_data=a['data'], n=np.int64(400))
+    for kind in ('norm_lap', 'norm_adj', 'kipf', 'lap'):
+        _, OM = grid_operator(20, kind)
+        c = csr_of(OM)
+        arrs.update({kind + '_indptr': c['indptr'], kind + '_indices': c['indices'], kind + '_data': c['data']})
+    arrs['x0'] = x0_blocks(20)
+    save('operators_grid400', **arrs)
+    # non-square canvas: n=10 nodes asked, ceil(sqrt) = 4 (heat_dynamics.py:81)
+    A5, _ = grid_operator(5)
+    c = csr_of(A5)
+    save('operators_grid25', A_indptr=c['indptr'], A_indices=c['indices'], A_data=c['data'], n=np.int64(25))
+    for name in ('cora', 'pubmed'):
+        adj = load_planetoid_adj(name)
+        adj.sort_indices()
+        arrs = dict(adj_indptr=adj.indptr.astype(np.int32), adj_indices=adj.indices.astype(np.int32),
+                    n=np.int64(adj.shape[0]))
+        for alpha in (0.0, 0.5):
+            with contextlib.redirect_stdout(io.StringIO()):
+                op = ref_prop.Propagation(adj).zipf_smoothing_alpha(alpha)
+            op = sp.csr_matrix(op).astype(np.float32)
+            op.sort_indices()
+            tag = 'alpha%02d' % int(alpha * 10)
+            arrs.update({tag + '_indptr': op.indptr.astype(np.int32), tag + '_indices': op.indices.astype(np.int32),
+                         tag + '_data': op.data.astype(np.float32)})
+        save('operators_%s' % name, **arrs)
+
+
+# ----------------------------------------------------------------------------- G7
+def gen_dgnn():
+    sys.path.insert(0, REF)
+    import utils as ref_utils
+    for name, H in (('cora', 64), ('pubmed', 16)):
+        adj = load_planetoid_adj(name)
+        with contextlib.redirect_stdout(io.StringIO()):
+            op = ref_prop.Propagation(adj).zipf_smoothing_alpha(0.0)
+        A = ref_utils.sparse_csr_matrix_to_torch_sparse_tensor(sp.csr_matrix(op))
+        torch.manual_seed(5)
+        x = torch.tanh(torch.randn(adj.shape[0], H))          # what Linear+Tanh would hand the block
+        t = torch.linspace(0, 1.2, 16)
+        f = ref_nd.ODEFunc(H, A, dropout=0.0, no_control=True)
+        cf = CountingFunc(f)
+        blk = ref_nd.ODEBlock2(cf, t, rtol=.1, atol=.1, method='dopri5', terminal=True)
+        log = StepLog()
+        with torch.no_grad(), log.attach():
+            y = blk(x)
+        save('dgnn_%s_H%d' % (name, H), x=x, t=t, out=y, steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn']
+    for w in which:
+        globals()['gen_' + w]()
