@@ -1,0 +1,203 @@
+/*
+ * ndcn_hip.h - C ABI of libndcn_hip.so: the MI355X (gfx950) implementation of the NDCN ODEFunc hot path.
+ *
+ * The reference (calvin-zcx/ndcn) is pure Python and has no FFI of its own; its hot path is a set of
+ * PyTorch op call sites.  Each entry point below replaces one of those call sites (or one
+ * solver-side group of them) and is what a binding of the reference for this path would call.  The
+ * reference-side ctypes stub is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_ (host) ;
+ *   - panels are dense row-major fp32, n_rows x H, H floats per node; 16-byte aligned base;
+ *   - CSR operators are {rowptr int32[n_rows+1], colidx int32[nnz], val fp32[nnz]}, columns of a row
+ *     in ascending order (summation order = stored order);
+ *   - `stream` is a hipStream_t (passed as void*; NULL = the null stream); calls only ENQUEUE work, they
+ *     never synchronise, allocate or free device memory, except where stated (ndcn_solver_*);
+ *   - return value: 0 on success, a negative NDCN_E* code otherwise; ndcn_last_error() gives the text.
+ *     Nothing throws across the boundary.
+ *   - the library never falls back to a host computation.
+ *
+ * Reference paths are relative to the reference repository root.
+ */
+#ifndef NDCN_HIP_H
+#define NDCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDCN_ABI_VERSION 1
+#define NDCN_API __attribute__((visibility("default")))
+
+#define NDCN_OK          0
+#define NDCN_EINVAL     -1   /* bad argument (null pointer, misaligned panel, unsupported H, ...) */
+#define NDCN_EHIP       -2   /* a HIP runtime call failed; see ndcn_last_error() */
+#define NDCN_ENONFINITE -3   /* solver: non-finite state  (dopri5.py:101-102 assertion)          */
+#define NDCN_EUNDERFLOW -4   /* solver: t0 + dt <= t0     (dopri5.py:100 assertion)              */
+#define NDCN_EMAXSTEPS  -5   /* solver: max_num_steps exceeded (dopri5.py:89 assertion)          */
+#define NDCN_ESTATE     -6   /* solver handle used out of order                                   */
+
+/* rhs / spmm flags */
+#define NDCN_F_RELU        1u   /* apply relu to the result            (neural_dynamics.py:36)   */
+#define NDCN_F_NO_GRAPH    2u   /* skip A*x                            (neural_dynamics.py:27)   */
+#define NDCN_F_NO_CONTROL  4u   /* skip the Linear                     (neural_dynamics.py:32)   */
+
+/* integrator methods (torchdiffeq/_impl/odeint.py:8-17, the in-scope subset) */
+#define NDCN_M_EULER    0
+#define NDCN_M_MIDPOINT 1
+#define NDCN_M_RK4      2   /* the 3/8 rule, rk_common.py:72-78 */
+#define NDCN_M_DOPRI5   3
+
+typedef struct ndcn_csr {
+    int64_t n_rows;
+    int64_t n_cols;           /* columns >= n_own address the halo panel (see ndcn_spmm_f32)     */
+    int64_t nnz;
+    const int32_t *rowptr;    /* [n_rows + 1] */
+    const int32_t *colidx;    /* [nnz]        */
+    const float   *val;       /* [nnz]        */
+} ndcn_csr;
+
+NDCN_API int         ndcn_abi_version(void);
+NDCN_API const char *ndcn_last_error(void);            /* thread-local, valid until the next failing call */
+/* {multiProcessorCount, 8 XCDs assumed, warpSize, clock kHz, totalGlobalMem>>20, l2CacheSize>>10}      */
+NDCN_API int         ndcn_device_info(int64_t h_out[6]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Y = alpha * (A X)   [then relu if NDCN_F_RELU]
+ * replaces torch.sparse.mm(A, x)  neural_dynamics.py:29 (and torch.mm(A, x) :31 for a dense A held as
+ * CSR); ode_gcn.py:53; models.py:18; heat_dynamics.py:201 (alpha = -k, H = 1).
+ * X_halo (nullable): rows of remote nodes; a column c >= n_own reads X_halo[c - n_own] (multi-GPU
+ * node-range sharding). With X_halo == NULL every column must be < n_own == A->n_cols.
+ * Y must not alias X.
+ */
+NDCN_API int ndcn_spmm_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
+                  float *Y, int H, float alpha, uint32_t flags, void *stream);
+
+/* Y[n, H_out] = S[n, H_in] W^T + b  [then relu]; W is nn.Linear's [H_out, H_in] row-major, b nullable.
+ * replaces self.wt(x) neural_dynamics.py:33 ; the encoder/decoder Linears :143-148 ; models.py:15.
+ * Y must not alias S. */
+NDCN_API int ndcn_linear_f32(const float *S, const float *W, const float *b, float *Y,
+                    int64_t n, int H_in, int H_out, uint32_t flags, void *stream);
+
+/* The whole ODEFunc.forward in one call: Y = relu(W (A X) + b) honouring NO_GRAPH / NO_CONTROL
+ * (neural_dynamics.py:20-39, dropout p = 0).  `work` is an n_rows x H scratch panel used when the
+ * fused kernel does not apply (may be NULL when it does; query with ndcn_rhs_needs_work). */
+NDCN_API int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
+                 const float *W, const float *b, float *Y, float *work, int H, uint32_t flags, void *stream);
+NDCN_API int ndcn_rhs_needs_work(int H, uint32_t flags);
+
+/* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
+NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Runge-Kutta bookkeeping, one pass each (the reference issues one ATen op per term).
+ * h_k: HOST array of n_k device pointers; h_c: HOST array of n_k fp32 coefficients ALREADY multiplied by
+ * dt and rounded to fp32, as misc.py:25 `(scale * x)` does.  Terms are added left to right, products and
+ * sums rounded separately (no FMA), exactly like `sum([...])` over tensors.
+ */
+/* out = y0 + sum_j c_j k_j          rk_common.py:51 via misc.py:22-25 ; dopri5.py:42 (y_mid)          */
+NDCN_API int ndcn_rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k,
+                        int64_t n_elem, void *stream);
+
+/* err = sum_j c_j k_j ; tol = atol + rtol * max(|y0|, |y1|) ; r = err / tol
+ * d_out[0] = sum r^2 (fp64, deterministic order), d_out[1] = number of non-finite elements of y1.
+ * rk_common.py:60 + misc.py:146-157 + the finiteness assertion of the NEXT step (dopri5.py:101-102).
+ * d_ws: device scratch of ndcn_reduce_ws_bytes() bytes.                                               */
+NDCN_API int ndcn_rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k,
+                      float rtol, float atol, int64_t n_elem, double *d_out, void *d_ws, void *stream);
+
+/* d_out[0] = sum ((a - b) / (atol + |y| * rtol))^2  (b nullable), d_out[1] = non-finite count of a.
+ * The three RMS norms of misc.py:123-138 (d0, d1, d2).                                               */
+NDCN_API int ndcn_scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol,
+                          int64_t n_elem, double *d_out, void *d_ws, void *stream);
+NDCN_API int64_t ndcn_reduce_ws_bytes(void);
+
+/* Dense-output fit of an accepted dopri5 step: y_mid from the 7 stage derivatives, then the quartic's
+ * a, b, c, d (e aliases y0).  h_cmid = dt * DPS_C_MID rounded to fp32; dt in the state dtype.
+ * dopri5.py:39-45 + interp.py:21-35.                                                                 */
+NDCN_API int ndcn_dopri5_interp_fit_f32(const float *y0, const float *y1, const float *const *h_k /*7*/,
+                               const float *h_cmid /*7*/, float dt, float *a, float *b, float *c, float *d,
+                               int64_t n_elem, void *stream);
+/* out = a x^4 + b x^3 + c x^2 + d x + e with h_xpow = {x^4, x^3, x^2, x, 1} formed by the caller in fp32
+ * (interp.py:59-65).                                                                                  */
+NDCN_API int ndcn_interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e,
+                         const float h_xpow[5], float *out, int64_t n_elem, void *stream);
+
+/* Fixed-grid stage algebra with the reference's operator order (fixed_grid.py:8,18-19; rk_common.py:72-78).
+ *   op 0  out = y + dt * k1                          euler update (y + dt*f)
+ *   op 1  out = y + k1 * dt / 2                      midpoint stage
+ *   op 2  out = y + dt * k1 / 3                      rk4 stage 2
+ *   op 3  out = y + dt * (k1 / -3 + k2)              rk4 stage 3
+ *   op 4  out = y + dt * (k1 - k2 + k3)              rk4 stage 4
+ *   op 5  out = y + (k1 + 3 k2 + 3 k3 + k4) * (dt/8) rk4 update
+ * unused k pointers may be NULL.  out may alias y.                                                     */
+NDCN_API int ndcn_fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2,
+                         const float *k3, const float *k4, float dt, int64_t n_elem, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Truth dynamics of the three drivers on an N x 1 state, O(nnz).
+ *   heat   : ndcn_spmm_f32 with H = 1, alpha = -k on L                    heat_dynamics.py:197-204
+ *   gene   : out = -b x^f + A (x^h / (x^h + 1))                           gene_dynamics.py:201-204
+ *   mutual : out = b + x(1-x/k)(x/c-1) + sum_j A_ij x_i x_j/(d + e x_j + h x_i)   (the branch that
+ *            executes for N x 1, mutualistic_dynamics.py:206-216)
+ */
+NDCN_API int ndcn_gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, void *stream);
+NDCN_API int ndcn_mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d,
+                        float e, float h, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident integrator for the ODEFunc RHS (state, stage derivatives and dense-output coefficients
+ * stay in HBM across steps; the host only reads the 16-byte error record per adaptive step).
+ * Mirrors the reference's per-call solver object (odeint.py:71-72; dopri5.py:58-122; solvers.py:79-99).
+ *
+ * The solver lives in ONE device workspace of ndcn_solver_workspace_bytes(desc) bytes (256-byte aligned):
+ * pass the caller's (e.g. a torch allocation, so repeated solves reuse cached memory) or NULL to let
+ * ndcn_solver_create hipMalloc it (that synchronises; ndcn_solver_destroy frees it).  All other calls only
+ * enqueue work on `stream`, except that the dopri5 controller waits for each step's 16-byte error record.
+ */
+typedef struct ndcn_solver ndcn_solver;
+
+typedef struct ndcn_solver_desc {
+    int      method;          /* NDCN_M_*                                                            */
+    int      H;
+    uint32_t rhs_flags;       /* NDCN_F_RELU | NO_GRAPH | NO_CONTROL                                  */
+    int      use_graph;       /* fixed-grid methods: replay one captured hipGraph per step            */
+    ndcn_csr A;
+    const float *W, *b;       /* nullable under NO_CONTROL                                            */
+    double   rtol, atol;      /* dopri5                                                               */
+    int64_t  max_num_steps;   /* dopri5.py:61 (2^31-1 in the reference)                               */
+} ndcn_solver_desc;
+
+NDCN_API int64_t ndcn_solver_workspace_bytes(const ndcn_solver_desc *desc);
+NDCN_API int ndcn_solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t workspace_bytes,
+                                ndcn_solver **out);
+NDCN_API int ndcn_solver_destroy(ndcn_solver *s);
+/* Start at (t0, y0): copies y0 in; dopri5 also evaluates f0 and the initial step (dopri5.py:77-83).   */
+NDCN_API int ndcn_solver_begin(ndcn_solver *s, const float *y0, double t0, void *stream);
+/* Integrate to next_t and write y(next_t) to `out` (n_rows x H).
+ * fixed grid: ONE step of size next_t - t (solvers.py:89-97).
+ * dopri5: adaptive steps until t1 >= next_t, at most `step_budget` of them (<= 0: unlimited), then the
+ * dense-output evaluation (dopri5.py:85-92).  When the budget is exhausted first, returns 1 and leaves
+ * `out` untouched; call again to continue.                                                            */
+NDCN_API int ndcn_solver_advance(ndcn_solver *s, double next_t, float *out, int64_t step_budget, void *stream);
+/* h_stats = {steps attempted, steps accepted, rhs evaluations, t1, dt_next, last mean_sq_error_ratio} */
+NDCN_API int ndcn_solver_stats(const ndcn_solver *s, double h_stats[6]);
+/* Copies up to `cap` rows {t0, dt, accepted, ratio, dt_next} of the per-attempt log; returns the count. */
+NDCN_API int64_t ndcn_solver_steplog(const ndcn_solver *s, double *h_rows, int64_t cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py `roofline`): when enabled, every kernel launch made by this library is
+ * bracketed by HIP events recorded on the launch stream.  ndcn_prof_read drains them into
+ * h_out[kind*4 + {0: launches, 1: total ms, 2: total algorithmic bytes, 3: total flops}] for
+ * kind in 0..ndcn_prof_kinds()-1 = {spmm, linear, rhs_fused, combine, error, sumsq, interp_fit,
+ * interp_eval, fixed_stage, gather_rows, truth_dynamics}; returns 1 if the record ring overflowed.  */
+NDCN_API int ndcn_prof_enable(int on);
+NDCN_API int ndcn_prof_read(double *h_out, int n_kinds);
+NDCN_API int ndcn_prof_kinds(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDCN_HIP_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libndcn_hip.so (include/ndcn_hip.h).
+
+The shared library is the product: there is no Python or CPU fallback behind it.  If it has not been
+built, or a call is made without a ROCm device, the failure is loud (`NdcnHipError`).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must come first: the library binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
+
+ABI_VERSION = 1
+
+OK = 0
+EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
+
+F_RELU, F_NO_GRAPH, F_NO_CONTROL = 1, 2, 4
+M_EULER, M_MIDPOINT, M_RK4, M_DOPRI5 = 0, 1, 2, 3
+METHODS = {'euler': M_EULER, 'midpoint': M_MIDPOINT, 'rk4': M_RK4, 'dopri5': M_DOPRI5}
+PROF_KINDS = ('spmm', 'linear', 'rhs_fused', 'combine', 'error', 'sumsq', 'interp_fit', 'interp_eval',
+              'fixed_stage', 'gather_rows', 'truth_dynamics')
+
+
+class NdcnHipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__('libndcn_hip: error %d: %s' % (code, text))
+        self.code = code
+
+
+class CsrView(ctypes.Structure):
+    """struct ndcn_csr"""
+    _fields_ = [('n_rows', ctypes.c_int64), ('n_cols', ctypes.c_int64), ('nnz', ctypes.c_int64),
+                ('rowptr', ctypes.c_void_p), ('colidx', ctypes.c_void_p), ('val', ctypes.c_void_p)]
+
+
+class SolverDesc(ctypes.Structure):
+    """struct ndcn_solver_desc"""
+    _fields_ = [('method', ctypes.c_int), ('H', ctypes.c_int), ('rhs_flags', ctypes.c_uint32),
+                ('use_graph', ctypes.c_int), ('A', CsrView), ('W', ctypes.c_void_p), ('b', ctypes.c_void_p),
+                ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('max_num_steps', ctypes.c_int64)]
+
+
+_P, _I, _L, _F, _D, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_uint32
+_CSR = ctypes.POINTER(CsrView)
+
+# name -> (restype, argtypes); the single source of truth for "what include/ndcn_hip.h declares"
+SIGNATURES = {
+    'ndcn_abi_version': (_I, []),
+    'ndcn_last_error': (ctypes.c_char_p, []),
+    'ndcn_device_info': (_I, [ctypes.POINTER(_L)]),
+    'ndcn_spmm_f32': (_I, [_CSR, _P, _P, _L, _P, _I, _F, _U, _P]),
+    'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
+    'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
+    'ndcn_rhs_needs_work': (_I, [_I, _U]),
+    'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
+    'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
+    'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),
+    'ndcn_scaled_sumsq_f32': (_I, [_P, _P, _P, _F, _F, _L, _P, _P, _P]),
+    'ndcn_reduce_ws_bytes': (_L, []),
+    'ndcn_dopri5_interp_fit_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _F, _P, _P, _P, _P, _L, _P]),
+    'ndcn_interp_eval_f32': (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(_F), _P, _L, _P]),
+    'ndcn_fixed_stage_f32': (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _L, _P]),
+    'ndcn_gene_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _P]),
+    'ndcn_mutual_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
+    'ndcn_solver_workspace_bytes': (_L, [ctypes.POINTER(SolverDesc)]),
+    'ndcn_solver_create': (_I, [ctypes.POINTER(SolverDesc), _P, _L, ctypes.POINTER(_P)]),
+    'ndcn_solver_destroy': (_I, [_P]),
+    'ndcn_solver_begin': (_I, [_P, _P, _D, _P]),
+    'ndcn_solver_advance': (_I, [_P, _D, _P, _L, _P]),
+    'ndcn_solver_stats': (_I, [_P, ctypes.POINTER(_D)]),
+    'ndcn_solver_steplog': (_L, [_P, ctypes.POINTER(_D), _L]),
+    'ndcn_prof_enable': (_I, [_I]),
+    'ndcn_prof_read': (_I, [ctypes.POINTER(_D), _I]),
+    'ndcn_prof_kinds': (_I, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises NdcnHipError when the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NdcnHipError(EHIP, '%s not built - run `python -c "import __graft_entry__ as g; g.build()"` '
+                                 '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)         # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ndcn_abi_version() != ABI_VERSION:
+        raise NdcnHipError(EINVAL, 'ABI version mismatch: library %d, binding %d' % (lib.ndcn_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code < 0:
+        raise NdcnHipError(code, load().ndcn_last_error().decode('utf-8', 'replace'))
+    return code
+
+
+def require_device(t, what='tensor'):
+    """The HIP path is the only path: refuse host tensors instead of computing on the CPU."""
+    if not t.is_cuda:
+        raise NdcnHipError(EINVAL, '%s lives on %s; ndcn_amd computes on a ROCm device only (no CPU fallback). '
+                                   'Move it with .to("cuda").' % (what, t.device))
+    if t.dtype != torch.float32:
+        raise NdcnHipError(EINVAL, '%s has dtype %s; the HIP path computes in float32' % (what, t.dtype))
+    return t
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

@@ -1,0 +1,142 @@
+"""CSR container for graph operators handed to the HIP kernels.
+
+The reference keeps its operator `A` as a dense torch matrix or a torch sparse COO tensor
+(heat_dynamics.py:150-175; utils.py:12-23).  The kernels want CSR with int32 indices, fp32 values and
+column-ascending rows; this module converts once and caches the result next to the tensor it came from.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class CsrOperator:
+    """rowptr int32[n_rows+1], colidx int32[nnz], val fp32[nnz]; all three on one device."""
+
+    def __init__(self, rowptr, colidx, val, shape):
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.colidx = colidx.to(torch.int32).contiguous()
+        self.val = val.to(torch.float32).contiguous()
+        self.shape = (int(shape[0]), int(shape[1]))
+        assert self.rowptr.numel() == self.shape[0] + 1
+        assert self.colidx.numel() == self.val.numel()
+        self._view = None
+        self._t = None
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_arrays(cls, indptr, indices, data, shape, device=None):
+        mk = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt)
+        op = cls(mk(indptr, torch.int32), mk(indices, torch.int32), mk(data, torch.float32), shape)
+        return op.to(device) if device is not None else op
+
+    @classmethod
+    def from_scipy(cls, m, device=None):
+        m = m.tocsr()
+        m.sort_indices()
+        return cls.from_arrays(m.indptr, m.indices, m.data, m.shape, device)
+
+    @classmethod
+    def from_coo(cls, rows, cols, vals, shape):
+        """Entries -> CSR on the entries' device; duplicates are summed (torch coalesce semantics)."""
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        key = rows.to(torch.int64) * n_cols + cols.to(torch.int64)
+        order = torch.argsort(key, stable=True)
+        key, vals = key[order], vals[order].to(torch.float32)
+        uniq, inv = torch.unique_consecutive(key, return_inverse=True)
+        if uniq.numel() != key.numel():
+            summed = torch.zeros(uniq.numel(), dtype=torch.float32, device=vals.device)
+            summed.index_add_(0, inv, vals)
+            key, vals = uniq, summed
+        r = torch.div(key, n_cols, rounding_mode='floor')
+        c = key - r * n_cols
+        counts = torch.bincount(r, minlength=n_rows)
+        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=vals.device)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        return cls(rowptr, c, vals, (n_rows, n_cols))
+
+    @classmethod
+    def from_torch(cls, A):
+        """Dense matrix, sparse COO (the reference's `--sparse` layout) or sparse CSR torch tensor."""
+        if isinstance(A, CsrOperator):
+            return A
+        if A.layout == torch.sparse_csr:
+            return cls(A.crow_indices(), A.col_indices(), A.values(), A.shape)
+        if A.is_sparse:
+            idx, vals = A._indices(), A._values()
+            return cls.from_coo(idx[0], idx[1], vals, A.shape)
+        assert A.dim() == 2, 'operator must be a matrix'
+        nz = A.nonzero()                       # row-major order, as torch_sensor_to_torch_sparse_tensor
+        vals = A[nz[:, 0], nz[:, 1]]
+        counts = torch.bincount(nz[:, 0], minlength=A.shape[0])
+        rowptr = torch.zeros(A.shape[0] + 1, dtype=torch.int64, device=A.device)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        return cls(rowptr, nz[:, 1], vals, A.shape)
+
+    # ------------------------------------------------------------------ accessors
+    @property
+    def device(self):
+        return self.val.device
+
+    @property
+    def nnz(self):
+        return int(self.val.numel())
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.val.device:
+            return self
+        return CsrOperator(self.rowptr.to(device), self.colidx.to(device), self.val.to(device), self.shape)
+
+    def view(self):
+        """ctypes struct ndcn_csr borrowing this object's device arrays."""
+        if self._view is None:
+            self._view = _lib.CsrView(self.shape[0], self.shape[1], self.nnz,
+                                      self.rowptr.data_ptr(), self.colidx.data_ptr() if self.nnz else None,
+                                      self.val.data_ptr() if self.nnz else None)
+        return self._view
+
+    def view_ref(self):
+        return ctypes.byref(self.view())
+
+    def scaled(self, alpha):
+        return CsrOperator(self.rowptr, self.colidx, self.val * float(alpha), self.shape)
+
+    def transpose(self):
+        """CSR of A^T (cached): the operator of the SpMM backward, g_X = A^T g_Y."""
+        if self._t is None:
+            rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device),
+                                           (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64))
+            self._t = CsrOperator.from_coo(self.colidx.to(torch.int64), rows, self.val, (self.shape[1], self.shape[0]))
+        return self._t
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val.cpu().numpy(), self.colidx.cpu().numpy(), self.rowptr.cpu().numpy()),
+                             shape=self.shape)
+
+    def to_torch_coo(self):
+        rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device),
+                                       (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64))
+        return torch.sparse_coo_tensor(torch.stack([rows, self.colidx.to(torch.int64)]), self.val, self.shape)
+
+
+def as_csr(A):
+    """CSR view of whatever the caller holds as its operator; converted once per tensor.
+
+    The reference holds `A` by reference on the module (neural_dynamics.py:14) and never mutates it, so
+    the conversion is cached on the tensor object itself, keyed on its version counter."""
+    if isinstance(A, CsrOperator):
+        return A
+    ver = getattr(A, '_version', 0)
+    tag = getattr(A, '_ndcn_csr', None)
+    if tag is not None and tag[0] == ver and tag[1].device == A.device:
+        return tag[1]
+    op = CsrOperator.from_torch(A)
+    try:
+        A._ndcn_csr = (ver, op)
+    except Exception:       # objects that refuse attributes just reconvert
+        pass
+    return op

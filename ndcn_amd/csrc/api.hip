@@ -1,0 +1,168 @@
+// extern "C" boundary of libndcn_hip.so: argument validation + forwarding.  See include/ndcn_hip.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include "kernels.h"
+
+namespace ndcn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int check_csr(const ndcn_csr *A, const char *who) {
+    if (!A) { set_error("%s: null operator", who); return NDCN_EINVAL; }
+    if (A->n_rows < 0 || A->n_cols < 0 || A->nnz < 0 || A->n_rows >= (1ll << 31) - 1 || A->nnz >= (1ll << 31) - 1) {
+        set_error("%s: operator dimensions out of range", who);
+        return NDCN_EINVAL;
+    }
+    if (!A->rowptr || (A->nnz > 0 && (!A->colidx || !A->val))) { set_error("%s: null CSR array", who); return NDCN_EINVAL; }
+    return NDCN_OK;
+}
+
+}  // namespace ndcn
+
+using namespace ndcn;
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" {
+
+int ndcn_abi_version(void) { return NDCN_ABI_VERSION; }
+const char *ndcn_last_error(void) { return g_err; }
+
+int ndcn_device_info(int64_t h_out[6]) {
+    NDCN_CHECK_ARG(h_out, "null output");
+    int dev = 0;
+    NDCN_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    NDCN_HIP(hipGetDeviceProperties(&p, dev));
+    h_out[0] = p.multiProcessorCount;
+    h_out[1] = kXcds;
+    h_out[2] = p.warpSize;
+    h_out[3] = p.clockRate;
+    h_out[4] = (int64_t)(p.totalGlobalMem >> 20);
+    h_out[5] = (int64_t)(p.l2CacheSize >> 10);
+    return NDCN_OK;
+}
+
+int ndcn_spmm_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, float *Y, int H, float alpha,
+                  uint32_t flags, void *stream) {
+    int rc = check_csr(A, __func__);
+    if (rc) return rc;
+    NDCN_CHECK_ARG(H > 0, "H must be positive");
+    NDCN_CHECK_ARG(A->n_rows == 0 || (X && Y), "null panel");
+    NDCN_CHECK_ARG(X != Y, "Y must not alias X");
+    NDCN_CHECK_ARG(X_halo || n_own >= A->n_cols, "columns beyond n_own need a halo panel");
+    return spmm_f32(A, X, X_halo, n_own, Y, H, alpha, flags, ST(stream));
+}
+
+int ndcn_linear_f32(const float *S, const float *W, const float *b, float *Y, int64_t n, int H_in, int H_out,
+                    uint32_t flags, void *stream) {
+    NDCN_CHECK_ARG(n >= 0 && H_in > 0 && H_out > 0, "bad shape");
+    NDCN_CHECK_ARG(n == 0 || (S && W && Y), "null pointer");
+    NDCN_CHECK_ARG(S != Y, "Y must not alias S");
+    return linear_f32(S, W, b, Y, n, H_in, H_out, flags, ST(stream));
+}
+
+int ndcn_rhs_needs_work(int H, uint32_t flags) { return rhs_needs_work(H, flags); }
+
+int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
+                 float *Y, float *work, int H, uint32_t flags, void *stream) {
+    NDCN_CHECK_ARG(A, "null operator descriptor (n_rows is read from it even under NO_GRAPH)");
+    NDCN_CHECK_ARG(H > 0, "H must be positive");
+    if (!(flags & NDCN_F_NO_GRAPH)) {
+        int rc = check_csr(A, __func__);
+        if (rc) return rc;
+        NDCN_CHECK_ARG(X_halo || n_own >= A->n_cols, "columns beyond n_own need a halo panel");
+    }
+    NDCN_CHECK_ARG(A->n_rows == 0 || (X && Y), "null panel");
+    NDCN_CHECK_ARG(X != Y, "Y must not alias X");
+    NDCN_CHECK_ARG((flags & NDCN_F_NO_CONTROL) || W, "weight missing");
+    return rhs_f32(A, X, X_halo, n_own, W, b, Y, work, H, flags, ST(stream));
+}
+
+int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream) {
+    NDCN_CHECK_ARG(n_idx >= 0 && H > 0, "bad shape");
+    NDCN_CHECK_ARG(n_idx == 0 || (X && idx && out), "null pointer");
+    return gather_rows_f32(X, idx, n_idx, H, out, ST(stream));
+}
+
+int ndcn_rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n_elem,
+                        void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && h_k && h_c, "bad argument");
+    NDCN_CHECK_ARG(n_elem == 0 || (out && y0), "null panel");
+    return rk_combine_f32(out, y0, h_k, h_c, n_k, n_elem, ST(stream));
+}
+
+int ndcn_rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
+                      float atol, int64_t n_elem, double *d_out, void *d_ws, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && h_k && h_c && d_out && d_ws, "bad argument");
+    NDCN_CHECK_ARG(n_elem == 0 || (y0 && y1), "null panel");
+    return rk_error_f32(y0, y1, h_k, h_c, n_k, rtol, atol, n_elem, d_out, d_ws, ST(stream));
+}
+
+int ndcn_scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n_elem,
+                          double *d_out, void *d_ws, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && d_out && d_ws, "bad argument");
+    NDCN_CHECK_ARG(n_elem == 0 || (a && y), "null panel");
+    return scaled_sumsq_f32(a, b, y, rtol, atol, n_elem, d_out, d_ws, ST(stream));
+}
+
+int64_t ndcn_reduce_ws_bytes(void) { return reduce_ws_bytes(); }
+
+int ndcn_dopri5_interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                               float *a, float *b, float *c, float *d, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && h_k && h_cmid, "bad argument");
+    NDCN_CHECK_ARG(n_elem == 0 || (y0 && y1 && a && b && c && d), "null panel");
+    return interp_fit_f32(y0, y1, h_k, h_cmid, dt, a, b, c, d, n_elem, ST(stream));
+}
+
+int ndcn_interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e,
+                         const float h_xpow[5], float *out, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && h_xpow, "bad argument");
+    NDCN_CHECK_ARG(n_elem == 0 || (a && b && c && d && e && out), "null panel");
+    return interp_eval_f32(a, b, c, d, e, h_xpow, out, n_elem, ST(stream));
+}
+
+int ndcn_fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
+                         const float *k4, float dt, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0, "bad size");
+    NDCN_CHECK_ARG(n_elem == 0 || (out && y), "null panel");
+    return fixed_stage_f32(op, out, y, k1, k2, k3, k4, dt, n_elem, ST(stream));
+}
+
+int ndcn_gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, void *stream) {
+    int rc = check_csr(A, __func__);
+    if (rc) return rc;
+    NDCN_CHECK_ARG(A->n_rows == 0 || (x && out), "null vector");
+    NDCN_CHECK_ARG(x != out, "out must not alias x");
+    return gene_rhs_f32(A, x, out, b, f, h, ST(stream));
+}
+
+int ndcn_mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d, float e,
+                        float h, void *stream) {
+    int rc = check_csr(A, __func__);
+    if (rc) return rc;
+    NDCN_CHECK_ARG(A->n_rows == 0 || (x && out), "null vector");
+    NDCN_CHECK_ARG(x != out, "out must not alias x");
+    return mutual_rhs_f32(A, x, out, b, k, c, d, e, h, ST(stream));
+}
+
+int64_t ndcn_solver_workspace_bytes(const ndcn_solver_desc *desc) { return solver_workspace_bytes(desc); }
+int ndcn_solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t workspace_bytes, ndcn_solver **out) {
+    return solver_create(desc, workspace, workspace_bytes, out);
+}
+int ndcn_solver_destroy(ndcn_solver *s) { return solver_destroy(s); }
+int ndcn_solver_begin(ndcn_solver *s, const float *y0, double t0, void *stream) { return solver_begin(s, y0, t0, ST(stream)); }
+int ndcn_solver_advance(ndcn_solver *s, double next_t, float *out, int64_t step_budget, void *stream) {
+    return solver_advance(s, next_t, out, step_budget, ST(stream));
+}
+int ndcn_solver_stats(const ndcn_solver *s, double h_stats[6]) { return solver_stats(s, h_stats); }
+int64_t ndcn_solver_steplog(const ndcn_solver *s, double *h_rows, int64_t cap) { return solver_steplog(s, h_rows, cap); }
+
+}  // extern "C"

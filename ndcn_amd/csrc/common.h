@@ -1,0 +1,64 @@
+// Internal helpers shared by the kernels of libndcn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ndcn_hip.h"
+#include "prof.h"
+
+namespace ndcn {
+
+void set_error(const char *fmt, ...);
+
+#define NDCN_CHECK_ARG(cond, msg)                                         \
+    do {                                                                  \
+        if (!(cond)) {                                                    \
+            ::ndcn::set_error("%s: %s", __func__, msg);                   \
+            return NDCN_EINVAL;                                           \
+        }                                                                 \
+    } while (0)
+
+#define NDCN_HIP(call)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ::ndcn::set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_)); \
+            return NDCN_EHIP;                                                              \
+        }                                                                                  \
+    } while (0)
+
+#define NDCN_LAUNCH_CHECK()                                                                   \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            ::ndcn::set_error("%s: kernel launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return NDCN_EHIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kXcds = 8;        // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
+constexpr int kCus = 256;
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Contiguous-chunk-per-XCD remap of a 1-D grid (bijective for any grid size): blocks that the
+// dispatcher places on one XCD (b % 8 equal) get CONSECUTIVE logical ids, so neighbouring row blocks
+// share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk / kXcds, r = nblk % kXcds;
+    const int xcd = b % kXcds, k = b / kXcds;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+// grid size for streaming elementwise kernels: enough blocks to fill the chip, grid-stride the rest
+inline int stream_grid(int64_t n_items, int block) {
+    int64_t g = (n_items + block - 1) / block;
+    const int64_t cap = (int64_t)kCus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace ndcn

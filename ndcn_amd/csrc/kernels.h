@@ -1,0 +1,43 @@
+// Internal (C++) entry points of the kernels; the extern "C" layer in api.hip validates arguments and
+// forwards here.
+#pragma once
+#include "common.h"
+
+namespace ndcn {
+
+int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
+             uint32_t flags, hipStream_t st);
+int gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, hipStream_t st);
+int linear_f32(const float *S, const float *W, const float *b, float *Y, int64_t n, int Hi, int Ho, uint32_t flags,
+               hipStream_t st);
+int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *Y,
+            float *work, int H, uint32_t flags, hipStream_t st);
+int rhs_needs_work(int H, uint32_t flags);
+
+int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n,
+                   hipStream_t st);
+int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
+                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st);
+int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
+                     void *d_ws, hipStream_t st);
+int64_t reduce_ws_bytes();
+int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt, float *a,
+                   float *b, float *c, float *d, int64_t n, hipStream_t st);
+int interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e, const float xp[5],
+                    float *out, int64_t n, hipStream_t st);
+int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
+                    const float *k4, float dt, int64_t n, hipStream_t st);
+
+int gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, hipStream_t st);
+int mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d, float e, float h,
+                   hipStream_t st);
+
+int64_t solver_workspace_bytes(const ndcn_solver_desc *desc);
+int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_bytes, ndcn_solver **out);
+int solver_destroy(ndcn_solver *s);
+int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st);
+int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st);
+int solver_stats(const ndcn_solver *s, double h[6]);
+int64_t solver_steplog(const ndcn_solver *s, double *rows, int64_t cap);
+
+}  // namespace ndcn

@@ -1,0 +1,47 @@
+// ODEFunc.forward as one entry point: Y = relu(W (A X) + b)   (neural_dynamics.py:20-39, dropout p = 0).
+// Composition of the SpMM and the MFMA Linear through a scratch panel; shapes the fused kernel covers
+// (rhs_fused.hip) bypass the scratch.
+#include "kernels.h"
+
+namespace ndcn {
+
+int rhs_fused_supported(int H, uint32_t flags);
+int rhs_fused_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b,
+                  float *Y, int H, uint32_t flags, hipStream_t st);
+
+__global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n,
+                                                        int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+int rhs_needs_work(int H, uint32_t flags) {
+    const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
+    if (!(graph && ctl)) return 0;
+    return rhs_fused_supported(H, flags) ? 0 : 1;
+}
+
+int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *Y,
+            float *work, int H, uint32_t flags, hipStream_t st) {
+    const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
+    const uint32_t act = flags & NDCN_F_RELU;
+    const int64_t n = A->n_rows;
+    if (graph && ctl) {
+        if (rhs_fused_supported(H, flags)) return rhs_fused_f32(A, X, Xh, n_own, W, b, Y, H, flags, st);
+        if (!work) { set_error("rhs: scratch panel required for H=%d", H); return NDCN_EINVAL; }
+        int rc = spmm_f32(A, X, Xh, n_own, work, H, 1.f, 0, st);
+        if (rc) return rc;
+        return linear_f32(work, W, b, Y, n, H, H, act, st);
+    }
+    if (graph) return spmm_f32(A, X, Xh, n_own, Y, H, 1.f, act, st);          // no_control: relu(A x)
+    if (ctl) return linear_f32(X, W, b, Y, n, H, H, act, st);                   // no_graph: relu(W x + b)
+    const int64_t total = n * (int64_t)H;                                       // neither: relu(x)
+    if (total == 0) return NDCN_OK;
+    hipLaunchKernelGGL(relu_copy_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, X, Y, total, act ? 1 : 0);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+}  // namespace ndcn

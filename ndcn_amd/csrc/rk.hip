@@ -1,0 +1,399 @@
+// Runge-Kutta bookkeeping kernels: every one is a single streaming pass (HBM-bound) that replaces a
+// chain of separate ATen elementwise ops in the reference's integrator.
+//
+// Rounding follows the reference term by term: coefficients arrive already rounded to fp32 as dt*beta
+// (misc.py:25), products and sums are rounded separately and added left to right.  FP contraction is
+// therefore switched OFF for this translation unit - an fma here would change the last bit relative to
+// the reference's separate mul / add kernels.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace ndcn {
+
+constexpr int kMaxTerms = 8;
+constexpr int kRedBlocks = 2048;       // partial sums per reduction (deterministic two-pass)
+
+struct Terms {
+    const float *k[kMaxTerms];
+    float c[kMaxTerms];
+    int n;
+};
+
+__device__ __forceinline__ float4 ld4(const float *p, int64_t i) { return reinterpret_cast<const float4 *>(p)[i]; }
+__device__ __forceinline__ void st4(float *p, int64_t i, float4 v) { reinterpret_cast<float4 *>(p)[i] = v; }
+
+// sum_j c_j * k_j[i], left to right, separate roundings  (misc.py:22-25)
+__device__ __forceinline__ float wsum1(const Terms &t, int64_t i) {
+    float acc = t.c[0] * t.k[0][i];
+#pragma unroll
+    for (int j = 1; j < kMaxTerms; ++j)
+        if (j < t.n) acc = acc + t.c[j] * t.k[j][i];
+    return acc;
+}
+__device__ __forceinline__ float4 wsum4(const Terms &t, int64_t i) {
+    float4 k = ld4(t.k[0], i);
+    float4 acc = make_float4(t.c[0] * k.x, t.c[0] * k.y, t.c[0] * k.z, t.c[0] * k.w);
+#pragma unroll
+    for (int j = 1; j < kMaxTerms; ++j)
+        if (j < t.n) {
+            k = ld4(t.k[j], i);
+            const float c = t.c[j];
+            acc.x = acc.x + c * k.x; acc.y = acc.y + c * k.y; acc.z = acc.z + c * k.z; acc.w = acc.w + c * k.w;
+        }
+    return acc;
+}
+
+// -------------------------------------------------------------------------------- combine
+// out = y0 + sum_j c_j k_j
+template <bool VEC>
+__global__ __launch_bounds__(256) void combine_kernel(float *__restrict__ out, const float *__restrict__ y0, Terms t,
+                                                      int64_t n_items) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 s = wsum4(t, i);
+            const float4 y = ld4(y0, i);
+            st4(out, i, make_float4(y.x + s.x, y.y + s.y, y.z + s.z, y.w + s.w));
+        } else {
+            out[i] = y0[i] + wsum1(t, i);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------- reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-level sum of two doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum2(double &a, double &b) {
+    __shared__ double sa[4], sb[4];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sa[w] = a; sb[w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = ((sa[0] + sa[1]) + sa[2]) + sa[3];
+        b = ((sb[0] + sb[1]) + sb[2]) + sb[3];
+    }
+}
+
+__device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.402823466e38f); }
+
+__device__ __forceinline__ float err_ratio_sq(float e, float a, float b, float rtol, float atol) {
+    // misc.py:151-156: tol = atol + rtol * max(|y0|, |y1|); r = err / tol; r * r
+    const float tol = atol + rtol * fmaxf(fabsf(a), fabsf(b));
+    const float r = e / tol;
+    return r * r;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void rk_error_kernel(const float *__restrict__ y0, const float *__restrict__ y1,
+                                                       Terms t, float rtol, float atol, int64_t n_items,
+                                                       double *__restrict__ partial) {
+    double s = 0.0, bad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 e = wsum4(t, i);
+            const float4 a = ld4(y0, i), b = ld4(y1, i);
+            s += (double)err_ratio_sq(e.x, a.x, b.x, rtol, atol);
+            s += (double)err_ratio_sq(e.y, a.y, b.y, rtol, atol);
+            s += (double)err_ratio_sq(e.z, a.z, b.z, rtol, atol);
+            s += (double)err_ratio_sq(e.w, a.w, b.w, rtol, atol);
+            bad += (double)((int)nonfinite(b.x) + (int)nonfinite(b.y) + (int)nonfinite(b.z) + (int)nonfinite(b.w));
+        } else {
+            const float b = y1[i];
+            s += (double)err_ratio_sq(wsum1(t, i), y0[i], b, rtol, atol);
+            bad += (double)(int)nonfinite(b);
+        }
+    }
+    block_sum2(s, bad);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = bad; }
+}
+
+__device__ __forceinline__ float scaled_sq(float a, float b, float y, float rtol, float atol) {
+    // misc.py:121-138: scale = atol + |y0| * rtol ; ((a - b) / scale)^2
+    const float scale = atol + fabsf(y) * rtol;
+    const float q = (a - b) / scale;
+    return q * q;
+}
+
+template <bool VEC, bool HASB>
+__global__ __launch_bounds__(256) void scaled_sumsq_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           const float *__restrict__ y, float rtol, float atol,
+                                                           int64_t n_items, double *__restrict__ partial) {
+    double s = 0.0, bad = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 av = ld4(a, i), yv = ld4(y, i);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HASB) bv = ld4(b, i);
+            if (HASB) {
+                s += (double)scaled_sq(av.x, bv.x, yv.x, rtol, atol);
+                s += (double)scaled_sq(av.y, bv.y, yv.y, rtol, atol);
+                s += (double)scaled_sq(av.z, bv.z, yv.z, rtol, atol);
+                s += (double)scaled_sq(av.w, bv.w, yv.w, rtol, atol);
+            } else {
+                // no subtraction at all when b is absent: (a / scale)^2 as misc.py:123-124
+                float q;
+                q = av.x / (atol + fabsf(yv.x) * rtol); s += (double)(q * q);
+                q = av.y / (atol + fabsf(yv.y) * rtol); s += (double)(q * q);
+                q = av.z / (atol + fabsf(yv.z) * rtol); s += (double)(q * q);
+                q = av.w / (atol + fabsf(yv.w) * rtol); s += (double)(q * q);
+            }
+            bad += (double)((int)nonfinite(av.x) + (int)nonfinite(av.y) + (int)nonfinite(av.z) + (int)nonfinite(av.w));
+        } else {
+            const float av = a[i];
+            if (HASB) {
+                s += (double)scaled_sq(av, b[i], y[i], rtol, atol);
+            } else {
+                const float q = av / (atol + fabsf(y[i]) * rtol);
+                s += (double)(q * q);
+            }
+            bad += (double)(int)nonfinite(av);
+        }
+    }
+    block_sum2(s, bad);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = bad; }
+}
+
+// fixed-order final sum of the per-block partials
+__global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__restrict__ partial, int n_partial,
+                                                            double *__restrict__ out) {
+    double s = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) { s += partial[2 * i]; bad += partial[2 * i + 1]; }
+    block_sum2(s, bad);
+    if (threadIdx.x == 0) { out[0] = s; out[1] = bad; }
+}
+
+// -------------------------------------------------------------------------------- dense output
+struct FitArgs {
+    const float *y0, *y1;
+    Terms mid;              // dt * DPS_C_MID terms (zero coefficients already dropped by the caller)
+    const float *f0, *f1;
+    float dt;
+    float *a, *b, *c, *d;
+};
+
+__device__ __forceinline__ void fit1(float y0, float y1, float ms, float f0, float f1, float dt, float &a, float &b,
+                                     float &c, float &d) {
+    const float ym = y0 + ms;                                                  // dopri5.py:42
+    // interp.py:21-35 -- `_dot_product` sums c*x products left to right; -2*dt etc. are fp32 scalars
+    a = ((((-2.f * dt) * f0 + (2.f * dt) * f1) + -8.f * y0) + -8.f * y1) + 16.f * ym;
+    b = ((((5.f * dt) * f0 + (-3.f * dt) * f1) + 18.f * y0) + 14.f * y1) + -32.f * ym;
+    c = ((((-4.f * dt) * f0 + dt * f1) + -11.f * y0) + -5.f * y1) + 16.f * ym;
+    d = dt * f0;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void interp_fit_kernel(FitArgs p, int64_t n_items) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 ms = wsum4(p.mid, i);
+            const float4 y0 = ld4(p.y0, i), y1 = ld4(p.y1, i), f0 = ld4(p.f0, i), f1 = ld4(p.f1, i);
+            float4 a, b, c, d;
+            fit1(y0.x, y1.x, ms.x, f0.x, f1.x, p.dt, a.x, b.x, c.x, d.x);
+            fit1(y0.y, y1.y, ms.y, f0.y, f1.y, p.dt, a.y, b.y, c.y, d.y);
+            fit1(y0.z, y1.z, ms.z, f0.z, f1.z, p.dt, a.z, b.z, c.z, d.z);
+            fit1(y0.w, y1.w, ms.w, f0.w, f1.w, p.dt, a.w, b.w, c.w, d.w);
+            st4(p.a, i, a); st4(p.b, i, b); st4(p.c, i, c); st4(p.d, i, d);
+        } else {
+            float a, b, c, d;
+            fit1(p.y0[i], p.y1[i], wsum1(p.mid, i), p.f0[i], p.f1[i], p.dt, a, b, c, d);
+            p.a[i] = a; p.b[i] = b; p.c[i] = c; p.d[i] = d;
+        }
+    }
+}
+
+struct EvalArgs {
+    const float *a, *b, *c, *d, *e;
+    float x4, x3, x2, x1, x0;
+    float *out;
+};
+
+__device__ __forceinline__ float eval1(float a, float b, float c, float d, float e, const EvalArgs &p) {
+    // interp.py:65: a*x^4 + b*x^3 + c*x^2 + d*x + e*1, left to right
+    return (((a * p.x4 + b * p.x3) + c * p.x2) + d * p.x1) + e * p.x0;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void interp_eval_kernel(EvalArgs p, int64_t n_items) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 a = ld4(p.a, i), b = ld4(p.b, i), c = ld4(p.c, i), d = ld4(p.d, i), e = ld4(p.e, i);
+            st4(p.out, i, make_float4(eval1(a.x, b.x, c.x, d.x, e.x, p), eval1(a.y, b.y, c.y, d.y, e.y, p),
+                                      eval1(a.z, b.z, c.z, d.z, e.z, p), eval1(a.w, b.w, c.w, d.w, e.w, p)));
+        } else {
+            p.out[i] = eval1(p.a[i], p.b[i], p.c[i], p.d[i], p.e[i], p);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------- fixed-grid stages
+template <int OP>
+__device__ __forceinline__ float stage1(float y, float k1, float k2, float k3, float k4, float dt) {
+    if (OP == 0) return y + dt * k1;                                   // fixed_grid.py:8 + solvers.py:92
+    if (OP == 1) return y + k1 * dt / 2.f;                             // fixed_grid.py:18
+    if (OP == 2) return y + dt * k1 / 3.f;                             // rk_common.py:75
+    if (OP == 3) return y + dt * (k1 / -3.f + k2);                     // rk_common.py:76
+    if (OP == 4) return y + dt * (k1 - k2 + k3);                       // rk_common.py:77
+    return y + (k1 + 3.f * k2 + 3.f * k3 + k4) * (dt / 8.f);           // rk_common.py:78 + solvers.py:92
+}
+
+template <int OP, bool VEC>
+__global__ __launch_bounds__(256) void fixed_stage_kernel(float *out, const float *y, const float *k1, const float *k2,
+                                                          const float *k3, const float *k4, float dt, int64_t n_items) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 yv = ld4(y, i), a = ld4(k1, i);
+            const float4 b = (OP >= 3) ? ld4(k2, i) : z;
+            const float4 c = (OP >= 4) ? ld4(k3, i) : z;
+            const float4 d = (OP >= 5) ? ld4(k4, i) : z;
+            st4(out, i, make_float4(stage1<OP>(yv.x, a.x, b.x, c.x, d.x, dt), stage1<OP>(yv.y, a.y, b.y, c.y, d.y, dt),
+                                    stage1<OP>(yv.z, a.z, b.z, c.z, d.z, dt), stage1<OP>(yv.w, a.w, b.w, c.w, d.w, dt)));
+        } else {
+            out[i] = stage1<OP>(y[i], k1[i], OP >= 3 ? k2[i] : 0.f, OP >= 4 ? k3[i] : 0.f, OP >= 5 ? k4[i] : 0.f, dt);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------- host wrappers
+static bool fill_terms(Terms &t, const float *const *h_k, const float *h_c, int n_k, bool &vec) {
+    if (n_k < 1 || n_k > kMaxTerms) return false;
+    t.n = n_k;
+    for (int j = 0; j < kMaxTerms; ++j) {
+        t.k[j] = j < n_k ? h_k[j] : h_k[0];
+        t.c[j] = j < n_k ? h_c[j] : 0.f;
+        if (j < n_k) {
+            if (!h_k[j]) return false;
+            vec = vec && aligned16(h_k[j]);
+        }
+    }
+    return true;
+}
+
+int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n,
+                   hipStream_t st) {
+    Terms t;
+    bool vec = (n % 4 == 0) && aligned16(out) && aligned16(y0);
+    if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_combine: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_COMBINE, st, 4.0 * n * (n_k + 2), 2.0 * n * n_k);
+    if (vec) hipLaunchKernelGGL((combine_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, out, y0, t, n / 4);
+    else hipLaunchKernelGGL((combine_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, out, y0, t, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int64_t reduce_ws_bytes() { return (int64_t)kRedBlocks * 2 * sizeof(double); }
+
+static int red_grid(int64_t items) {
+    int g = stream_grid(items, 256);
+    return g > kRedBlocks ? kRedBlocks : g;
+}
+
+int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
+                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st) {
+    Terms t;
+    bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1);
+    if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_error: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
+    double *partial = static_cast<double *>(d_ws);
+    const int64_t items = vec ? n / 4 : n;
+    const int g = red_grid(items);
+    ProfScope prof(PROF_ERROR, st, 4.0 * n * (n_k + 2), 2.0 * n * (n_k + 4));
+    if (vec) hipLaunchKernelGGL((rk_error_kernel<true>), dim3(g), dim3(256), 0, st, y0, y1, t, rtol, atol, items, partial);
+    else hipLaunchKernelGGL((rk_error_kernel<false>), dim3(g), dim3(256), 0, st, y0, y1, t, rtol, atol, items, partial);
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
+                     void *d_ws, hipStream_t st) {
+    const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(y) && (!b || aligned16(b));
+    double *partial = static_cast<double *>(d_ws);
+    const int64_t items = vec ? n / 4 : n;
+    const int g = red_grid(items);
+    ProfScope prof(PROF_SUMSQ, st, 4.0 * n * (b ? 3 : 2), 6.0 * n);
+#define NDCN_SS(V, B) hipLaunchKernelGGL((scaled_sumsq_kernel<V, B>), dim3(g), dim3(256), 0, st, a, b, y, rtol, atol, items, partial)
+    if (vec) { if (b) NDCN_SS(true, true); else NDCN_SS(true, false); }
+    else { if (b) NDCN_SS(false, true); else NDCN_SS(false, false); }
+#undef NDCN_SS
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt, float *a,
+                   float *b, float *c, float *d, int64_t n, hipStream_t st) {
+    FitArgs p;
+    bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1) && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d);
+    // drop zero coefficients (c_mid[1] == 0): the product would be an exact zero
+    const float *kk[kMaxTerms];
+    float cc[kMaxTerms];
+    int m = 0;
+    for (int j = 0; j < 7; ++j) {
+        if (!h_k[j]) { set_error("interp_fit: null stage pointer"); return NDCN_EINVAL; }
+        vec = vec && aligned16(h_k[j]);
+        if (h_cmid[j] != 0.f) { kk[m] = h_k[j]; cc[m] = h_cmid[j]; ++m; }
+    }
+    if (m == 0) { kk[0] = h_k[0]; cc[0] = 0.f; m = 1; }
+    bool dummy = true;
+    fill_terms(p.mid, kk, cc, m, dummy);
+    p.y0 = y0; p.y1 = y1; p.f0 = h_k[0]; p.f1 = h_k[6]; p.dt = dt; p.a = a; p.b = b; p.c = c; p.d = d;
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_FIT, st, 4.0 * n * (2 + m + 4), 2.0 * n * (m + 16));
+    if (vec) hipLaunchKernelGGL((interp_fit_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_fit_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e, const float xp[5],
+                    float *out, int64_t n, hipStream_t st) {
+    EvalArgs p{a, b, c, d, e, xp[0], xp[1], xp[2], xp[3], xp[4], out};
+    const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d) && aligned16(e) && aligned16(out);
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_EVAL, st, 4.0 * n * 6, 9.0 * n);
+    if (vec) hipLaunchKernelGGL((interp_eval_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_eval_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+template <int OP>
+static void launch_stage(bool vec, float *out, const float *y, const float *k1, const float *k2, const float *k3,
+                         const float *k4, float dt, int64_t n, hipStream_t st) {
+    if (vec) hipLaunchKernelGGL((fixed_stage_kernel<OP, true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, n / 4);
+    else hipLaunchKernelGGL((fixed_stage_kernel<OP, false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, n);
+}
+
+int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
+                    const float *k4, float dt, int64_t n, hipStream_t st) {
+    const int need = op <= 2 ? 1 : op == 3 ? 2 : op == 4 ? 3 : 4;
+    const float *ks[4] = {k1, k2, k3, k4};
+    bool vec = (n % 4 == 0) && aligned16(out) && aligned16(y);
+    for (int j = 0; j < need; ++j) {
+        if (!ks[j]) { set_error("fixed_stage: op %d needs %d stage pointers", op, need); return NDCN_EINVAL; }
+        vec = vec && aligned16(ks[j]);
+    }
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_STAGE, st, 4.0 * n * (need + 2), 2.0 * n * need);
+    switch (op) {
+        case 0: launch_stage<0>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        case 1: launch_stage<1>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        case 2: launch_stage<2>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        case 3: launch_stage<3>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        case 4: launch_stage<4>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        case 5: launch_stage<5>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        default: set_error("fixed_stage: unknown op %d", op); return NDCN_EINVAL;
+    }
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+}  // namespace ndcn

@@ -1,0 +1,469 @@
+// Device-resident integrator for the ODEFunc right-hand side.
+//
+// State, stage derivatives and dense-output coefficients live in HBM for the whole solve; the host runs
+// only the scalar control flow of the reference's solvers:
+//   fixed grid (euler / midpoint / rk4 3-8 rule)  torchdiffeq/_impl/solvers.py:79-99, fixed_grid.py, rk_common.py:72-78
+//   dopri5                                         torchdiffeq/_impl/dopri5.py:58-122, rk_common.py:22-61,
+//                                                  misc.py:84-170, interp.py:5-65
+// and reads back one 16-byte record {sum r^2, non-finite count} per adaptive step.
+// Scalar arithmetic mirrors the reference's dtypes: time/step-size controller in float64, everything
+// that the reference forms as a 0-d tensor of the state dtype (dt*beta, stage times, the initial-step
+// heuristic, the interpolation abscissa) in float32.
+#include <math.h>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ndcn {
+
+// Dormand-Prince 5(4): dopri5.py:11-36, written as the same rational expressions (evaluated in double,
+// rounded to float where the reference multiplies them with a float32 0-d tensor).
+static const double kAlpha[6] = {1. / 5, 3. / 10, 4. / 5, 8. / 9, 1., 1.};
+static const double kBeta[6][6] = {
+    {1. / 5},
+    {3. / 40, 9. / 40},
+    {44. / 45, -56. / 15, 32. / 9},
+    {19372. / 6561, -25360. / 2187, 64448. / 6561, -212. / 729},
+    {9017. / 3168, -355. / 33, 46732. / 5247, 49. / 176, -5103. / 18656},
+    {35. / 384, 0, 500. / 1113, 125. / 192, -2187. / 6784, 11. / 84},
+};
+static const double kCErr[7] = {
+    35. / 384 - 1951. / 21600, 0, 500. / 1113 - 22642. / 50085, 125. / 192 - 451. / 720,
+    -2187. / 6784 - -12231. / 42400, 11. / 84 - 649. / 6300, -1. / 60.,
+};
+static const double kCMid[7] = {
+    6025192743. / 30085553152. / 2, 0, 51252292925. / 65400821598. / 2, -2691868925. / 45128329728. / 2,
+    187940372067. / 1594534317056. / 2, -1776094331. / 19743644256. / 2, 11237099. / 235043384. / 2,
+};
+
+static inline double nan_max(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : (a > b ? a : b); }
+static inline double nan_min(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : (a < b ? a : b); }
+
+}  // namespace ndcn
+
+using namespace ndcn;
+
+struct ndcn_solver {
+    ndcn_solver_desc d;
+    int64_t n_rows = 0, n_elem = 0;
+    // panels
+    float *ycur = nullptr, *ynext = nullptr, *yold = nullptr, *ytmp = nullptr, *work = nullptr;
+    float *k[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *ca = nullptr, *cb = nullptr, *cc = nullptr, *cd = nullptr;
+    const float *ce = nullptr;     // interpolation "e" = y at the start of the fitted step
+    void *slab = nullptr;          // one workspace: caller-provided or hipMalloc'ed here
+    size_t slab_bytes = 0, slab_used = 0;
+    bool slab_owned = false;
+    double *d_red = nullptr;       // device {sum, nonfinite}
+    void *d_ws = nullptr;
+    double *h_red = nullptr;       // pinned host mirror
+    hipEvent_t ev = nullptr;
+    // scalar state
+    bool begun = false;
+    double t0 = 0, t1 = 0, dt = 0; // dopri5: last interval [t0, t1], next step size
+    float tf = 0;                  // fixed grid: current time in the state dtype
+    bool fit_pending = false;      // last accepted step not yet fitted
+    bool fit_valid = false;
+    float fit_dt = 0;
+    bool cur_is_borrowed = false;  // ycur points into a caller buffer (fixed grid)
+    float *ycur_own = nullptr;
+    int64_t n_attempt = 0, n_accept = 0, n_rhs = 0;
+    double last_ratio = 0;
+    int64_t pending_bad = 0;       // non-finite elements seen in the state that starts the next step
+    std::vector<double> log;       // 5 doubles per attempt
+};
+
+namespace {
+
+inline size_t align_up(size_t v) { return (v + 255u) & ~(size_t)255u; }
+
+int n_panels(const ndcn_solver_desc *d) {
+    const int nk = d->method == NDCN_M_DOPRI5 ? 7 : d->method == NDCN_M_RK4 ? 4 : 1;
+    int n = 2 + nk;                                       // ycur, ytmp, k[]
+    if (rhs_needs_work(d->H, d->rhs_flags)) n += 1;       // scratch of the two-kernel RHS
+    if (d->method == NDCN_M_DOPRI5) n += 6;               // ynext, yold, a, b, c, d
+    return n;
+}
+
+size_t workspace_bytes(const ndcn_solver_desc *d) {
+    const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
+    return (size_t)n_panels(d) * panel + align_up((size_t)reduce_ws_bytes()) + 512;
+}
+
+int carve(ndcn_solver *s, size_t bytes, void **p) {
+    const size_t off = align_up(s->slab_used);
+    if (off + bytes > s->slab_bytes) {
+        set_error("solver workspace too small: need %zu more bytes", off + bytes - s->slab_bytes);
+        return NDCN_EINVAL;
+    }
+    *p = static_cast<char *>(s->slab) + off;
+    s->slab_used = off + bytes;
+    return NDCN_OK;
+}
+
+int alloc_panel(ndcn_solver *s, float **p) {
+    void *q = nullptr;
+    int rc = carve(s, (size_t)s->n_elem * sizeof(float) + 16, &q);
+    if (rc) return rc;
+    *p = static_cast<float *>(q);
+    return NDCN_OK;
+}
+
+int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
+    s->n_rhs++;
+    return rhs_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, out, s->work, s->d.H, s->d.rhs_flags, st);
+}
+
+// wait for the reduction record enqueued last on `st`
+int fetch_record(ndcn_solver *s, hipStream_t st, double &sum, double &bad) {
+    NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    NDCN_HIP(hipEventRecord(s->ev, st));
+    NDCN_HIP(hipEventSynchronize(s->ev));
+    sum = s->h_red[0];
+    bad = s->h_red[1];
+    return NDCN_OK;
+}
+
+int rms_scaled(ndcn_solver *s, const float *a, const float *b, const float *y, float rtol, float atol, hipStream_t st,
+               float &rms, double &bad) {
+    int rc = scaled_sumsq_f32(a, b, y, rtol, atol, s->n_elem, s->d_red, s->d_ws, st);
+    if (rc) return rc;
+    double sum;
+    rc = fetch_record(s, st, sum, bad);
+    if (rc) return rc;
+    // misc.py:71-76: x.norm() / numel ** 0.5, a float32 0-d tensor divided by a python float
+    const float nrm = (float)sqrt(sum);
+    rms = nrm / (float)sqrt((double)s->n_elem);
+    return NDCN_OK;
+}
+
+// misc.py:84-143 with order = 4 (dopri5.py:80)
+int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
+    const float rtol = (float)s->d.rtol, atol = (float)s->d.atol;
+    float d0, d1, d2;
+    double bad0, bad;
+    int rc = rms_scaled(s, s->ycur, nullptr, s->ycur, rtol, atol, st, d0, bad0);
+    if (rc) return rc;
+    s->pending_bad = (int64_t)bad0;
+    rc = rms_scaled(s, s->k[0], nullptr, s->ycur, rtol, atol, st, d1, bad);
+    if (rc) return rc;
+    float h0;
+    if (d0 < 1e-5 || d1 < 1e-5) h0 = 1e-6f;
+    else h0 = 0.01f * (d0 / d1);
+    // y1 = y0 + h0 * f0 ; f1 = f(t0 + h0, y1)
+    const float *kp[1] = {s->k[0]};
+    const float cp[1] = {h0};
+    rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, 1, s->n_elem, st);
+    if (rc) return rc;
+    rc = rhs(s, s->ytmp, s->k[1], st);
+    if (rc) return rc;
+    rc = rms_scaled(s, s->k[1], s->k[0], s->ycur, rtol, atol, st, d2, bad);
+    if (rc) return rc;
+    d2 = d2 / h0;
+    float h1;
+    if (d1 <= 1e-15 && d2 <= 1e-15) {
+        const float a = 1e-6f, b = h0 * 1e-3f;
+        h1 = a > b ? a : b;
+    } else {
+        const float m = d1 > d2 ? d1 : d2;
+        h1 = powf(0.01f / m, (float)(1. / 5.));
+    }
+    const float h100 = 100.f * h0;
+    h_out = (double)(h100 < h1 ? h100 : h1);
+    if (isnan(h100) || isnan(h1)) h_out = NAN;
+    return NDCN_OK;
+}
+
+void dt_coeffs(float dt32, const double *beta, int n, const float *const *kall, const float **kp, float *cp, int &m) {
+    // (scale * x) of misc.py:25 in float32; exact-zero tableau entries are dropped (their product is 0)
+    m = 0;
+    for (int j = 0; j < n; ++j) {
+        const float bj = (float)beta[j];
+        if (bj == 0.f) continue;
+        kp[m] = kall[j];
+        cp[m] = dt32 * bj;
+        ++m;
+    }
+}
+
+// dopri5.py:94-122
+int dopri5_step(ndcn_solver *s, hipStream_t st) {
+    const double t_start = s->t1, dt = s->dt;
+    if (!(t_start + dt > t_start)) {
+        set_error("underflow in dt %g", dt);
+        return NDCN_EUNDERFLOW;
+    }
+    if (s->pending_bad > 0) {
+        set_error("non-finite values in state `y` (%lld elements)", (long long)s->pending_bad);
+        return NDCN_ENONFINITE;
+    }
+    const float dt32 = (float)dt;
+    const float *kp[8];
+    float cp[8];
+    int m, rc;
+    for (int i = 0; i < 6; ++i) {
+        dt_coeffs(dt32, kBeta[i], i + 1, s->k, kp, cp, m);
+        float *dst = (i == 5) ? s->ynext : s->ytmp;          // the 6th stage input IS y1 (rk_common.py:54-58)
+        rc = rk_combine_f32(dst, s->ycur, kp, cp, m, s->n_elem, st);
+        if (rc) return rc;
+        rc = rhs(s, dst, s->k[i + 1], st);
+        if (rc) return rc;
+    }
+    dt_coeffs(dt32, kCErr, 7, s->k, kp, cp, m);
+    rc = rk_error_f32(s->ycur, s->ynext, kp, cp, m, (float)s->d.rtol, (float)s->d.atol, s->n_elem, s->d_red, s->d_ws, st);
+    if (rc) return rc;
+    double sum, bad;
+    rc = fetch_record(s, st, sum, bad);
+    if (rc) return rc;
+    // misc.py:156 mean in the state dtype; dopri5.py:109
+    const float ratio = (float)(sum / (double)s->n_elem);
+    const bool accept = ratio <= 1.f;
+    // misc.py:160-170.  safety / dfactor passed through a float32 tensor in the reference (dopri5.py:72-74)
+    double dt_next;
+    if (ratio == 0.f) {
+        dt_next = dt * 10.0;
+    } else {
+        const double dfac = ratio < 1.f ? 1.0 : (double)0.2f;
+        const double er = (double)sqrtf(ratio);
+        const double expo = (double)0.2f;
+        const double factor = nan_max(1.0 / 10.0, nan_min(pow(er, expo) / (double)0.9f, 1.0 / dfac));
+        dt_next = dt / factor;
+    }
+    s->n_attempt++;
+    s->last_ratio = ratio;
+    const double row[5] = {t_start, dt, accept ? 1.0 : 0.0, (double)ratio, dt_next};
+    s->log.insert(s->log.end(), row, row + 5);
+    if (accept) {
+        s->n_accept++;
+        // keep {y0, y1, k[0..6]} of this step intact for a lazy dense-output fit; rotate the state
+        s->fit_pending = true;
+        s->fit_valid = false;
+        s->fit_dt = dt32;
+        s->t0 = t_start;
+        s->t1 = t_start + dt;
+        s->pending_bad = (int64_t)bad;
+    } else {
+        s->t0 = s->t1 = t_start;
+    }
+    s->dt = dt_next;
+    return NDCN_OK;
+}
+
+// After an accepted step: y0 = ycur, y1 = ynext, f0 = k[0], f1 = k[6].  Rotate for the next step.
+void rotate_after_accept(ndcn_solver *s) {
+    float *old = s->yold;
+    s->yold = s->ycur;       // becomes "e" if this step gets fitted
+    s->ycur = s->ynext;
+    s->ynext = old;
+    float *f = s->k[0];
+    s->k[0] = s->k[6];       // FSAL
+    s->k[6] = f;
+}
+
+int do_fit(ndcn_solver *s, hipStream_t st) {
+    // called BEFORE the rotation: ycur = y0, ynext = y1
+    float cm[7];
+    for (int j = 0; j < 7; ++j) cm[j] = s->fit_dt * (float)kCMid[j];
+    int rc = interp_fit_f32(s->ycur, s->ynext, s->k, cm, s->fit_dt, s->ca, s->cb, s->cc, s->cd, s->n_elem, st);
+    if (rc) return rc;
+    return NDCN_OK;
+}
+
+}  // namespace
+
+namespace ndcn {
+
+int64_t solver_workspace_bytes(const ndcn_solver_desc *desc) {
+    if (!desc || desc->H <= 0 || desc->A.n_rows < 0) return NDCN_EINVAL;
+    return (int64_t)workspace_bytes(desc);
+}
+
+int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_bytes, ndcn_solver **out) {
+    NDCN_CHECK_ARG(desc && out, "null argument");
+    NDCN_CHECK_ARG(desc->method >= NDCN_M_EULER && desc->method <= NDCN_M_DOPRI5, "unknown method");
+    NDCN_CHECK_ARG(desc->H > 0, "H must be positive");
+    const bool no_graph = desc->rhs_flags & NDCN_F_NO_GRAPH, no_ctl = desc->rhs_flags & NDCN_F_NO_CONTROL;
+    NDCN_CHECK_ARG(no_graph || (desc->A.rowptr && (desc->A.nnz == 0 || (desc->A.colidx && desc->A.val))), "operator missing");
+    NDCN_CHECK_ARG(no_ctl || desc->W, "weight missing");
+    ndcn_solver *s = new (std::nothrow) ndcn_solver();
+    if (!s) { set_error("out of host memory"); return NDCN_EINVAL; }
+    s->d = *desc;
+    s->n_rows = desc->A.n_rows;
+    s->n_elem = s->n_rows * (int64_t)desc->H;
+    if (workspace) {
+        s->slab = workspace;
+        s->slab_bytes = (size_t)ws_bytes;
+    } else {
+        s->slab_bytes = workspace_bytes(desc);
+        if (hipMalloc(&s->slab, s->slab_bytes) != hipSuccess) {
+            set_error("hipMalloc of %zu workspace bytes failed", s->slab_bytes);
+            delete s;
+            return NDCN_EHIP;
+        }
+        s->slab_owned = true;
+    }
+    int rc = NDCN_OK;
+    auto fail = [&](int code) { solver_destroy(s); return code; };
+    if ((rc = alloc_panel(s, &s->ycur))) return fail(rc);
+    s->ycur_own = s->ycur;
+    if ((rc = alloc_panel(s, &s->ytmp))) return fail(rc);
+    if (rhs_needs_work(desc->H, desc->rhs_flags))
+        if ((rc = alloc_panel(s, &s->work))) return fail(rc);
+    const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;
+    for (int j = 0; j < nk; ++j)
+        if ((rc = alloc_panel(s, &s->k[j]))) return fail(rc);
+    if (desc->method == NDCN_M_DOPRI5) {
+        if ((rc = alloc_panel(s, &s->ynext))) return fail(rc);
+        if ((rc = alloc_panel(s, &s->yold))) return fail(rc);
+        if ((rc = alloc_panel(s, &s->ca))) return fail(rc);
+        if ((rc = alloc_panel(s, &s->cb))) return fail(rc);
+        if ((rc = alloc_panel(s, &s->cc))) return fail(rc);
+        if ((rc = alloc_panel(s, &s->cd))) return fail(rc);
+    }
+    void *q = nullptr;
+    if ((rc = carve(s, 2 * sizeof(double), &q))) return fail(rc);
+    s->d_red = static_cast<double *>(q);
+    if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);
+    s->d_ws = q;
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        return fail(NDCN_EHIP);
+    }
+    if (hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(NDCN_EHIP); }
+    *out = s;
+    return NDCN_OK;
+}
+
+int solver_destroy(ndcn_solver *s) {
+    if (!s) return NDCN_OK;
+    if (s->slab_owned && s->slab) (void)hipFree(s->slab);
+    if (s->h_red) (void)hipHostFree(s->h_red);
+    if (s->ev) (void)hipEventDestroy(s->ev);
+    delete s;
+    return NDCN_OK;
+}
+
+int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st) {
+    NDCN_CHECK_ARG(s && y0, "null argument");
+    s->ycur = s->ycur_own;
+    s->cur_is_borrowed = false;
+    NDCN_HIP(hipMemcpyAsync(s->ycur, y0, (size_t)s->n_elem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    s->n_attempt = s->n_accept = s->n_rhs = 0;
+    s->log.clear();
+    s->fit_pending = s->fit_valid = false;
+    s->pending_bad = 0;
+    s->last_ratio = 0;
+    s->t0 = s->t1 = t0;
+    s->tf = (float)t0;
+    if (s->d.method == NDCN_M_DOPRI5) {
+        // dopri5.py:77-83
+        int rc = rhs(s, s->ycur, s->k[0], st);
+        if (rc) return rc;
+        double h;
+        rc = initial_step(s, st, h);
+        if (rc) return rc;
+        s->dt = h;
+    }
+    s->begun = true;
+    return NDCN_OK;
+}
+
+static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t st) {
+    // solvers.py:81-97 with grid == t: one step of size t1 - t0 formed in the state dtype
+    const float t1 = (float)next_t;
+    const float dt = t1 - s->tf;
+    const int64_t n = s->n_elem;
+    float *dst = out ? out : s->ycur_own;
+    int rc;
+    if ((rc = rhs(s, s->ycur, s->k[0], st))) return rc;
+    switch (s->d.method) {
+        case NDCN_M_EULER:
+            rc = fixed_stage_f32(0, dst, s->ycur, s->k[0], nullptr, nullptr, nullptr, dt, n, st);
+            break;
+        case NDCN_M_MIDPOINT:
+            if ((rc = fixed_stage_f32(1, s->ytmp, s->ycur, s->k[0], nullptr, nullptr, nullptr, dt, n, st))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[0], st))) return rc;
+            rc = fixed_stage_f32(0, dst, s->ycur, s->k[0], nullptr, nullptr, nullptr, dt, n, st);
+            break;
+        default:  // rk4, 3/8 rule
+            if ((rc = fixed_stage_f32(2, s->ytmp, s->ycur, s->k[0], nullptr, nullptr, nullptr, dt, n, st))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[1], st))) return rc;
+            if ((rc = fixed_stage_f32(3, s->ytmp, s->ycur, s->k[0], s->k[1], nullptr, nullptr, dt, n, st))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[2], st))) return rc;
+            if ((rc = fixed_stage_f32(4, s->ytmp, s->ycur, s->k[0], s->k[1], s->k[2], nullptr, dt, n, st))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[3], st))) return rc;
+            rc = fixed_stage_f32(5, dst, s->ycur, s->k[0], s->k[1], s->k[2], s->k[3], dt, n, st);
+            break;
+    }
+    if (rc) return rc;
+    s->ycur = dst;                 // the next step reads the state from where it was written
+    s->cur_is_borrowed = (dst != s->ycur_own);
+    s->tf = t1;
+    s->t0 = s->t1;
+    s->t1 = next_t;
+    s->n_attempt++;
+    s->n_accept++;
+    return NDCN_OK;
+}
+
+int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st) {
+    NDCN_CHECK_ARG(s, "null solver");
+    if (!s->begun) { set_error("ndcn_solver_advance before ndcn_solver_begin"); return NDCN_ESTATE; }
+    if (s->d.method != NDCN_M_DOPRI5) return fixed_advance(s, next_t, out, st);
+    int64_t done = 0;
+    int64_t n_here = 0;
+    while (next_t > s->t1) {                                   // dopri5.py:88
+        if (budget > 0 && done >= budget) return 1;
+        if (s->d.max_num_steps > 0 && n_here >= s->d.max_num_steps) {
+            set_error("max_num_steps exceeded (%lld>=%lld)", (long long)n_here, (long long)s->d.max_num_steps);
+            return NDCN_EMAXSTEPS;
+        }
+        if (s->fit_pending) {          // previous accepted step is being left without ever being evaluated
+            rotate_after_accept(s);
+            s->fit_pending = false;
+        }
+        int rc = dopri5_step(s, st);
+        if (rc) return rc;
+        ++done;
+        ++n_here;
+    }
+    if (!out) return NDCN_OK;
+    if (!s->fit_valid) {
+        if (!s->fit_pending) { set_error("no accepted step covers t=%g", next_t); return NDCN_ESTATE; }
+        int rc = do_fit(s, st);
+        if (rc) return rc;
+        s->ce = s->ycur;               // y0 of the fitted step; becomes yold at the rotation
+        s->fit_valid = true;
+    }
+    // interp.py:51-65: abscissa and its powers in the state dtype
+    const float a0 = (float)s->t0, a1 = (float)s->t1, at = (float)next_t;
+    if (!(a0 <= at && at <= a1)) {
+        set_error("invalid interpolation, fails `t0 <= t <= t1`: %g, %g, %g", a0, at, a1);
+        return NDCN_ESTATE;
+    }
+    const float x = (at - a0) / (a1 - a0);
+    float xp[5];
+    xp[4] = 1.f; xp[3] = x; xp[2] = xp[3] * x; xp[1] = xp[2] * x; xp[0] = xp[1] * x;
+    return interp_eval_f32(s->ca, s->cb, s->cc, s->cd, s->ce, xp, out, s->n_elem, st);
+}
+
+int solver_stats(const ndcn_solver *s, double h[6]) {
+    NDCN_CHECK_ARG(s && h, "null argument");
+    h[0] = (double)s->n_attempt; h[1] = (double)s->n_accept; h[2] = (double)s->n_rhs;
+    h[3] = s->t1; h[4] = s->dt; h[5] = s->last_ratio;
+    return NDCN_OK;
+}
+
+int64_t solver_steplog(const ndcn_solver *s, double *rows, int64_t cap) {
+    if (!s) return 0;
+    const int64_t n = (int64_t)s->log.size() / 5;
+    if (rows) {
+        const int64_t m = n < cap ? n : cap;
+        for (int64_t i = 0; i < m * 5; ++i) rows[i] = s->log[i];
+    }
+    return n;
+}
+
+}  // namespace ndcn

@@ -1,0 +1,215 @@
+// CSR SpMM  Y = alpha * (A X) [relu]  for a dense row-major fp32 feature panel X (n x H).
+//
+// Replaces torch.sparse.mm(A, x) at neural_dynamics.py:29 (and its siblings, see include/ndcn_hip.h).
+//
+// Shape of the work on MI355X: HBM-bound gather.  Algorithmic bytes 8 nnz + 4 (N+1) + 8 N H
+// (SURVEY.md 8d).  Design:
+//   * one 256-thread workgroup owns a block of consecutive rows; the block's slice of rowptr and its
+//     (contiguous) slice of colidx/val are staged into LDS with coalesced loads, once;
+//   * a group of LPR lanes walks one row: every lane owns one 16-byte column slot of the H-wide panel row,
+//     so a neighbour row is fetched by ONE fully coalesced access (H=256: 64 lanes x 16 B = the 1 KiB row);
+//     the neighbour loop is unrolled 4x so four independent row fetches are in flight per group;
+//   * logical row blocks are remapped so each XCD walks a contiguous range of rows: neighbouring rows
+//     share neighbours, which then hit in that XCD's private 4 MiB L2;
+//   * accumulation order = stored (column-ascending) order, one fma per non-zero.
+#include "common.h"
+
+namespace ndcn {
+
+constexpr int kSpmmThreads = 256;
+constexpr int kStageCap = 2048;     // staged non-zeros per workgroup (16 KiB of LDS -> 8 workgroups per CU)
+constexpr int kMaxRowsPerBlock = 256;
+
+template <int VW> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+__device__ __forceinline__ void vfma(float4 &a, float v, const float4 &x) {
+    a.x = fmaf(v, x.x, a.x); a.y = fmaf(v, x.y, a.y); a.z = fmaf(v, x.z, a.z); a.w = fmaf(v, x.w, a.w);
+}
+__device__ __forceinline__ void vfma(float &a, float v, const float &x) { a = fmaf(v, x, a); }
+__device__ __forceinline__ float4 vzero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <int VW> __device__ __forceinline__ typename VecT<VW>::type vzero();
+template <> __device__ __forceinline__ float4 vzero<4>() { return vzero4(); }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+__device__ __forceinline__ float4 vfinish(float4 a, float alpha, bool relu) {
+    a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    return a;
+}
+__device__ __forceinline__ float vfinish(float a, float alpha, bool relu) {
+    a *= alpha;
+    return relu ? fmaxf(a, 0.f) : a;
+}
+
+// One row: acc = sum_j val[j] * X[col[j], slot]; `cols`/`vals` index from `j0` (LDS or global view).
+template <int VW, bool HALO>
+__device__ __forceinline__ typename VecT<VW>::type
+row_gather(const int *__restrict__ cols, const float *__restrict__ vals, int j0, int j1,
+           const typename VecT<VW>::type *__restrict__ X, const typename VecT<VW>::type *__restrict__ Xh,
+           int n_own, size_t row_stride /* in vector units */, int slot) {
+    using V = typename VecT<VW>::type;
+    V acc = vzero<VW>();
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        int c0 = cols[j], c1 = cols[j + 1], c2 = cols[j + 2], c3 = cols[j + 3];
+        float v0 = vals[j], v1 = vals[j + 1], v2 = vals[j + 2], v3 = vals[j + 3];
+        const V *p0 = X, *p1 = X, *p2 = X, *p3 = X;
+        if (HALO) {
+            if (c0 >= n_own) { p0 = Xh; c0 -= n_own; }
+            if (c1 >= n_own) { p1 = Xh; c1 -= n_own; }
+            if (c2 >= n_own) { p2 = Xh; c2 -= n_own; }
+            if (c3 >= n_own) { p3 = Xh; c3 -= n_own; }
+        }
+        V x0 = p0[(size_t)c0 * row_stride + slot];
+        V x1 = p1[(size_t)c1 * row_stride + slot];
+        V x2 = p2[(size_t)c2 * row_stride + slot];
+        V x3 = p3[(size_t)c3 * row_stride + slot];
+        vfma(acc, v0, x0); vfma(acc, v1, x1); vfma(acc, v2, x2); vfma(acc, v3, x3);
+    }
+    for (; j < j1; ++j) {
+        int c = cols[j];
+        float v = vals[j];
+        const V *p = X;
+        if (HALO && c >= n_own) { p = Xh; c -= n_own; }
+        vfma(acc, v, p[(size_t)c * row_stride + slot]);
+    }
+    return acc;
+}
+
+// VW: floats per lane slot (4 -> float4, needs H % 4 == 0 ; 1 -> scalar).
+// LPR: lanes that share one row (power of two <= 64).
+template <int VW, int LPR, bool HALO>
+__global__ __launch_bounds__(kSpmmThreads) void spmm_csr_kernel(
+    const int *__restrict__ rowptr, const int *__restrict__ colidx, const float *__restrict__ val,
+    const float *__restrict__ Xf, const float *__restrict__ Xhf, int n_own, float *__restrict__ Yf,
+    int n_rows, int H, float alpha, int relu, int rows_per_block) {
+    using V = typename VecT<VW>::type;
+    __shared__ int s_rp[kMaxRowsPerBlock + 1];
+    __shared__ int s_col[kStageCap];
+    __shared__ float s_val[kStageCap];
+
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = blk * rows_per_block;
+    if (r0 >= n_rows) return;
+    const int nr = min(rows_per_block, n_rows - r0);
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i <= nr; i += kSpmmThreads) s_rp[i] = rowptr[r0 + i];
+    __syncthreads();
+    const int e_lo = s_rp[0];
+    const int e_hi = s_rp[nr];
+    const int n_stage = min(e_hi - e_lo, kStageCap);
+    for (int i = tid; i < n_stage; i += kSpmmThreads) {
+        s_col[i] = colidx[e_lo + i];
+        s_val[i] = val[e_lo + i];
+    }
+    __syncthreads();
+
+    const V *X = reinterpret_cast<const V *>(Xf);
+    const V *Xh = reinterpret_cast<const V *>(Xhf);
+    V *Y = reinterpret_cast<V *>(Yf);
+    const int slots = H / VW;                       // vector slots per panel row
+    const size_t stride = (size_t)slots;
+    constexpr int kGroups = kSpmmThreads / LPR;     // rows in flight per workgroup
+    const int grp = tid / LPR;
+    const int li = tid % LPR;
+
+    for (int r = grp; r < nr; r += kGroups) {
+        const int j0 = s_rp[r], j1 = s_rp[r + 1];
+        const bool staged = (j1 - e_lo) <= kStageCap;
+        for (int slot = li; slot < slots; slot += LPR) {
+            V acc;
+            if (staged)
+                acc = row_gather<VW, HALO>(s_col, s_val, j0 - e_lo, j1 - e_lo, X, Xh, n_own, stride, slot);
+            else
+                acc = row_gather<VW, HALO>(colidx, val, j0, j1, X, Xh, n_own, stride, slot);
+            Y[(size_t)(r0 + r) * stride + slot] = vfinish(acc, alpha, relu != 0);
+        }
+    }
+}
+
+template <int VW, int LPR>
+static int launch_spmm(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H,
+                       float alpha, uint32_t flags, hipStream_t st) {
+    const int n_rows = (int)A->n_rows;
+    constexpr int groups = kSpmmThreads / LPR;
+    // rows per workgroup: enough rows that every lane group gets >= 8 of them when rows are short,
+    // bounded so the block's non-zeros usually fit the LDS stage
+    int rpb = groups * 8;
+    if (rpb < 64) rpb = 64;
+    if (rpb > kMaxRowsPerBlock) rpb = kMaxRowsPerBlock;
+    const double avg = n_rows > 0 ? (double)A->nnz / (double)n_rows : 0.0;
+    while (rpb > groups && rpb > 16 && avg * rpb > kStageCap) rpb /= 2;
+    const int nblk = (n_rows + rpb - 1) / rpb;
+    if (nblk == 0) return NDCN_OK;
+    const int relu = (flags & NDCN_F_RELU) ? 1 : 0;
+    if (Xh)
+        hipLaunchKernelGGL((spmm_csr_kernel<VW, LPR, true>), dim3(nblk), dim3(kSpmmThreads), 0, st, A->rowptr,
+                           A->colidx, A->val, X, Xh, (int)n_own, Y, n_rows, H, alpha, relu, rpb);
+    else
+        hipLaunchKernelGGL((spmm_csr_kernel<VW, LPR, false>), dim3(nblk), dim3(kSpmmThreads), 0, st, A->rowptr,
+                           A->colidx, A->val, X, Xh, (int)n_own, Y, n_rows, H, alpha, relu, rpb);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+template <int VW>
+static int dispatch_lpr(int slots, const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y,
+                        int H, float alpha, uint32_t flags, hipStream_t st) {
+    if (slots > 32) return launch_spmm<VW, 64>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+    if (slots > 16) return launch_spmm<VW, 32>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+    if (slots > 8) return launch_spmm<VW, 16>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+    if (slots > 4) return launch_spmm<VW, 8>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+    if (slots > 2) return launch_spmm<VW, 4>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+    if (slots > 1) return launch_spmm<VW, 2>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+    return launch_spmm<VW, 1>(A, X, Xh, n_own, Y, H, alpha, flags, st);
+}
+
+int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
+             uint32_t flags, hipStream_t st) {
+    const bool vec = (H % 4 == 0) && aligned16(X) && aligned16(Y) && (Xh == nullptr || aligned16(Xh));
+    ProfScope prof(PROF_SPMM, st, 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * H * (double)(A->n_rows + A->n_cols),
+                   2.0 * A->nnz * H);
+    if (vec) return dispatch_lpr<4>(H / 4, A, X, Xh, n_own, Y, H, alpha, flags, st);
+    return dispatch_lpr<1>(H, A, X, Xh, n_own, Y, H, alpha, flags, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[i, :] = X[idx[i], :]   (halo send-buffer packing)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ X, const int *__restrict__ idx,
+                                                          int64_t n_idx, int H, float *__restrict__ out) {
+    const int64_t total = n_idx * (int64_t)H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / H;
+        const int c = (int)(i - r * H);
+        out[i] = X[(size_t)idx[r] * H + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows4_kernel(const float4 *__restrict__ X, const int *__restrict__ idx,
+                                                           int64_t n_idx, int H4, float4 *__restrict__ out) {
+    const int64_t total = n_idx * (int64_t)H4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / H4;
+        const int c = (int)(i - r * H4);
+        out[i] = X[(size_t)idx[r] * H4 + c];
+    }
+}
+
+int gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, hipStream_t st) {
+    if (n_idx == 0) return NDCN_OK;
+    ProfScope prof(PROF_GATHER, st, 8.0 * n_idx * H + 4.0 * n_idx, 0.0);
+    if (H % 4 == 0 && aligned16(X) && aligned16(out)) {
+        const int64_t total = n_idx * (H / 4);
+        hipLaunchKernelGGL(gather_rows4_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(X), idx, n_idx, H / 4, reinterpret_cast<float4 *>(out));
+    } else {
+        const int64_t total = n_idx * (int64_t)H;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, X, idx, n_idx, H, out);
+    }
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+}  // namespace ndcn

@@ -1,0 +1,322 @@
+"""Host logic of the integrator, written against a small panel-ops interface (ndcn_amd.ops.HipOps).
+
+Mirrors the control flow and scalar arithmetic of the reference's vendored torchdiffeq:
+  input checks      torchdiffeq/_impl/misc.py:173-195, odeint.py:61-76
+  fixed grid        torchdiffeq/_impl/solvers.py:79-99 ; fixed_grid.py:7-8,17-19,28-29 ; rk_common.py:72-78
+  dopri5            torchdiffeq/_impl/dopri5.py:58-122 ; rk_common.py:22-61 ; misc.py:84-170 ; interp.py:5-65
+All per-element work is delegated to `ops` (one fused HIP kernel per reference op chain); what stays
+here is scalar: times and the step-size controller in float64, every quantity the reference forms as a
+0-d tensor of the state dtype (dt*beta, stage times, initial-step heuristic, interpolation abscissa)
+in numpy float32.  State may be a tensor or a tuple of tensors (misc.py:175-182).
+"""
+import math
+import warnings
+
+import numpy as np
+import torch
+
+f32 = np.float32
+
+# Dormand-Prince 5(4) - dopri5.py:11-36, same rational expressions
+DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1., 1.]
+DP_BETA = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+DP_C_ERR = [
+    35 / 384 - 1951 / 21600,
+    0,
+    500 / 1113 - 22642 / 50085,
+    125 / 192 - 451 / 720,
+    -2187 / 6784 - -12231 / 42400,
+    11 / 84 - 649 / 6300,
+    -1. / 60.,
+]
+DP_C_MID = [
+    6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+    187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2
+]
+# dopri5.py:60,72-74: the defaults go through torch.tensor(float) (float32) before widening to float64
+SAFETY = float(f32(0.9))
+IFACTOR = 10.0
+DFACTOR = float(f32(0.2))
+
+FIXED_METHODS = ('euler', 'midpoint', 'rk4')
+METHODS = FIXED_METHODS + ('dopri5',)
+# methods the reference lists (odeint.py:8-17) but this build does not provide
+UNSUPPORTED = ('explicit_adams', 'fixed_adams', 'adams', 'tsit5')
+
+
+def _nan_max(a, b):
+    return float('nan') if (math.isnan(a) or math.isnan(b)) else max(a, b)
+
+
+def _nan_min(a, b):
+    return float('nan') if (math.isnan(a) or math.isnan(b)) else min(a, b)
+
+
+def dt_terms(dt32, coeffs, ks):
+    """(scale * x) of misc.py:25 in float32; exact-zero tableau entries contribute an exact zero and are
+    dropped (the reference multiplies them out, which only matters for non-finite k)."""
+    cs, kk = [], []
+    for c, k in zip(coeffs, ks):
+        c32 = f32(c)
+        if c32 == 0:
+            continue
+        cs.append(f32(dt32 * c32))
+        kk.append(k)
+    return kk, cs
+
+
+class TimeArg:
+    """Builds the `t` argument of func(t, y): a 0-d tensor in the state's dtype on the state's device,
+    as the reference passes (rk_common.py:45-50; solvers.py:90).  Autonomous right-hand sides (ours)
+    never read it, so one cached tensor is reused instead of a host-to-device copy per evaluation."""
+
+    def __init__(self, like, autonomous):
+        self.like = like
+        self.cached = torch.zeros((), dtype=like.dtype, device=like.device) if autonomous else None
+
+    def __call__(self, value):
+        if self.cached is not None:
+            return self.cached
+        return torch.tensor(float(value), dtype=self.like.dtype, device=self.like.device)
+
+
+def check_inputs(func, y0, t):
+    """misc.py:173-195.  Returns (tensor_input, func_on_tuples, y0_tuple, t, sign)."""
+    tensor_input = False
+    if torch.is_tensor(y0):
+        tensor_input = True
+        y0 = (y0,)
+        base = func
+        func = lambda tt, y: (base(tt, y[0]),)
+    assert isinstance(y0, tuple), 'y0 must be either a torch.Tensor or a tuple'
+    for y0_ in y0:
+        assert torch.is_tensor(y0_), 'each element must be a torch.Tensor but received {}'.format(type(y0_))
+    if bool((t[1:] < t[:-1]).all()):
+        t = -t
+        rev = func
+        func = lambda tt, y: tuple(-f_ for f_ in rev(-tt, y))
+    for y0_ in y0:
+        if not torch.is_floating_point(y0_):
+            raise TypeError('`y0` must be a floating point Tensor but is a {}'.format(y0_.type()))
+    if not torch.is_floating_point(t):
+        raise TypeError('`t` must be a floating point Tensor but is a {}'.format(t.type()))
+    return tensor_input, func, y0, t
+
+
+def assert_increasing(t):
+    assert bool((t[1:] > t[:-1]).all()), 't must be strictly increasing or decrasing'
+
+
+# ---------------------------------------------------------------------------------------------------
+# fixed grid
+# ---------------------------------------------------------------------------------------------------
+
+def integrate_fixed(ops, func, y0, t, method, autonomous=False):
+    """solvers.py:79-99 with the default grid (grid == t).  Returns a list (per tick) of tuples."""
+    assert_increasing(t)
+    dtype = y0[0].dtype
+    tg = t.detach().to('cpu').to(dtype).numpy()          # solvers.py:81: times in the state dtype
+    targ = TimeArg(y0[0], autonomous)
+    sol = [y0]
+    y = y0
+    for i in range(len(tg) - 1):
+        t0, t1 = tg[i], tg[i + 1]
+        dt = t1 - t0                                      # float32 subtraction, as `t1 - t0` on 0-d tensors
+        if method == 'euler':
+            k1 = func(targ(t0), y)
+            y = tuple(ops.fixed_stage(0, y_, k_, dt=dt) for y_, k_ in zip(y, k1))
+        elif method == 'midpoint':
+            k1 = func(targ(t0), y)
+            ym = tuple(ops.fixed_stage(1, y_, k_, dt=dt) for y_, k_ in zip(y, k1))
+            k2 = func(targ(t0 + dt / f32(2)), ym)
+            y = tuple(ops.fixed_stage(0, y_, k_, dt=dt) for y_, k_ in zip(y, k2))
+        else:
+            k1 = func(targ(t0), y)
+            y2 = tuple(ops.fixed_stage(2, y_, a, dt=dt) for y_, a in zip(y, k1))
+            k2 = func(targ(t0 + dt / f32(3)), y2)
+            y3 = tuple(ops.fixed_stage(3, y_, a, b, dt=dt) for y_, a, b in zip(y, k1, k2))
+            k3 = func(targ(t0 + dt * f32(2) / f32(3)), y3)
+            y4 = tuple(ops.fixed_stage(4, y_, a, b, c, dt=dt) for y_, a, b, c in zip(y, k1, k2, k3))
+            k4 = func(targ(t0 + dt), y4)
+            y = tuple(ops.fixed_stage(5, y_, a, b, c, d, dt=dt) for y_, a, b, c, d in zip(y, k1, k2, k3, k4))
+        sol.append(y)
+    return sol
+
+
+# ---------------------------------------------------------------------------------------------------
+# dopri5
+# ---------------------------------------------------------------------------------------------------
+
+def _rms(ops, a, b, y, rtol, atol):
+    """misc.py:71-76 on (a - b) / (atol + |y| rtol): float32 norm divided by numel ** 0.5."""
+    s, bad = ops.scaled_sumsq(a, b, y, rtol, atol)
+    nrm = f32(math.sqrt(s)) if s == s and s >= 0 else f32('nan')
+    return f32(nrm / f32(math.sqrt(a.numel()))), bad
+
+
+def select_initial_step(ops, func, targ, t0, y0, order, rtol, atol, f0):
+    """misc.py:84-143 (Hairer II.4).  Returns (h as python float (a float32 value), non-finite count of y0)."""
+    t0 = f32(t0)
+    stats0 = [_rms(ops, y, None, y, rtol, atol) for y in y0]
+    d0 = [s[0] for s in stats0]
+    bad0 = sum(s[1] for s in stats0)
+    d1 = [_rms(ops, f, None, y, rtol, atol)[0] for f, y in zip(f0, y0)]
+    if float(max(d0)) < 1e-5 or float(max(d1)) < 1e-5:
+        h0 = f32(1e-6)
+    else:
+        h0 = f32(f32(0.01) * max(f32(a / b) for a, b in zip(d0, d1)))
+    y1 = tuple(ops.combine(y, [f], [h0]) for y, f in zip(y0, f0))
+    f1 = func(targ(f32(t0 + h0)), y1)
+    d2 = [f32(_rms(ops, b, a, y, rtol, atol)[0] / h0) for b, a, y in zip(f1, f0, y0)]
+    if float(max(d1)) <= 1e-15 and float(max(d2)) <= 1e-15:
+        h1 = max(f32(1e-6), f32(h0 * f32(1e-3)))
+    else:
+        m = max(d1 + d2)                       # list concatenation, as in the reference: max over both
+        h1 = f32(np.power(f32(f32(0.01) / m), f32(1. / float(order + 1))))
+    h100 = f32(f32(100) * h0)
+    if np.isnan(h100) or np.isnan(h1):
+        return float('nan'), bad0
+    return float(min(h100, h1)), bad0
+
+
+def optimal_step_size(dt, ratio32):
+    """misc.py:160-170 in float64 with the reference's float32-born constants."""
+    if ratio32 == 0:
+        return dt * IFACTOR
+    dfac = 1.0 if ratio32 < 1 else DFACTOR
+    er = float(np.sqrt(f32(ratio32)))
+    expo = float(f32(0.2))
+    factor = _nan_max(1.0 / IFACTOR, _nan_min(math.pow(er, expo) / SAFETY if er == er else float('nan'), 1.0 / dfac))
+    return dt / factor
+
+
+class Dopri5:
+    """dopri5.py:58-122 as a resumable object: begin() = before_integrate, advance() = advance."""
+
+    def __init__(self, ops, func, y0, rtol, atol, autonomous=False, max_num_steps=2 ** 31 - 1, first_step=None):
+        self.ops, self.func = ops, func
+        self.y = y0
+        self.rtol, self.atol = rtol, atol
+        self.max_num_steps = max_num_steps
+        self.first_step = first_step
+        self.targ = TimeArg(y0[0], autonomous)
+        self.n_elem = [y.numel() for y in y0]
+        self.log = []                 # (t0, dt, accepted, mean_sq_error_ratio, dt_next) per attempt
+        self.nfe = 0
+
+    def _f(self, tval, y):
+        self.nfe += 1
+        return self.func(self.targ(tval), y)
+
+    def begin(self, t0):
+        self.t0 = self.t1 = float(t0)
+        self.f = self._f(f32(t0), self.y)
+        if self.first_step is None:
+            h, bad = select_initial_step(self.ops, lambda tt, yy: self._count(tt, yy), self.targ, t0, self.y, 4,
+                                         self.rtol, self.atol, self.f)
+        else:
+            h, bad = 0.01, 0          # dopri5.py:82: a supplied first_step is ignored, 0.01 is used
+        self.dt = h
+        self.pending_bad = bad
+        self.fit = None               # (a, b, c, d, e) tuples-of-tensors of the last fitted step
+        self.stage = None             # (y0, y1, k) of the last accepted, not yet fitted step
+
+    def _count(self, tt, yy):
+        self.nfe += 1
+        return self.func(tt, yy)
+
+    def step(self):
+        """dopri5.py:94-122, one attempt."""
+        ops = self.ops
+        t0, dt = self.t1, self.dt
+        assert t0 + dt > t0, 'underflow in dt {}'.format(dt)
+        assert self.pending_bad == 0, 'non-finite values in state `y`: {} elements'.format(int(self.pending_bad))
+        dt32 = f32(dt)
+        t032 = f32(t0)
+        y0 = self.y
+        k = [[f] for f in self.f]
+        yi = y0
+        for a_i, b_i in zip(DP_ALPHA, DP_BETA):
+            ti = f32(t032 + f32(f32(a_i) * dt32))
+            new = []
+            for y_, k_ in zip(y0, k):
+                kk, cs = dt_terms(dt32, b_i, k_)
+                new.append(ops.combine(y_, kk, cs))
+            yi = tuple(new)
+            for k_, f_ in zip(k, self._f(ti, yi)):
+                k_.append(f_)
+        y1 = yi
+        ratios, bad_total = [], 0
+        for y0_, y1_, k_, n in zip(y0, y1, k, self.n_elem):
+            kk, cs = dt_terms(dt32, DP_C_ERR, k_)
+            s, bad = ops.error(y0_, y1_, kk, cs, self.rtol, self.atol)
+            ratios.append(f32(s / n) if n else f32('nan'))        # misc.py:156: a float32 mean
+            bad_total += bad
+        accept = all(bool(r <= 1) for r in ratios)                 # dopri5.py:109
+        worst = f32('nan') if any(np.isnan(r) for r in ratios) else max(ratios)
+        dt_next = optimal_step_size(dt, worst)
+        self.log.append((t0, dt, 1.0 if accept else 0.0, float(worst), dt_next))
+        if accept:
+            self.stage = (y0, y1, k, dt32)
+            self.fit = None
+            self.y = y1
+            self.f = tuple(k_[-1] for k_ in k)
+            self.t0, self.t1 = t0, t0 + dt
+            self.pending_bad = bad_total
+        else:
+            self.t0 = self.t1 = t0
+        self.dt = dt_next
+        return accept
+
+    def advance(self, next_t):
+        """dopri5.py:85-92: step until t1 >= next_t, then evaluate the dense output at next_t."""
+        next_t = float(next_t)
+        n_steps = 0
+        while next_t > self.t1:
+            assert n_steps < self.max_num_steps, 'max_num_steps exceeded ({}>={})'.format(n_steps, self.max_num_steps)
+            self.step()
+            n_steps += 1
+        if self.fit is None:
+            y0, y1, k, dt32 = self.stage
+            cmid = [f32(dt32 * f32(c)) for c in DP_C_MID]
+            abcd = [self.ops.interp_fit(a_, b_, k_, cmid, dt32) for a_, b_, k_ in zip(y0, y1, k)]
+            self.fit = (abcd, y0)
+        abcd, e = self.fit
+        # interp.py:51-65: abscissa and powers in the state dtype
+        a0, a1, at = f32(self.t0), f32(self.t1), f32(next_t)
+        assert (a0 <= at) and (at <= a1), 'invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}'.format(a0, at, a1)
+        x = f32(f32(at - a0) / f32(a1 - a0))
+        x2 = f32(x * x)
+        x3 = f32(x2 * x)
+        x4 = f32(x3 * x)
+        xp = (x4, x3, x2, x, f32(1))
+        return tuple(self.ops.interp_eval(c[0], c[1], c[2], c[3], e_, xp) for c, e_ in zip(abcd, e))
+
+
+def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=None, **options):
+    """solvers.py:25-33."""
+    assert_increasing(t)
+    unused = {k: v for k, v in options.items() if k not in ('first_step', 'safety', 'ifactor', 'dfactor', 'max_num_steps')}
+    if unused:
+        warnings.warn('Dopri5Solver: Unexpected arguments {}'.format(unused))
+    for name in ('safety', 'ifactor', 'dfactor'):
+        if name in options:
+            raise NotImplementedError('dopri5 option `%s` is fixed at the reference default in this build' % name)
+    tt = t.detach().to('cpu', torch.float64).numpy()
+    solver = Dopri5(ops, func, y0, rtol, atol, autonomous=autonomous,
+                    max_num_steps=options.get('max_num_steps', 2 ** 31 - 1), first_step=options.get('first_step'))
+    solver.begin(tt[0])
+    sol = [y0]
+    for i in range(1, len(tt)):
+        sol.append(solver.advance(tt[i]))
+    if step_log is not None:
+        step_log.extend(solver.log)
+        step_log.append(('nfe', solver.nfe))
+    return sol

@@ -1,0 +1,195 @@
+"""`odeint(func, y0, t, rtol, atol, method, options)` - drop-in for the reference's vendored
+torchdiffeq entry point (torchdiffeq/_impl/odeint.py:20-76), computed by HIP kernels.
+
+Two execution paths, both on the GPU:
+  * device-resident: `func` is this package's ODEFunc acting on one N x H fp32 panel -> the whole solve
+    runs inside libndcn_hip.so (`ndcn_solver_*`): state, stages and dense-output coefficients never
+    leave HBM and the host sees one 16-byte record per adaptive step;
+  * generic: any callable / tuple state -> the reference's solver control flow (core.py) with one fused
+    HIP kernel per bookkeeping chain and `func` called back in Python.
+Host tensors are refused: there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from ...ops import hip
+from . import core
+
+SOLVERS = {m: m for m in core.METHODS}      # the in-scope subset of odeint.py:8-17
+
+
+def _autonomous(func):
+    return bool(getattr(func, 'ndcn_autonomous', False))
+
+
+def _needs_grad(func, y0):
+    if not torch.is_grad_enabled():
+        return False
+    if any(y.requires_grad for y in y0):
+        return True
+    if isinstance(func, torch.nn.Module):
+        return any(p.requires_grad for p in func.parameters())
+    return False
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_log=None):
+    """Integrate dy/dt = func(t, y), y(t[0]) = y0; returns y at every t (first dim), y0 first.
+
+    Same signature, defaults, return layout and exceptions as the reference (odeint.py:20-76):
+    TypeError for non-float y0 / t, ValueError for `options` without `method`, KeyError for an unknown
+    method, AssertionError for a non-monotone t.  Deviations: only dopri5 / euler / midpoint / rk4 are
+    provided (the others raise NotImplementedError); the state must be float32 on a ROCm device;
+    `step_log` (a list) optionally receives the dopri5 per-attempt log.
+    """
+    user_func = func
+    tensor_input, func, y0, t = core.check_inputs(func, y0, t)
+
+    if options is None:
+        options = {}
+    elif method is None:
+        raise ValueError('cannot supply `options` without specifying `method`')
+    if method is None:
+        method = 'dopri5'
+    if method in core.UNSUPPORTED:
+        raise NotImplementedError('method %r of the reference is outside the accelerated path '
+                                  '(dopri5, euler, midpoint, rk4 are provided)' % method)
+    method = SOLVERS[method]                     # KeyError for an unknown name, as the reference's dict lookup
+
+    for y in y0:
+        _lib.require_device(y, 'state y0')
+    if _needs_grad(user_func, y0):
+        from .autograd_path import odeint_with_grad
+        sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func))
+    elif _device_resident_ok(user_func, tensor_input, y0, t, method, options):
+        return _device_resident(user_func, y0[0], t, rtol, atol, method, options, step_log)
+    elif method == 'dopri5':
+        sol = core.integrate_dopri5(hip, func, y0, t, rtol, atol, autonomous=_autonomous(user_func),
+                                    step_log=step_log, **options)
+    else:
+        if options:
+            raise NotImplementedError('fixed-grid options %s: only the default grid (grid == t) is provided'
+                                      % sorted(options))
+        sol = core.integrate_fixed(hip, func, y0, t, method, autonomous=_autonomous(user_func))
+    out = tuple(torch.stack([s[i] for s in sol]) for i in range(len(y0)))
+    return out[0] if tensor_input else out
+
+
+# ---------------------------------------------------------------------------------------------------
+# device-resident path
+# ---------------------------------------------------------------------------------------------------
+
+def _device_resident_ok(user_func, tensor_input, y0, t, method, options):
+    from ...neural_dynamics import ODEFunc
+    if not (tensor_input and type(user_func) is ODEFunc):
+        return False
+    y = y0[0]
+    if y.dim() != 2 or y.shape[1] != user_func.hidden_size:
+        return False
+    if user_func.training and user_func.dropout > 0:
+        return False
+    if set(options) - {'max_num_steps'}:
+        return False
+    if bool((t[1:] < t[:-1]).any()):            # decreasing grids go through the generic sign flip
+        return False
+    return True
+
+
+class DeviceSolver:
+    """RAII wrapper of ndcn_solver_* for one (ODEFunc, method) pair; the workspace is a torch allocation."""
+
+    def __init__(self, odefunc, n_rows, method, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1, use_graph=False):
+        from ...csr import as_csr
+        self.lib = _lib.load()
+        H = odefunc.hidden_size
+        flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
+        dev = odefunc.wt.weight.device
+        if odefunc.no_graph:
+            view = _lib.CsrView(n_rows, n_rows, 0, None, None, None)
+            self._keep = ()
+        else:
+            csr = as_csr(odefunc.A)
+            if csr.device != dev:
+                raise _lib.NdcnHipError(_lib.EINVAL, 'operator on %s, weights on %s' % (csr.device, dev))
+            assert csr.shape[0] == n_rows, 'operator has %d rows, state has %d' % (csr.shape[0], n_rows)
+            view = csr.view()
+            self._keep = (csr,)
+        W = odefunc.wt.weight.detach().contiguous()
+        b = odefunc.wt.bias.detach().contiguous() if odefunc.wt.bias is not None else None
+        _lib.require_device(W, 'weight')
+        self._keep += (W, b)
+        self.desc = _lib.SolverDesc(_lib.METHODS[method], H, flags, 1 if use_graph else 0, view,
+                                    W.data_ptr(), b.data_ptr() if b is not None else None,
+                                    float(rtol), float(atol), int(max_num_steps))
+        self.device = dev
+        self.shape = (n_rows, H)
+        nbytes = int(self.lib.ndcn_solver_workspace_bytes(ctypes.byref(self.desc)))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.ndcn_solver_create(ctypes.byref(self.desc), _lib.ptr(self.workspace), nbytes,
+                                                   ctypes.byref(self.handle)))
+
+    def begin(self, y0, t0):
+        y0 = _lib.require_device(y0, 'state y0').contiguous()
+        assert tuple(y0.shape) == self.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ndcn_solver_begin(self.handle, _lib.ptr(y0), float(t0), _lib.stream_ptr()))
+
+    def advance(self, next_t, out=None, step_budget=0):
+        """Returns True when next_t was reached (and `out` written), False when the step budget ran out."""
+        with torch.cuda.device(self.device):
+            rc = _lib.check(self.lib.ndcn_solver_advance(self.handle, float(next_t), _lib.ptr(out), int(step_budget),
+                                                         _lib.stream_ptr()))
+        return rc == 0
+
+    def stats(self):
+        buf = (ctypes.c_double * 6)()
+        _lib.check(self.lib.ndcn_solver_stats(self.handle, buf))
+        keys = ('steps', 'accepted', 'nfe', 't1', 'dt_next', 'last_ratio')
+        return dict(zip(keys, list(buf)))
+
+    def steplog(self):
+        n = int(self.lib.ndcn_solver_steplog(self.handle, None, 0))
+        buf = (ctypes.c_double * (5 * max(n, 1)))()
+        self.lib.ndcn_solver_steplog(self.handle, buf, n)
+        return [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+
+    def close(self):
+        if self.handle:
+            self.lib.ndcn_solver_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
+    core.assert_increasing(t)
+    tt = t.detach().to('cpu', torch.float64).tolist()
+    if method != 'dopri5':
+        # solvers.py:81: the fixed grid is t in the state dtype
+        tt = t.detach().to('cpu').to(y0.dtype).to(torch.float64).tolist()
+    solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, options.get('max_num_steps', 2 ** 31 - 1))
+    try:
+        out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
+        out[0].copy_(y0)
+        solver.begin(y0, tt[0])
+        for i in range(1, len(tt)):
+            try:
+                solver.advance(tt[i], out[i])
+            except _lib.NdcnHipError as e:
+                if e.code in (_lib.ENONFINITE, _lib.EUNDERFLOW, _lib.EMAXSTEPS, _lib.ESTATE):
+                    raise AssertionError(str(e)) from None     # the reference raises AssertionError here
+                raise
+        if step_log is not None:
+            step_log.extend(solver.steplog())
+            step_log.append(('nfe', int(solver.stats()['nfe'])))
+        torch.cuda.current_stream().synchronize()    # the workspace is released below
+        return out
+    finally:
+        solver.close()

@@ -1,0 +1,113 @@
+"""Oracle-backed test double of the panel-ops interface (ndcn_amd.ops.HipOps).
+
+TEST INFRASTRUCTURE: lets the CPU suite drive the product's host logic
+(ndcn_amd/torchdiffeq/_impl/core.py, ndcn_amd/sharding.py) without a GPU.  Never imported by product code.
+Every method is the torch-CPU statement of what the corresponding HIP kernel computes, with the
+reference's op order (see oracle/ndcn_oracle.py for the reference line numbers).
+"""
+import numpy as np
+import torch
+
+from oracle import ndcn_oracle as orc
+
+
+def _c(v):
+    return torch.tensor(float(v), dtype=torch.float32)
+
+
+def _wsum(ks, cs):
+    acc = 0
+    for c, k in zip(cs, ks):
+        acc = acc + _c(c) * k
+    return acc
+
+
+def _bad(x):
+    return float((~torch.isfinite(x)).sum())
+
+
+class OracleOps:
+    name = 'oracle'
+
+    @staticmethod
+    def _coo(A):
+        if hasattr(A, 'rowptr'):       # ndcn_amd.csr.CsrOperator on the CPU
+            return orc.coo_from_csr(A.rowptr.numpy(), A.colidx.numpy(), A.val.numpy(), A.shape)
+        return A
+
+    @classmethod
+    def spmm(cls, A, X, X_halo=None, alpha=1.0, relu=False, out=None):
+        A = cls._coo(A)
+        full = X if X_halo is None else torch.cat([X, X_halo], 0)
+        y = orc.apply_operator(A, full)
+        if alpha != 1.0:
+            y = y * alpha
+        return torch.relu(y) if relu else y
+
+    @staticmethod
+    def linear(S, W, b=None, relu=False):
+        y = torch.nn.functional.linear(S, W, b)
+        return torch.relu(y) if relu else y
+
+    @classmethod
+    def rhs(cls, A, X, W, b, no_graph=False, no_control=False, X_halo=None, out=None):
+        x = X
+        if not no_graph:
+            x = cls.spmm(A, X, X_halo)
+        if not no_control:
+            x = torch.nn.functional.linear(x, W, b)
+        return torch.relu(x)
+
+    @staticmethod
+    def gather_rows(X, idx):
+        return X[idx.long()]
+
+    @staticmethod
+    def combine(y0, ks, cs):
+        return y0 + _wsum(ks, cs)
+
+    @staticmethod
+    def error(y0, y1, ks, cs, rtol, atol):
+        err = _wsum(ks, cs)
+        tol = atol + rtol * torch.max(torch.abs(y0), torch.abs(y1))
+        r = err / tol
+        return float((r * r).double().sum()), _bad(y1)
+
+    @staticmethod
+    def scaled_sumsq(a, b, y, rtol, atol):
+        scale = atol + torch.abs(y) * rtol
+        q = (a / scale) if b is None else ((a - b) / scale)
+        return float((q * q).double().sum()), _bad(a)
+
+    @staticmethod
+    def interp_fit(y0, y1, ks, cmid, dt):
+        dt = _c(dt)
+        ymid = y0 + _wsum(ks, cmid)
+        f0, f1 = ks[0], ks[-1]
+        a = orc._dot([-2 * dt, 2 * dt, -8, -8, 16], [f0, f1, y0, y1, ymid])
+        b = orc._dot([5 * dt, -3 * dt, 18, 14, -32], [f0, f1, y0, y1, ymid])
+        c = orc._dot([-4 * dt, dt, -11, -5, 16], [f0, f1, y0, y1, ymid])
+        d = dt * f0
+        return a, b, c, d
+
+    @staticmethod
+    def interp_eval(a, b, c, d, e, xpow, out=None):
+        xs = [_c(v) for v in xpow]
+        return orc._dot((a, b, c, d, e), xs)
+
+    @staticmethod
+    def fixed_stage(op, y, k1, k2=None, k3=None, k4=None, dt=0.0, out=None):
+        dt = _c(dt)
+        if op == 0:
+            return y + dt * k1
+        if op == 1:
+            return y + k1 * dt / 2
+        if op == 2:
+            return y + dt * k1 / 3
+        if op == 3:
+            return y + dt * (k1 / -3 + k2)
+        if op == 4:
+            return y + dt * (k1 - k2 + k3)
+        if op == 5:
+            return y + (k1 + 3 * k2 + 3 * k3 + k4) * (dt / 8)
+        raise ValueError(op)

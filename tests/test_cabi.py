@@ -1,0 +1,66 @@
+"""The C-ABI library builds, loads, and exports exactly what include/ndcn_hip.h declares.  No compute
+calls (there is no GPU in the CPU suite)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'ndcn_hip.h')).read()
+    return sorted(set(re.findall(r'NDCN_API[^;(]*?\b(ndcn_\w+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    from ndcn_amd import _lib
+    assert header_functions() == sorted(_lib.SIGNATURES)
+
+
+def test_library_loads_and_exports_every_symbol():
+    from ndcn_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'build it: python -c "import __graft_entry__ as g; g.build()"'
+    lib = _lib.load()                      # resolves every symbol of SIGNATURES
+    assert lib.ndcn_abi_version() == _lib.ABI_VERSION
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r' T (ndcn_\w+)', out)))
+    assert exported == header_functions()
+
+
+def test_library_has_gfx950_code_object():
+    from ndcn_amd import _lib
+    out = subprocess.run(['strings', '-a', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'gfx950' in out
+
+
+def test_host_tensors_are_refused():
+    import torch
+    from ndcn_amd import _lib, hip
+    from ndcn_amd import torchdiffeq as ode
+    with pytest.raises(_lib.NdcnHipError):
+        hip.combine(torch.ones(4), [torch.ones(4)], [1.0])
+    with pytest.raises(_lib.NdcnHipError):
+        ode.odeint(lambda t, y: -y, torch.ones(4), torch.tensor([0., 1.]), method='euler')
+
+
+def test_argument_errors_match_reference():
+    import torch
+    from ndcn_amd import torchdiffeq as ode
+    f = lambda t, y: -y
+    y0 = torch.ones(3)
+    with pytest.raises(TypeError):
+        ode.odeint(f, torch.ones(3, dtype=torch.int64), torch.tensor([0., 1.]), method='euler')
+    with pytest.raises(TypeError):
+        ode.odeint(f, y0, torch.tensor([0, 1]), method='euler')
+    with pytest.raises(ValueError):
+        ode.odeint(f, y0, torch.tensor([0., 1.]), options={'step_size': 0.1})
+    with pytest.raises(KeyError):
+        ode.odeint(f, y0, torch.tensor([0., 1.]), method='nope')
+    with pytest.raises(NotImplementedError):
+        ode.odeint(f, y0, torch.tensor([0., 1.]), method='tsit5')
+    with pytest.raises(AssertionError):
+        ode.odeint(f, [y0], torch.tensor([0., 1.]), method='euler')
+    with pytest.raises(ValueError):
+        ode.odeint_adjoint(f, y0, torch.tensor([0., 1.]))

@@ -1,0 +1,233 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against the CPU oracle / golden fixtures.
+All calls go through libndcn_hip.so (ndcn_amd.ops.hip)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import ndcn_oracle as orc
+from _oracle_ops import OracleOps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    from ndcn_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def names(pattern):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern)))
+
+
+def rand_csr(n_rows, n_cols, avg, seed, hubs=0):
+    rng = np.random.RandomState(seed)
+    deg = rng.poisson(avg, size=n_rows)
+    deg[rng.randint(0, n_rows, size=max(1, n_rows // 50))] = 0          # some empty rows
+    for h in range(hubs):
+        deg[rng.randint(0, n_rows)] = min(n_cols, 3000 + 500 * h)        # rows longer than the LDS stage
+    rows = np.repeat(np.arange(n_rows), deg)
+    cols = rng.randint(0, n_cols, size=rows.size)
+    m = sp.csr_matrix((rng.randn(rows.size).astype(np.float32), (rows, cols)), shape=(n_rows, n_cols))
+    m.sum_duplicates()
+    m.sort_indices()
+    return m
+
+
+# ------------------------------------------------------------------------------------------- SpMM
+@pytest.mark.parametrize('H', [1, 2, 3, 4, 8, 20, 32, 64, 100, 128, 256, 260, 512])
+def test_spmm_vs_fp64(dev, H):
+    from ndcn_amd import hip, CsrOperator
+    m = rand_csr(3001, 3001, 9, seed=H, hubs=2)
+    X = torch.randn(3001, H)
+    Y = hip.spmm(CsrOperator.from_scipy(m, dev), X.to(dev)).cpu().numpy()
+    ref = orc.spmm_f64(m.indptr, m.indices, m.data, X.numpy())
+    scale = np.abs(m).dot(np.abs(X.numpy()).astype(np.float64))
+    assert np.all(np.abs(Y - ref) <= 2e-6 * scale + 1e-6)
+
+
+def test_spmm_alpha_relu_rect_and_empty(dev):
+    from ndcn_amd import hip, CsrOperator
+    m = rand_csr(517, 1200, 5, seed=3)
+    X = torch.randn(1200, 36)
+    A = CsrOperator.from_scipy(m, dev)
+    Y = hip.spmm(A, X.to(dev), alpha=-2.5, relu=True).cpu().numpy()
+    ref = np.maximum(-2.5 * orc.spmm_f64(m.indptr, m.indices, m.data, X.numpy()), 0)
+    assert np.abs(Y - ref).max() < 1e-4
+    # N x 1 and 1-D panels (the truth dynamics' layout)
+    v = torch.randn(1200)
+    y1 = hip.spmm(A, v.to(dev)).cpu().numpy()
+    assert np.abs(y1 - orc.spmm_f64(m.indptr, m.indices, m.data, v.numpy().reshape(-1, 1)).ravel()).max() < 1e-4
+    # empty operator / zero rows
+    E = CsrOperator.from_scipy(sp.csr_matrix((64, 64), dtype=np.float32), dev)
+    assert float(hip.spmm(E, torch.randn(64, 8).to(dev)).abs().max()) == 0.0
+    Z = CsrOperator.from_scipy(sp.csr_matrix((0, 64), dtype=np.float32), dev)
+    assert hip.spmm(Z, torch.randn(64, 8).to(dev)).shape == (0, 8)
+
+
+def test_spmm_halo_split_equals_whole(dev):
+    from ndcn_amd import hip, CsrOperator
+    m = rand_csr(800, 2000, 7, seed=11)
+    X = torch.randn(2000, 64).to(dev)
+    A = CsrOperator.from_scipy(m, dev)
+    whole = hip.spmm(A, X)
+    split = hip.spmm(A, X[:1100].contiguous(), X_halo=X[1100:].contiguous())
+    assert torch.equal(whole, split)
+
+
+def test_spmm_dense_and_coo_inputs_match_reference_layouts(dev):
+    from ndcn_amd import hip
+    d = load_golden('rhs_grid400_H20_no_control_coo')
+    dense = orc.dense_from_csr(d['indptr'], d['indices'], d['data'], d['shape'])
+    coo = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape'])
+    x = T(d['x']).to(dev)
+    y_dense = hip.spmm(dense.to(dev), x, relu=True).cpu().numpy()
+    y_coo = hip.spmm(coo.to(dev), x, relu=True).cpu().numpy()
+    assert np.array_equal(y_dense, y_coo)
+    assert np.abs(y_coo - d['out']).max() < 1e-5
+
+
+def test_gather_rows(dev):
+    from ndcn_amd import hip
+    X = torch.randn(1000, 20).to(dev)
+    idx = torch.randint(0, 1000, (333,), dtype=torch.int32).to(dev)
+    assert torch.equal(hip.gather_rows(X, idx), X[idx.long()])
+    X = torch.randn(1000, 256).to(dev)
+    assert torch.equal(hip.gather_rows(X, idx), X[idx.long()])
+
+
+# ------------------------------------------------------------------------------------------- Linear / RHS
+@pytest.mark.parametrize('n,Hi,Ho', [(400, 20, 20), (1000, 256, 256), (777, 1, 20), (777, 20, 1), (130, 64, 48),
+                                      (65, 100, 200), (4096, 128, 128), (33, 256, 7), (50, 17, 33)])
+def test_linear_vs_torch_fp32(dev, n, Hi, Ho):
+    from ndcn_amd import hip
+    torch.manual_seed(n + Hi)
+    S, W, b = torch.randn(n, Hi), torch.randn(Ho, Hi) / Hi ** 0.5, torch.randn(Ho)
+    ref = torch.nn.functional.linear(S.double(), W.double(), b.double())
+    for relu in (False, True):
+        for bias in (b, None):
+            y = hip.linear(S.to(dev), W.to(dev), None if bias is None else bias.to(dev), relu=relu).cpu().double()
+            r = ref - (0 if bias is not None else b.double())
+            r = torch.relu(r) if relu else r
+            assert (y - r).abs().max() < 2e-5 * max(1.0, float(r.abs().max()))
+
+
+def test_linear_is_an_exact_fp32_fma_chain(dev):
+    # v_mfma_f32_32x32x2_f32 accumulates k in order with one rounding per product-add: compare bitwise
+    from ndcn_amd import hip
+    torch.manual_seed(1)
+    S, W = torch.randn(64, 64), torch.randn(64, 64)
+    y = hip.linear(S.to(dev), W.to(dev)).cpu().numpy()
+    ref = np.zeros((64, 64), dtype=np.float32)
+    Sn, Wn = S.numpy(), W.numpy()
+    for k in range(64):
+        ref = (Sn[:, k:k + 1].astype(np.float64) * Wn[:, k][None, :].astype(np.float64) + ref.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(y, ref)
+    # transposition detector: an asymmetric weight
+    W2 = torch.zeros(64, 64); W2[3, 5] = 1.0
+    out = hip.linear(torch.eye(64).to(dev), W2.to(dev)).cpu()
+    assert out[5, 3] == 1.0 and out.sum() == 1.0
+
+
+@pytest.mark.parametrize('name', names('rhs_*.npz'))
+def test_rhs_golden(dev, name):
+    from ndcn_amd import hip, CsrOperator
+    d = load_golden(name)
+    A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)
+    out = hip.rhs(A, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev),
+                  no_graph='no_graph' in name, no_control='no_control' in name).cpu().numpy()
+    assert np.abs(out - d['out']).max() <= 2e-5
+
+
+def test_rhs_module_matches_reference_semantics(dev):
+    # ODEFunc module incl. state_dict round trip through the reference's key names
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('rhs_grid400_H20_default_coo')
+    A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape']).to(dev)
+    f = ODEFunc(20, A).to(dev)
+    f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+    with torch.no_grad():
+        out = f(torch.tensor(0.0), T(d['x']).to(dev)).cpu().numpy()
+    assert np.abs(out - d['out']).max() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------- RK bookkeeping
+@pytest.mark.parametrize('shape', [(400, 20), (1001, 1), (257, 3), (4096, 256)])
+def test_rk_kernels_bitwise_vs_reference_op_order(dev, shape):
+    """combine / interp / fixed-stage kernels reproduce the reference's separately-rounded op chains."""
+    from ndcn_amd import hip
+    torch.manual_seed(shape[0])
+    y0, y1 = torch.randn(shape), torch.randn(shape)
+    ks = [torch.randn(shape) for _ in range(7)]
+    cs = [np.float32(c) for c in np.random.RandomState(0).randn(7)]
+    g = lambda x: x.to(dev)
+    for n in (1, 2, 5, 7):
+        got = hip.combine(g(y0), [g(k) for k in ks[:n]], cs[:n]).cpu()
+        assert torch.equal(got, OracleOps.combine(y0, ks[:n], cs[:n]))
+    dt = np.float32(0.37)
+    cmid = [np.float32(dt * np.float32(c)) for c in orc.DP_C_MID]
+    got = hip.interp_fit(g(y0), g(y1), [g(k) for k in ks], cmid, dt)
+    ref = OracleOps.interp_fit(y0, y1, [k for k, c in zip(ks, cmid)], cmid, dt)
+    for a, b in zip(got, ref):
+        assert torch.equal(a.cpu(), b)
+    x = np.float32(0.3)
+    xp = (np.float32(x * x * x * x), np.float32(x * x * x), np.float32(x * x), x, np.float32(1))
+    got = hip.interp_eval(*[g(v) for v in ref], g(y0), xp).cpu()
+    assert torch.equal(got, OracleOps.interp_eval(*ref, y0, xp))
+    for op in range(6):
+        got = hip.fixed_stage(op, g(y0), g(ks[0]), g(ks[1]), g(ks[2]), g(ks[3]), dt=dt).cpu()
+        assert torch.equal(got, OracleOps.fixed_stage(op, y0, ks[0], ks[1], ks[2], ks[3], dt=dt)), op
+
+
+@pytest.mark.parametrize('n', [1, 63, 4096, 1000003])
+def test_reductions(dev, n):
+    from ndcn_amd import hip
+    torch.manual_seed(n)
+    y0, y1, a, b = (torch.randn(n) for _ in range(4))
+    ks = [torch.randn(n) for _ in range(6)]
+    cs = [np.float32(c) for c in (0.1, -0.2, 0.3, 0.05, -0.07, 0.01)]
+    g = lambda x: x.to(dev)
+    s, bad = hip.error(g(y0), g(y1), [g(k) for k in ks], cs, 1e-2, 1e-3)
+    rs, rbad = OracleOps.error(y0, y1, ks, cs, np.float32(1e-2), np.float32(1e-3))
+    assert bad == 0 and abs(s - rs) <= 1e-9 * abs(rs)
+    s, bad = hip.scaled_sumsq(g(a), g(b), g(y0), 1e-2, 1e-3)
+    rs, _ = OracleOps.scaled_sumsq(a, b, y0, np.float32(1e-2), np.float32(1e-3))
+    assert abs(s - rs) <= 1e-9 * abs(rs)
+    s, bad = hip.scaled_sumsq(g(a), None, g(y0), 1e-2, 1e-3)
+    rs, _ = OracleOps.scaled_sumsq(a, None, y0, np.float32(1e-2), np.float32(1e-3))
+    assert abs(s - rs) <= 1e-9 * abs(rs)
+    # determinism: same bits on a second run
+    assert hip.scaled_sumsq(g(a), None, g(y0), 1e-2, 1e-3)[0] == s
+    # non-finite detection
+    y1[n // 2] = float('inf')
+    a[0] = float('nan')
+    assert hip.error(g(y0), g(y1), [g(k) for k in ks], cs, 1e-2, 1e-3)[1] == 1
+    assert hip.scaled_sumsq(g(a), None, g(y0), 1e-2, 1e-3)[1] == 1
+
+
+# ------------------------------------------------------------------------------------------- truth dynamics
+def test_truth_rhs_kernels(dev):
+    from ndcn_amd import hip, CsrOperator
+    d = load_golden('truth_mutual_coo')
+    n = int(d['n'])
+    A = CsrOperator.from_arrays(d['A_indptr'], d['A_indices'], d['A_data'], (n, n), dev)
+    Ac = orc.coo_from_csr(d['A_indptr'], d['A_indices'], d['A_data'], (n, n))
+    for k in (0, 3, 20):
+        x = T(d['traj'][k])
+        got = hip.mutual_rhs(A, x.to(dev)).cpu()
+        ref = orc.mutual_rhs(Ac, x)
+        assert (got - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+        got = hip.gene_rhs(A, x.to(dev)).cpu()
+        ref = orc.gene_rhs(Ac, x)
+        assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))

@@ -1,0 +1,216 @@
+"""End-to-end parity of the drop-in API on a real MI355X: odeint / ODEBlock / NDCN / truth dynamics
+against the golden fixtures captured from the reference and against the CPU oracle.
+Tolerance: north_star's trajectory L1 < 1e-4 (tests use tighter max-abs bounds where the data allow)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import ndcn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+L1_TOL = 1e-4          # BASELINE.json north_star: trajectory L1 error vs CPU reference < 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def names(pattern):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern)))
+
+
+def make_func(d, dev, as_module=True, **kw):
+    """our ODEFunc (device-resident path) or a plain closure over hip ops (generic path)."""
+    from ndcn_amd import CsrOperator, hip
+    from ndcn_amd.neural_dynamics import ODEFunc
+    A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)
+    H = d['W'].shape[0]
+    if as_module:
+        f = ODEFunc(H, A, **kw).to(dev)
+        f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+        return f.eval()
+    W, b = T(d['W']).to(dev), T(d['b']).to(dev)
+    return lambda t, x: hip.rhs(A, x, W, b, no_graph=kw.get('no_graph', False), no_control=kw.get('no_control', False))
+
+
+def check_traj(y, ref, l1=L1_TOL, mx=1e-3):
+    err = np.abs(y - ref)
+    scale = max(1.0, np.abs(ref).max())
+    assert err.mean() < l1 * scale, 'L1 %.3e' % err.mean()
+    assert err.max() < mx * scale, 'max %.3e' % err.max()
+
+
+@pytest.mark.parametrize('as_module', [True, False], ids=['device_resident', 'generic'])
+@pytest.mark.parametrize('name', names('fixed_*.npz'))
+def test_fixed_grid_golden(dev, name, as_module):
+    from ndcn_amd import torchdiffeq as ode
+    d = load_golden(name)
+    f = make_func(d, dev, as_module)
+    with torch.no_grad():
+        y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), method=name.split('_')[1])
+    assert y.shape == d['traj'].shape
+    assert np.array_equal(y[0].cpu().numpy(), d['x0'])
+    check_traj(y.cpu().numpy(), d['traj'], l1=1e-5, mx=1e-4)
+
+
+@pytest.mark.parametrize('as_module', [True, False], ids=['device_resident', 'generic'])
+@pytest.mark.parametrize('name', names('dopri5_*.npz'))
+def test_dopri5_golden(dev, name, as_module):
+    from ndcn_amd import torchdiffeq as ode
+    d = load_golden(name)
+    f = make_func(d, dev, as_module, no_control='no_control' in name)
+    log = []
+    with torch.no_grad():
+        y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), rtol=float(d['rtol']), atol=float(d['atol']),
+                       method='dopri5', step_log=log)
+    nfe = dict([log.pop()])['nfe']
+    ref = d['steplog']
+    log = np.array(log)
+    check_traj(y.cpu().numpy(), d['traj'], l1=1e-5, mx=2e-4)
+    if name == 'dopri5_tight':
+        assert abs(nfe - int(d['nfe'])) <= 0.15 * int(d['nfe'])     # see tests/test_host_logic.py
+        return
+    assert nfe == int(d['nfe'])
+    assert np.array_equal(log[:, 2], ref[:, 2])                       # identical accept / reject sequence
+    assert np.allclose(log[:, [0, 1, 4]], ref[:, [0, 1, 4]], rtol=1e-4)
+    assert np.allclose(log[:, 3], ref[:, 3], rtol=5e-3, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', names('ndcn_*.npz'))
+def test_ndcn_end_to_end_golden(dev, name):
+    from ndcn_amd.neural_dynamics import NDCN
+    d = load_golden(name)
+    variant, method = name[len('ndcn_'):].rsplit('_', 1)
+    A = orc.dense_from_csr(d['indptr'], d['indices'], d['data'], d['shape']).to(dev)    # the drivers' dense layout
+    m = NDCN(input_size=1, hidden_size=1 if variant == 'no_embed' else 20, A=A, num_classes=1, dropout=0.0,
+             no_embed=variant == 'no_embed', no_graph=variant == 'no_graph', no_control=variant == 'no_control',
+             rtol=.01, atol=.001, method=method).to(dev)
+    sd = {k[4:].replace('__', '.'): T(v) for k, v in d.items() if k.startswith('sd__')}
+    m.load_state_dict(sd)                       # the reference's own key names
+    with torch.no_grad():
+        out = m(T(d['t']).to(dev), T(d['x0']).to(dev))
+    assert out.shape == d['out'].shape
+    check_traj(out.cpu().numpy(), d['out'], l1=1e-5, mx=2e-4)
+
+
+@pytest.mark.parametrize('name', names('truth_*_coo.npz'))
+def test_truth_dynamics_golden(dev, name):
+    """Ground-truth generation of the three drivers (odeint defaults rtol 1e-7 / atol 1e-9, N x 1 state)."""
+    from ndcn_amd import CsrOperator, hip
+    from ndcn_amd import torchdiffeq as ode
+    d = load_golden(name)
+    n = int(d['n'])
+    A = CsrOperator.from_arrays(d['A_indptr'], d['A_indices'], d['A_data'], (n, n), dev)
+    L = CsrOperator.from_arrays(d['L_indptr'], d['L_indices'], d['L_data'], (n, n), dev)
+    if 'heat' in name:
+        f = lambda t, x: hip.spmm(L, x, alpha=-1.0)
+    elif 'gene' in name:
+        f = lambda t, x: hip.gene_rhs(A, x)
+    else:
+        f = lambda t, x: hip.mutual_rhs(A, x)
+    with torch.no_grad():
+        y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), method='dopri5')
+    check_traj(y.cpu().numpy(), d['traj'], l1=2e-5, mx=2e-4)
+    if 'heat' in name:      # K1: closed form
+        Ld = orc.dense_from_csr(d['L_indptr'], d['L_indices'], d['L_data'], (n, n)).numpy()
+        exact = orc.heat_closed_form(Ld, d['x0'], d['t'])
+        assert np.abs(y.cpu().numpy() - exact).mean() < 2e-5
+        assert abs(float(y[-1].sum()) - float(d['x0'].sum())) < 5e-2      # K2 conservation
+
+
+@pytest.mark.parametrize('name,H', [('cora', 64), ('pubmed', 16)])
+def test_dgnn_block_golden(dev, name, H):
+    """dgnn.py's differential_gcn hot path: ODEBlock2(ODEFunc(no_control), terminal=True) on the Planetoid topology."""
+    from ndcn_amd import CsrOperator
+    from ndcn_amd.neural_dynamics import ODEFunc, ODEBlock2
+    d = load_golden('dgnn_%s_H%d' % (name, H))
+    g = load_golden('operators_' + name)
+    n = int(g['n'])
+    A = CsrOperator.from_arrays(g['alpha00_indptr'], g['alpha00_indices'], g['alpha00_data'], (n, n), dev)
+    blk = ODEBlock2(ODEFunc(H, A, dropout=0.0, no_control=True), T(d['t']).to(dev), rtol=.1, atol=.1,
+                    method='dopri5', terminal=True).to(dev).eval()
+    with torch.no_grad():
+        y = blk(T(d['x']).to(dev))
+    assert y.shape == d['out'].shape
+    check_traj(y.cpu().numpy(), d['out'], l1=1e-5, mx=2e-4)
+
+
+def test_tuple_state_generic_path(dev):
+    from ndcn_amd import torchdiffeq as ode
+
+    def f(t, y):
+        a, b = y
+        return (-a * t + b.mean(), torch.sin(t) * b - a.sum() * 0.01)
+    y0 = (torch.rand(7, 3), torch.rand(5))
+    t = torch.linspace(0., 2., 9)
+    for method in ('euler', 'rk4', 'dopri5'):
+        ref = orc.odeint(f, y0, t, rtol=1e-4, atol=1e-6, method=method)
+        got = ode.odeint(f, tuple(v.to(dev) for v in y0), t.to(dev), rtol=1e-4, atol=1e-6, method=method)
+        for gx, r in zip(got, ref):
+            assert (gx.cpu() - r).abs().max() < 1e-4
+
+
+def test_error_behaviour_on_device(dev):
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd import graphs
+    A = graphs.to_device(graphs.normalized_laplacian(graphs.grid_8_neighbor(8)), dev)
+    f = ODEFunc(8, A).to(dev).eval()
+    x = torch.rand(64, 8).to(dev)
+    with torch.no_grad():
+        with pytest.raises(AssertionError):
+            ode.odeint(f, x, torch.tensor([0., 1., 0.5]).to(dev), method='dopri5')
+        bad = x.clone(); bad[3, 3] = float('nan')
+        with pytest.raises(AssertionError):
+            ode.odeint(f, bad, torch.tensor([0., 1.]).to(dev), method='dopri5')
+        with pytest.raises(AssertionError):
+            ode.odeint(lambda t, y: y * float('inf'), x, torch.tensor([0., 1.]).to(dev), method='dopri5')
+
+
+def test_large_grid_properties(dev):
+    """Full-size properties at the metric's case (1M-node grid, H = 256), where the oracle cannot run a whole
+    solve in seconds: (i) SpMM linearity, (ii) row-sum identity of the normalised Laplacian on D^1/2 1,
+    (iii) device-resident and generic dopri5 agree, (iv) a sampled row block equals the fp64 oracle."""
+    from ndcn_amd import graphs, hip
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    S, H = 1000, 256
+    Agrid = graphs.grid_8_neighbor(S)
+    L = graphs.normalized_laplacian(Agrid)
+    A = graphs.to_device(L, dev)
+    torch.manual_seed(0)
+    X = torch.rand(S * S, H, device=dev)
+    Z = torch.rand(S * S, H, device=dev)
+    lin = hip.spmm(A, X + 2 * Z) - (hip.spmm(A, X) + 2 * hip.spmm(A, Z))
+    assert float(lin.abs().max()) < 1e-4
+    # L (D^1/2 1) = 0 for the normalised Laplacian
+    deg = torch.from_numpy(np.asarray(Agrid.sum(1)).reshape(-1).astype(np.float32))
+    v = deg.sqrt().to(dev).view(-1, 1).repeat(1, 4).contiguous()
+    assert float(hip.spmm(A, v).abs().max()) < 1e-5
+    # sampled rows vs fp64
+    rows = np.r_[0:64, 500000:500064, S * S - 64:S * S]
+    sub = L[rows]
+    got = hip.spmm(A, X)[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    ref = orc.spmm_f64(sub.indptr, sub.indices, sub.data, X.cpu().numpy())
+    assert np.abs(got - ref).max() < 1e-5
+    del Z, lin
+    # solver agreement at full size
+    f = ODEFunc(H, A).to(dev).eval()
+    x0 = torch.rand(S * S, H, device=dev)
+    t = torch.tensor([0., 0.6], device=dev)
+    with torch.no_grad():
+        la, lb = [], []
+        ya = ode.odeint(f, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=la)
+        yb = ode.odeint(lambda tt, y: f(tt, y), x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
+    assert la[-1] == lb[-1]
+    assert float((ya[-1] - yb[-1]).abs().max()) < 1e-4

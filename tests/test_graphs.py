@@ -1,0 +1,77 @@
+"""O(nnz) graph / operator builders (ndcn_amd/graphs.py) against the reference's dense builders
+(fixtures operators_*.npz) and structural properties at scale.  CPU-only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+from ndcn_amd import graphs
+
+
+def csr_from(d, prefix, n):
+    return sp.csr_matrix((d[prefix + '_data'] if prefix + '_data' in d else np.ones(len(d[prefix + '_indices']), np.float32),
+                          d[prefix + '_indices'], d[prefix + '_indptr']), shape=(n, n))
+
+
+def test_grid_and_operators_equal_reference_bitwise():
+    d = load_golden('operators_grid400')
+    A = graphs.grid_8_neighbor(20)
+    ref_A = csr_from(d, 'A', 400)
+    assert (A != ref_A).nnz == 0
+    for kind in ('norm_lap', 'norm_adj', 'kipf', 'lap'):
+        op = graphs.make_operator(A, kind)
+        ref = csr_from(d, kind, 400)
+        op.eliminate_zeros()
+        assert np.array_equal(op.indptr, ref.indptr) and np.array_equal(op.indices, ref.indices), kind
+        assert np.array_equal(op.data.astype(np.float32), ref.data), kind     # bit-exact values
+    assert np.array_equal(graphs.x0_blocks(20), d['x0'])
+    d5 = load_golden('operators_grid25')
+    assert (graphs.grid_8_neighbor(5) != csr_from(d5, 'A', 25)).nnz == 0
+
+
+@pytest.mark.parametrize('name', ['cora', 'pubmed'])
+def test_zipf_alpha_equals_reference(name):
+    d = load_golden('operators_' + name)
+    n = int(d['n'])
+    adj = csr_from(d, 'adj', n)
+    for alpha, tag in ((0.0, 'alpha00'), (0.5, 'alpha05')):
+        op = graphs.zipf_smoothing_alpha(adj, alpha)
+        ref = csr_from(d, tag, n)
+        assert abs(op - ref).max() <= 1e-7
+
+
+def test_grid_nnz_formula_and_scale():
+    # nnz(norm_lap) = 4 (S-1)(2S-1) + S^2 ; 1000 x 1000 -> 8 988 004
+    A = graphs.grid_8_neighbor(300)
+    assert A.nnz == 4 * 299 * 599
+    L = graphs.normalized_laplacian(A)
+    assert L.nnz == 4 * 299 * 599 + 300 * 300
+    assert abs(L - L.T).max() < 1e-7
+    assert np.allclose(L.diagonal(), 1.0)
+
+
+@pytest.mark.parametrize('network,lo,hi', [('random', 38, 42), ('power_law', 9.5, 10.1), ('small_world', 5.5, 6.1),
+                                           ('community', 20, 45)])
+def test_generators_structure(network, lo, hi):
+    n = 20000
+    A = graphs.make_graph(network, n, seed=1)
+    assert A.shape == (n, n)
+    assert (A != A.T).nnz == 0                     # undirected
+    assert A.diagonal().sum() == 0                 # no self loops
+    assert set(np.unique(A.data)) == {1.0}
+    assert lo <= A.nnz / n <= hi, A.nnz / n
+    B = graphs.make_graph(network, n, seed=1)
+    assert (A != B).nnz == 0                       # seeded
+
+
+def test_zero_degree_nodes_are_defined():
+    A = sp.csr_matrix(np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]], dtype=np.float32))
+    for kind in ('norm_lap', 'norm_adj', 'kipf', 'lap'):
+        op = graphs.make_operator(A, kind).toarray()
+        assert np.isfinite(op).all()
+    assert graphs.normalized_adj(A).toarray()[2].sum() == 0
+
+
+def test_algorithmic_bytes_of_the_metric_case():
+    # 1M-node grid, H=256 -> 2.124 GB per SpMM
+    assert abs(graphs.spmm_bytes(10 ** 6, 8988004, 256) / 1e9 - 2.124) < 1e-3
