@@ -82,11 +82,12 @@ NDCN_API int ndcn_linear_f32(const float *S, const float *W, const float *b, flo
                     int64_t n, int H_in, int H_out, uint32_t flags, void *stream);
 
 /* The whole ODEFunc.forward in one call: Y = relu(W (A X) + b) honouring NO_GRAPH / NO_CONTROL
- * (neural_dynamics.py:20-39, dropout p = 0).  `work` is an n_rows x H scratch panel used when the
- * fused kernel does not apply (may be NULL when it does; query with ndcn_rhs_needs_work). */
+ * (neural_dynamics.py:20-39, dropout p = 0).  `work`: device scratch of ndcn_rhs_work_bytes() bytes, 16-byte
+ * aligned (H = 256: the fused SpMM->LDS->MFMA kernel keeps its packed weights there; other widths: the
+ * S = A X panel between the SpMM and the Linear kernel; 0 bytes when the Linear or the SpMM is skipped). */
 NDCN_API int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
                  const float *W, const float *b, float *Y, float *work, int H, uint32_t flags, void *stream);
-NDCN_API int ndcn_rhs_needs_work(int H, uint32_t flags);
+NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 
 /* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
 NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);

@@ -53,7 +53,7 @@ SIGNATURES = {
     'ndcn_spmm_f32': (_I, [_CSR, _P, _P, _L, _P, _I, _F, _U, _P]),
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
-    'ndcn_rhs_needs_work': (_I, [_I, _U]),
+    'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
     'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),

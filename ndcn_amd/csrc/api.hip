@@ -69,7 +69,7 @@ int ndcn_linear_f32(const float *S, const float *W, const float *b, float *Y, in
     return linear_f32(S, W, b, Y, n, H_in, H_out, flags, ST(stream));
 }
 
-int ndcn_rhs_needs_work(int H, uint32_t flags) { return rhs_needs_work(H, flags); }
+int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) { return rhs_work_bytes(n_rows, H, flags); }
 
 int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
                  float *Y, float *work, int H, uint32_t flags, void *stream) {

@@ -12,7 +12,11 @@ int linear_f32(const float *S, const float *W, const float *b, float *Y, int64_t
                hipStream_t st);
 int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *Y,
             float *work, int H, uint32_t flags, hipStream_t st);
-int rhs_needs_work(int H, uint32_t flags);
+int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
+int rhs_fused_supported(int H, uint32_t flags);
+int pack_weight_256(const float *W, float *Wp, hipStream_t st);
+int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
+                         const float *b, float *Y, uint32_t flags, hipStream_t st);
 
 int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n,
                    hipStream_t st);

@@ -1,13 +1,14 @@
 // ODEFunc.forward as one entry point: Y = relu(W (A X) + b)   (neural_dynamics.py:20-39, dropout p = 0).
-// Composition of the SpMM and the MFMA Linear through a scratch panel; shapes the fused kernel covers
-// (rhs_fused.hip) bypass the scratch.
+// H = 256 runs the fused kernel (rhs_fused.hip); other widths compose the SpMM and the MFMA Linear through a
+// scratch panel.
 #include "kernels.h"
 
 namespace ndcn {
 
 int rhs_fused_supported(int H, uint32_t flags);
+int64_t rhs_fused_work_bytes(int H);
 int rhs_fused_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b,
-                  float *Y, int H, uint32_t flags, hipStream_t st);
+                  float *Y, float *work, int H, uint32_t flags, hipStream_t st);
 
 __global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n,
                                                         int relu) {
@@ -17,10 +18,11 @@ __global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict_
     }
 }
 
-int rhs_needs_work(int H, uint32_t flags) {
+int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) {
     const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
     if (!(graph && ctl)) return 0;
-    return rhs_fused_supported(H, flags) ? 0 : 1;
+    if (rhs_fused_supported(H, flags)) return rhs_fused_work_bytes(H);       // packed weights
+    return n_rows * (int64_t)H * (int64_t)sizeof(float);                        // S = A X between the two kernels
 }
 
 int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *Y,
@@ -29,8 +31,8 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
     const uint32_t act = flags & NDCN_F_RELU;
     const int64_t n = A->n_rows;
     if (graph && ctl) {
-        if (rhs_fused_supported(H, flags)) return rhs_fused_f32(A, X, Xh, n_own, W, b, Y, H, flags, st);
-        if (!work) { set_error("rhs: scratch panel required for H=%d", H); return NDCN_EINVAL; }
+        if (!work) { set_error("rhs: scratch of ndcn_rhs_work_bytes() bytes required for H=%d", H); return NDCN_EINVAL; }
+        if (rhs_fused_supported(H, flags)) return rhs_fused_f32(A, X, Xh, n_own, W, b, Y, work, H, flags, st);
         int rc = spmm_f32(A, X, Xh, n_own, work, H, 1.f, 0, st);
         if (rc) return rc;
         return linear_f32(work, W, b, Y, n, H, H, act, st);

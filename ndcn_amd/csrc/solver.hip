@@ -62,6 +62,7 @@ struct ndcn_solver {
     hipEvent_t ev = nullptr;
     // scalar state
     bool begun = false;
+    bool fused = false;            // H = 256 fused RHS: `work` holds the packed weights
     double t0 = 0, t1 = 0, dt = 0; // dopri5: last interval [t0, t1], next step size
     float tf = 0;                  // fixed grid: current time in the state dtype
     bool fit_pending = false;      // last accepted step not yet fitted
@@ -82,14 +83,14 @@ inline size_t align_up(size_t v) { return (v + 255u) & ~(size_t)255u; }
 int n_panels(const ndcn_solver_desc *d) {
     const int nk = d->method == NDCN_M_DOPRI5 ? 7 : d->method == NDCN_M_RK4 ? 4 : 1;
     int n = 2 + nk;                                       // ycur, ytmp, k[]
-    if (rhs_needs_work(d->H, d->rhs_flags)) n += 1;       // scratch of the two-kernel RHS
     if (d->method == NDCN_M_DOPRI5) n += 6;               // ynext, yold, a, b, c, d
     return n;
 }
 
 size_t workspace_bytes(const ndcn_solver_desc *d) {
     const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
-    return (size_t)n_panels(d) * panel + align_up((size_t)reduce_ws_bytes()) + 512;
+    const size_t work = align_up((size_t)rhs_work_bytes(d->A.n_rows, d->H, d->rhs_flags) + 16);
+    return (size_t)n_panels(d) * panel + work + align_up((size_t)reduce_ws_bytes()) + 512;
 }
 
 int carve(ndcn_solver *s, size_t bytes, void **p) {
@@ -113,6 +114,8 @@ int alloc_panel(ndcn_solver *s, float **p) {
 
 int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
     s->n_rhs++;
+    if (s->fused)       // weights were packed once in solver_begin
+        return rhs_fused_packed_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, st);
     return rhs_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, out, s->work, s->d.H, s->d.rhs_flags, st);
 }
 
@@ -309,8 +312,16 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     if ((rc = alloc_panel(s, &s->ycur))) return fail(rc);
     s->ycur_own = s->ycur;
     if ((rc = alloc_panel(s, &s->ytmp))) return fail(rc);
-    if (rhs_needs_work(desc->H, desc->rhs_flags))
-        if ((rc = alloc_panel(s, &s->work))) return fail(rc);
+    {
+        const int64_t wb = rhs_work_bytes(s->n_rows, desc->H, desc->rhs_flags);
+        if (wb > 0) {
+            void *wq = nullptr;
+            if ((rc = carve(s, (size_t)wb + 16, &wq))) return fail(rc);
+            s->work = static_cast<float *>(wq);
+        }
+        const bool both = !(desc->rhs_flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
+        s->fused = both && rhs_fused_supported(desc->H, desc->rhs_flags);
+    }
     const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;
     for (int j = 0; j < nk; ++j)
         if ((rc = alloc_panel(s, &s->k[j]))) return fail(rc);
@@ -357,6 +368,10 @@ int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st) {
     s->last_ratio = 0;
     s->t0 = s->t1 = t0;
     s->tf = (float)t0;
+    if (s->fused) {
+        int rcp = pack_weight_256(s->d.W, s->work, st);
+        if (rcp) return rcp;
+    }
     if (s->d.method == NDCN_M_DOPRI5) {
         // dopri5.py:77-83
         int rc = rhs(s, s->ycur, s->k[0], st);

@@ -12,6 +12,8 @@
 //   * logical row blocks are remapped so each XCD walks a contiguous range of rows: neighbouring rows
 //     share neighbours, which then hit in that XCD's private 4 MiB L2;
 //   * accumulation order = stored (column-ascending) order, one fma per non-zero.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ndcn {
@@ -129,6 +131,143 @@ __global__ __launch_bounds__(kSpmmThreads) void spmm_csr_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wide panels (H a multiple of 256): persistent waves, ONE row per wave at a time, no LDS, no barriers.
+//
+// Why a second kernel: with 64 rows per workgroup and ~256 workgroups resident per XCD the rows in flight on
+// one XCD span ~16 lattice rows of the 1000 x 1000 grid; their neighbour rows (18 MB of X) do not fit the
+// XCD's 4 MiB L2, so every X row was re-fetched ~3x from the Infinity Cache / HBM (measured 2.7 TB/s
+// algorithmic).  Here every XCD owns a contiguous chunk of rows and its waves walk that chunk ROW-INTERLEAVED
+// (wave w takes rows w, w + W, w + 2W, ...), so at any moment the rows in flight on an XCD are ~W consecutive
+// rows and the X window they touch (W + 2 * bandwidth rows) stays L2-resident.
+// The row's (col, val) pairs are fetched by one coalesced load (lane j holds entry j) and broadcast with
+// v_readlane; each neighbour row is one 1 KiB coalesced access per 256 columns; 4 neighbour fetches in flight.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// U neighbour rows of one output row: broadcast (col, val) of entries i .. i+U-1 from the lanes that hold
+// them, issue the U (x NV) coalesced fetches back to back, then accumulate in stored order.
+template <int U, int NV, bool HALO>
+__device__ __forceinline__ void wide_batch(int c, float v, int i, const f32x4 *__restrict__ X,
+                                           const f32x4 *__restrict__ Xh, int n_own, int lane, f32x4 (&acc)[NV]) {
+    constexpr size_t stride = 64 * NV;
+    int cc[U];
+    float vv[U];
+    const f32x4 *pp[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        cc[q] = __builtin_amdgcn_readlane(c, i + q);
+        vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i + q));
+        pp[q] = X;
+        if (HALO && cc[q] >= n_own) { pp[q] = Xh; cc[q] -= n_own; }
+    }
+    f32x4 x[U][NV];
+#pragma unroll
+    for (int q = 0; q < U; ++q)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) x[q][u] = pp[q][(size_t)cc[q] * stride + lane + 64 * u];
+#pragma unroll
+    for (int q = 0; q < U; ++q)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) acc[u] = vv[q] * x[q][u] + acc[u];
+}
+
+template <int NV, bool HALO>
+__device__ __forceinline__ void wide_chunk(int c, float v, int cnt, const f32x4 *__restrict__ X,
+                                           const f32x4 *__restrict__ Xh, int n_own, int lane, f32x4 (&acc)[NV]) {
+    int i = 0;
+    for (; i + 8 <= cnt; i += 8) wide_batch<8, NV, HALO>(c, v, i, X, Xh, n_own, lane, acc);
+    if (i + 4 <= cnt) { wide_batch<4, NV, HALO>(c, v, i, X, Xh, n_own, lane, acc); i += 4; }
+    if (i + 2 <= cnt) { wide_batch<2, NV, HALO>(c, v, i, X, Xh, n_own, lane, acc); i += 2; }
+    if (i < cnt) wide_batch<1, NV, HALO>(c, v, i, X, Xh, n_own, lane, acc);
+}
+
+template <int NV, bool HALO>
+__global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                                        const float *__restrict__ val, const float *__restrict__ Xf,
+                                                        const float *__restrict__ Xhf, int n_own,
+                                                        float *__restrict__ Yf, int n_rows, float alpha, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x % kXcds;
+    const int waves_per_xcd = (gridDim.x / kXcds) * 4;
+    const int w = (blockIdx.x / kXcds) * 4 + (threadIdx.x >> 6);
+    const int chunk = (n_rows + kXcds - 1) / kXcds;
+    const int row_lo = xcd * chunk;
+    const int row_hi = min(n_rows, row_lo + chunk);
+    const f32x4 *X = reinterpret_cast<const f32x4 *>(Xf);
+    const f32x4 *Xh = reinterpret_cast<const f32x4 *>(Xhf);
+    f32x4 *Y = reinterpret_cast<f32x4 *>(Yf);
+    constexpr size_t stride = 64 * NV;                    // float4 slots per panel row
+
+    int r = __builtin_amdgcn_readfirstlane(row_lo + w);
+    if (r >= row_hi) return;
+    // software pipeline: the first <= 64 (col, val) pairs of the NEXT row are fetched while this row's
+    // neighbour rows are in flight
+    int j0 = rowptr[r], j1 = rowptr[r + 1];
+    int c = 0;
+    float v = 0.f;
+    if (lane < j1 - j0) { c = colidx[j0 + lane]; v = val[j0 + lane]; }
+    while (true) {
+        const int rn = r + waves_per_xcd;
+        const bool more = rn < row_hi;
+        int nj0 = 0, nj1 = 0;
+        if (more) { nj0 = rowptr[rn]; nj1 = rowptr[rn + 1]; }
+        f32x4 acc[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int nc = 0;
+        float nv = 0.f;
+        if (j1 - j0 <= 64) {
+            // common case: the whole row sits in the lanes already
+            if (more && lane < nj1 - nj0) { nc = colidx[nj0 + lane]; nv = val[nj0 + lane]; }
+            wide_chunk<NV, HALO>(c, v, j1 - j0, X, Xh, n_own, lane, acc);
+        } else {
+            wide_chunk<NV, HALO>(c, v, 64, X, Xh, n_own, lane, acc);
+            for (int jb = j0 + 64; jb < j1; jb += 64) {
+                const int cnt = min(64, j1 - jb);
+                int c2 = 0;
+                float v2 = 0.f;
+                if (lane < cnt) { c2 = colidx[jb + lane]; v2 = val[jb + lane]; }
+                wide_chunk<NV, HALO>(c2, v2, cnt, X, Xh, n_own, lane, acc);
+            }
+            if (more && lane < nj1 - nj0) { nc = colidx[nj0 + lane]; nv = val[nj0 + lane]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            f32x4 o = acc[u] * alpha;
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            __builtin_nontemporal_store(o, &Y[(size_t)r * stride + lane + 64 * u]);
+        }
+        if (!more) break;
+        r = rn; j0 = nj0; j1 = nj1; c = nc; v = nv;
+    }
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+template <int NV>
+static int launch_wide(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha,
+                       uint32_t flags, hipStream_t st) {
+    const int n_rows = (int)A->n_rows;
+    if (n_rows == 0) return NDCN_OK;
+    static const int bpc = env_int("NDCN_SPMM_BLOCKS_PER_CU", 4);          // 4 waves each
+    int per_xcd = (kCus / kXcds) * bpc;
+    const int need = ((n_rows + kXcds - 1) / kXcds + 3) / 4;               // no more waves than rows
+    if (per_xcd > need) per_xcd = need < 1 ? 1 : need;
+    const int relu = (flags & NDCN_F_RELU) ? 1 : 0;
+    const dim3 grid(per_xcd * kXcds), block(256);
+    if (Xh)
+        hipLaunchKernelGGL((spmm_wide_kernel<NV, true>), grid, block, 0, st, A->rowptr, A->colidx, A->val, X, Xh,
+                           (int)n_own, Y, n_rows, alpha, relu);
+    else
+        hipLaunchKernelGGL((spmm_wide_kernel<NV, false>), grid, block, 0, st, A->rowptr, A->colidx, A->val, X, Xh,
+                           (int)n_own, Y, n_rows, alpha, relu);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 template <int VW, int LPR>
 static int launch_spmm(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H,
                        float alpha, uint32_t flags, hipStream_t st) {
@@ -171,6 +310,15 @@ int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, 
     const bool vec = (H % 4 == 0) && aligned16(X) && aligned16(Y) && (Xh == nullptr || aligned16(Xh));
     ProfScope prof(PROF_SPMM, st, 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * H * (double)(A->n_rows + A->n_cols),
                    2.0 * A->nnz * H);
+    if (vec && H % 256 == 0 && H <= 1024) {
+        static const int use_wide = env_int("NDCN_SPMM_WIDE", 1);
+        if (use_wide) {
+            if (H == 256) return launch_wide<1>(A, X, Xh, n_own, Y, alpha, flags, st);
+            if (H == 512) return launch_wide<2>(A, X, Xh, n_own, Y, alpha, flags, st);
+            if (H == 768) return launch_wide<3>(A, X, Xh, n_own, Y, alpha, flags, st);
+            return launch_wide<4>(A, X, Xh, n_own, Y, alpha, flags, st);
+        }
+    }
     if (vec) return dispatch_lpr<4>(H / 4, A, X, Xh, n_own, Y, H, alpha, flags, st);
     return dispatch_lpr<1>(H, A, X, Xh, n_own, Y, H, alpha, flags, st);
 }

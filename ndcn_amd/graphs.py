@@ -64,6 +64,35 @@ def grid_8_neighbor(S):
     return m
 
 
+def grid_8_neighbor_rect(R, C):
+    """R x C lattice, 8 neighbours, node (x, y) -> x*C + y (the square case is grid_8_neighbor)."""
+    R, C = int(R), int(C)
+    idx = np.arange(R * C, dtype=np.int64).reshape(R, C)
+    us, vs = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            if dx == 0 and dy == 0:
+                continue
+            us.append(idx[max(0, -dx):R - max(0, dx), max(0, -dy):C - max(0, dy)].ravel())
+            vs.append(idx[max(0, dx):R - max(0, -dx), max(0, dy):C - max(0, -dy)].ravel())
+    u, v = np.concatenate(us), np.concatenate(vs)
+    m = sp.csr_matrix((np.ones(u.size, dtype=np.float32), (u, v)), shape=(R * C, R * C))
+    m.sort_indices()
+    return m
+
+
+def grid_operator_row_block(R, C, x0, x1, kind='norm_lap'):
+    """Rows [x0*C, x1*C) of the operator of the R x C grid, with GLOBAL column ids, built from a window of
+    lattice rows [x0-2, x1+2) only (degrees of every node that appears in those rows are exact), so a
+    rank can build its shard of a grid that is too large to build whole."""
+    lo, hi = max(0, x0 - 2), min(R, x1 + 2)
+    sub = make_operator(grid_8_neighbor_rect(hi - lo, C), kind).tocsr()
+    block = sub[(x0 - lo) * C:(x1 - lo) * C]
+    block = sp.csr_matrix((block.data, block.indices.astype(np.int64) + lo * C, block.indptr),
+                          shape=(block.shape[0], R * C))
+    return block
+
+
 def erdos_renyi(n, p, seed=0):
     """G(n, p) (heat_dynamics.py:89) sampled in O(expected edges): draw the edge count, then distinct pairs."""
     rng = np.random.RandomState(seed)

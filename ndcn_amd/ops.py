@@ -125,8 +125,9 @@ class HipOps:
             X_halo = _panel(X_halo, 'halo panel')
         Y = out if out is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
         work = None
-        if lib.ndcn_rhs_needs_work(H, flags):
-            work = torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
+        wbytes = int(lib.ndcn_rhs_work_bytes(n_rows, H, flags))
+        if wbytes:
+            work = torch.empty(wbytes, dtype=torch.uint8, device=X.device)
         with torch.cuda.device(X.device):
             check(lib.ndcn_rhs_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                    ptr(None if no_control else b), ptr(Y), ptr(work), H, flags, stream_ptr()))

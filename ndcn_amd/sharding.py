@@ -1,0 +1,193 @@
+"""Node-range sharding of the hot path across the GPUs of one node.
+
+Rank r owns a contiguous range of nodes: the matching rows of the operator and of every state panel.
+Everything in a solver step is row-local except A X, which needs the X rows of remote column neighbours
+("halo").  Per RHS evaluation: pack the rows other ranks need (HIP gather kernel), ONE all-to-all-v over
+RCCL (point-to-point sends over xGMI; only the referenced rows travel, not an all-gather of the panel),
+then the local SpMM reads own rows and halo rows from two panels (ndcn_spmm_f32's X / X_halo).  The
+adaptive controller needs two global scalars per step (sum of squared error ratios, non-finite count):
+one 16-byte all-reduce.  All ranks see identical scalars, hence take identical accept/reject decisions.
+
+torch.distributed is the transport ("nccl" = RCCL on ROCm; "gloo" in the CPU tests, which drive this same
+code with the oracle-backed ops double).
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .csr import CsrOperator
+
+
+def even_bounds(n, world):
+    """Contiguous node ranges: [bounds[r], bounds[r+1])."""
+    return [(n * r) // world for r in range(world + 1)]
+
+
+class HaloPlan:
+    """What this rank must send / receive before each A X, and the operator remapped to [own | halo] columns."""
+
+    def __init__(self, rows_block, bounds, rank, device, group=None):
+        """rows_block: scipy CSR, this rank's rows x ALL global columns."""
+        self.group = group
+        self.rank, self.world = rank, len(bounds) - 1
+        self.bounds = list(bounds)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        self.n_own = hi - lo
+        blk = rows_block.tocsr()
+        blk.sort_indices()
+        assert blk.shape[0] == self.n_own
+        cols = blk.indices.astype(np.int64)
+        remote = (cols < lo) | (cols >= hi)
+        need = np.unique(cols[remote])                                   # sorted global ids = halo order
+        owner = np.searchsorted(np.asarray(bounds[1:]), need, side='right')
+        self.recv_counts = [int((owner == p).sum()) for p in range(self.world)]
+        self.n_halo = int(need.size)
+        # remap columns: own -> c - lo ; remote -> n_own + position in `need`
+        new_cols = np.where(remote, self.n_own + np.searchsorted(need, cols), cols - lo)
+        local = sp.csr_matrix((blk.data.astype(np.float32), new_cols, blk.indptr),
+                              shape=(self.n_own, self.n_own + self.n_halo))
+        local.sort_indices()
+        self.local_op = CsrOperator.from_scipy(local, device)
+        self.local_nnz = int(local.nnz)
+        # tell every owner which of its rows we need (plan-time exchange of index lists)
+        want = [need[owner == p] - bounds[p] for p in range(self.world)]     # owner-local row ids
+        self.send_counts, send_idx = self._exchange_requests(want, device)
+        self.send_idx = send_idx.to(torch.int32)                             # rows of OUR panel to pack, grouped by peer
+        self.device = device
+
+    def _exchange_requests(self, want, device):
+        world = self.world
+        comm_dev = device if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+        counts_out = torch.tensor([len(w) for w in want], dtype=torch.int64, device=comm_dev)
+        counts_in = torch.empty(world, dtype=torch.int64, device=comm_dev)
+        dist.all_to_all_single(counts_in, counts_out, group=self.group)
+        send_counts = [int(c) for c in counts_in.tolist()]
+        flat_out = torch.from_numpy(np.concatenate(want).astype(np.int64) if world else np.empty(0, np.int64)).to(comm_dev)
+        flat_in = torch.empty(sum(send_counts), dtype=torch.int64, device=comm_dev)
+        dist.all_to_all_single(flat_in, flat_out, send_counts, [int(c) for c in counts_out.tolist()], group=self.group)
+        return send_counts, flat_in.to(device)
+
+    def bytes_per_exchange(self, H):
+        return 4 * H * (sum(self.send_counts) + self.n_halo)
+
+    def exchange(self, ops, X):
+        """Returns the halo panel (n_halo x H) for the local panel X."""
+        H = X.shape[1]
+        halo = torch.empty((self.n_halo, H), dtype=X.dtype, device=X.device)
+        if self.world == 1:
+            return halo
+        packed = ops.gather_rows(X, self.send_idx) if self.send_idx.numel() else X[:0]
+        dist.all_to_all_single(halo, packed, self.recv_counts, self.send_counts, group=self.group)
+        return halo
+
+
+class ShardedODEFunc(nn.Module):
+    """ODEFunc on one shard: halo exchange, then the local fused RHS over [own | halo]
+    (neural_dynamics.py:20-39 semantics on the global graph)."""
+
+    ndcn_autonomous = True
+
+    def __init__(self, odefunc, plan, ops):
+        super().__init__()
+        self.f = odefunc
+        self.plan = plan
+        self.ops = ops
+        self.nfe = 0
+        self.halo_bytes = 0
+
+    def forward(self, t, x):
+        self.nfe += 1
+        f = self.f
+        if f.no_graph:
+            return self.ops.rhs(None, x, f.wt.weight, f.wt.bias, no_graph=True, no_control=f.no_control)
+        halo = self.plan.exchange(self.ops, x)
+        self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
+        return self.ops.rhs(self.plan.local_op, x, f.wt.weight, f.wt.bias, no_control=f.no_control, X_halo=halo)
+
+
+class DistOps:
+    """Panel ops whose reductions span all ranks (everything else is row-local and forwarded untouched)."""
+
+    def __init__(self, base, n_global_rows, n_local_rows, group=None):
+        self.base = base
+        self.group = group
+        self.ratio = n_global_rows / float(n_local_rows) if n_local_rows else 1.0
+        self.n_global_rows, self.n_local_rows = n_global_rows, n_local_rows
+        self.name = 'dist(%s)' % getattr(base, 'name', '?')
+
+    def __getattr__(self, item):
+        return getattr(self.base, item)
+
+    def numel(self, t):
+        return (t.numel() // self.n_local_rows) * self.n_global_rows if self.n_local_rows else 0
+
+    def _allreduce(self, s, bad, like):
+        dev = like.device if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+        v = torch.tensor([s, bad], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, group=self.group)
+        s, bad = v.tolist()
+        return s, bad
+
+    def error(self, y0, y1, ks, cs, rtol, atol):
+        s, bad = self.base.error(y0, y1, ks, cs, rtol, atol)
+        return self._allreduce(s, bad, y0)
+
+    def scaled_sumsq(self, a, b, y, rtol, atol):
+        s, bad = self.base.scaled_sumsq(a, b, y, rtol, atol)
+        return self._allreduce(s, bad, a)
+
+
+def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, atol=1e-9, method='dopri5', step_log=None,
+                   group=None):
+    """odeint on this rank's rows of the global system; returns (len(t), n_local, H)."""
+    from .torchdiffeq._impl import core
+    f = ShardedODEFunc(odefunc, plan, ops)
+    dops = DistOps(ops, n_global_rows, x_local.shape[0], group)
+    _, func, y0, tt = core.check_inputs(f, x_local, t)
+    if method == 'dopri5':
+        sol = core.integrate_dopri5(dops, func, y0, tt, rtol, atol, autonomous=True, step_log=step_log)
+    else:
+        sol = core.integrate_fixed(dops, func, y0, tt, method, autonomous=True)
+    return torch.stack([s[0] for s in sol])
+
+
+class ShardedGridBench:
+    """bench.py's N > 1 workload: the (S*world) x S grid, rank r owns lattice rows [r*S, (r+1)*S)."""
+
+    def __init__(self, odefunc, S, world, rank, device, T, rtol, atol, ops=None, group=None):
+        from . import graphs
+        from .torchdiffeq._impl import core
+        if ops is None:
+            from .ops import hip as ops
+        R = S * world
+        block = graphs.grid_operator_row_block(R, S, rank * S, (rank + 1) * S, 'norm_lap')
+        bounds = [r * S * S for r in range(world + 1)]
+        self.plan = HaloPlan(block, bounds, rank, device, group)
+        self.local_nnz = self.plan.local_nnz
+        self.func = ShardedODEFunc(odefunc, self.plan, ops)
+        self.dops = DistOps(ops, R * S, S * S, group)
+        self.x0 = torch.rand(S * S, odefunc.hidden_size, generator=torch.Generator().manual_seed(rank)).to(device)
+        self.T, self.rtol, self.atol = T, rtol, atol
+        self.core = core
+        self._begin()
+
+    def _begin(self):
+        f = lambda t, y: (self.func(t, y[0]),)
+        self.solver = self.core.Dopri5(self.dops, f, (self.x0,), self.rtol, self.atol, autonomous=True)
+        self.solver.begin(0.0)
+
+    def run_steps(self, k):
+        done = 0
+        while done < k:
+            before = len(self.solver.log)
+            out = self.solver.advance(self.T, step_budget=k - done)
+            done += len(self.solver.log) - before
+            if out is not None:
+                self._nfe_base = getattr(self, '_nfe_base', 0) + self.solver.nfe
+                self._begin()
+        return done
+
+    def nfe(self):
+        return getattr(self, '_nfe_base', 0) + self.solver.nfe

@@ -154,11 +154,18 @@ def integrate_fixed(ops, func, y0, t, method, autonomous=False):
 # dopri5
 # ---------------------------------------------------------------------------------------------------
 
+def _numel(ops, t):
+    """Element count behind a reduction: the tensor's own, or the GLOBAL count when `ops` reduces across
+    ranks (ndcn_amd.sharding.DistOps)."""
+    fn = getattr(ops, 'numel', None)
+    return fn(t) if fn is not None else t.numel()
+
+
 def _rms(ops, a, b, y, rtol, atol):
     """misc.py:71-76 on (a - b) / (atol + |y| rtol): float32 norm divided by numel ** 0.5."""
     s, bad = ops.scaled_sumsq(a, b, y, rtol, atol)
     nrm = f32(math.sqrt(s)) if s == s and s >= 0 else f32('nan')
-    return f32(nrm / f32(math.sqrt(a.numel()))), bad
+    return f32(nrm / f32(math.sqrt(_numel(ops, a)))), bad
 
 
 def select_initial_step(ops, func, targ, t0, y0, order, rtol, atol, f0):
@@ -207,7 +214,7 @@ class Dopri5:
         self.max_num_steps = max_num_steps
         self.first_step = first_step
         self.targ = TimeArg(y0[0], autonomous)
-        self.n_elem = [y.numel() for y in y0]
+        self.n_elem = [_numel(ops, y) for y in y0]
         self.log = []                 # (t0, dt, accepted, mean_sq_error_ratio, dt_next) per attempt
         self.nfe = 0
 
@@ -275,12 +282,15 @@ class Dopri5:
         self.dt = dt_next
         return accept
 
-    def advance(self, next_t):
-        """dopri5.py:85-92: step until t1 >= next_t, then evaluate the dense output at next_t."""
+    def advance(self, next_t, step_budget=None):
+        """dopri5.py:85-92: step until t1 >= next_t, then evaluate the dense output at next_t.
+        With `step_budget`, stops after that many attempts and returns None if next_t is not reached yet."""
         next_t = float(next_t)
         n_steps = 0
         while next_t > self.t1:
             assert n_steps < self.max_num_steps, 'max_num_steps exceeded ({}>={})'.format(n_steps, self.max_num_steps)
+            if step_budget is not None and n_steps >= step_budget:
+                return None
             self.step()
             n_steps += 1
         if self.fit is None:

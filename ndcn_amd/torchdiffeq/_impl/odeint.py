@@ -44,6 +44,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
     `step_log` (a list) optionally receives the dopri5 per-attempt log.
     """
     user_func = func
+    t_user = t
     tensor_input, func, y0, t = core.check_inputs(func, y0, t)
 
     if options is None:
@@ -62,7 +63,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
     if _needs_grad(user_func, y0):
         from .autograd_path import odeint_with_grad
         sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func))
-    elif _device_resident_ok(user_func, tensor_input, y0, t, method, options):
+    elif _device_resident_ok(user_func, tensor_input, y0, t_user, method, options):
         return _device_resident(user_func, y0[0], t, rtol, atol, method, options, step_log)
     elif method == 'dopri5':
         sol = core.integrate_dopri5(hip, func, y0, t, rtol, atol, autonomous=_autonomous(user_func),

@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: two gloo ranks run the product's sharding code (HaloPlan, halo exchange,
+global reductions, solver control flow) with the oracle-backed ops double; the stitched result must equal
+the single-process oracle on the whole graph.  (On the GPU box the same code runs with HipOps over RCCL.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, case, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ndcn_amd import graphs, sharding
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from _oracle_ops import OracleOps
+        cpu = torch.device('cpu')
+        H = 12
+        torch.manual_seed(0)
+        f = ODEFunc(H, None)
+        if case == 'grid':
+            R, C = 14, 9
+            full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(R, C))
+            bounds = [(R * r // world) * C for r in range(world + 1)]
+            block = graphs.grid_operator_row_block(R, C, bounds[rank] // C, bounds[rank + 1] // C)
+            assert abs(block - full[bounds[rank]:bounds[rank + 1]]).max() < 1e-7      # windowed build == global build
+        else:
+            full = graphs.normalized_laplacian(graphs.make_graph('small_world', 150, seed=3))
+            bounds = sharding.even_bounds(150, world)
+            block = full[bounds[rank]:bounds[rank + 1]]
+        n = full.shape[0]
+        plan = sharding.HaloPlan(block, bounds, rank, cpu)
+        x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
+        xl = x[bounds[rank]:bounds[rank + 1]].contiguous()
+        t = torch.linspace(0., 1.5, 4)
+        out = {}
+        for method in ('rk4', 'dopri5'):
+            log = []
+            y = sharding.sharded_odeint(OracleOps, f, plan, n, xl, t, rtol=1e-3, atol=1e-4, method=method, step_log=log)
+            out[method] = y.detach().numpy()
+            out[method + '_log'] = [r for r in log if r[0] != 'nfe']
+        out['halo'] = plan.n_halo
+        out['W'] = f.wt.weight.detach().numpy()
+        out['b'] = f.wt.bias.detach().numpy()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['grid', 'small_world'])
+def test_two_rank_sharded_solve_equals_single_process_oracle(case):
+    world = 2
+    port = 29600 + (os.getpid() % 300) + (0 if case == 'grid' else 1)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    sys.path.insert(0, ROOT)
+    from ndcn_amd import graphs, sharding
+    from oracle import ndcn_oracle as orc
+    H = 12
+    if case == 'grid':
+        full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(14, 9))
+    else:
+        full = graphs.normalized_laplacian(graphs.make_graph('small_world', 150, seed=3))
+    n = full.shape[0]
+    A = orc.coo_from_csr(full.indptr, full.indices, full.data, full.shape)
+    f = orc.OracleODEFunc(A, torch.from_numpy(ret[0]['W']), torch.from_numpy(ret[0]['b']))
+    x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
+    t = torch.linspace(0., 1.5, 4)
+    assert ret[0]['halo'] > 0 and ret[1]['halo'] > 0
+    for method in ('rk4', 'dopri5'):
+        log = []
+        ref = orc.odeint(f, x, t, rtol=1e-3, atol=1e-4, method=method, step_log=log).numpy()
+        got = np.concatenate([ret[r][method] for r in range(world)], axis=1)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 5e-6
+        if method == 'dopri5':
+            assert ret[0]['dopri5_log'] == ret[1]['dopri5_log']            # identical decisions on every rank
+            assert [r[2] for r in ret[0]['dopri5_log']] == [r[2] for r in log]
+            assert np.allclose([r[1] for r in ret[0]['dopri5_log']], [r[1] for r in log], rtol=1e-5)

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmarks on the metric's case (1M-node grid, H=256) - tuning aid, not the judged bench.
+Each variant runs in its own process because the library reads its tuning knobs (env) once.
+    python tools/bench_kernels.py            # sweep
+    python tools/bench_kernels.py --one NAME # one variant in this process
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VARIANTS = {
+    'spmm_blocked': {'NDCN_SPMM_WIDE': '0'},
+    'spmm_wide_bpc2': {'NDCN_SPMM_BLOCKS_PER_CU': '2'},
+    'spmm_wide_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4'},
+    'spmm_wide_bpc6': {'NDCN_SPMM_BLOCKS_PER_CU': '6'},
+    'spmm_wide_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8'},
+    'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
+    'rhs_fused_p4': {'NDCN_RHS_PRODUCERS': '4'},
+    'rhs_fused_p8': {'NDCN_RHS_PRODUCERS': '8'},
+}
+
+
+def one(name, side=1000, H=256, reps=20):
+    import torch
+    from ndcn_amd import graphs, hip
+    dev = torch.device('cuda:0')
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    A = graphs.to_device(L, dev)
+    n = side * side
+    torch.manual_seed(0)
+    X = torch.rand(n, H, device=dev)
+    lin = torch.nn.Linear(H, H).to(dev)
+    W, b = lin.weight.detach(), lin.bias.detach()
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = {'variant': name}
+    Y = torch.empty_like(X)
+    if name.startswith('spmm'):
+        ms = timeit(lambda: hip.spmm(A, X, out=Y))
+        res.update(ms=ms, GBps=graphs.spmm_bytes(n, L.nnz, H) / ms / 1e6)
+        ref = torch.sparse.mm(A.to_torch_coo()[:0 + 0] if False else A.to_torch_coo(), X[:, :4].contiguous()) if False else None
+    else:
+        ms = timeit(lambda: hip.rhs(A, X, W, b, out=Y))
+        fl = 2.0 * L.nnz * H + 2.0 * n * H * H
+        res.update(ms=ms, TFLOPs=fl / ms / 1e9, GBps=graphs.spmm_bytes(n, L.nnz, H) / ms / 1e6)
+        # cross-check fused vs unfused result on a row sample
+        S = hip.spmm(A, X)
+        ref = torch.relu(torch.nn.functional.linear(S[:4096].double(), W.double(), b.double()))
+        res['max_err_vs_fp64'] = float((Y[:4096].double() - ref).abs().max())
+    if name == 'rhs_unfused':
+        S = torch.empty_like(X)
+        res['linear_ms'] = timeit(lambda: hip.linear(X, W, b, relu=True))
+        ks = [torch.rand_like(X) for _ in range(6)]
+        cs = [0.1 * (i + 1) for i in range(6)]
+        for nk in (1, 3, 6):
+            ms = timeit(lambda: hip.combine(X, ks[:nk], cs[:nk]))
+            res['combine%d_ms' % nk] = ms
+            res['combine%d_GBps' % nk] = 4.0 * n * H * (nk + 2) / ms / 1e6
+        ms = timeit(lambda: Y.copy_(X))
+        res['copy_GBps'] = 8.0 * n * H / ms / 1e6
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == '__main__':
+    if '--one' in sys.argv:
+        one(sys.argv[sys.argv.index('--one') + 1])
+    else:
+        for name, env in VARIANTS.items():
+            e = dict(os.environ)
+            e.update(env)
+            subprocess.run([sys.executable, os.path.abspath(__file__), '--one', name], env=e)
