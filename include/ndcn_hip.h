@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 1
+#define NDCN_ABI_VERSION 2
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -57,6 +57,9 @@ typedef struct ndcn_csr {
     const int32_t *rowptr;    /* [n_rows + 1] */
     const int32_t *colidx;    /* [nnz]        */
     const float   *val;       /* [nnz]        */
+    const int32_t *row_order; /* [n_rows] or NULL: a permutation of the rows giving the order in which the
+                                 kernels WALK them (a cache-locality hint, e.g. lattice tiles); results are
+                                 identical for any permutation                                              */
 } ndcn_csr;
 
 NDCN_API int         ndcn_abi_version(void);

@@ -24,6 +24,7 @@ class CsrOperator:
         assert self.colidx.numel() == self.val.numel()
         self._view = None
         self._t = None
+        self.row_order = None        # optional int32 permutation: the order in which kernels walk the rows
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -88,14 +89,26 @@ class CsrOperator:
         device = torch.device(device)
         if device == self.val.device:
             return self
-        return CsrOperator(self.rowptr.to(device), self.colidx.to(device), self.val.to(device), self.shape)
+        op = CsrOperator(self.rowptr.to(device), self.colidx.to(device), self.val.to(device), self.shape)
+        if self.row_order is not None:
+            op.row_order = self.row_order.to(device)
+        return op
+
+    def set_row_order(self, order):
+        """Attach a walk order (a permutation of range(n_rows)); purely a locality hint."""
+        order = torch.as_tensor(np.asarray(order), dtype=torch.int32)
+        assert order.numel() == self.shape[0]
+        self.row_order = order.to(self.device).contiguous()
+        self._view = None
+        return self
 
     def view(self):
         """ctypes struct ndcn_csr borrowing this object's device arrays."""
         if self._view is None:
             self._view = _lib.CsrView(self.shape[0], self.shape[1], self.nnz,
                                       self.rowptr.data_ptr(), self.colidx.data_ptr() if self.nnz else None,
-                                      self.val.data_ptr() if self.nnz else None)
+                                      self.val.data_ptr() if self.nnz else None,
+                                      self.row_order.data_ptr() if self.row_order is not None else None)
         return self._view
 
     def view_ref(self):

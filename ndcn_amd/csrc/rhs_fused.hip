@@ -79,7 +79,7 @@ __device__ __forceinline__ void produce_rows(const int *__restrict__ rowptr, con
                                              const float *__restrict__ val, const f32x4 *__restrict__ X,
                                              const f32x4 *__restrict__ Xh, int n_own, int n_rows, int row0, int first,
                                              int count, int lane, float *dst) {
-    for (int rr = first; rr < first + count; ++rr) {
+    for (int rr = first; rr < first + count && rr < kTileRows; ++rr) {
         const int r = row0 + rr;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (r < n_rows) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256 + 64 * NPROD) void rhs_fused_256_kernel(
     const int wgs_per_xcd = gridDim.x / kXcds;
     const int chunk = (n_tiles + kXcds - 1) / kXcds;
     const int t_lo = xcd * chunk, t_hi = min(n_tiles, t_lo + chunk);
-    constexpr int kRowsPerProducer = kTileRows / NPROD;
+    constexpr int kRowsPerProducer = (kTileRows + NPROD - 1) / NPROD;      // 12 producers: 6 rows, the last 2 idle
 
     int t = t_lo + wg;
     if (t >= t_hi) return;                                     // whole workgroup: uniform
@@ -234,7 +234,8 @@ int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int
             hipLaunchKernelGGL((rhs_fused_256_kernel<NP, false>), grid, dim3(256 + 64 * NP), 0, st, A->rowptr,      \
                                A->colidx, A->val, X, Xh, (int)n_own, Wp, b, Y, n_rows, n_tiles, relu);              \
     } while (0)
-    if (nprod >= 8) NDCN_FUSED(8);
+    if (nprod >= 12) NDCN_FUSED(12);
+    else if (nprod >= 8) NDCN_FUSED(8);
     else NDCN_FUSED(4);
 #undef NDCN_FUSED
     NDCN_LAUNCH_CHECK();

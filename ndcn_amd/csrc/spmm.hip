@@ -183,7 +183,8 @@ __device__ __forceinline__ void wide_chunk(int c, float v, int cnt, const f32x4 
 
 template <int NV, bool HALO>
 __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ rowptr, const int *__restrict__ colidx,
-                                                        const float *__restrict__ val, const float *__restrict__ Xf,
+                                                        const float *__restrict__ val, const int *__restrict__ order,
+                                                        const float *__restrict__ Xf,
                                                         const float *__restrict__ Xhf, int n_own,
                                                         float *__restrict__ Yf, int n_rows, float alpha, int relu) {
     const int lane = threadIdx.x & 63;
@@ -198,8 +199,9 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
     f32x4 *Y = reinterpret_cast<f32x4 *>(Yf);
     constexpr size_t stride = 64 * NV;                    // float4 slots per panel row
 
-    int r = __builtin_amdgcn_readfirstlane(row_lo + w);
-    if (r >= row_hi) return;
+    int pos = __builtin_amdgcn_readfirstlane(row_lo + w);          // position in the walk order
+    if (pos >= row_hi) return;
+    int r = order ? order[pos] : pos;
     // software pipeline: the first <= 64 (col, val) pairs of the NEXT row are fetched while this row's
     // neighbour rows are in flight
     int j0 = rowptr[r], j1 = rowptr[r + 1];
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
     float v = 0.f;
     if (lane < j1 - j0) { c = colidx[j0 + lane]; v = val[j0 + lane]; }
     while (true) {
-        const int rn = r + waves_per_xcd;
-        const bool more = rn < row_hi;
-        int nj0 = 0, nj1 = 0;
-        if (more) { nj0 = rowptr[rn]; nj1 = rowptr[rn + 1]; }
+        const int pn = pos + waves_per_xcd;
+        const bool more = pn < row_hi;
+        int rn = 0, nj0 = 0, nj1 = 0;
+        if (more) { rn = order ? order[pn] : pn; nj0 = rowptr[rn]; nj1 = rowptr[rn + 1]; }
         f32x4 acc[NV];
 #pragma unroll
         for (int u = 0; u < NV; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
             __builtin_nontemporal_store(o, &Y[(size_t)r * stride + lane + 64 * u]);
         }
         if (!more) break;
-        r = rn; j0 = nj0; j1 = nj1; c = nc; v = nv;
+        pos = pn; r = rn; j0 = nj0; j1 = nj1; c = nc; v = nv;
     }
 }
 
@@ -259,11 +261,11 @@ static int launch_wide(const ndcn_csr *A, const float *X, const float *Xh, int64
     const int relu = (flags & NDCN_F_RELU) ? 1 : 0;
     const dim3 grid(per_xcd * kXcds), block(256);
     if (Xh)
-        hipLaunchKernelGGL((spmm_wide_kernel<NV, true>), grid, block, 0, st, A->rowptr, A->colidx, A->val, X, Xh,
-                           (int)n_own, Y, n_rows, alpha, relu);
+        hipLaunchKernelGGL((spmm_wide_kernel<NV, true>), grid, block, 0, st, A->rowptr, A->colidx, A->val,
+                           A->row_order, X, Xh, (int)n_own, Y, n_rows, alpha, relu);
     else
-        hipLaunchKernelGGL((spmm_wide_kernel<NV, false>), grid, block, 0, st, A->rowptr, A->colidx, A->val, X, Xh,
-                           (int)n_own, Y, n_rows, alpha, relu);
+        hipLaunchKernelGGL((spmm_wide_kernel<NV, false>), grid, block, 0, st, A->rowptr, A->colidx, A->val,
+                           A->row_order, X, Xh, (int)n_own, Y, n_rows, alpha, relu);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

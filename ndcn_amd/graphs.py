@@ -287,6 +287,23 @@ def x0_blocks(S):
     return x0.reshape(-1, 1)
 
 
+def grid_tile_order(R, C, tile_cols=256, n_chunks=8):
+    """Walk order for an R x C lattice operator: the rows are cut into `n_chunks` contiguous lattice-row bands
+    (one per XCD, matching the kernels' contiguous chunking of the order array) and each band is walked in
+    column strips of `tile_cols`, lattice row by lattice row inside a strip.  A node's 8 neighbours then recur
+    within ~2 (tile_cols + 2) walked rows instead of ~2 C, which keeps the X window inside one XCD's L2."""
+    R, C = int(R), int(C)
+    n = R * C
+    per = (n + n_chunks - 1) // n_chunks          # the kernels chunk POSITIONS evenly; keep bands aligned to that
+    order = np.empty(n, dtype=np.int32)
+    idx = np.arange(n, dtype=np.int64)
+    x, y = idx // C, idx % C
+    band = idx // per
+    key = (band * ((C + tile_cols - 1) // tile_cols + 1) + y // tile_cols) * (R + 1) + x
+    order[:] = np.lexsort((y, key)).astype(np.int32)
+    return order
+
+
 def to_device(m, device):
     return CsrOperator.from_scipy(m, device)
 

@@ -108,7 +108,7 @@ class HipOps:
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
         lib = _lib.load()
         if no_graph:
-            view = _lib.CsrView(X.shape[0], X.shape[0], 0, None, None, None)
+            view = _lib.CsrView(X.shape[0], X.shape[0], 0, None, None, None, None)
             view_ref = ctypes.byref(view)
             n_rows = X.shape[0]
         else:

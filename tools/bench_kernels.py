@@ -18,7 +18,17 @@ VARIANTS = {
     'spmm_wide_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4'},
     'spmm_wide_bpc6': {'NDCN_SPMM_BLOCKS_PER_CU': '6'},
     'spmm_wide_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8'},
+    'spmm_wide_tile64': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '64'},
+    'spmm_wide_tile128': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '128'},
+    'spmm_wide_tile256': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '256'},
+    'spmm_wide_tile256_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'TILE': '256'},
+    'spmm_wide_tile500': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '500'},
+    'spmm_band9_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'SYNTH': 'band9'},
+    'spmm_band9_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'SYNTH': 'band9'},
+    'spmm_self9_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'SYNTH': 'self9'},
+    'spmm_diag1_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'SYNTH': 'diag1'},
     'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
+    'rhs_fused_p12': {'NDCN_RHS_PRODUCERS': '12'},
     'rhs_fused_p4': {'NDCN_RHS_PRODUCERS': '4'},
     'rhs_fused_p8': {'NDCN_RHS_PRODUCERS': '8'},
 }
@@ -28,9 +38,25 @@ def one(name, side=1000, H=256, reps=20):
     import torch
     from ndcn_amd import graphs, hip
     dev = torch.device('cuda:0')
-    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
-    A = graphs.to_device(L, dev)
     n = side * side
+    synth = os.environ.get('SYNTH')
+    if synth:
+        import numpy as np
+        import scipy.sparse as sp
+        i = np.arange(n, dtype=np.int64)
+        if synth == 'band9':
+            cols = np.clip(i[:, None] + np.arange(-4, 5)[None, :], 0, n - 1)
+        elif synth == 'self9':
+            cols = np.repeat(i[:, None], 9, 1)
+        else:
+            cols = i[:, None]
+        k = cols.shape[1]
+        L = sp.csr_matrix((np.full(n * k, 0.1, np.float32), cols.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+    else:
+        L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    A = graphs.to_device(L, dev)
+    if os.environ.get('TILE'):
+        A.set_row_order(graphs.grid_tile_order(side, side, int(os.environ['TILE'])))
     torch.manual_seed(0)
     X = torch.rand(n, H, device=dev)
     lin = torch.nn.Linear(H, H).to(dev)
@@ -53,7 +79,9 @@ def one(name, side=1000, H=256, reps=20):
     if name.startswith('spmm'):
         ms = timeit(lambda: hip.spmm(A, X, out=Y))
         res.update(ms=ms, GBps=graphs.spmm_bytes(n, L.nnz, H) / ms / 1e6)
-        ref = torch.sparse.mm(A.to_torch_coo()[:0 + 0] if False else A.to_torch_coo(), X[:, :4].contiguous()) if False else None
+        if os.environ.get('TILE'):       # order hint must not change the result
+            Y0 = hip.spmm(graphs.to_device(L, dev), X)
+            res['equal_to_unordered'] = bool(torch.equal(Y0, Y))
     else:
         ms = timeit(lambda: hip.rhs(A, X, W, b, out=Y))
         fl = 2.0 * L.nnz * H + 2.0 * n * H * H
