@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 2
+#define NDCN_ABI_VERSION 3
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -60,6 +60,17 @@ typedef struct ndcn_csr {
     const int32_t *row_order; /* [n_rows] or NULL: a permutation of the rows giving the order in which the
                                  kernels WALK them (a cache-locality hint, e.g. lattice tiles); results are
                                  identical for any permutation                                              */
+    /* Optional "row-group union" plan (NULL / 0 when absent), built once per operator by the host
+     * (ndcn_amd/csr.py:build_union_plan): rows are cut into groups of `ug_rows`; for group g the DISTINCT
+     * columns its rows reference are ug_cols[ug_ptr[g] .. ug_ptr[g+1]) (ascending) and entry j of the CSR
+     * refers to ug_cols[ug_ptr[g] + ug_lidx[j]].  A kernel then fetches each distinct neighbour row of a group
+     * ONCE into LDS and serves the group's rows from there.  A group whose union exceeds the plan's cap has
+     * an empty range and ug_lidx unused: the kernel gathers it directly.                                    */
+    int32_t        ug_rows;
+    int32_t        ug_cap;    /* largest union size in the plan (LDS rows the kernel must provide)            */
+    const int32_t *ug_ptr;    /* [n_groups + 1] */
+    const int32_t *ug_cols;   /* [ug_ptr[n_groups]] */
+    const uint16_t *ug_lidx;  /* [nnz] */
 } ndcn_csr;
 
 NDCN_API int         ndcn_abi_version(void);

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
@@ -33,7 +33,9 @@ class CsrView(ctypes.Structure):
     """struct ndcn_csr"""
     _fields_ = [('n_rows', ctypes.c_int64), ('n_cols', ctypes.c_int64), ('nnz', ctypes.c_int64),
                 ('rowptr', ctypes.c_void_p), ('colidx', ctypes.c_void_p), ('val', ctypes.c_void_p),
-                ('row_order', ctypes.c_void_p)]
+                ('row_order', ctypes.c_void_p),
+                ('ug_rows', ctypes.c_int32), ('ug_cap', ctypes.c_int32), ('ug_ptr', ctypes.c_void_p),
+                ('ug_cols', ctypes.c_void_p), ('ug_lidx', ctypes.c_void_p)]
 
 
 class SolverDesc(ctypes.Structure):

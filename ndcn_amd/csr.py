@@ -5,6 +5,7 @@ The reference keeps its operator `A` as a dense torch matrix or a torch sparse C
 column-ascending rows; this module converts once and caches the result next to the tensor it came from.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -25,6 +26,7 @@ class CsrOperator:
         self._view = None
         self._t = None
         self.row_order = None        # optional int32 permutation: the order in which kernels walk the rows
+        self.union = None            # optional row-group union plan (build_union_plan)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -92,6 +94,8 @@ class CsrOperator:
         op = CsrOperator(self.rowptr.to(device), self.colidx.to(device), self.val.to(device), self.shape)
         if self.row_order is not None:
             op.row_order = self.row_order.to(device)
+        if self.union is not None:
+            op.union = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.union.items()}
         return op
 
     def set_row_order(self, order):
@@ -102,13 +106,71 @@ class CsrOperator:
         self._view = None
         return self
 
+    def build_union_plan(self, rows_per_group=16, cap=56):
+        """Row-group union plan (see include/ndcn_hip.h): per group of consecutive rows, the distinct columns
+        they reference and, per CSR entry, its index into that list.  One-off preprocessing with torch ops on
+        the operator's device; groups whose union exceeds `cap` get an empty range (the kernel gathers them
+        directly).  Returns the fraction of non-zeros served from a group union (0 = no reuse worth staging)."""
+        n, R = self.shape[0], int(rows_per_group)
+        dev = self.device
+        ng = (n + R - 1) // R
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+        grp = torch.div(rows, R, rounding_mode='floor')
+        key = grp * self.shape[1] + self.colidx.to(torch.int64)
+        uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+        ugrp = torch.div(uniq, self.shape[1], rounding_mode='floor')
+        usize = torch.bincount(ugrp, minlength=ng)
+        ok = usize <= cap                                   # groups that fit the LDS stage
+        uptr_all = torch.zeros(ng + 1, dtype=torch.int64, device=dev)
+        uptr_all[1:] = torch.cumsum(usize, 0)
+        keep_u = ok[ugrp]
+        kept_size = torch.where(ok, usize, torch.zeros_like(usize))
+        ptr = torch.zeros(ng + 1, dtype=torch.int64, device=dev)
+        ptr[1:] = torch.cumsum(kept_size, 0)
+        cols = (uniq - ugrp * self.shape[1])[keep_u]
+        lidx = inv - uptr_all[grp]                           # position of the entry's column inside its group
+        lidx = torch.where(ok[grp], lidx, torch.zeros_like(lidx))
+        staged_nnz = int(ok[grp].sum()) if self.nnz else 0
+        self.union = {'rows': R, 'cap': int(kept_size.max()) if ng else 0, 'ptr': ptr.to(torch.int32).contiguous(),
+                      'cols': cols.to(torch.int32).contiguous(),
+                      'lidx': lidx.to(torch.int16).contiguous(),       # < cap <= 65535; reinterpreted as uint16
+                      'loads_per_row': float(kept_size.sum() + (counts.sum() - staged_nnz)) / max(n, 1)}
+        if cols.numel() == 0:
+            self.union['cols'] = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._view = None
+        return staged_nnz / max(self.nnz, 1)
+
+    def ensure_plans(self, H):
+        """One-off, lazy: attach the row-group union plan when the panel width has a kernel that uses it
+        (H = 256) and the graph has enough neighbour sharing between consecutive rows for it to pay."""
+        if H != 256 or self.union is not None or getattr(self, '_union_tried', False) or self.device.type != 'cuda':
+            return self
+        self._union_tried = True
+        rows = int(os.environ.get('NDCN_UNION_ROWS', '16'))
+        cap = int(os.environ.get('NDCN_UNION_CAP', '56'))
+        if rows <= 0 or self.nnz == 0:
+            return self
+        self.build_union_plan(rows, cap)
+        avg = self.nnz / max(self.shape[0], 1)
+        if self.union['loads_per_row'] > 0.75 * avg:        # < 25 % fewer fetches: not worth the LDS round trip
+            self.union = None
+            self._view = None
+        return self
+
     def view(self):
         """ctypes struct ndcn_csr borrowing this object's device arrays."""
         if self._view is None:
             self._view = _lib.CsrView(self.shape[0], self.shape[1], self.nnz,
                                       self.rowptr.data_ptr(), self.colidx.data_ptr() if self.nnz else None,
                                       self.val.data_ptr() if self.nnz else None,
-                                      self.row_order.data_ptr() if self.row_order is not None else None)
+                                      self.row_order.data_ptr() if self.row_order is not None else None,
+                                      0, 0, None, None, None)
+            if self.union is not None:
+                u = self.union
+                self._view.ug_rows, self._view.ug_cap = u['rows'], u['cap']
+                self._view.ug_ptr, self._view.ug_cols = u['ptr'].data_ptr(), u['cols'].data_ptr()
+                self._view.ug_lidx = u['lidx'].data_ptr()
         return self._view
 
     def view_ref(self):

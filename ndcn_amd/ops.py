@@ -77,6 +77,7 @@ class HipOps:
             'operator has %d columns, panels supply %d rows' % (A.shape[1], n_own + (0 if X_halo is None else X_halo.shape[0]))
         if A.device != X2.device:
             raise _lib.NdcnHipError(_lib.EINVAL, 'operator on %s, panel on %s' % (A.device, X2.device))
+        A.ensure_plans(H)
         Y = out if out is not None else torch.empty((A.shape[0], H), dtype=torch.float32, device=X2.device)
         with torch.cuda.device(X2.device):
             check(_lib.load().ndcn_spmm_f32(A.view_ref(), ptr(X2), ptr(X_halo), n_own, ptr(Y), H, float(alpha),
@@ -108,13 +109,14 @@ class HipOps:
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
         lib = _lib.load()
         if no_graph:
-            view = _lib.CsrView(X.shape[0], X.shape[0], 0, None, None, None, None)
+            view = _lib.CsrView(X.shape[0], X.shape[0], 0, None, None, None, None, 0, 0, None, None, None)
             view_ref = ctypes.byref(view)
             n_rows = X.shape[0]
         else:
             A = as_csr(A)
             if A.device != X.device:
                 raise _lib.NdcnHipError(_lib.EINVAL, 'operator on %s, panel on %s' % (A.device, X.device))
+            A.ensure_plans(H)
             view_ref = A.view_ref()
             n_rows = A.shape[0]
         if not no_control:
@@ -190,7 +192,9 @@ class HipOps:
         return a, b, c, d
 
     @staticmethod
-    def interp_eval(a, b, c, d, e, xpow, out=None):
+    def interp_eval(fit, e, xpow, out=None):
+        """`fit` = the (a, b, c, d) panels interp_fit returned; e = y at the start of the fitted step."""
+        a, b, c, d = fit
         e = _panel(e)
         if out is None:
             out = torch.empty_like(e)

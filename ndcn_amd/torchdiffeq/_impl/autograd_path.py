@@ -1,8 +1,12 @@
-"""odeint when a gradient is required (backprop through the solver, as the reference drivers train:
-heat_dynamics.py:333).  SURVEY.md 8f rank 1 - not built yet; fails loudly instead of returning a
-forward-only result that autograd would treat as a constant."""
+"""odeint when a gradient is required: backpropagation THROUGH the solver, as the reference drivers train
+(heat_dynamics.py:333, dgnn.py:204) - the reference's control flow (core.py) over differentiable HIP ops."""
+from ...autograd_ops import autograd_ops
+from . import core
 
 
 def odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=False):
-    raise NotImplementedError('ndcn_amd.odeint: backward through the HIP solver is not built yet '
-                              '(SURVEY.md 8f rank 1). Run under torch.no_grad() / with parameters frozen.')
+    if method == 'dopri5':
+        return core.integrate_dopri5(autograd_ops, func, y0, t, rtol, atol, autonomous=autonomous, **options)
+    if options:
+        raise NotImplementedError('fixed-grid options %s: only the default grid (grid == t) is provided' % sorted(options))
+    return core.integrate_fixed(autograd_ops, func, y0, t, method, autonomous=autonomous)

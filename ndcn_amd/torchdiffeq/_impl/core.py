@@ -296,9 +296,9 @@ class Dopri5:
         if self.fit is None:
             y0, y1, k, dt32 = self.stage
             cmid = [f32(dt32 * f32(c)) for c in DP_C_MID]
-            abcd = [self.ops.interp_fit(a_, b_, k_, cmid, dt32) for a_, b_, k_ in zip(y0, y1, k)]
-            self.fit = (abcd, y0)
-        abcd, e = self.fit
+            fits = [self.ops.interp_fit(a_, b_, k_, cmid, dt32) for a_, b_, k_ in zip(y0, y1, k)]
+            self.fit = (fits, y0)
+        fits, e = self.fit
         # interp.py:51-65: abscissa and powers in the state dtype
         a0, a1, at = f32(self.t0), f32(self.t1), f32(next_t)
         assert (a0 <= at) and (at <= a1), 'invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}'.format(a0, at, a1)
@@ -307,7 +307,7 @@ class Dopri5:
         x3 = f32(x2 * x)
         x4 = f32(x3 * x)
         xp = (x4, x3, x2, x, f32(1))
-        return tuple(self.ops.interp_eval(c[0], c[1], c[2], c[3], e_, xp) for c, e_ in zip(abcd, e))
+        return tuple(self.ops.interp_eval(fit, e_, xp) for fit, e_ in zip(fits, e))
 
 
 def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=None, **options):

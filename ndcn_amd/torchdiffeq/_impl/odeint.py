@@ -107,13 +107,14 @@ class DeviceSolver:
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
         dev = odefunc.wt.weight.device
         if odefunc.no_graph:
-            view = _lib.CsrView(n_rows, n_rows, 0, None, None, None, None)
+            view = _lib.CsrView(n_rows, n_rows, 0, None, None, None, None, 0, 0, None, None, None)
             self._keep = ()
         else:
             csr = as_csr(odefunc.A)
             if csr.device != dev:
                 raise _lib.NdcnHipError(_lib.EINVAL, 'operator on %s, weights on %s' % (csr.device, dev))
             assert csr.shape[0] == n_rows, 'operator has %d rows, state has %d' % (csr.shape[0], n_rows)
+            csr.ensure_plans(H)
             view = csr.view()
             self._keep = (csr,)
         W = odefunc.wt.weight.detach().contiguous()

@@ -91,7 +91,8 @@ class OracleOps:
         return a, b, c, d
 
     @staticmethod
-    def interp_eval(a, b, c, d, e, xpow, out=None):
+    def interp_eval(fit, e, xpow, out=None):
+        a, b, c, d = fit
         xs = [_c(v) for v in xpow]
         return orc._dot((a, b, c, d, e), xs)
 

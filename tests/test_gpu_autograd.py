@@ -1,0 +1,118 @@
+"""Backward of the path on a real MI355X: gradients of the HIP ops / solver against
+torch autograd through the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ndcn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize('name', ['rhs_grid400_H20_default_coo', 'rhs_grid400_H20_no_control_coo',
+                                  'rhs_grid400_H20_no_graph_coo', 'rhs_grid400_H256_default_coo'])
+def test_rhs_gradients(dev, name):
+    from ndcn_amd import CsrOperator
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden(name)
+    H = d['W'].shape[0]
+    kw = dict(no_graph='no_graph' in name, no_control='no_control' in name)
+    f = ODEFunc(H, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev), **kw).to(dev)
+    f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+    x = T(d['x']).to(dev).requires_grad_(True)
+    g = torch.randn(400, H, generator=torch.Generator().manual_seed(0))
+    y = f(torch.tensor(0.0), x)
+    assert np.abs(y.detach().cpu().numpy() - d['out']).max() < 2e-5
+    (y * g.to(dev)).sum().backward()
+    # oracle autograd
+    A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape'])
+    W, b, xc = T(d['W']).requires_grad_(True), T(d['b']).requires_grad_(True), T(d['x']).requires_grad_(True)
+    (orc.odefunc_rhs(A, xc, W, b, **kw) * g).sum().backward()
+    assert rel(x.grad.cpu(), xc.grad) < 1e-4
+    if not kw['no_control']:
+        assert rel(f.wt.weight.grad.cpu(), W.grad) < 1e-4
+        assert rel(f.wt.bias.grad.cpu(), b.grad) < 1e-4
+    else:
+        assert f.wt.weight.grad is None or float(f.wt.weight.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('method,rtol,atol,tol', [('euler', 0, 0, 2e-4), ('midpoint', 0, 0, 2e-4), ('rk4', 0, 0, 2e-4),
+                                                  ('dopri5', 1e-6, 1e-8, 2e-3)])
+def test_backprop_through_solver(dev, method, rtol, atol, tol):
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('fixed_rk4_equal')
+    t = torch.linspace(0., 1., 5)
+    f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
+    f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+    x = T(d['x0']).to(dev).requires_grad_(True)
+    target = torch.rand(5, 400, 20, generator=torch.Generator().manual_seed(1))
+    y = ode.odeint(f, x, t.to(dev), rtol=rtol or 1e-7, atol=atol or 1e-9, method=method)
+    loss = torch.nn.functional.l1_loss(y, target.to(dev))
+    loss.backward()
+    A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape'])
+    W, b, xc = T(d['W']).requires_grad_(True), T(d['b']).requires_grad_(True), T(d['x0']).requires_grad_(True)
+    fo = lambda tt, xx: orc.odefunc_rhs(A, xx, W, b)
+    yo = orc.odeint(fo, xc, t, rtol=rtol or 1e-7, atol=atol or 1e-9, method=method)
+    lo = torch.nn.functional.l1_loss(yo, target)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 1e-5
+    assert rel(x.grad.cpu(), xc.grad) < tol
+    assert rel(f.wt.weight.grad.cpu(), W.grad) < tol
+    assert rel(f.wt.bias.grad.cpu(), b.grad) < tol
+
+
+def test_ndcn_training_step_matches_reference_semantics(dev):
+    """One Adam step of the heat driver's loop (heat_dynamics.py:313-334) on the HIP path vs the oracle."""
+    from ndcn_amd.neural_dynamics import NDCN
+    d = load_golden('ndcn_ndcn_euler')
+    A = orc.dense_from_csr(d['indptr'], d['indices'], d['data'], d['shape'])
+    sd = {k[4:].replace('__', '.'): T(v) for k, v in d.items() if k.startswith('sd__')}
+    m = NDCN(1, 20, A.to(dev), 1, method='euler').to(dev)
+    m.load_state_dict(sd)
+    t, x0 = T(d['t']), T(d['x0'])
+    target = T(d['out']) * 0.9 + 0.1
+    opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-3)
+    opt.zero_grad()
+    pred = m(t.to(dev), x0.to(dev))
+    loss = torch.nn.functional.l1_loss(pred, target.to(dev))
+    loss.backward()
+    # oracle
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    po = orc.ndcn_forward(ps, A, t, x0, 'euler')
+    lo = torch.nn.functional.l1_loss(po, target)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 1e-5
+    for k, p in m.named_parameters():
+        assert rel(p.grad.cpu(), ps[k].grad) < 5e-4, k
+    opt.step()
+    with torch.no_grad():
+        l2 = torch.nn.functional.l1_loss(m(t.to(dev), x0.to(dev)), target.to(dev))
+    assert float(l2) < float(loss)
+
+
+def test_forward_only_kernels_are_not_used_silently(dev):
+    # requires_grad inputs must yield a graph, never a constant
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('fixed_rk4_equal')
+    f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
+    y = ode.odeint(f, T(d['x0']).to(dev), torch.tensor([0., .1, .2]).to(dev), method='dopri5', rtol=1e-3, atol=1e-4)
+    assert y.requires_grad and y.grad_fn is not None

@@ -98,6 +98,32 @@ def test_spmm_dense_and_coo_inputs_match_reference_layouts(dev):
     assert np.abs(y_coo - d['out']).max() < 1e-5
 
 
+@pytest.mark.parametrize('rows,cap', [(16, 56), (8, 30), (4, 60)])
+def test_spmm_union_plan_kernel(dev, rows, cap):
+    """H = 256 with a row-group union plan: staged groups, fallback groups, long rows, halo - all must equal
+    the plain kernel bit for bit (same summation order)."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(45))                  # 2025 rows, staged
+    rnd = rand_csr(2025, 2025, 9, seed=5, hubs=2)                                    # no sharing -> fallback
+    mixed = sp.vstack([grid[:1000], rnd[1000:]]).tocsr()
+    X = torch.randn(2025, 256).to(dev)
+    for m in (grid, mixed, rnd):
+        m.sort_indices()
+        plain = CsrOperator.from_scipy(m, dev)
+        plain._union_tried = True                                                    # keep it plan-free
+        ref = hip.spmm(plain, X)
+        A = CsrOperator.from_scipy(m, dev)
+        A._union_tried = True
+        A.build_union_plan(rows, cap)
+        assert torch.equal(hip.spmm(A, X), ref)
+        assert torch.equal(hip.spmm(A, X, alpha=-1.5, relu=True), hip.spmm(plain, X, alpha=-1.5, relu=True))
+        # halo split
+        got = hip.spmm(A, X[:1200].contiguous(), X_halo=X[1200:].contiguous())
+        assert torch.equal(got, ref)
+    ref64 = orc.spmm_f64(grid.indptr, grid.indices, grid.data, X.cpu().numpy())
+    assert np.abs(hip.spmm(A, X).cpu().numpy() - orc.spmm_f64(rnd.indptr, rnd.indices, rnd.data, X.cpu().numpy())).max() < 1e-3
+
+
 def test_gather_rows(dev):
     from ndcn_amd import hip
     X = torch.randn(1000, 20).to(dev)
@@ -183,8 +209,8 @@ def test_rk_kernels_bitwise_vs_reference_op_order(dev, shape):
         assert torch.equal(a.cpu(), b)
     x = np.float32(0.3)
     xp = (np.float32(x * x * x * x), np.float32(x * x * x), np.float32(x * x), x, np.float32(1))
-    got = hip.interp_eval(*[g(v) for v in ref], g(y0), xp).cpu()
-    assert torch.equal(got, OracleOps.interp_eval(*ref, y0, xp))
+    got = hip.interp_eval(tuple(g(v) for v in ref), g(y0), xp).cpu()
+    assert torch.equal(got, OracleOps.interp_eval(ref, y0, xp))
     for op in range(6):
         got = hip.fixed_stage(op, g(y0), g(ks[0]), g(ks[1]), g(ks[2]), g(ks[3]), dt=dt).cpu()
         assert torch.equal(got, OracleOps.fixed_stage(op, y0, ks[0], ks[1], ks[2], ks[3], dt=dt)), op

@@ -75,3 +75,30 @@ def test_zero_degree_nodes_are_defined():
 def test_algorithmic_bytes_of_the_metric_case():
     # 1M-node grid, H=256 -> 2.124 GB per SpMM
     assert abs(graphs.spmm_bytes(10 ** 6, 8988004, 256) / 1e9 - 2.124) < 1e-3
+
+
+def test_union_plan_reconstructs_the_columns():
+    """CsrOperator.build_union_plan: ug_cols[ug_ptr[g] + ug_lidx[j]] == colidx[j] for every staged entry."""
+    import torch
+    from ndcn_amd import CsrOperator
+    import scipy.sparse as sp
+    rng = np.random.RandomState(0)
+    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(40))
+    rnd = sp.random(1600, 1600, density=0.01, random_state=rng, format='csr', dtype=np.float32)
+    mixed = sp.vstack([grid[:800], rnd[800:]]).tocsr()
+    for m, rows, cap in ((grid, 16, 56), (grid, 8, 30), (mixed, 16, 56), (rnd, 16, 56)):
+        m.sort_indices()
+        A = CsrOperator.from_scipy(m)
+        frac = A.build_union_plan(rows, cap)
+        u = A.union
+        ptr, cols, lidx = u['ptr'].numpy().astype(np.int64), u['cols'].numpy(), u['lidx'].numpy().astype(np.uint16).astype(np.int64)
+        r = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
+        g = r // rows
+        staged = (ptr[g + 1] - ptr[g]) > 0
+        assert abs(staged.mean() - frac) < 1e-9
+        assert np.array_equal(cols[ptr[g[staged]] + lidx[staged]], m.indices[staged])
+        assert (ptr[1:] - ptr[:-1]).max() <= cap and u['cap'] == (ptr[1:] - ptr[:-1]).max()
+        for gi in np.unique(g[staged])[:50]:                      # union lists are ascending and duplicate-free
+            seg = cols[ptr[gi]:ptr[gi + 1]]
+            assert np.all(np.diff(seg) > 0)
+    assert frac == 0.0 or frac < 0.2          # the random matrix has (almost) no staged groups

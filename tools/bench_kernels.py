@@ -13,20 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'spmm_blocked': {'NDCN_SPMM_WIDE': '0'},
-    'spmm_wide_bpc2': {'NDCN_SPMM_BLOCKS_PER_CU': '2'},
-    'spmm_wide_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4'},
-    'spmm_wide_bpc6': {'NDCN_SPMM_BLOCKS_PER_CU': '6'},
-    'spmm_wide_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8'},
-    'spmm_wide_tile64': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '64'},
-    'spmm_wide_tile128': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '128'},
-    'spmm_wide_tile256': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '256'},
-    'spmm_wide_tile256_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'TILE': '256'},
-    'spmm_wide_tile500': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'TILE': '500'},
-    'spmm_band9_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'SYNTH': 'band9'},
-    'spmm_band9_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'SYNTH': 'band9'},
-    'spmm_self9_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'SYNTH': 'self9'},
-    'spmm_diag1_bpc8': {'NDCN_SPMM_BLOCKS_PER_CU': '8', 'SYNTH': 'diag1'},
+    'spmm_union_r16': {'NDCN_UNION_ROWS': '16', 'NDCN_UNION_CAP': '56'},
+    'spmm_union_r8': {'NDCN_UNION_ROWS': '8', 'NDCN_UNION_CAP': '30'},
+    'spmm_union_r12': {'NDCN_UNION_ROWS': '12', 'NDCN_UNION_CAP': '42'},
+    'spmm_union_r20': {'NDCN_UNION_ROWS': '20', 'NDCN_UNION_CAP': '63'},
+    'spmm_blocked': {'NDCN_SPMM_WIDE': '0', 'NDCN_UNION_ROWS': '0'},
+    'spmm_wide_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'NDCN_UNION_ROWS': '0'},
+    'spmm_diag1_wide': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'SYNTH': 'diag1', 'NDCN_UNION_ROWS': '0'},
     'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
     'rhs_fused_p12': {'NDCN_RHS_PRODUCERS': '12'},
     'rhs_fused_p4': {'NDCN_RHS_PRODUCERS': '4'},
