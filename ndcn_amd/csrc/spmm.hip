@@ -269,7 +269,7 @@ __device__ __forceinline__ void lds_batch(int li, float v, int i, const f32x4 *s
     for (int q = 0; q < U; ++q) acc = vv[q] * x[q] + acc;
 }
 
-template <bool HALO>
+template <bool HALO, bool DMA>
 __global__ __launch_bounds__(256) void spmm_union_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colidx, const float *__restrict__ val,
     const int *__restrict__ ug_ptr, const int *__restrict__ ug_cols, const unsigned short *__restrict__ ug_lidx,
@@ -289,7 +289,20 @@ __global__ __launch_bounds__(256) void spmm_union_kernel(
     const int r_hi = min(n_rows, r_lo + ug_rows);
 
     if (nu > 0) {
-        // ---- stage the union: wave w takes entries w, w+4, ...; 8 fetches in flight per wave
+        // ---- stage the union: wave w takes entries w, w+4, ...
+        if (DMA) {
+            // LDS-DMA: global -> LDS without a VGPR round trip; the LDS address is the wave-uniform row base,
+            // the hardware adds lane * 16
+            for (int u = wave; u < nu; u += 4) {
+                int c = ug_cols[u0 + u];
+                const f32x4 *p = X;
+                if (HALO && c >= n_own) { p = Xh; c -= n_own; }
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(p + (size_t)c * 64 + lane),
+                    (__attribute__((address_space(3))) void *)(s_x + u * 64), 16, 0, 0);
+            }
+        } else
+        // 8 fetches in flight per wave through registers
         for (int base = wave; base < nu; base += 32) {
             f32x4 x[8];
 #pragma unroll
@@ -423,14 +436,14 @@ int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, 
             const int n_groups = (n_rows + A->ug_rows - 1) / A->ug_rows;
             const size_t lds = (size_t)(A->ug_cap > 0 ? A->ug_cap : 1) * 1024;
             const int relu = (flags & NDCN_F_RELU) ? 1 : 0;
-            if (Xh)
-                hipLaunchKernelGGL((spmm_union_kernel<true>), dim3(n_groups), dim3(256), lds, st, A->rowptr, A->colidx,
-                                   A->val, A->ug_ptr, A->ug_cols, A->ug_lidx, (int)A->ug_rows, X, Xh, (int)n_own, Y,
-                                   n_rows, alpha, relu);
-            else
-                hipLaunchKernelGGL((spmm_union_kernel<false>), dim3(n_groups), dim3(256), lds, st, A->rowptr, A->colidx,
-                                   A->val, A->ug_ptr, A->ug_cols, A->ug_lidx, (int)A->ug_rows, X, Xh, (int)n_own, Y,
-                                   n_rows, alpha, relu);
+            static const int dma = env_int("NDCN_UNION_DMA", 0);
+#define NDCN_UNION(HALO_, DMA_)                                                                                       \
+    hipLaunchKernelGGL((spmm_union_kernel<HALO_, DMA_>), dim3(n_groups), dim3(256), lds, st, A->rowptr, A->colidx,    \
+                       A->val, A->ug_ptr, A->ug_cols, A->ug_lidx, (int)A->ug_rows, X, Xh, (int)n_own, Y, n_rows,      \
+                       alpha, relu)
+            if (Xh) { if (dma) NDCN_UNION(true, true); else NDCN_UNION(true, false); }
+            else { if (dma) NDCN_UNION(false, true); else NDCN_UNION(false, false); }
+#undef NDCN_UNION
             NDCN_LAUNCH_CHECK();
             return NDCN_OK;
         }

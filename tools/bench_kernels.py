@@ -13,10 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'spmm_union_r16': {'NDCN_UNION_ROWS': '16', 'NDCN_UNION_CAP': '56'},
+    'spmm_union_r4': {'NDCN_UNION_ROWS': '4', 'NDCN_UNION_CAP': '18'},
+    'spmm_union_r6': {'NDCN_UNION_ROWS': '6', 'NDCN_UNION_CAP': '24'},
     'spmm_union_r8': {'NDCN_UNION_ROWS': '8', 'NDCN_UNION_CAP': '30'},
-    'spmm_union_r12': {'NDCN_UNION_ROWS': '12', 'NDCN_UNION_CAP': '42'},
-    'spmm_union_r20': {'NDCN_UNION_ROWS': '20', 'NDCN_UNION_CAP': '63'},
+    'spmm_union_r4_dma': {'NDCN_UNION_ROWS': '4', 'NDCN_UNION_CAP': '18', 'NDCN_UNION_DMA': '1'},
+    'spmm_union_r6_dma': {'NDCN_UNION_ROWS': '6', 'NDCN_UNION_CAP': '24', 'NDCN_UNION_DMA': '1'},
+    'spmm_union_r8_dma': {'NDCN_UNION_ROWS': '8', 'NDCN_UNION_CAP': '30', 'NDCN_UNION_DMA': '1'},
+    'spmm_union_r16_dma': {'NDCN_UNION_ROWS': '16', 'NDCN_UNION_CAP': '56', 'NDCN_UNION_DMA': '1'},
     'spmm_blocked': {'NDCN_SPMM_WIDE': '0', 'NDCN_UNION_ROWS': '0'},
     'spmm_wide_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'NDCN_UNION_ROWS': '0'},
     'spmm_diag1_wide': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'SYNTH': 'diag1', 'NDCN_UNION_ROWS': '0'},
@@ -72,6 +75,10 @@ def one(name, side=1000, H=256, reps=20):
     if name.startswith('spmm'):
         ms = timeit(lambda: hip.spmm(A, X, out=Y))
         res.update(ms=ms, GBps=graphs.spmm_bytes(n, L.nnz, H) / ms / 1e6)
+        if os.environ.get('NDCN_UNION_DMA'):
+            plain = graphs.to_device(L, dev)
+            plain._union_tried = True
+            res['equal_to_plain'] = bool(torch.equal(hip.spmm(plain, X), Y))
         if os.environ.get('TILE'):       # order hint must not change the result
             Y0 = hip.spmm(graphs.to_device(L, dev), X)
             res['equal_to_unordered'] = bool(torch.equal(Y0, Y))
