@@ -106,7 +106,7 @@ class CsrOperator:
         self._view = None
         return self
 
-    def build_union_plan(self, rows_per_group=16, cap=56):
+    def build_union_plan(self, rows_per_group=8, cap=30):
         """Row-group union plan (see include/ndcn_hip.h): per group of consecutive rows, the distinct columns
         they reference and, per CSR entry, its index into that list.  One-off preprocessing with torch ops on
         the operator's device; groups whose union exceeds `cap` get an empty range (the kernel gathers them
@@ -147,8 +147,8 @@ class CsrOperator:
         if H != 256 or self.union is not None or getattr(self, '_union_tried', False) or self.device.type != 'cuda':
             return self
         self._union_tried = True
-        rows = int(os.environ.get('NDCN_UNION_ROWS', '16'))
-        cap = int(os.environ.get('NDCN_UNION_CAP', '56'))
+        rows = int(os.environ.get('NDCN_UNION_ROWS', '8'))       # = the fused RHS kernel's row group
+        cap = int(os.environ.get('NDCN_UNION_CAP', '30'))        # LDS rows per staged group
         if rows <= 0 or self.nnz == 0:
             return self
         self.build_union_plan(rows, cap)

@@ -15,6 +15,12 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
 int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 int rhs_fused_supported(int H, uint32_t flags);
 int pack_weight_256(const float *W, float *Wp, hipStream_t st);
+int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);
+int64_t rhs_fused2_partials_bytes();
+// mode 0: K only; 1: also y_next = y0 + sum c_m kprev_m + c_new K; 2: also the dopri5 error record into d_out
+int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
+                   float *K, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c,
+                   int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 

@@ -32,7 +32,19 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
     const int64_t n = A->n_rows;
     if (graph && ctl) {
         if (!work) { set_error("rhs: scratch of ndcn_rhs_work_bytes() bytes required for H=%d", H); return NDCN_EINVAL; }
-        if (rhs_fused_supported(H, flags)) return rhs_fused_f32(A, X, Xh, n_own, W, b, Y, work, H, flags, st);
+        if (rhs_fused_supported(H, flags)) {
+            if (rhs_fused2_supported(A, H, flags)) {          // operator carries a row-group union plan
+                if (!(aligned16(X) && aligned16(Y) && aligned16(W) && aligned16(work) && (!Xh || aligned16(Xh)))) {
+                    set_error("rhs: panels must be 16-byte aligned");
+                    return NDCN_EINVAL;
+                }
+                int rc = pack_weight_256(W, work, st);
+                if (rc) return rc;
+                return rhs_fused2_f32(A, X, Xh, n_own, work, b, Y, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f,
+                                      0.f, nullptr, nullptr, st);
+            }
+            return rhs_fused_f32(A, X, Xh, n_own, W, b, Y, work, H, flags, st);
+        }
         int rc = spmm_f32(A, X, Xh, n_own, work, H, 1.f, 0, st);
         if (rc) return rc;
         return linear_f32(work, W, b, Y, n, H, H, act, st);

@@ -58,11 +58,14 @@ struct ndcn_solver {
     bool slab_owned = false;
     double *d_red = nullptr;       // device {sum, nonfinite}
     void *d_ws = nullptr;
+    void *d_ws2 = nullptr;         // fused2 error partials
     double *h_red = nullptr;       // pinned host mirror
     hipEvent_t ev = nullptr;
     // scalar state
     bool begun = false;
     bool fused = false;            // H = 256 fused RHS: `work` holds the packed weights
+    bool fused2 = false;           // ... and the operator has a union plan: RK algebra rides in the RHS epilogue
+    float *ytmp2 = nullptr;        // second stage-input panel (fused2: a stage's input must outlive its epilogue)
     double t0 = 0, t1 = 0, dt = 0; // dopri5: last interval [t0, t1], next step size
     float tf = 0;                  // fixed grid: current time in the state dtype
     bool fit_pending = false;      // last accepted step not yet fitted
@@ -82,7 +85,7 @@ inline size_t align_up(size_t v) { return (v + 255u) & ~(size_t)255u; }
 
 int n_panels(const ndcn_solver_desc *d) {
     const int nk = d->method == NDCN_M_DOPRI5 ? 7 : d->method == NDCN_M_RK4 ? 4 : 1;
-    int n = 2 + nk;                                       // ycur, ytmp, k[]
+    int n = 3 + nk;                                       // ycur, ytmp, ytmp2, k[]
     if (d->method == NDCN_M_DOPRI5) n += 6;               // ynext, yold, a, b, c, d
     return n;
 }
@@ -90,7 +93,8 @@ int n_panels(const ndcn_solver_desc *d) {
 size_t workspace_bytes(const ndcn_solver_desc *d) {
     const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
     const size_t work = align_up((size_t)rhs_work_bytes(d->A.n_rows, d->H, d->rhs_flags) + 16);
-    return (size_t)n_panels(d) * panel + work + align_up((size_t)reduce_ws_bytes()) + 512;
+    return (size_t)n_panels(d) * panel + work + align_up((size_t)reduce_ws_bytes()) +
+           align_up((size_t)rhs_fused2_partials_bytes()) + 1024;
 }
 
 int carve(ndcn_solver *s, size_t bytes, void **p) {
@@ -114,6 +118,9 @@ int alloc_panel(ndcn_solver *s, float **p) {
 
 int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
     s->n_rhs++;
+    if (s->fused2)
+        return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, 0, nullptr,
+                              nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st);
     if (s->fused)       // weights were packed once in solver_begin
         return rhs_fused_packed_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, st);
     return rhs_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, out, s->work, s->d.H, s->d.rhs_flags, st);
@@ -206,6 +213,47 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
     const float *kp[8];
     float cp[8];
     int m, rc;
+    if (s->fused2) {
+        // Stage algebra rides in the RHS epilogues: the evaluation that produces k[i+1] also forms the NEXT stage
+        // input y0 + dt * sum_m beta[i+1][m] k[m] (its own K as the last term), the last one the error record.
+        dt_coeffs(dt32, kBeta[0], 1, s->k, kp, cp, m);
+        rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st);
+        if (rc) return rc;
+        float *in = s->ytmp;
+        for (int i = 0; i < 6; ++i) {
+            s->n_rhs++;
+            if (i < 5) {
+                float *out = (i == 4) ? s->ynext : (in == s->ytmp ? s->ytmp2 : s->ytmp);   // stage-6 input IS y1
+                int mp = 0;
+                for (int j = 0; j <= i; ++j) {                 // previous stages k[0..i] with non-zero coefficients
+                    const float bj = (float)kBeta[i + 1][j];
+                    if (bj == 0.f) continue;
+                    kp[mp] = s->k[j];
+                    cp[mp] = dt32 * bj;
+                    ++mp;
+                }
+                cp[mp] = dt32 * (float)kBeta[i + 1][i + 1];   // the K being produced, last term
+                rc = rhs_fused2_f32(&s->d.A, in, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[i + 1], s->d.rhs_flags, 1,
+                                    s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st);
+                if (rc) return rc;
+                in = out;
+            } else {
+                int mp = 0;
+                for (int j = 0; j < 6; ++j) {
+                    const float cj = (float)kCErr[j];
+                    if (cj == 0.f) continue;
+                    kp[mp] = s->k[j];
+                    cp[mp] = dt32 * cj;
+                    ++mp;
+                }
+                cp[mp] = dt32 * (float)kCErr[6];
+                rc = rhs_fused2_f32(&s->d.A, in, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[6], s->d.rhs_flags, 2,
+                                    s->ycur, kp, cp, mp, nullptr, (float)s->d.rtol, (float)s->d.atol, s->d_red, s->d_ws2,
+                                    st);
+                if (rc) return rc;
+            }
+        }
+    } else {
     for (int i = 0; i < 6; ++i) {
         dt_coeffs(dt32, kBeta[i], i + 1, s->k, kp, cp, m);
         float *dst = (i == 5) ? s->ynext : s->ytmp;          // the 6th stage input IS y1 (rk_common.py:54-58)
@@ -217,6 +265,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
     dt_coeffs(dt32, kCErr, 7, s->k, kp, cp, m);
     rc = rk_error_f32(s->ycur, s->ynext, kp, cp, m, (float)s->d.rtol, (float)s->d.atol, s->n_elem, s->d_red, s->d_ws, st);
     if (rc) return rc;
+    }
     double sum, bad;
     rc = fetch_record(s, st, sum, bad);
     if (rc) return rc;
@@ -312,6 +361,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     if ((rc = alloc_panel(s, &s->ycur))) return fail(rc);
     s->ycur_own = s->ycur;
     if ((rc = alloc_panel(s, &s->ytmp))) return fail(rc);
+    if ((rc = alloc_panel(s, &s->ytmp2))) return fail(rc);
     {
         const int64_t wb = rhs_work_bytes(s->n_rows, desc->H, desc->rhs_flags);
         if (wb > 0) {
@@ -321,6 +371,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         }
         const bool both = !(desc->rhs_flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
         s->fused = both && rhs_fused_supported(desc->H, desc->rhs_flags);
+        s->fused2 = s->fused && rhs_fused2_supported(&desc->A, desc->H, desc->rhs_flags);
     }
     const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;
     for (int j = 0; j < nk; ++j)
@@ -338,6 +389,8 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     s->d_red = static_cast<double *>(q);
     if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);
     s->d_ws = q;
+    if ((rc = carve(s, (size_t)rhs_fused2_partials_bytes(), &q))) return fail(rc);
+    s->d_ws2 = q;
     if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         return fail(NDCN_EHIP);
@@ -392,6 +445,22 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
     const int64_t n = s->n_elem;
     float *dst = out ? out : s->ycur_own;
     int rc;
+    if (s->fused2 && s->d.method == NDCN_M_EULER && dst != s->ycur) {
+        // y + dt * f in the RHS epilogue (one term: identical rounding to fixed_stage op 0)
+        const float c1[1] = {dt};
+        s->n_rhs++;
+        rc = rhs_fused2_f32(&s->d.A, s->ycur, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[0], s->d.rhs_flags, 1, s->ycur,
+                            nullptr, c1, 0, dst, 0.f, 0.f, nullptr, nullptr, st);
+        if (rc) return rc;
+        s->ycur = dst;
+        s->cur_is_borrowed = (dst != s->ycur_own);
+        s->tf = t1;
+        s->t0 = s->t1;
+        s->t1 = next_t;
+        s->n_attempt++;
+        s->n_accept++;
+        return NDCN_OK;
+    }
     if ((rc = rhs(s, s->ycur, s->k[0], st))) return rc;
     switch (s->d.method) {
         case NDCN_M_EULER:

@@ -289,6 +289,20 @@ __global__ __launch_bounds__(256) void spmm_union_kernel(
     const int r_hi = min(n_rows, r_lo + ug_rows);
 
     if (nu > 0) {
+        // ---- index data of this wave's rows (2 per wave for 8-row groups) is requested first, so that after the
+        // barrier nothing but LDS reads stands between the wave and its stores
+        constexpr int kPre = 2;
+        int pj0[kPre], pj1[kPre], pli[kPre];
+        float pv[kPre];
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            const int r = r_lo + wave + 4 * i;
+            pj0[i] = pj1[i] = 0; pli[i] = 0; pv[i] = 0.f;
+            if (r < r_hi) {
+                pj0[i] = rowptr[r]; pj1[i] = rowptr[r + 1];
+                if (lane < pj1[i] - pj0[i]) { pli[i] = ug_lidx[pj0[i] + lane]; pv[i] = val[pj0[i] + lane]; }
+            }
+        }
         // ---- stage the union: wave w takes entries w, w+4, ...
         if (DMA) {
             // LDS-DMA: global -> LDS without a VGPR round trip; the LDS address is the wave-uniform row base,
@@ -323,14 +337,18 @@ __global__ __launch_bounds__(256) void spmm_union_kernel(
         }
         __syncthreads();
         // ---- rows of the group from LDS
-        for (int r = r_lo + wave; r < r_hi; r += 4) {
-            const int j0 = rowptr[r], j1 = rowptr[r + 1];
+        int slot = 0;
+        for (int r = r_lo + wave; r < r_hi; r += 4, ++slot) {
+            int j0, j1;
+            if (slot < kPre) { j0 = slot == 0 ? pj0[0] : pj0[1]; j1 = slot == 0 ? pj1[0] : pj1[1]; }
+            else { j0 = rowptr[r]; j1 = rowptr[r + 1]; }
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int jb = j0; jb < j1; jb += 64) {
                 const int cnt = min(64, j1 - jb);
                 int li = 0;
                 float v = 0.f;
-                if (lane < cnt) { li = ug_lidx[jb + lane]; v = val[jb + lane]; }
+                if (slot < kPre && jb == j0) { li = slot == 0 ? pli[0] : pli[1]; v = slot == 0 ? pv[0] : pv[1]; }
+                else if (lane < cnt) { li = ug_lidx[jb + lane]; v = val[jb + lane]; }
                 int i = 0;
                 for (; i + 8 <= cnt; i += 8) lds_batch<8>(li, v, i, s_x, lane, acc);
                 if (i + 4 <= cnt) { lds_batch<4>(li, v, i, s_x, lane, acc); i += 4; }

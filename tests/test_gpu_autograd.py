@@ -118,10 +118,15 @@ def test_ndcn_training_step_matches_reference_semantics(dev):
     assert abs(float(loss) - float(lo)) < 1e-5
     for k, p in m.named_parameters():
         assert rel(p.grad.cpu(), ps[k].grad) < 5e-4, k
+    # the same optimizer step on both sides lands on the same loss
     opt.step()
+    names = [k for k, _ in m.named_parameters()]
+    opt_o = torch.optim.Adam([ps[k] for k in names], lr=0.01, weight_decay=1e-3)
+    opt_o.step()
     with torch.no_grad():
         l2 = torch.nn.functional.l1_loss(m(t.to(dev), x0.to(dev)), target.to(dev))
-    assert float(l2) < float(loss)
+        l2o = torch.nn.functional.l1_loss(orc.ndcn_forward({k: v.detach() for k, v in ps.items()}, A, t, x0, 'euler'), target)
+    assert abs(float(l2) - float(l2o)) < 1e-3 * max(1.0, float(l2o))
 
 
 def test_forward_only_kernels_are_not_used_silently(dev):

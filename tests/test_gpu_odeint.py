@@ -145,6 +145,37 @@ def test_dgnn_block_golden(dev, name, H):
     check_traj(y.cpu().numpy(), d['out'], l1=1e-5, mx=2e-4)
 
 
+@pytest.mark.parametrize('side', [55, 64])
+def test_fused_epilogue_solver_equals_generic_path(dev, side):
+    """H = 256: the device-resident solver runs the stage algebra / error norm inside the fused RHS epilogue
+    (rhs_fused2.hip); the generic path runs the same RHS kernel plus the separate rk.hip kernels.  Same
+    summation orders on both sides, so trajectories and step logs must agree to rounding of the controller."""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    A = graphs.to_device(graphs.normalized_laplacian(graphs.grid_8_neighbor(side)), dev)     # 55^2 = 3025: ragged tail
+    torch.manual_seed(2)
+    f = ODEFunc(256, A).to(dev).eval()
+    x0 = torch.rand(side * side, 256, device=dev)
+    with torch.no_grad():
+        for method, t in (('euler', torch.linspace(0., 1., 5)), ('dopri5', torch.tensor([0., 0.4, 1.5, 3.0]))):
+            la, lb = [], []
+            ya = ode.odeint(f, x0, t.to(dev), rtol=.01, atol=.001, method=method, step_log=la)
+            yb = ode.odeint(lambda tt, y: f(tt, y), x0, t.to(dev), rtol=.01, atol=.001, method=method, step_log=lb)
+            assert float((ya - yb).abs().max()) <= 1e-5 * float(yb.abs().max())
+            if method == 'dopri5':
+                assert la[-1] == lb[-1]                                   # same number of RHS evaluations
+                assert [r[2] for r in la[:-1]] == [r[2] for r in lb[:-1]]
+                assert np.allclose([r[3] for r in la[:-1]], [r[3] for r in lb[:-1]], rtol=1e-4)
+        # oracle check on the smaller case
+        if side == 55:
+            L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+            Ao = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
+            fo = orc.OracleODEFunc(Ao, f.wt.weight.detach().cpu(), f.wt.bias.detach().cpu())
+            ref = orc.odeint(fo, x0.cpu(), torch.tensor([0., 0.4, 1.5, 3.0]), rtol=.01, atol=.001, method='dopri5')
+            check_traj(ya.cpu().numpy(), ref.numpy(), l1=1e-5, mx=2e-4)
+
+
 def test_tuple_state_generic_path(dev):
     from ndcn_amd import torchdiffeq as ode
 

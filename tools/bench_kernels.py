@@ -13,20 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'spmm_union_r4': {'NDCN_UNION_ROWS': '4', 'NDCN_UNION_CAP': '18'},
-    'spmm_union_r6': {'NDCN_UNION_ROWS': '6', 'NDCN_UNION_CAP': '24'},
-    'spmm_union_r8': {'NDCN_UNION_ROWS': '8', 'NDCN_UNION_CAP': '30'},
+    'spmm_union_r8': {},
+    'spmm_union_r8_dma': {'NDCN_UNION_DMA': '1'},
     'spmm_union_r4_dma': {'NDCN_UNION_ROWS': '4', 'NDCN_UNION_CAP': '18', 'NDCN_UNION_DMA': '1'},
-    'spmm_union_r6_dma': {'NDCN_UNION_ROWS': '6', 'NDCN_UNION_CAP': '24', 'NDCN_UNION_DMA': '1'},
-    'spmm_union_r8_dma': {'NDCN_UNION_ROWS': '8', 'NDCN_UNION_CAP': '30', 'NDCN_UNION_DMA': '1'},
-    'spmm_union_r16_dma': {'NDCN_UNION_ROWS': '16', 'NDCN_UNION_CAP': '56', 'NDCN_UNION_DMA': '1'},
-    'spmm_blocked': {'NDCN_SPMM_WIDE': '0', 'NDCN_UNION_ROWS': '0'},
-    'spmm_wide_bpc4': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'NDCN_UNION_ROWS': '0'},
-    'spmm_diag1_wide': {'NDCN_SPMM_BLOCKS_PER_CU': '4', 'SYNTH': 'diag1', 'NDCN_UNION_ROWS': '0'},
+    'spmm_wide_bpc4': {'NDCN_UNION_ROWS': '0'},
+    'rhs_fused2': {},
+    'rhs_fused_v1': {'NDCN_RHS_FUSED2': '0'},
     'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
-    'rhs_fused_p12': {'NDCN_RHS_PRODUCERS': '12'},
-    'rhs_fused_p4': {'NDCN_RHS_PRODUCERS': '4'},
-    'rhs_fused_p8': {'NDCN_RHS_PRODUCERS': '8'},
 }
 
 
