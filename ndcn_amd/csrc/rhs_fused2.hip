@@ -1,4 +1,4 @@
-// Fused ODEFunc right-hand side, second generation (H = 256):
+// Fused ODEFunc right-hand side with Runge-Kutta epilogue (H = 256):
 //
 //     K = relu((A X) W^T + b)          [neural_dynamics.py:27-36]
 //   + optionally, in the same pass, the Runge-Kutta algebra that consumes K:
@@ -6,27 +6,26 @@
 //       ERROR   :  sum ((sum_m c_m k_m) / (atol + rtol max(|y0|, |y1|)))^2 and the non-finite count of y1
 //                                                                  [rk_common.py:60, misc.py:146-157, dopri5.py:101]
 //
-// What changed against rhs_fused.hip (measured on the 1M-node grid, MI355X):
-//   * the gather was bound by the CU's vector-memory pipe (9 x 1 KiB loads per row, ~18 cycles each even on a
-//     hit) and by latency (few producer waves).  Producers now stage, per group of 8 consecutive rows, the
-//     DISTINCT neighbour rows once in LDS (ndcn_csr::ug_* plan: 30 rows for 72 non-zeros on the lattice) with
-//     the next group's fetches in flight while the current group's rows are summed out of LDS;
-//   * consumers no longer store their accumulators with 4-byte scattered stores: they drop the K tile into the
-//     LDS tile they just consumed, and the producers stream it out as whole 1 KiB rows - together with the RK
-//     stage algebra, whose extra panels are row-local and ride on the same coalesced pass.
+// One persistent workgroup per CU: 4 consumer waves (one per SIMD, fp32 MFMA) + 8 producer waves; 64-row tiles;
+// LDS = S[2][64][260] fp32 (133 120 B).
 //
-// Workgroup = 4 consumer waves (one per SIMD, fp32 MFMA) + NPROD producer waves, persistent, one per CU.
-// Tile = 32 rows.  LDS: S[2][32][260] fp32 (66.5 KB) + stage[2][30][256] fp32 (60 KB) + sync word.
+//   phase A(t): consumers  MFMA on S[t&1]                            -> K_t in registers
+//               producers  epilogue of K_{t-1} (sits in S[(t-1)&1]): whole 1 KiB rows of K (and of the RK
+//                          algebra: y0 / earlier stages are row-local) streamed to HBM;
+//                          then gather S_{t+1} = (A X)[tile t+1] into S[(t-1)&1]
+//   barrier
+//   phase B(t): consumers  K_t (+bias, relu) -> S[t&1], row-major
+//   barrier
+// A producer wave owns the same rows of every tile (p, p+8, ..., p+56): it first reads K out of them, then
+// overwrites them with the gathered S, so phase A needs no producer-to-producer synchronisation.
 //
-//   phase A(t): consumers  MFMA on S[t&1]                         -> K_t in registers
-//               producers  epilogue of K_{t-1} (in S[(t-1)&1]) -> HBM ; then gather S_{t+1} into S[(t-1)&1]
-//   barrier
-//   phase B(t): consumers  K_t (+bias, relu) -> S[t&1] row-major
-//   barrier
-// A producer wave always touches the same rows of a tile (row 8 g + p of every group g), first reading K
-// out of them, then overwriting them with the gathered S - no cross-wave hazard inside phase A.  Producer waves
-// synchronise among themselves (stage complete / stage free) with an LDS counter, so the MFMA waves never wait
-// on a memory phase boundary.
+// Measured lessons built in (1M-node grid, MI355X; profiles/r01*):
+//   * the first fused kernel ran its MFMA loop at ~50 % because hipcc scheduled the L2 weight fetch of step q+1
+//     late inside step q and then waited vmcnt(0): the weight operands now sit in a 4-deep register ring (a
+//     fetch is issued right after its slot is consumed, three steps = 3072 MFMA cycles before it is needed);
+//   * accumulators leave through LDS as full rows instead of 64 scattered 4-byte stores per lane;
+//   * a union-staged gather (fetch each distinct neighbour row of 8 rows once) needed a producer barrier per
+//     group and was latency-bound (2.1 ms vs 1.8 ms); the gather here is direct, two rows in flight per wave.
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -39,20 +38,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kH2 = 256;
-constexpr int kTile2 = 32;
-constexpr int kLd2 = kH2 + 4;
+constexpr int kTile2 = 64;
+constexpr int kLd2 = kH2 + 4;              // +4 floats: row m starts on 16-byte slot (4 m) mod 64 -> conflict-free b128
 constexpr int kTileFloats2 = kTile2 * kLd2;
-constexpr int kGroupRows = 8;              // must equal the union plan's ug_rows
-constexpr int kGroupsPerTile = kTile2 / kGroupRows;
-constexpr int kStageCap = 30;              // distinct neighbour rows staged per group
-constexpr int kStageFloats = kStageCap * kH2;
+constexpr int kProd = 8;
+constexpr int kRowsPerProd = kTile2 / kProd;
 constexpr int kMaxPrev = 7;
 
 struct Fused2Args {
     const int *rowptr, *colidx;
     const float *val;
-    const int *ug_ptr, *ug_cols;
-    const unsigned short *ug_lidx;
     const float *X, *Xh;
     int n_own;
     const float *Wp, *bias;
@@ -65,7 +60,7 @@ struct Fused2Args {
     int n_prev;
     float *y_next;
     float rtol, atol;
-    double *partials;                       // ERROR: [gridDim.x * NPROD][2]
+    double *partials;                       // ERROR: [gridDim.x * kProd][2]
 };
 
 enum { MODE_PLAIN = 0, MODE_COMBINE = 1, MODE_ERROR = 2 };
@@ -74,67 +69,48 @@ __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 a) {
     return (f32x4){fmaf(s, x.x, a.x), fmaf(s, x.y, a.y), fmaf(s, x.z, a.z), fmaf(s, x.w, a.w)};
 }
 
-template <int U>
-__device__ __forceinline__ void stage_batch(int li, float v, int i, const f32x4 *st, int lane, f32x4 &acc) {
-    int ll[U];
-    float vv[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-        ll[q] = __builtin_amdgcn_readlane(li, i + q);
-        vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i + q));
-    }
-    f32x4 x[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) x[q] = st[ll[q] * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < U; ++q) acc = fma4(vv[q], x[q], acc);
-}
-
+// issue U neighbour-row fetches of one output row (entries i .. i+U-1 of the lane-held (col, val) pairs)
 template <int U, bool HALO>
-__device__ __forceinline__ void direct_batch(int c, float v, int i, const f32x4 *__restrict__ X,
-                                             const f32x4 *__restrict__ Xh, int n_own, int lane, f32x4 &acc) {
-    int cc[U];
-    float vv[U];
-    const f32x4 *pp[U];
+__device__ __forceinline__ void g_issue(int c, float v, int i, const f32x4 *__restrict__ X, const f32x4 *__restrict__ Xh,
+                                        int n_own, int lane, f32x4 (&x)[8], float (&vv)[8]) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-        cc[q] = __builtin_amdgcn_readlane(c, i + q);
+        int cc = __builtin_amdgcn_readlane(c, i + q);
         vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i + q));
-        pp[q] = X;
-        if (HALO && cc[q] >= n_own) { pp[q] = Xh; cc[q] -= n_own; }
+        const f32x4 *pp = X;
+        if (HALO && cc >= n_own) { pp = Xh; cc -= n_own; }
+        x[q] = pp[(size_t)cc * 64 + lane];
     }
-    f32x4 x[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) x[q] = pp[q][(size_t)cc[q] * 64 + lane];
+}
+template <int U>
+__device__ __forceinline__ void g_accum(const f32x4 (&x)[8], const float (&vv)[8], f32x4 &acc) {
 #pragma unroll
     for (int q = 0; q < U; ++q) acc = fma4(vv[q], x[q], acc);
 }
 
-// LDS counter barrier among the producer waves only
-__device__ __forceinline__ void producer_barrier(int *cnt, int nprod, int &target, int lane) {
-    target += nprod;
-    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+// remaining entries [i, cnt) of a row in batches of 8 / 4 / 2 / 1
+template <bool HALO>
+__device__ __forceinline__ void g_rest(int c, float v, int i, int cnt, const f32x4 *__restrict__ X,
+                                       const f32x4 *__restrict__ Xh, int n_own, int lane, f32x4 &acc) {
+    f32x4 x[8];
+    float vv[8];
+    for (; i + 8 <= cnt; i += 8) { g_issue<8, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<8>(x, vv, acc); }
+    if (i + 4 <= cnt) { g_issue<4, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<4>(x, vv, acc); i += 4; }
+    if (i + 2 <= cnt) { g_issue<2, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<2>(x, vv, acc); i += 2; }
+    if (i < cnt) { g_issue<1, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<1>(x, vv, acc); }
 }
 
-template <int NPROD, bool HALO, int MODE>
-__global__ __launch_bounds__(256 + 64 * NPROD) void rhs_fused2_kernel(Fused2Args a) {
-    static_assert(NPROD == kGroupRows, "one producer wave per row of a group");
-    __shared__ __attribute__((aligned(16))) float s_mem[2 * kTileFloats2 + 2 * kStageFloats + 4];
-    float *s_tile = s_mem;
-    float *s_stage = s_mem + 2 * kTileFloats2;
-    int *s_cnt = reinterpret_cast<int *>(s_mem + 2 * kTileFloats2 + 2 * kStageFloats);
+template <bool HALO, int MODE>
+__global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args a) {
+    __shared__ __attribute__((aligned(16))) float s_tile[2 * kTileFloats2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool producer = wave >= 4;
-    const int p = wave - 4;                                   // producer index 0..NPROD-1
+    const int p = wave - 4;                                   // producer index 0..7
     const f32x4 *X = reinterpret_cast<const f32x4 *>(a.X);
     const f32x4 *Xh = reinterpret_cast<const f32x4 *>(a.Xh);
     const f32x4 *Wp = reinterpret_cast<const f32x4 *>(a.Wp);
-
-    if (threadIdx.x == 0) *s_cnt = 0;
-    __syncthreads();
 
     // tiles of this workgroup: XCD x owns a contiguous chunk; its workgroups take tiles round-robin
     const int xcd = blockIdx.x % kXcds;
@@ -146,122 +122,83 @@ __global__ __launch_bounds__(256 + 64 * NPROD) void rhs_fused2_kernel(Fused2Args
     const int my_tiles = t_first < t_hi ? (t_hi - t_first + wgs_per_xcd - 1) / wgs_per_xcd : 0;
     if (my_tiles == 0) return;                                // uniform per workgroup
 
-    int pb_target = 0;                                        // producer-barrier epoch
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 
-    // ---- producer helpers -------------------------------------------------------------------------
-    // Fetch (issue only) everything this wave needs for group `g`: its share of the group's union rows of X
-    // (into registers) and the index data of ITS row of the group (row 8 g + p).
-    f32x4 pend[4];
-    int pend_nu = 0, pend_j0 = 0, pend_j1 = 0, pend_idx = 0;
-    float pend_v = 0.f;
-    auto issue_stage = [&](int g) {
-        const int u0 = a.ug_ptr[g];
-        const int nu = a.ug_ptr[g + 1] - u0;
-        pend_nu = nu;
-        const int r = g * kGroupRows + p;
-        pend_j0 = pend_j1 = 0;
-        if (r < a.n_rows) { pend_j0 = a.rowptr[r]; pend_j1 = a.rowptr[r + 1]; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = p + NPROD * q;
-            if (u < nu) {
-                int c = a.ug_cols[u0 + u];
-                const f32x4 *src = X;
-                if (HALO && c >= a.n_own) { src = Xh; c -= a.n_own; }
-                pend[q] = src[(size_t)c * 64 + lane];
-            }
-        }
-        pend_idx = 0; pend_v = 0.f;
-        if (lane < pend_j1 - pend_j0) {
-            pend_idx = nu > 0 ? (int)a.ug_lidx[pend_j0 + lane] : a.colidx[pend_j0 + lane];
-            pend_v = a.val[pend_j0 + lane];
-        }
-    };
-    auto commit_stage = [&](int sb) {
-        f32x4 *st = reinterpret_cast<f32x4 *>(s_stage + sb * kStageFloats);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = p + NPROD * q;
-            if (u < pend_nu) st[u * 64 + lane] = pend[q];
-        }
-    };
-    // Sum one row out of stage buffer `sb` (or directly when its group has no union) into LDS row dst.
-    // (j0, j1, idx, v) = the row's extent and its first <= 64 (index, value) pairs, prefetched by issue_stage.
-    auto gather_row = [&](bool staged, int j0, int j1, int idx, float v, int sb, float *dst) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const f32x4 *st = reinterpret_cast<const f32x4 *>(s_stage + sb * kStageFloats);
-        for (int jb = j0; jb < j1; jb += 64) {
-            const int cnt = min(64, j1 - jb);
-            if (jb != j0) {
-                idx = 0; v = 0.f;
-                if (lane < cnt) {
-                    idx = staged ? (int)a.ug_lidx[jb + lane] : a.colidx[jb + lane];
-                    v = a.val[jb + lane];
-                }
-            }
-            int i = 0;
-            if (staged) {
-                for (; i + 8 <= cnt; i += 8) stage_batch<8>(idx, v, i, st, lane, acc);
-                if (i + 4 <= cnt) { stage_batch<4>(idx, v, i, st, lane, acc); i += 4; }
-                if (i + 2 <= cnt) { stage_batch<2>(idx, v, i, st, lane, acc); i += 2; }
-                if (i < cnt) stage_batch<1>(idx, v, i, st, lane, acc);
-            } else {
-                for (; i + 8 <= cnt; i += 8) direct_batch<8, HALO>(idx, v, i, X, Xh, a.n_own, lane, acc);
-                if (i + 4 <= cnt) { direct_batch<4, HALO>(idx, v, i, X, Xh, a.n_own, lane, acc); i += 4; }
-                if (i + 2 <= cnt) { direct_batch<2, HALO>(idx, v, i, X, Xh, a.n_own, lane, acc); i += 2; }
-                if (i < cnt) direct_batch<1, HALO>(idx, v, i, X, Xh, a.n_own, lane, acc);
-            }
-        }
-        *reinterpret_cast<f32x4 *>(dst + 4 * lane) = acc;
-    };
-    // Gather tile `t` into LDS tile `dst_tile`: 4 groups, stage double-buffered across groups.
-    // Precondition: group 4t's fetches were issued (issue_stage) by the caller.
-    auto gather_tile = [&](int t, float *dst_tile, int t_next_or_neg) {
-        for (int k = 0; k < kGroupsPerTile; ++k) {
-            const int g = t * kGroupsPerTile + k;
-            commit_stage(k & 1);                               // this wave's part of group g is in LDS
-            const bool staged = pend_nu > 0;
-            const int j0 = pend_j0, j1 = pend_j1, idx = pend_idx;
-            const float v = pend_v;
-            producer_barrier(s_cnt, NPROD, pb_target, lane);  // all parts landed; stage[(k+1)&1] is free
-            // next group's fetches fly while this group is summed
-            int gn = -1;
-            if (k + 1 < kGroupsPerTile) gn = g + 1;
-            else if (t_next_or_neg >= 0) gn = t_next_or_neg * kGroupsPerTile;
-            if (gn >= 0 && gn * kGroupRows < a.n_rows) issue_stage(gn);
-            else { pend_nu = 0; pend_j0 = pend_j1 = 0; }
-            gather_row(staged, j0, j1, idx, v, k & 1, dst_tile + (k * kGroupRows + p) * kLd2);
-        }
-    };
-    // Stream K rows of tile `t` out of LDS tile `src_tile` (+ RK algebra).
-    auto epilogue_tile = [&](int t, const float *src_tile) {
+    // ---- producer: gather tile `t` into LDS tile dst, rows p, p+8, ... two rows in flight ------------
+    auto gather_tile = [&](int t, float *dst) {
 #pragma unroll 1
-        for (int k = 0; k < kGroupsPerTile; ++k) {
-            const int lr = k * kGroupRows + p;
+        for (int k = 0; k < kRowsPerProd; k += 2) {
+            const int lrA = p + kProd * k, lrB = lrA + kProd;
+            const int rA = t * kTile2 + lrA, rB = t * kTile2 + lrB;
+            int jA0 = 0, jA1 = 0, jB0 = 0, jB1 = 0;
+            if (rA < a.n_rows) { jA0 = a.rowptr[rA]; jA1 = a.rowptr[rA + 1]; }
+            if (rB < a.n_rows) { jB0 = a.rowptr[rB]; jB1 = a.rowptr[rB + 1]; }
+            const int cntA = min(64, jA1 - jA0), cntB = min(64, jB1 - jB0);
+            int cA = 0, cB = 0;
+            float vA = 0.f, vB = 0.f;
+            if (lane < cntA) { cA = a.colidx[jA0 + lane]; vA = a.val[jA0 + lane]; }
+            if (lane < cntB) { cB = a.colidx[jB0 + lane]; vB = a.val[jB0 + lane]; }
+            f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
+            int iA = 0, iB = 0;
+            // first batches of both rows in flight together (16 x 1 KiB per wave)
+            {
+                f32x4 xA[8], xB[8];
+                float wA[8], wB[8];
+                const bool fa = cntA >= 8, fb = cntB >= 8;
+                if (fa) g_issue<8, HALO>(cA, vA, 0, X, Xh, a.n_own, lane, xA, wA);
+                if (fb) g_issue<8, HALO>(cB, vB, 0, X, Xh, a.n_own, lane, xB, wB);
+                if (fa) { g_accum<8>(xA, wA, accA); iA = 8; }
+                if (fb) { g_accum<8>(xB, wB, accB); iB = 8; }
+            }
+            g_rest<HALO>(cA, vA, iA, cntA, X, Xh, a.n_own, lane, accA);
+            g_rest<HALO>(cB, vB, iB, cntB, X, Xh, a.n_own, lane, accB);
+            // rows longer than 64 entries
+            for (int jb = jA0 + 64; jb < jA1; jb += 64) {
+                const int cnt = min(64, jA1 - jb);
+                int c = 0; float v = 0.f;
+                if (lane < cnt) { c = a.colidx[jb + lane]; v = a.val[jb + lane]; }
+                g_rest<HALO>(c, v, 0, cnt, X, Xh, a.n_own, lane, accA);
+            }
+            for (int jb = jB0 + 64; jb < jB1; jb += 64) {
+                const int cnt = min(64, jB1 - jb);
+                int c = 0; float v = 0.f;
+                if (lane < cnt) { c = a.colidx[jb + lane]; v = a.val[jb + lane]; }
+                g_rest<HALO>(c, v, 0, cnt, X, Xh, a.n_own, lane, accB);
+            }
+            *reinterpret_cast<f32x4 *>(dst + lrA * kLd2 + 4 * lane) = accA;
+            *reinterpret_cast<f32x4 *>(dst + lrB * kLd2 + 4 * lane) = accB;
+        }
+    };
+
+    // ---- producer: stream K rows of tile `t` out of LDS tile src (+ RK algebra) ----------------------
+    auto epilogue_tile = [&](int t, const float *src) {
+#pragma unroll 1
+        for (int k = 0; k < kRowsPerProd; ++k) {
+            const int lr = p + kProd * k;
             const int r = t * kTile2 + lr;
             if (r >= a.n_rows) continue;
-            const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_tile + lr * kLd2 + 4 * lane);
+            const f32x4 kn = *reinterpret_cast<const f32x4 *>(src + lr * kLd2 + 4 * lane);
             const size_t off = (size_t)r * 64 + lane;
             __builtin_nontemporal_store(kn, reinterpret_cast<f32x4 *>(a.K) + off);
             if (MODE != MODE_PLAIN) {
-                f32x4 s;
-                bool first = true;
+                f32x4 km[kMaxPrev];
 #pragma unroll
                 for (int m = 0; m < kMaxPrev; ++m)
-                    if (m < a.n_prev) {
-                        const f32x4 km = reinterpret_cast<const f32x4 *>(a.kprev[m])[off];
-                        const f32x4 term = km * a.c[m];
-                        s = first ? term : s + term;
-                        first = false;
-                    }
-                const f32x4 tn = kn * a.c[a.n_prev];
-                s = first ? tn : s + tn;
+                    if (m < a.n_prev) km[m] = reinterpret_cast<const f32x4 *>(a.kprev[m])[off];
                 const f32x4 y0v = reinterpret_cast<const f32x4 *>(a.y0)[off];
+                f32x4 y1v = y0v;
+                if (MODE == MODE_ERROR) y1v = X[off];          // the input of this evaluation is y1
+                f32x4 s = kn * a.c[a.n_prev];                  // only term when n_prev == 0
+                if (a.n_prev > 0) {
+                    s = km[0] * a.c[0];
+#pragma unroll
+                    for (int m = 1; m < kMaxPrev; ++m)
+                        if (m < a.n_prev) s = s + km[m] * a.c[m];
+                    s = s + kn * a.c[a.n_prev];                // the new stage is the last term of the sum
+                }
                 if (MODE == MODE_COMBINE) {
                     __builtin_nontemporal_store(y0v + s, reinterpret_cast<f32x4 *>(a.y_next) + off);
                 } else {
-                    const f32x4 y1v = X[off];                  // the input of this evaluation is y1
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float tol = a.atol + a.rtol * fmaxf(fabsf(y0v[e]), fabsf(y1v[e]));
@@ -275,70 +212,74 @@ __global__ __launch_bounds__(256 + 64 * NPROD) void rhs_fused2_kernel(Fused2Args
     };
 
     // ---- consumer -----------------------------------------------------------------------------------
-    f32x16 acc0, acc1;
+    // wave w owns output columns [64 w, 64 w + 64) (n-tiles 2w, 2w+1) for both 32-row m-tiles
+    f32x16 acc00, acc01, acc10, acc11;
     auto mfma_tile = [&](const float *src) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-        const float *ap = src + (lane & 31) * kLd2 + 128 * (lane >> 5);
+        for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
+        const float *a0p = src + (lane & 31) * kLd2 + 128 * (lane >> 5);
+        const float *a1p = a0p + 32 * kLd2;
         const f32x4 *b0p = Wp + (size_t)(2 * wave) * 32 * 64 + lane;
         const f32x4 *b1p = b0p + 32 * 64;
-        f32x4 b0 = b0p[0], b1 = b1p[0];
-        f32x4 b0n = b0p[64], b1n = b1p[64];
-#pragma unroll 2
-        for (int q = 0; q < 32; ++q) {
-            const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 4 * q);
-            const f32x4 c0 = b0, c1 = b1;
-            b0 = b0n; b1 = b1n;
-            if (q + 2 < 32) { b0n = b0p[(q + 2) * 64]; b1n = b1p[(q + 2) * 64]; }
+        // 4-deep ring of weight operands: slot u holds step q with q % 4 == u
+        f32x4 r0[4], r1[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], c0[e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], c1[e], acc1, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) { r0[u] = b0p[u * 64]; r1[u] = b1p[u * 64]; }
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p), a1 = *reinterpret_cast<const f32x4 *>(a1p);
+#pragma unroll 1
+        for (int q0 = 0; q0 < 32; q0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u;
+                const f32x4 c0 = r0[u], c1 = r1[u], x0 = a0, x1 = a1;
+                if (q + 1 < 32) {
+                    a0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
+                    a1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
+                }
+                if (q + 4 < 32) { r0[u] = b0p[(q + 4) * 64]; r1[u] = b1p[(q + 4) * 64]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], c0[e], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], c1[e], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], c0[e], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], c1[e], acc11, 0, 0, 0);
+                }
             }
         }
     };
     auto dump_tile = [&](float *dst) {
-        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; wave owns columns [64 wave, 64 wave + 64)
+        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int col = 64 * wave + 32 * n + (lane & 31);
             const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float o = (n == 0 ? acc0[r] : acc1[r]) + bv;
-                if (a.relu) o = fmaxf(o, 0.f);
-                dst[m * kLd2 + col] = o;
-            }
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float o = (mt == 0 ? (n == 0 ? acc00[r] : acc01[r]) : (n == 0 ? acc10[r] : acc11[r])) + bv;
+                    if (a.relu) o = fmaxf(o, 0.f);
+                    dst[m * kLd2 + col] = o;
+                }
         }
     };
 
-    // ---- prologue: producers gather the first tile into S[0] ----------------------------------------
+    // Role-specialised loops (both execute the same sequence of workgroup barriers), so the accumulators of the
+    // MFMA waves and the fetch registers of the gather waves never share a live range.
     if (producer) {
-        issue_stage(t_first * kGroupsPerTile);
-        gather_tile(t_first, s_tile, my_tiles > 1 ? t_first + wgs_per_xcd : -1);
-    }
-    __syncthreads();
-
-    for (int it = 0; it < my_tiles; ++it) {
-        const int t = t_first + it * wgs_per_xcd;
-        const int b = it & 1;
-        float *cur = s_tile + b * kTileFloats2;
-        float *oth = s_tile + (b ^ 1) * kTileFloats2;
-        // ---- phase A
-        if (producer) {
+        gather_tile(t_first, s_tile);
+        __syncthreads();                                       // S[0] ready
+        for (int it = 0; it < my_tiles; ++it) {
+            const int t = t_first + it * wgs_per_xcd;
+            float *oth = s_tile + ((it & 1) ^ 1) * kTileFloats2;
+            // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             if (it > 0) epilogue_tile(t - wgs_per_xcd, oth);
-            if (it + 1 < my_tiles) gather_tile(t + wgs_per_xcd, oth, it + 2 < my_tiles ? t + 2 * wgs_per_xcd : -1);
-        } else {
-            mfma_tile(cur);
+            if (it + 1 < my_tiles) gather_tile(t + wgs_per_xcd, oth);
+            __syncthreads();
+            // phase B: consumers drop K_t into the tile they consumed
+            __syncthreads();
         }
-        __syncthreads();
-        // ---- phase B
-        if (!producer) dump_tile(cur);
-        __syncthreads();
-    }
-    // ---- drain: epilogue of the last tile
-    if (producer) {
         const int t_last = t_first + (my_tiles - 1) * wgs_per_xcd;
         epilogue_tile(t_last, s_tile + ((my_tiles - 1) & 1) * kTileFloats2);
         if (MODE == MODE_ERROR) {
@@ -348,9 +289,18 @@ __global__ __launch_bounds__(256 + 64 * NPROD) void rhs_fused2_kernel(Fused2Args
                 err_bad += __shfl_down(err_bad, off, 64);
             }
             if (lane == 0) {
-                a.partials[2 * (blockIdx.x * NPROD + p)] = err_sum;
-                a.partials[2 * (blockIdx.x * NPROD + p) + 1] = err_bad;
+                a.partials[2 * (blockIdx.x * kProd + p)] = err_sum;
+                a.partials[2 * (blockIdx.x * kProd + p) + 1] = err_bad;
             }
+        }
+    } else {
+        __syncthreads();                                       // S[0] ready
+        for (int it = 0; it < my_tiles; ++it) {
+            float *cur = s_tile + (it & 1) * kTileFloats2;
+            mfma_tile(cur);
+            __syncthreads();                                   // every consumer is done reading `cur`
+            dump_tile(cur);
+            __syncthreads();
         }
     }
 }
@@ -376,12 +326,12 @@ static int env_int3(const char *name, int dflt) {
 
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags) {
     static const int enabled = env_int3("NDCN_RHS_FUSED2", 1);
-    if (!enabled || H != kH2) return 0;
+    if (!enabled || H != kH2 || !A) return 0;
     if (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) return 0;
-    return (A && A->ug_ptr && A->ug_rows == kGroupRows && A->ug_cap <= kStageCap) ? 1 : 0;
+    return 1;
 }
 
-int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kGroupRows * 2 * sizeof(double); }
+int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kProd * 2 * sizeof(double); }
 
 // mode: 0 plain; 1 combine (y_next = y0 + sum c_m k_m, new K last); 2 error (d_out[0..1], d_ws scratch)
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
@@ -392,7 +342,6 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (n_prev < 0 || n_prev > kMaxPrev) { set_error("rhs_fused2: at most %d previous stages", kMaxPrev); return NDCN_EINVAL; }
     Fused2Args a;
     a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val;
-    a.ug_ptr = A->ug_ptr; a.ug_cols = A->ug_cols; a.ug_lidx = A->ug_lidx;
     a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wp = Wp; a.bias = b; a.K = K;
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     a.y0 = y0; a.n_prev = n_prev; a.y_next = y_next; a.rtol = rtol; a.atol = atol;
@@ -402,14 +351,13 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     int per_xcd = kCus / kXcds;
     const int need = (a.n_tiles + kXcds - 1) / kXcds;
     if (per_xcd > need) per_xcd = need;
-    const dim3 grid(per_xcd * kXcds), block(256 + 64 * kGroupRows);
+    const dim3 grid(per_xcd * kXcds), block(256 + 64 * kProd);
     const double P = 4.0 * kH2 * (double)A->n_rows;
     double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * kH2 * (double)(A->n_rows + A->n_cols) + 4.0 * kH2 * kH2;
-    if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);
-    if (mode == MODE_ERROR) bytes += P * (n_prev + 2);
+    if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
+    if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * kH2 + 2.0 * (double)A->n_rows * kH2 * kH2);
-#define NDCN_F2(HALO_, MODE_) \
-    hipLaunchKernelGGL((rhs_fused2_kernel<kGroupRows, HALO_, MODE_>), grid, block, 0, st, a)
+#define NDCN_F2(HALO_, MODE_) hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_>), grid, block, 0, st, a)
     if (Xh) {
         if (mode == MODE_PLAIN) NDCN_F2(true, MODE_PLAIN);
         else if (mode == MODE_COMBINE) NDCN_F2(true, MODE_COMBINE);
@@ -421,7 +369,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     }
 #undef NDCN_F2
     if (mode == MODE_ERROR)
-        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, a.partials, (int)grid.x * kGroupRows, d_out);
+        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, a.partials, (int)grid.x * kProd, d_out);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
