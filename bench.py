@@ -43,7 +43,8 @@ def parse():
     p.add_argument('--rtol', type=float, default=0.01)
     p.add_argument('--atol', type=float, default=0.001)
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-side', type=int, default=80, help='grid side of the bounded CPU-baseline sample')
+    p.add_argument('--cpu-threads', type=int, default=32, help='host threads of the CPU-baseline leg')
+    p.add_argument('--cpu-side', type=int, default=128, help='grid side of the bounded CPU-baseline sample')
     p.add_argument('--no-profile-pass', action='store_true')
     return p.parse_args()
 
@@ -76,12 +77,14 @@ class SingleGpuRunner:
         return self.nfe_done + int(self.solver.stats()['nfe'])
 
 
-def cpu_baseline(side, H, T, rtol, atol):
+def cpu_baseline(side, H, T, rtol, atol, threads):
     """The CPU oracle (torch-CPU restatement of the reference path: torch.sparse.mm on COO + F.linear + the
     restated dopri5 loop) on a bounded sample of the same workload: one solve on a side x side grid."""
     from ndcn_amd import graphs
     from oracle import ndcn_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the reference's op-per-term solver issues ~300 small tensor ops per step: beyond a few dozen threads the
+    # fork/join cost of each op outweighs the work, so the leg uses a bounded thread count and says which
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
     A = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
     torch.manual_seed(0)
@@ -220,7 +223,7 @@ def main():
         'device': device_info(),
     }
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(args.cpu_side, H, args.T, args.rtol, args.atol)
+        out['cpu_baseline'] = cpu_baseline(args.cpu_side, H, args.T, args.rtol, args.atol, args.cpu_threads)
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out), flush=True)

@@ -43,7 +43,7 @@ constexpr int kLd2 = kH2 + 4;              // +4 floats: row m starts on 16-byte
 constexpr int kTileFloats2 = kTile2 * kLd2;
 constexpr int kProd = 8;
 constexpr int kRowsPerProd = kTile2 / kProd;
-constexpr int kMaxPrev = 7;
+constexpr int kMaxPrev = 5;              // dopri5 needs at most 5 earlier stages with a non-zero coefficient
 
 struct Fused2Args {
     const int *rowptr, *colidx;
@@ -124,24 +124,39 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
 
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 
-    // ---- producer: gather tile `t` into LDS tile dst, rows p, p+8, ... two rows in flight ------------
-    auto gather_tile = [&](int t, float *dst) {
-#pragma unroll 1
+    // ---- producer: index data of the wave's 8 rows of a tile, fetched one tile ahead ------------------
+    // (rowptr pairs by one vector load, then the first <= 64 (col, val) pairs of each row: nothing but the
+    // neighbour-row fetches themselves is left on the critical path of gather_tile)
+    int ix_j0[kRowsPerProd], ix_j1[kRowsPerProd], ix_c[kRowsPerProd];
+    float ix_v[kRowsPerProd];
+    auto prefetch_index = [&](int t) {
+        int rp = 0;
+        if (lane < 2 * kRowsPerProd) {
+            int r = t * kTile2 + p + kProd * (lane >> 1) + (lane & 1);
+            rp = a.rowptr[min(r, a.n_rows)];
+        }
+#pragma unroll
+        for (int k = 0; k < kRowsPerProd; ++k) {
+            ix_j0[k] = __builtin_amdgcn_readlane(rp, 2 * k);
+            ix_j1[k] = __builtin_amdgcn_readlane(rp, 2 * k + 1);
+            if (t * kTile2 + p + kProd * k >= a.n_rows) ix_j1[k] = ix_j0[k];
+            ix_c[k] = 0; ix_v[k] = 0.f;
+            if (lane < ix_j1[k] - ix_j0[k]) { ix_c[k] = a.colidx[ix_j0[k] + lane]; ix_v[k] = a.val[ix_j0[k] + lane]; }
+        }
+    };
+
+    // ---- producer: gather the tile whose index data was prefetched into LDS tile dst; two rows in flight ----
+    auto gather_tile = [&](float *dst) {
+#pragma unroll
         for (int k = 0; k < kRowsPerProd; k += 2) {
             const int lrA = p + kProd * k, lrB = lrA + kProd;
-            const int rA = t * kTile2 + lrA, rB = t * kTile2 + lrB;
-            int jA0 = 0, jA1 = 0, jB0 = 0, jB1 = 0;
-            if (rA < a.n_rows) { jA0 = a.rowptr[rA]; jA1 = a.rowptr[rA + 1]; }
-            if (rB < a.n_rows) { jB0 = a.rowptr[rB]; jB1 = a.rowptr[rB + 1]; }
+            const int jA0 = ix_j0[k], jA1 = ix_j1[k], jB0 = ix_j0[k + 1], jB1 = ix_j1[k + 1];
             const int cntA = min(64, jA1 - jA0), cntB = min(64, jB1 - jB0);
-            int cA = 0, cB = 0;
-            float vA = 0.f, vB = 0.f;
-            if (lane < cntA) { cA = a.colidx[jA0 + lane]; vA = a.val[jA0 + lane]; }
-            if (lane < cntB) { cB = a.colidx[jB0 + lane]; vB = a.val[jB0 + lane]; }
+            const int cA = ix_c[k], cB = ix_c[k + 1];
+            const float vA = ix_v[k], vB = ix_v[k + 1];
             f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
             int iA = 0, iB = 0;
-            // first batches of both rows in flight together (16 x 1 KiB per wave)
-            {
+            {   // first batches of both rows in flight together (16 x 1 KiB per wave)
                 f32x4 xA[8], xB[8];
                 float wA[8], wB[8];
                 const bool fa = cntA >= 8, fb = cntB >= 8;
@@ -152,8 +167,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
             }
             g_rest<HALO>(cA, vA, iA, cntA, X, Xh, a.n_own, lane, accA);
             g_rest<HALO>(cB, vB, iB, cntB, X, Xh, a.n_own, lane, accB);
-            // rows longer than 64 entries
-            for (int jb = jA0 + 64; jb < jA1; jb += 64) {
+            for (int jb = jA0 + 64; jb < jA1; jb += 64) {      // rows longer than 64 entries
                 const int cnt = min(64, jA1 - jb);
                 int c = 0; float v = 0.f;
                 if (lane < cnt) { c = a.colidx[jb + lane]; v = a.val[jb + lane]; }
@@ -171,43 +185,63 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
     };
 
     // ---- producer: stream K rows of tile `t` out of LDS tile src (+ RK algebra) ----------------------
+    // The row-local panels of row k+1 are requested before row k is finished (one row of fetches always in flight).
+    struct EpiRow { f32x4 km[kMaxPrev]; f32x4 y0v, y1v; };
+    auto epi_load = [&](int r, EpiRow &e) {
+        const size_t off = (size_t)r * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < kMaxPrev; ++m)
+            if (m < a.n_prev) e.km[m] = reinterpret_cast<const f32x4 *>(a.kprev[m])[off];
+        e.y0v = reinterpret_cast<const f32x4 *>(a.y0)[off];
+        if (MODE == MODE_ERROR) e.y1v = X[off];                // the input of this evaluation is y1
+    };
+    auto epi_finish = [&](int r, const float *src_row, const EpiRow &e) {
+        const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
+        const size_t off = (size_t)r * 64 + lane;
+        __builtin_nontemporal_store(kn, reinterpret_cast<f32x4 *>(a.K) + off);
+        if (MODE == MODE_PLAIN) return;
+        f32x4 s = kn * a.c[a.n_prev];                          // only term when n_prev == 0
+        if (a.n_prev > 0) {
+            s = e.km[0] * a.c[0];
+#pragma unroll
+            for (int m = 1; m < kMaxPrev; ++m)
+                if (m < a.n_prev) s = s + e.km[m] * a.c[m];
+            s = s + kn * a.c[a.n_prev];                        // the new stage is the last term of the sum
+        }
+        if (MODE == MODE_COMBINE) {
+            __builtin_nontemporal_store(e.y0v + s, reinterpret_cast<f32x4 *>(a.y_next) + off);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float tol = a.atol + a.rtol * fmaxf(fabsf(e.y0v[q]), fabsf(e.y1v[q]));
+                const float z = s[q] / tol;
+                err_sum += (double)(z * z);
+                err_bad += (double)(int)(!(fabsf(e.y1v[q]) <= 3.402823466e38f));
+            }
+        }
+    };
     auto epilogue_tile = [&](int t, const float *src) {
-#pragma unroll 1
-        for (int k = 0; k < kRowsPerProd; ++k) {
-            const int lr = p + kProd * k;
-            const int r = t * kTile2 + lr;
-            if (r >= a.n_rows) continue;
-            const f32x4 kn = *reinterpret_cast<const f32x4 *>(src + lr * kLd2 + 4 * lane);
-            const size_t off = (size_t)r * 64 + lane;
-            __builtin_nontemporal_store(kn, reinterpret_cast<f32x4 *>(a.K) + off);
-            if (MODE != MODE_PLAIN) {
-                f32x4 km[kMaxPrev];
+        const int r0 = t * kTile2 + p;
+        if (MODE == MODE_PLAIN) {
 #pragma unroll
-                for (int m = 0; m < kMaxPrev; ++m)
-                    if (m < a.n_prev) km[m] = reinterpret_cast<const f32x4 *>(a.kprev[m])[off];
-                const f32x4 y0v = reinterpret_cast<const f32x4 *>(a.y0)[off];
-                f32x4 y1v = y0v;
-                if (MODE == MODE_ERROR) y1v = X[off];          // the input of this evaluation is y1
-                f32x4 s = kn * a.c[a.n_prev];                  // only term when n_prev == 0
-                if (a.n_prev > 0) {
-                    s = km[0] * a.c[0];
-#pragma unroll
-                    for (int m = 1; m < kMaxPrev; ++m)
-                        if (m < a.n_prev) s = s + km[m] * a.c[m];
-                    s = s + kn * a.c[a.n_prev];                // the new stage is the last term of the sum
-                }
-                if (MODE == MODE_COMBINE) {
-                    __builtin_nontemporal_store(y0v + s, reinterpret_cast<f32x4 *>(a.y_next) + off);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float tol = a.atol + a.rtol * fmaxf(fabsf(y0v[e]), fabsf(y1v[e]));
-                        const float q = s[e] / tol;
-                        err_sum += (double)(q * q);
-                        err_bad += (double)(int)(!(fabsf(y1v[e]) <= 3.402823466e38f));
-                    }
+            for (int k = 0; k < kRowsPerProd; ++k) {
+                const int r = r0 + kProd * k;
+                if (r < a.n_rows) {
+                    EpiRow dummy;
+                    epi_finish(r, src + (p + kProd * k) * kLd2, dummy);
                 }
             }
+            return;
+        }
+        EpiRow ea, eb;
+        if (r0 < a.n_rows) epi_load(r0, ea);
+#pragma unroll
+        for (int k = 0; k < kRowsPerProd; k += 2) {
+            const int rA = r0 + kProd * k, rB = rA + kProd, rC = rB + kProd;
+            if (rB < a.n_rows) epi_load(rB, eb);
+            if (rA < a.n_rows) epi_finish(rA, src + (p + kProd * k) * kLd2, ea);
+            if (k + 2 < kRowsPerProd && rC < a.n_rows) epi_load(rC, ea);
+            if (rB < a.n_rows) epi_finish(rB, src + (p + kProd * (k + 1)) * kLd2, eb);
         }
     };
 
@@ -268,14 +302,15 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
     // Role-specialised loops (both execute the same sequence of workgroup barriers), so the accumulators of the
     // MFMA waves and the fetch registers of the gather waves never share a live range.
     if (producer) {
-        gather_tile(t_first, s_tile);
+        prefetch_index(t_first);
+        gather_tile(s_tile);
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             const int t = t_first + it * wgs_per_xcd;
             float *oth = s_tile + ((it & 1) ^ 1) * kTileFloats2;
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             if (it > 0) epilogue_tile(t - wgs_per_xcd, oth);
-            if (it + 1 < my_tiles) gather_tile(t + wgs_per_xcd, oth);
+            if (it + 1 < my_tiles) { prefetch_index(t + wgs_per_xcd); gather_tile(oth); }
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
             __syncthreads();
