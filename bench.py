@@ -44,8 +44,9 @@ def parse():
     p.add_argument('--atol', type=float, default=0.001)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-threads', type=int, default=32, help='host threads of the CPU-baseline leg')
-    p.add_argument('--cpu-side', type=int, default=128, help='grid side of the bounded CPU-baseline sample')
+    p.add_argument('--cpu-side', type=int, default=640, help='grid side of the bounded CPU-baseline sample')
     p.add_argument('--no-profile-pass', action='store_true')
+    p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (needs torchrun, works with 1 rank)')
     return p.parse_args()
 
 
@@ -110,8 +111,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_PORT', '29655')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, '--gpus %d but WORLD_SIZE %d' % (args.gpus, world)
@@ -124,7 +126,7 @@ def main():
     n_local = S * S
     torch.manual_seed(0)
     f = ODEFunc(H, None).to(dev).eval()                      # nn.Linear default init, seed 0
-    if world == 1:
+    if world == 1 and not args.sharded:
         L = graphs.normalized_laplacian(graphs.grid_8_neighbor(S))
         f.A = graphs.to_device(L, dev)
         nnz = int(L.nnz)

@@ -103,6 +103,23 @@ NDCN_API int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo
                  const float *W, const float *b, float *Y, float *work, int H, uint32_t flags, void *stream);
 NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 
+/* ODEFunc.forward PLUS the Runge-Kutta algebra that consumes its result, in one pass over the panel
+ * (H = 256: inside the fused kernel's epilogue; other widths: the same result from separate kernels).
+ *   rk_mode 0                  K = ODEFunc(X)                                   (= ndcn_rhs_f32)
+ *   rk_mode NDCN_RK_COMBINE    also y_next = y0 + sum_{m<n_prev} h_c[m] kprev[m] + h_c[n_prev] K
+ *                              (stage input of the NEXT evaluation, rk_common.py:51; K is the last term)
+ *   rk_mode NDCN_RK_ERROR      also d_out = {sum ((sum_m h_c[m] k_m) / (atol + rtol max(|y0|, |X|)))^2,
+ *                              non-finite count of X}: the dopri5 error record, X being y1 (rk_common.py:60,
+ *                              misc.py:146-157, dopri5.py:101-102); d_ws: ndcn_reduce_ws_bytes() bytes
+ * h_kprev / h_c are HOST arrays (n_prev <= 5 device pointers; n_prev + 1 coefficients, already dt * beta in
+ * fp32).  X, K, y_next, y0 and the kprev panels must not alias each other.                              */
+#define NDCN_RK_COMBINE 1
+#define NDCN_RK_ERROR   2
+NDCN_API int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
+                             const float *W, const float *b, float *K, float *work, int H, uint32_t flags,
+                             int rk_mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
+                             float *y_next, float rtol, float atol, double *d_out, void *d_ws, void *stream);
+
 /* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
 NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);
 

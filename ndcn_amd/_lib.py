@@ -17,6 +17,7 @@ OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
 
 F_RELU, F_NO_GRAPH, F_NO_CONTROL = 1, 2, 4
+RK_NONE, RK_COMBINE, RK_ERROR = 0, 1, 2
 M_EULER, M_MIDPOINT, M_RK4, M_DOPRI5 = 0, 1, 2, 3
 METHODS = {'euler': M_EULER, 'midpoint': M_MIDPOINT, 'rk4': M_RK4, 'dopri5': M_DOPRI5}
 PROF_KINDS = ('spmm', 'linear', 'rhs_fused', 'combine', 'error', 'sumsq', 'interp_fit', 'interp_eval',
@@ -57,6 +58,8 @@ SIGNATURES = {
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
+    'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
+                        _P, _F, _F, _P, _P, _P]),
     'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
     'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),

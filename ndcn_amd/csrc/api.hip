@@ -86,6 +86,30 @@ int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t
     return rhs_f32(A, X, X_halo, n_own, W, b, Y, work, H, flags, ST(stream));
 }
 
+int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
+                    float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
+                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, float rtol, float atol,
+                    double *d_out, void *d_ws, void *stream) {
+    NDCN_CHECK_ARG(A, "null operator descriptor");
+    NDCN_CHECK_ARG(H > 0, "H must be positive");
+    NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 2, "rk_mode must be 0, NDCN_RK_COMBINE or NDCN_RK_ERROR");
+    if (!(flags & NDCN_F_NO_GRAPH)) {
+        int rc = check_csr(A, __func__);
+        if (rc) return rc;
+        NDCN_CHECK_ARG(X_halo || n_own >= A->n_cols, "columns beyond n_own need a halo panel");
+    }
+    NDCN_CHECK_ARG(A->n_rows == 0 || (X && K), "null panel");
+    NDCN_CHECK_ARG(X != K, "K must not alias X");
+    NDCN_CHECK_ARG((flags & NDCN_F_NO_CONTROL) || W, "weight missing");
+    if (rk_mode != 0) {
+        NDCN_CHECK_ARG(y0 && h_c && (n_prev == 0 || h_kprev), "rk arguments missing");
+        NDCN_CHECK_ARG(rk_mode != NDCN_RK_COMBINE || (y_next && y_next != X && y_next != K), "y_next missing or aliased");
+        NDCN_CHECK_ARG(rk_mode != NDCN_RK_ERROR || (d_out && d_ws), "error record / scratch missing");
+    }
+    return rhs_rk_f32(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
+                      d_out, d_ws, ST(stream));
+}
+
 int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream) {
     NDCN_CHECK_ARG(n_idx >= 0 && H > 0, "bad shape");
     NDCN_CHECK_ARG(n_idx == 0 || (X && idx && out), "null pointer");

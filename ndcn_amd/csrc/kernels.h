@@ -13,6 +13,10 @@ int linear_f32(const float *S, const float *W, const float *b, float *Y, int64_t
 int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *Y,
             float *work, int H, uint32_t flags, hipStream_t st);
 int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
+int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *K,
+               float *work, int H, uint32_t flags, int rk_mode, const float *y0, const float *const *h_kprev,
+               const float *h_c, int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws,
+               hipStream_t st);
 int rhs_fused_supported(int H, uint32_t flags);
 int pack_weight_256(const float *W, float *Wp, hipStream_t st);
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);

@@ -58,4 +58,29 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
     return NDCN_OK;
 }
 
+int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *K,
+               float *work, int H, uint32_t flags, int rk_mode, const float *y0, const float *const *h_kprev,
+               const float *h_c, int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws,
+               hipStream_t st) {
+    if (rk_mode == 0) return rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
+    if (n_prev < 0 || n_prev > 5) { set_error("rhs_rk: n_prev must be 0..5"); return NDCN_EINVAL; }
+    const bool both = !(flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
+    if (both && rhs_fused2_supported(A, H, flags)) {
+        if (!work) { set_error("rhs_rk: scratch of ndcn_rhs_work_bytes() bytes required"); return NDCN_EINVAL; }
+        int rc = pack_weight_256(W, work, st);
+        if (rc) return rc;
+        return rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
+                              d_out, d_ws, st);
+    }
+    // composition with the same term order: K first, then the algebra over {kprev..., K}
+    int rc = rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
+    if (rc) return rc;
+    const float *kk[6];
+    for (int m = 0; m < n_prev; ++m) kk[m] = h_kprev[m];
+    kk[n_prev] = K;
+    const int64_t n = A->n_rows * (int64_t)H;
+    if (rk_mode == 1) return rk_combine_f32(y_next, y0, kk, h_c, n_prev + 1, n, st);
+    return rk_error_f32(y0, X, kk, h_c, n_prev + 1, rtol, atol, n, d_out, d_ws, st);
+}
+
 }  // namespace ndcn

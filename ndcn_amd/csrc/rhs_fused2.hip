@@ -61,6 +61,7 @@ struct Fused2Args {
     float *y_next;
     float rtol, atol;
     double *partials;                       // ERROR: [gridDim.x * kProd][2]
+    int dbg;                                // timing experiments only (NDCN_FUSED_DBG): 1 skip MFMA, 2 skip gather, 4 skip epilogue
 };
 
 enum { MODE_PLAIN = 0, MODE_COMBINE = 1, MODE_ERROR = 2 };
@@ -248,29 +249,35 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
     // ---- consumer -----------------------------------------------------------------------------------
     // wave w owns output columns [64 w, 64 w + 64) (n-tiles 2w, 2w+1) for both 32-row m-tiles
     f32x16 acc00, acc01, acc10, acc11;
+    // Ring of weight operands, kRing deep: slot u holds k-quad q with q % kRing == u.  The weights are the same
+    // for every tile, so the ring simply wraps around - it is already full when the next tile starts.
+    constexpr int kRing = 4;
+    const f32x4 *b0p = Wp + (size_t)(2 * (wave & 3)) * 32 * 64 + lane;
+    const f32x4 *b1p = b0p + 32 * 64;
+    f32x4 r0[kRing], r1[kRing];
+    auto ring_fill = [&]() {
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) { r0[u] = b0p[u * 64]; r1[u] = b1p[u * 64]; }
+    };
     auto mfma_tile = [&](const float *src) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
         const float *a0p = src + (lane & 31) * kLd2 + 128 * (lane >> 5);
         const float *a1p = a0p + 32 * kLd2;
-        const f32x4 *b0p = Wp + (size_t)(2 * wave) * 32 * 64 + lane;
-        const f32x4 *b1p = b0p + 32 * 64;
-        // 4-deep ring of weight operands: slot u holds step q with q % 4 == u
-        f32x4 r0[4], r1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { r0[u] = b0p[u * 64]; r1[u] = b1p[u * 64]; }
         f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p), a1 = *reinterpret_cast<const f32x4 *>(a1p);
 #pragma unroll 1
-        for (int q0 = 0; q0 < 32; q0 += 4) {
+        for (int q0 = 0; q0 < 32; q0 += kRing) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kRing; ++u) {
                 const int q = q0 + u;
                 const f32x4 c0 = r0[u], c1 = r1[u], x0 = a0, x1 = a1;
                 if (q + 1 < 32) {
                     a0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
                     a1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
                 }
-                if (q + 4 < 32) { r0[u] = b0p[(q + 4) * 64]; r1[u] = b1p[(q + 4) * 64]; }
+                const int qn = (q + kRing) & 31;               // wraps into the next tile's first quads
+                r0[u] = b0p[qn * 64];
+                r1[u] = b1p[qn * 64];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], c0[e], acc00, 0, 0, 0);
@@ -309,8 +316,8 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
             const int t = t_first + it * wgs_per_xcd;
             float *oth = s_tile + ((it & 1) ^ 1) * kTileFloats2;
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
-            if (it > 0) epilogue_tile(t - wgs_per_xcd, oth);
-            if (it + 1 < my_tiles) { prefetch_index(t + wgs_per_xcd); gather_tile(oth); }
+            if (it > 0 && !(a.dbg & 4)) epilogue_tile(t - wgs_per_xcd, oth);
+            if (it + 1 < my_tiles && !(a.dbg & 2)) { prefetch_index(t + wgs_per_xcd); gather_tile(oth); }
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
             __syncthreads();
@@ -329,10 +336,11 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
             }
         }
     } else {
+        ring_fill();                                           // weight fetches fly while the first tile is gathered
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             float *cur = s_tile + (it & 1) * kTileFloats2;
-            mfma_tile(cur);
+            if (!(a.dbg & 1)) mfma_tile(cur);
             __syncthreads();                                   // every consumer is done reading `cur`
             dump_tile(cur);
             __syncthreads();
@@ -381,6 +389,8 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     a.y0 = y0; a.n_prev = n_prev; a.y_next = y_next; a.rtol = rtol; a.atol = atol;
     a.partials = static_cast<double *>(d_ws);
+    static const int dbg = env_int3("NDCN_FUSED_DBG", 0);
+    a.dbg = dbg;
     for (int m = 0; m < kMaxPrev; ++m) a.kprev[m] = (m < n_prev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kMaxPrev; ++m) a.c[m] = (mode != MODE_PLAIN && m <= n_prev) ? h_c[m] : 0.f;
     int per_xcd = kCus / kXcds;

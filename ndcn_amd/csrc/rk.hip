@@ -289,7 +289,11 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
     return NDCN_OK;
 }
 
-int64_t reduce_ws_bytes() { return (int64_t)kRedBlocks * 2 * sizeof(double); }
+int64_t rhs_fused2_partials_bytes();
+int64_t reduce_ws_bytes() {
+    const int64_t a = (int64_t)kRedBlocks * 2 * sizeof(double), b = rhs_fused2_partials_bytes();
+    return a > b ? a : b;      // one scratch serves the reductions of rk.hip and of the fused RHS epilogue
+}
 
 static int red_grid(int64_t items) {
     int g = stream_grid(items, 256);

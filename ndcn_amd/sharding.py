@@ -106,6 +106,24 @@ class ShardedODEFunc(nn.Module):
         self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
         return self.ops.rhs(self.plan.local_op, x, f.wt.weight, f.wt.bias, no_control=f.no_control, X_halo=halo)
 
+    def rhs_rk(self, x, mode, y0, kprev, cs, rtol, atol):
+        """RHS + the stage algebra consuming it (core.Dopri5's `fused` protocol); the error record is summed
+        over ranks here so every rank sees the same controller input."""
+        self.nfe += 1
+        f = self.f
+        halo = None
+        if not f.no_graph:
+            halo = self.plan.exchange(self.ops, x)
+            self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
+        k, out = self.ops.rhs_rk(None if f.no_graph else self.plan.local_op, x, f.wt.weight, f.wt.bias, mode, y0, kprev, cs,
+                                 rtol, atol, no_graph=f.no_graph, no_control=f.no_control, X_halo=halo)
+        if mode == 'error' and self.plan.world > 1:
+            dev = x.device if dist.get_backend(self.plan.group) == 'nccl' else torch.device('cpu')
+            v = torch.tensor([out[0], out[1]], dtype=torch.float64, device=dev)
+            dist.all_reduce(v, group=self.plan.group)
+            out = tuple(v.tolist())
+        return k, out
+
 
 class DistOps:
     """Panel ops whose reductions span all ranks (everything else is row-local and forwarded untouched)."""
@@ -140,14 +158,15 @@ class DistOps:
 
 
 def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, atol=1e-9, method='dopri5', step_log=None,
-                   group=None):
+                   group=None, fused=True):
     """odeint on this rank's rows of the global system; returns (len(t), n_local, H)."""
     from .torchdiffeq._impl import core
     f = ShardedODEFunc(odefunc, plan, ops)
     dops = DistOps(ops, n_global_rows, x_local.shape[0], group)
     _, func, y0, tt = core.check_inputs(f, x_local, t)
     if method == 'dopri5':
-        sol = core.integrate_dopri5(dops, func, y0, tt, rtol, atol, autonomous=True, step_log=step_log)
+        sol = core.integrate_dopri5(dops, func, y0, tt, rtol, atol, autonomous=True, step_log=step_log,
+                                    fused=f if fused else None)
     else:
         sol = core.integrate_fixed(dops, func, y0, tt, method, autonomous=True)
     return torch.stack([s[0] for s in sol])
@@ -175,7 +194,8 @@ class ShardedGridBench:
 
     def _begin(self):
         f = lambda t, y: (self.func(t, y[0]),)
-        self.solver = self.core.Dopri5(self.dops, f, (self.x0,), self.rtol, self.atol, autonomous=True)
+        self.solver = self.core.Dopri5(self.dops, f, (self.x0,), self.rtol, self.atol, autonomous=True,
+                                       fused=self.func)
         self.solver.begin(0.0)
 
     def run_steps(self, k):

@@ -207,8 +207,13 @@ def optimal_step_size(dt, ratio32):
 class Dopri5:
     """dopri5.py:58-122 as a resumable object: begin() = before_integrate, advance() = advance."""
 
-    def __init__(self, ops, func, y0, rtol, atol, autonomous=False, max_num_steps=2 ** 31 - 1, first_step=None):
+    def __init__(self, ops, func, y0, rtol, atol, autonomous=False, max_num_steps=2 ** 31 - 1, first_step=None,
+                 fused=None):
+        """`fused`: optional object with rhs_rk(x, mode, y0, kprev, cs, rtol, atol) -> (k, y_next | (sum, bad)):
+        the right-hand side that also performs the stage algebra consuming its result (ndcn_rhs_rk_f32).
+        Single-tensor states only; the step then costs 1 combine + 6 fused evaluations."""
         self.ops, self.func = ops, func
+        self.fused = fused if len(y0) == 1 else None
         self.y = y0
         self.rtol, self.atol = rtol, atol
         self.max_num_steps = max_num_steps
@@ -248,6 +253,8 @@ class Dopri5:
         dt32 = f32(dt)
         t032 = f32(t0)
         y0 = self.y
+        if self.fused is not None:
+            return self._step_fused(t0, dt, dt32)
         k = [[f] for f in self.f]
         yi = y0
         for a_i, b_i in zip(DP_ALPHA, DP_BETA):
@@ -266,6 +273,9 @@ class Dopri5:
             s, bad = ops.error(y0_, y1_, kk, cs, self.rtol, self.atol)
             ratios.append(f32(s / n) if n else f32('nan'))        # misc.py:156: a float32 mean
             bad_total += bad
+        return self._finish_step(t0, dt, dt32, y0, y1, k, ratios, bad_total)
+
+    def _finish_step(self, t0, dt, dt32, y0, y1, k, ratios, bad_total):
         accept = all(bool(r <= 1) for r in ratios)                 # dopri5.py:109
         worst = f32('nan') if any(np.isnan(r) for r in ratios) else max(ratios)
         dt_next = optimal_step_size(dt, worst)
@@ -281,6 +291,30 @@ class Dopri5:
             self.t0 = self.t1 = t0
         self.dt = dt_next
         return accept
+
+    def _step_fused(self, t0, dt, dt32):
+        """One attempt with the stage algebra riding in the RHS epilogues (same terms, same order as step())."""
+        y0 = self.y[0]
+        k = [self.f[0]]
+        kk, cs = dt_terms(dt32, DP_BETA[0], k)
+        x = self.ops.combine(y0, kk, cs)
+        for i in range(1, 6):
+            # the evaluation producing k[i] also forms the input of stage i+1: y0 + dt * sum beta[i][m] k[m]
+            prev, cp = dt_terms(dt32, DP_BETA[i][:i], k)
+            c_new = f32(dt32 * f32(DP_BETA[i][i]))
+            self.nfe += 1
+            k_new, x_next = self.fused.rhs_rk(x, 'combine', y0, prev, cp + [c_new], 0.0, 0.0)
+            k.append(k_new)
+            x = x_next
+        y1 = x
+        prev, cp = dt_terms(dt32, DP_C_ERR[:6], k)
+        c_new = f32(dt32 * f32(DP_C_ERR[6]))
+        self.nfe += 1
+        k_new, (s, bad) = self.fused.rhs_rk(y1, 'error', y0, prev, cp + [c_new], self.rtol, self.atol)
+        k.append(k_new)
+        n = self.n_elem[0]
+        ratios = [f32(s / n) if n else f32('nan')]
+        return self._finish_step(t0, dt, dt32, (y0,), (y1,), [k], ratios, bad)
 
     def advance(self, next_t, step_budget=None):
         """dopri5.py:85-92: step until t1 >= next_t, then evaluate the dense output at next_t.
@@ -310,7 +344,7 @@ class Dopri5:
         return tuple(self.ops.interp_eval(fit, e_, xp) for fit, e_ in zip(fits, e))
 
 
-def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=None, **options):
+def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=None, fused=None, **options):
     """solvers.py:25-33."""
     assert_increasing(t)
     unused = {k: v for k, v in options.items() if k not in ('first_step', 'safety', 'ifactor', 'dfactor', 'max_num_steps')}
@@ -321,7 +355,8 @@ def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=No
             raise NotImplementedError('dopri5 option `%s` is fixed at the reference default in this build' % name)
     tt = t.detach().to('cpu', torch.float64).numpy()
     solver = Dopri5(ops, func, y0, rtol, atol, autonomous=autonomous,
-                    max_num_steps=options.get('max_num_steps', 2 ** 31 - 1), first_step=options.get('first_step'))
+                    max_num_steps=options.get('max_num_steps', 2 ** 31 - 1), first_step=options.get('first_step'),
+                    fused=fused)
     solver.begin(tt[0])
     sol = [y0]
     for i in range(1, len(tt)):

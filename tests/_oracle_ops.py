@@ -58,6 +58,14 @@ class OracleOps:
             x = torch.nn.functional.linear(x, W, b)
         return torch.relu(x)
 
+    @classmethod
+    def rhs_rk(cls, A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None):
+        k = cls.rhs(A, X, W, b, no_graph=no_graph, no_control=no_control, X_halo=X_halo)
+        ks = list(kprev) + [k]
+        if mode == 'combine':
+            return k, cls.combine(y0, ks, cs)
+        return k, cls.error(y0, X, ks, cs, rtol, atol)
+
     @staticmethod
     def gather_rows(X, idx):
         return X[idx.long()]

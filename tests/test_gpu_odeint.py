@@ -176,6 +176,38 @@ def test_fused_epilogue_solver_equals_generic_path(dev, side):
             check_traj(ya.cpu().numpy(), ref.numpy(), l1=1e-5, mx=2e-4)
 
 
+def test_sharded_path_single_rank_equals_device_solver(dev):
+    """The multi-GPU code path (ndcn_amd/sharding.py: halo plan, RCCL all-to-all-v, global reductions, Python
+    stepping over ndcn_rhs_rk_f32) run with ONE rank over the nccl backend must reproduce the device-resident
+    solver: same kernels, same order.  (Two-rank correctness is covered on CPU by tests/test_sharding_gloo.py.)"""
+    import torch.distributed as dist
+    from ndcn_amd import graphs, sharding, hip
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29641', rank=0, world_size=1, device_id=dev)
+    try:
+        side, H = 48, 256
+        L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+        torch.manual_seed(4)
+        f = ODEFunc(H, graphs.to_device(L, dev)).to(dev).eval()
+        x0 = torch.rand(side * side, H, device=dev)
+        t = torch.tensor([0., 0.7, 2.0], device=dev)
+        plan = sharding.HaloPlan(L, [0, side * side], 0, dev)
+        assert plan.n_halo == 0
+        with torch.no_grad():
+            la, lb = [], []
+            ya = ode.odeint(f, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=la)
+            yb = sharding.sharded_odeint(hip, f, plan, side * side, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
+        assert [r[2] for r in la[:-1]] == [r[2] for r in lb if r[0] != 'nfe']
+        assert float((ya - yb).abs().max()) <= 1e-5 * float(ya.abs().max())
+        # bench runner of the sharded path
+        runner = sharding.ShardedGridBench(f, 48, 1, 0, dev, 5.0, .01, .001)
+        assert runner.run_steps(3) == 3 and runner.nfe() >= 2 + 18
+    finally:
+        dist.destroy_process_group()
+
+
 def test_tuple_state_generic_path(dev):
     from ndcn_amd import torchdiffeq as ode
 

@@ -13,13 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'spmm_union_r8': {},
-    'spmm_union_r8_dma': {'NDCN_UNION_DMA': '1'},
-    'spmm_union_r4_dma': {'NDCN_UNION_ROWS': '4', 'NDCN_UNION_CAP': '18', 'NDCN_UNION_DMA': '1'},
-    'spmm_wide_bpc4': {'NDCN_UNION_ROWS': '0'},
     'rhs_fused2': {},
-    'rhs_fused_v1': {'NDCN_RHS_FUSED2': '0'},
-    'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
+    'rhs_fused2_noGather_noEpi': {'NDCN_FUSED_DBG': '6'},
+    'rhs_fused2_noMFMA': {'NDCN_FUSED_DBG': '1'},
 }
 
 
