@@ -44,7 +44,7 @@ def parse():
     p.add_argument('--atol', type=float, default=0.001)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-threads', type=int, default=32, help='host threads of the CPU-baseline leg')
-    p.add_argument('--cpu-side', type=int, default=640, help='grid side of the bounded CPU-baseline sample')
+    p.add_argument('--cpu-side', type=int, default=512, help='grid side of the bounded CPU-baseline sample')
     p.add_argument('--no-profile-pass', action='store_true')
     p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (needs torchrun, works with 1 rank)')
     return p.parse_args()

@@ -40,7 +40,7 @@ int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, co
 int interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e, const float xp[5],
                     float *out, int64_t n, hipStream_t st);
 int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
-                    const float *k4, float dt, int64_t n, hipStream_t st);
+                    const float *k4, float dt, int64_t n, hipStream_t st, const float *dt_dev = nullptr);
 
 int gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, hipStream_t st);
 int mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d, float e, float h,

@@ -121,7 +121,13 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
     const int t_lo = xcd * chunk, t_hi = min(a.n_tiles, t_lo + chunk);
     const int t_first = t_lo + wg;
     const int my_tiles = t_first < t_hi ? (t_hi - t_first + wgs_per_xcd - 1) / wgs_per_xcd : 0;
-    if (my_tiles == 0) return;                                // uniform per workgroup
+    if (my_tiles == 0) {                                      // uniform per workgroup
+        if (MODE == MODE_ERROR && producer && lane == 0) {    // the finish kernel sums EVERY slot
+            a.partials[2 * (blockIdx.x * kProd + p)] = 0.0;
+            a.partials[2 * (blockIdx.x * kProd + p) + 1] = 0.0;
+        }
+        return;
+    }
 
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 

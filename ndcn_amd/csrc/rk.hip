@@ -245,7 +245,11 @@ __device__ __forceinline__ float stage1(float y, float k1, float k2, float k3, f
 
 template <int OP, bool VEC>
 __global__ __launch_bounds__(256) void fixed_stage_kernel(float *out, const float *y, const float *k1, const float *k2,
-                                                          const float *k3, const float *k4, float dt, int64_t n_items) {
+                                                          const float *k3, const float *k4, float dt_val,
+                                                          const float *__restrict__ dt_dev, int64_t n_items) {
+    // dt_dev != NULL: the step size lives in device memory, so ONE captured hipGraph serves every step of an
+    // irregular time grid (solvers.py:51: the grid is the caller's t, each interval has its own dt)
+    const float dt = dt_dev ? *dt_dev : dt_val;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         if (VEC) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -371,13 +375,13 @@ int interp_eval_f32(const float *a, const float *b, const float *c, const float 
 
 template <int OP>
 static void launch_stage(bool vec, float *out, const float *y, const float *k1, const float *k2, const float *k3,
-                         const float *k4, float dt, int64_t n, hipStream_t st) {
-    if (vec) hipLaunchKernelGGL((fixed_stage_kernel<OP, true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, n / 4);
-    else hipLaunchKernelGGL((fixed_stage_kernel<OP, false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, n);
+                         const float *k4, float dt, const float *dt_dev, int64_t n, hipStream_t st) {
+    if (vec) hipLaunchKernelGGL((fixed_stage_kernel<OP, true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, dt_dev, n / 4);
+    else hipLaunchKernelGGL((fixed_stage_kernel<OP, false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, dt_dev, n);
 }
 
 int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
-                    const float *k4, float dt, int64_t n, hipStream_t st) {
+                    const float *k4, float dt, int64_t n, hipStream_t st, const float *dt_dev) {
     const int need = op <= 2 ? 1 : op == 3 ? 2 : op == 4 ? 3 : 4;
     const float *ks[4] = {k1, k2, k3, k4};
     bool vec = (n % 4 == 0) && aligned16(out) && aligned16(y);
@@ -388,12 +392,12 @@ int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const f
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_STAGE, st, 4.0 * n * (need + 2), 2.0 * n * need);
     switch (op) {
-        case 0: launch_stage<0>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
-        case 1: launch_stage<1>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
-        case 2: launch_stage<2>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
-        case 3: launch_stage<3>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
-        case 4: launch_stage<4>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
-        case 5: launch_stage<5>(vec, out, y, k1, k2, k3, k4, dt, n, st); break;
+        case 0: launch_stage<0>(vec, out, y, k1, k2, k3, k4, dt, dt_dev, n, st); break;
+        case 1: launch_stage<1>(vec, out, y, k1, k2, k3, k4, dt, dt_dev, n, st); break;
+        case 2: launch_stage<2>(vec, out, y, k1, k2, k3, k4, dt, dt_dev, n, st); break;
+        case 3: launch_stage<3>(vec, out, y, k1, k2, k3, k4, dt, dt_dev, n, st); break;
+        case 4: launch_stage<4>(vec, out, y, k1, k2, k3, k4, dt, dt_dev, n, st); break;
+        case 5: launch_stage<5>(vec, out, y, k1, k2, k3, k4, dt, dt_dev, n, st); break;
         default: set_error("fixed_stage: unknown op %d", op); return NDCN_EINVAL;
     }
     NDCN_LAUNCH_CHECK();

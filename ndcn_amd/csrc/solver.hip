@@ -77,6 +77,14 @@ struct ndcn_solver {
     double last_ratio = 0;
     int64_t pending_bad = 0;       // non-finite elements seen in the state that starts the next step
     std::vector<double> log;       // 5 doubles per attempt
+    // fixed-grid hipGraph replay (launch-bound graphs): one captured step, dt in device memory
+    bool graph_on = false;
+    hipStream_t gstream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipEvent_t gev_in = nullptr, gev_out = nullptr;
+    float *d_dt = nullptr;         // device step size read by the captured stage kernels
+    float *h_dt = nullptr;         // pinned ring of step sizes (async H2D source must stay untouched until consumed)
+    int64_t g_step = 0;
 };
 
 namespace {
@@ -94,7 +102,7 @@ size_t workspace_bytes(const ndcn_solver_desc *d) {
     const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
     const size_t work = align_up((size_t)rhs_work_bytes(d->A.n_rows, d->H, d->rhs_flags) + 16);
     return (size_t)n_panels(d) * panel + work + align_up((size_t)reduce_ws_bytes()) +
-           align_up((size_t)rhs_fused2_partials_bytes()) + 1024;
+           align_up((size_t)rhs_fused2_partials_bytes()) + 2048;
 }
 
 int carve(ndcn_solver *s, size_t bytes, void **p) {
@@ -396,6 +404,10 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         return fail(NDCN_EHIP);
     }
     if (hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(NDCN_EHIP); }
+    if ((rc = carve(s, 256, &q))) return fail(rc);
+    s->d_dt = static_cast<float *>(q);
+    // hipGraph replay pays off where the step is launch-bound; the fused H = 256 path passes dt by value
+    s->graph_on = desc->use_graph && desc->method != NDCN_M_DOPRI5 && !s->fused2;
     *out = s;
     return NDCN_OK;
 }
@@ -405,6 +417,11 @@ int solver_destroy(ndcn_solver *s) {
     if (s->slab_owned && s->slab) (void)hipFree(s->slab);
     if (s->h_red) (void)hipHostFree(s->h_red);
     if (s->ev) (void)hipEventDestroy(s->ev);
+    if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
+    if (s->gev_in) (void)hipEventDestroy(s->gev_in);
+    if (s->gev_out) (void)hipEventDestroy(s->gev_out);
+    if (s->gstream) (void)hipStreamDestroy(s->gstream);
+    if (s->h_dt) (void)hipHostFree(s->h_dt);
     delete s;
     return NDCN_OK;
 }
@@ -438,7 +455,81 @@ int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st) {
     return NDCN_OK;
 }
 
+constexpr int kDtRing = 4096;
+
+// the kernel sequence of one fixed-grid step on the solver's own buffers (y updated in place), dt from d_dt
+static int enqueue_fixed_step(ndcn_solver *s, hipStream_t st) {
+    const int64_t n = s->n_elem;
+    float *y = s->ycur_own;
+    const float *dtp = s->d_dt;
+    int rc;
+    if ((rc = rhs(s, y, s->k[0], st))) return rc;
+    switch (s->d.method) {
+        case NDCN_M_EULER:
+            return fixed_stage_f32(0, y, y, s->k[0], nullptr, nullptr, nullptr, 0.f, n, st, dtp);
+        case NDCN_M_MIDPOINT:
+            if ((rc = fixed_stage_f32(1, s->ytmp, y, s->k[0], nullptr, nullptr, nullptr, 0.f, n, st, dtp))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[0], st))) return rc;
+            return fixed_stage_f32(0, y, y, s->k[0], nullptr, nullptr, nullptr, 0.f, n, st, dtp);
+        default:
+            if ((rc = fixed_stage_f32(2, s->ytmp, y, s->k[0], nullptr, nullptr, nullptr, 0.f, n, st, dtp))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[1], st))) return rc;
+            if ((rc = fixed_stage_f32(3, s->ytmp, y, s->k[0], s->k[1], nullptr, nullptr, 0.f, n, st, dtp))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[2], st))) return rc;
+            if ((rc = fixed_stage_f32(4, s->ytmp, y, s->k[0], s->k[1], s->k[2], nullptr, 0.f, n, st, dtp))) return rc;
+            if ((rc = rhs(s, s->ytmp, s->k[3], st))) return rc;
+            return fixed_stage_f32(5, y, y, s->k[0], s->k[1], s->k[2], s->k[3], 0.f, n, st, dtp);
+    }
+}
+
+static int graph_setup(ndcn_solver *s) {
+    NDCN_HIP(hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking));
+    NDCN_HIP(hipEventCreateWithFlags(&s->gev_in, hipEventDisableTiming));
+    NDCN_HIP(hipEventCreateWithFlags(&s->gev_out, hipEventDisableTiming));
+    NDCN_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_dt), kDtRing * sizeof(float), hipHostMallocDefault));
+    hipGraph_t graph = nullptr;
+    NDCN_HIP(hipStreamBeginCapture(s->gstream, hipStreamCaptureModeThreadLocal));
+    const int64_t rhs_before = s->n_rhs;
+    const int rc = enqueue_fixed_step(s, s->gstream);
+    s->n_rhs = rhs_before;                                      // capturing is not evaluating
+    hipError_t e = hipStreamEndCapture(s->gstream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return NDCN_EHIP; }
+    e = hipGraphInstantiate(&s->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return NDCN_EHIP; }
+    return NDCN_OK;
+}
+
+static int graph_advance(ndcn_solver *s, double next_t, float *out, hipStream_t st) {
+    const float t1 = (float)next_t;
+    const float dt = t1 - s->tf;
+    if (!s->gexec) {
+        int rc = graph_setup(s);
+        if (rc) return rc;
+    }
+    if (s->ycur != s->ycur_own) { set_error("graph mode: state must live in the solver"); return NDCN_ESTATE; }
+    float *slot = s->h_dt + (s->g_step++ % kDtRing);
+    *slot = dt;
+    NDCN_HIP(hipEventRecord(s->gev_in, st));                    // order after the caller's stream (begin / previous copies)
+    NDCN_HIP(hipStreamWaitEvent(s->gstream, s->gev_in, 0));
+    NDCN_HIP(hipMemcpyAsync(s->d_dt, slot, sizeof(float), hipMemcpyHostToDevice, s->gstream));
+    NDCN_HIP(hipGraphLaunch(s->gexec, s->gstream));
+    if (out) NDCN_HIP(hipMemcpyAsync(out, s->ycur_own, (size_t)s->n_elem * sizeof(float), hipMemcpyDeviceToDevice, s->gstream));
+    NDCN_HIP(hipEventRecord(s->gev_out, s->gstream));
+    NDCN_HIP(hipStreamWaitEvent(st, s->gev_out, 0));            // the caller's stream sees the result
+    const int per = s->d.method == NDCN_M_EULER ? 1 : s->d.method == NDCN_M_MIDPOINT ? 2 : 4;
+    s->n_rhs += per;
+    s->tf = t1;
+    s->t0 = s->t1;
+    s->t1 = next_t;
+    s->n_attempt++;
+    s->n_accept++;
+    return NDCN_OK;
+}
+
 static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t st) {
+    if (s->graph_on) return graph_advance(s, next_t, out, st);
     // solvers.py:81-97 with grid == t: one step of size t1 - t0 formed in the state dtype
     const float t1 = (float)next_t;
     const float dt = t1 - s->tf;

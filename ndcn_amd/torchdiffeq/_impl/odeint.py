@@ -10,6 +10,7 @@ Two execution paths, both on the GPU:
 Host tensors are refused: there is no CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -18,6 +19,7 @@ from ...ops import hip
 from . import core
 
 SOLVERS = {m: m for m in core.METHODS}      # the in-scope subset of odeint.py:8-17
+GRAPH_MAX_ELEMS = 1 << 22                   # below ~4M state elements a step is launch-bound
 
 
 def _autonomous(func):
@@ -176,7 +178,10 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     if method != 'dopri5':
         # solvers.py:81: the fixed grid is t in the state dtype
         tt = t.detach().to('cpu').to(y0.dtype).to(torch.float64).tolist()
-    solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, options.get('max_num_steps', 2 ** 31 - 1))
+    # launch-bound sizes replay one captured hipGraph per fixed-grid step (dt lives in device memory)
+    use_graph = method != 'dopri5' and y0.numel() <= GRAPH_MAX_ELEMS and os.environ.get('NDCN_HIPGRAPH', '1') != '0'
+    solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, options.get('max_num_steps', 2 ** 31 - 1),
+                          use_graph=use_graph)
     try:
         out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         out[0].copy_(y0)

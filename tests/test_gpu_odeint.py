@@ -145,7 +145,32 @@ def test_dgnn_block_golden(dev, name, H):
     check_traj(y.cpu().numpy(), d['out'], l1=1e-5, mx=2e-4)
 
 
-@pytest.mark.parametrize('side', [55, 64])
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])
+def test_hipgraph_replay_equals_eager(dev, method):
+    """Fixed-grid steps replayed from one captured hipGraph (dt read from device memory) give bit-identical
+    trajectories to eager launches, on equal and irregular time grids."""
+    from ndcn_amd.torchdiffeq._impl.odeint import DeviceSolver
+    d = load_golden('fixed_%s_irregular' % method)
+    f = make_func(d, dev)
+    x0, t = T(d['x0']).to(dev), T(d['t'])
+    outs = []
+    for use_graph in (False, True):
+        s = DeviceSolver(f, x0.shape[0], method, use_graph=use_graph)
+        s.begin(x0, float(t[0]))
+        traj = [x0.clone()]
+        for ti in t[1:].tolist():
+            o = torch.empty_like(x0)
+            s.advance(ti, o)
+            traj.append(o)
+        torch.cuda.synchronize()
+        assert s.stats()['nfe'] == {'euler': 1, 'midpoint': 2, 'rk4': 4}[method] * (len(t) - 1)
+        s.close()
+        outs.append(torch.stack(traj))
+    assert torch.equal(outs[0], outs[1])
+    check_traj(outs[1].cpu().numpy(), d['traj'], l1=1e-5, mx=1e-4)
+
+
+@pytest.mark.parametrize('side', [48, 55, 64])       # 48: some workgroups of the persistent grid get no tile
 def test_fused_epilogue_solver_equals_generic_path(dev, side):
     """H = 256: the device-resident solver runs the stage algebra / error norm inside the fused RHS epilogue
     (rhs_fused2.hip); the generic path runs the same RHS kernel plus the separate rk.hip kernels.  Same
@@ -278,3 +303,47 @@ def test_large_grid_properties(dev):
         yb = ode.odeint(lambda tt, y: f(tt, y), x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
     assert la[-1] == lb[-1]
     assert float((ya[-1] - yb[-1]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('kind', ['heat', 'gene', 'mutualistic'])
+def test_driver_counterpart_trains(dev, kind, capsys):
+    """the build's driver counterpart (flags, split, Adam/L1 loop, log format) runs config C1 end to
+    end on the HIP path and the training loss goes down."""
+    from ndcn_amd.drivers.dynamics import main
+    out = main(kind, ['--network', 'grid', '--sampled_time', 'equal', '--baseline', 'ndcn', '--gpu', '0',
+                      '--niters', '30', '--test_freq', '10', '--time_tick', '20', '--method', 'euler'])
+    text = capsys.readouterr().out
+    lines = [l for l in text.splitlines() if l.startswith('Iter ')]
+    assert len(lines) == 4 and 'Train Loss' in lines[0] and 'Test Loss' in lines[0] and '| Time ' in lines[0]
+    first = float(lines[0].split('Train Loss ')[1].split('(')[0])
+    last = float(lines[-1].split('Train Loss ')[1].split('(')[0])
+    assert last < first
+    assert out['params'] == 901                                     # BASELINE.md: 901 parameters at H = 20
+
+
+@pytest.mark.parametrize('network,n', [('power_law', 6000), ('small_world', 6000), ('random', 3000)])
+def test_irregular_graphs_fused_path_vs_oracle(dev, network, n):
+    """Configs C2-C4 in miniature: hub rows longer than one 64-entry chunk (Barabasi-Albert), random shortcuts,
+    G(n,p) with mean degree 40 - through the fused H = 256 kernel and its RK epilogues, against the CPU oracle."""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    G = graphs.make_graph(network, n, seed=2)
+    L = graphs.normalized_laplacian(G)
+    if network == 'power_law':
+        assert np.diff(L.indptr).max() > 64                          # exercises the long-row path
+    torch.manual_seed(7)
+    f = ODEFunc(256, graphs.to_device(L, dev)).to(dev).eval()
+    x0 = torch.rand(n, 256, generator=torch.Generator().manual_seed(8))
+    t = torch.tensor([0., 0.5, 1.0])
+    log = []
+    with torch.no_grad():
+        y = ode.odeint(f, x0.to(dev), t.to(dev), rtol=.01, atol=.001, method='dopri5', step_log=log)
+        yr = ode.odeint(f, x0.to(dev), t.to(dev), method='rk4')
+    Ao = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
+    fo = orc.OracleODEFunc(Ao, f.wt.weight.detach().cpu(), f.wt.bias.detach().cpu())
+    lo = []
+    ref = orc.odeint(fo, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lo)
+    assert [r[2] for r in log[:-1]] == [r[2] for r in lo]
+    check_traj(y.cpu().numpy(), ref.numpy(), l1=1e-5, mx=3e-4)
+    check_traj(yr.cpu().numpy(), orc.odeint(fo, x0, t, method='rk4').numpy(), l1=1e-5, mx=3e-4)
