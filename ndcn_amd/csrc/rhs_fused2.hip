@@ -281,9 +281,12 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
                     a0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
                     a1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
                 }
-                const int qn = (q + kRing) & 31;               // wraps into the next tile's first quads
-                r0[u] = b0p[qn * 64];
-                r1[u] = b1p[qn * 64];
+                // the refill wraps into the next tile's first quads (dbg bit 8 = do not wrap: A/B switch)
+                if (!(a.dbg & 8) || q + kRing < 32) {
+                    const int qn = (q + kRing) & 31;
+                    r0[u] = b0p[qn * 64];
+                    r1[u] = b1p[qn * 64];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], c0[e], acc00, 0, 0, 0);
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             float *cur = s_tile + (it & 1) * kTileFloats2;
+            if ((a.dbg & 8) && it > 0) ring_fill();
             if (!(a.dbg & 1)) mfma_tile(cur);
             __syncthreads();                                   // every consumer is done reading `cur`
             dump_tile(cur);

@@ -347,3 +347,25 @@ def test_irregular_graphs_fused_path_vs_oracle(dev, network, n):
     assert [r[2] for r in log[:-1]] == [r[2] for r in lo]
     check_traj(y.cpu().numpy(), ref.numpy(), l1=1e-5, mx=3e-4)
     check_traj(yr.cpu().numpy(), orc.odeint(fo, x0, t, method='rk4').numpy(), l1=1e-5, mx=3e-4)
+
+
+def test_dgnn_cora_accuracy_parity(dev):
+    """Config C5 on Cora (the Pubmed feature blob is missing from the reference mount): the README command
+    (README.md:64) - differential_gcn, hidden 256, T 1.2, 16 ticks, dopri5 rtol = atol = .1, no_control, alpha 0,
+    100 epochs, weight decay .024 - trained on the HIP path.  README.md:67-73 reports 83.18 % +/- 0.76 over 5 runs
+    (min 82.6, max 84.5); a seeded run here must land in that neighbourhood."""
+    from ndcn_amd import CsrOperator
+    from ndcn_amd.drivers import dgnn
+    d = load_golden('dataset_cora')
+    g = load_golden('operators_cora')
+    n = int(g['n'])
+    import scipy.sparse as sp
+    adj = CsrOperator.from_arrays(g['alpha00_indptr'], g['alpha00_indices'], g['alpha00_data'], (n, n), dev)
+    feats = sp.csr_matrix((d['feat_data'], d['feat_indices'].astype(np.int64), d['feat_indptr']), shape=tuple(d['feat_shape']))
+    data = (adj, torch.from_numpy(feats.toarray()).to(dev), torch.from_numpy(d['labels'].astype(np.int64)).to(dev),
+            torch.from_numpy(d['idx_train'].astype(np.int64)).to(dev), torch.from_numpy(d['idx_val'].astype(np.int64)).to(dev),
+            torch.from_numpy(d['idx_test'].astype(np.int64)).to(dev))
+    accs = dgnn.main(['--dataset', 'cora', '--model', 'differential_gcn', '--iter', '2', '--dropout', '0', '--hidden', '256',
+                      '--T', '1.2', '--time_tick', '16', '--epochs', '100', '--weight_decay', '0.024', '--no_control',
+                      '--method', 'dopri5', '--alpha', '0', '--seed', '0'], data=data, quiet=True)
+    assert 0.80 <= accs.mean() <= 0.86, accs

@@ -102,3 +102,25 @@ def test_union_plan_reconstructs_the_columns():
             seg = cols[ptr[gi]:ptr[gi + 1]]
             assert np.all(np.diff(seg) > 0)
     assert frac == 0.0 or frac < 0.2          # the random matrix has (almost) no staged groups
+
+
+def test_planetoid_loader_against_reference_steps():
+    """ndcn_amd/planetoid.py vs the fixture assembled from the reference's data files (tools/gen_golden.py G8).
+    Needs the reference's data directory; skipped where it is absent (GPU box)."""
+    import os
+    import pytest
+    import torch
+    ref_data = '/root/reference/data'
+    if not os.path.isdir(ref_data):
+        pytest.skip('reference data directory not present')
+    from ndcn_amd import planetoid
+    d = load_golden('dataset_cora')
+    adj, feats, labels, itr, iva, ite = planetoid.load_data('cora', 0.0, ref_data)
+    ref_feat = sp.csr_matrix((d['feat_data'], d['feat_indices'].astype(np.int64), d['feat_indptr']), shape=tuple(d['feat_shape']))
+    assert np.abs(feats.numpy() - ref_feat.toarray()).max() < 1e-7
+    assert np.array_equal(labels.numpy(), d['labels'].astype(np.int64))
+    assert np.array_equal(itr.numpy(), d['idx_train']) and np.array_equal(iva.numpy(), d['idx_val'])
+    assert np.array_equal(ite.numpy(), d['idx_test'])
+    g = load_golden('operators_cora')
+    ref_op = sp.csr_matrix((g['alpha00_data'], g['alpha00_indices'], g['alpha00_indptr']), shape=(2708, 2708))
+    assert abs(adj.to_scipy() - ref_op).max() < 1e-7

@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'rhs_fused2': {},
-    'rhs_fused2_noGather_noEpi': {'NDCN_FUSED_DBG': '6'},
-    'rhs_fused2_noMFMA': {'NDCN_FUSED_DBG': '1'},
+    'rhs_fused2_wrap': {},
+    'rhs_fused2_nowrap': {'NDCN_FUSED_DBG': '8'},
+    'rhs_fused2_wrap_b': {},
+    'rhs_fused2_nowrap_b': {'NDCN_FUSED_DBG': '8'},
 }
 
 

@@ -338,7 +338,33 @@ def gen_dgnn():
         save('dgnn_%s_H%d' % (name, H), x=x, t=t, out=y, steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe)
 
 
+# ----------------------------------------------------------------------------- G8
+def gen_dataset():
+    """Cora as utils.load_data (utils.py:91-230) assembles it - that function itself no longer runs under scipy 1.15
+    (SURVEY 8c), so its steps are replayed here on the reference's own data files: features = vstack(allx, tx) with
+    the test rows re-ordered, row-normalised (propagation.py:30-37); labels likewise; the reference's index split."""
+    name = 'cora'
+    objs = []
+    for part in ('x', 'y', 'tx', 'ty', 'allx', 'ally'):
+        with open(os.path.join(REF, 'data', name, 'ind.%s.%s' % (name, part)), 'rb') as fh:
+            objs.append(pickle.load(fh, encoding='latin1'))
+    x, y, tx, ty, allx, ally = objs
+    test_idx_reorder = np.loadtxt(os.path.join(REF, 'data', name, 'ind.%s.test.index' % name), dtype=np.int64)
+    test_idx_range = np.sort(test_idx_reorder)
+    features = sp.vstack((allx, tx)).tolil()
+    features[test_idx_reorder, :] = features[test_idx_range, :]
+    labels = np.vstack((ally, ty))
+    labels[test_idx_reorder, :] = labels[test_idx_range, :]
+    with contextlib.redirect_stdout(io.StringIO()):
+        fn = sp.csr_matrix(ref_prop.Propagation(sp.csr_matrix(features)).row_normalization()).astype(np.float32)
+    fn.sort_indices()
+    save('dataset_cora', feat_indptr=fn.indptr.astype(np.int32), feat_indices=fn.indices.astype(np.int16),
+         feat_data=fn.data.astype(np.float32), feat_shape=np.array(fn.shape, dtype=np.int64),
+         labels=labels.argmax(1).astype(np.int16), idx_train=np.arange(len(y), dtype=np.int32),
+         idx_val=np.arange(len(y), len(y) + 500, dtype=np.int32), idx_test=test_idx_range.astype(np.int32))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn']
+    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset']
     for w in which:
         globals()['gen_' + w]()
