@@ -6,9 +6,9 @@ HIP kernels too (g_X = A^T g through the SpMM on the transposed CSR, g_S = g W t
 the weight gradient g^T S is a plain library GEMM (torch.mm -> rocBLAS) and the per-term scalings of the
 Runge-Kutta algebra are elementwise torch ops on the gradient.
 
-Deviation: the reference's old torchdiffeq lets gradients flow through the adaptive step SIZES (dt is a
-function of the error ratio, misc.py:160-170); here step sizes and the interpolation abscissa are constants of
-the backward pass (what later torchdiffeq versions also do).  Fixed-grid gradients are unaffected.
+dopri5: the reference differentiates through its step-size controller too; that chain lives in
+ndcn_amd/torchdiffeq/_impl/autograd_path.py.  The wrappers below serve the right-hand side and the fixed-grid
+solvers, whose step sizes are data-independent.
 """
 import numpy as np
 import torch

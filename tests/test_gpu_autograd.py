@@ -52,7 +52,8 @@ def test_rhs_gradients(dev, name):
 
 
 @pytest.mark.parametrize('method,rtol,atol,tol', [('euler', 0, 0, 2e-4), ('midpoint', 0, 0, 2e-4), ('rk4', 0, 0, 2e-4),
-                                                  ('dopri5', 1e-6, 1e-8, 2e-3)])
+                                                  ('dopri5', 1e-6, 1e-8, 2e-3), ('dopri5', 1e-3, 1e-4, 2e-3),
+                                                  ('dopri5', 1e-1, 1e-1, 2e-3)])
 def test_backprop_through_solver(dev, method, rtol, atol, tol):
     from ndcn_amd import CsrOperator
     from ndcn_amd import torchdiffeq as ode
@@ -73,23 +74,10 @@ def test_backprop_through_solver(dev, method, rtol, atol, tol):
     lo = torch.nn.functional.l1_loss(yo, target)
     lo.backward()
     assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5
-    if method == 'dopri5':
-        # The reference's old torchdiffeq differentiates THROUGH the step-size controller (dt is a function of
-        # the error ratio, misc.py:160-170); this build freezes step sizes in the backward.
-        # Measured on CPU with identical ops: the two gradients differ by 3 % at rtol 1e-6 (35 % at 1e-3).
-        # So: tight agreement with the frozen-grid gradient of the same algorithm on the CPU oracle ops, loose
-        # agreement with the reference-style gradient.
-        from ndcn_amd.torchdiffeq._impl import core
-        from _oracle_ops import OracleOps
-        W2, b2, x2 = T(d['W']).requires_grad_(True), T(d['b']).requires_grad_(True), T(d['x0']).requires_grad_(True)
-        _, fz, y0z, tz = core.check_inputs(lambda tt, xx: orc.odefunc_rhs(A, xx, W2, b2), x2, t)
-        sol = core.integrate_dopri5(OracleOps, fz, y0z, tz, rtol, atol)
-        torch.nn.functional.l1_loss(torch.stack([s[0] for s in sol]), target).backward()
-        assert rel(x.grad.cpu(), x2.grad) < tol
-        assert rel(f.wt.weight.grad.cpu(), W2.grad) < tol
-        assert rel(f.wt.bias.grad.cpu(), b2.grad) < tol
-        assert rel(x.grad.cpu(), xc.grad) < 0.1
-        return
+    # dopri5: the reference differentiates THROUGH the step-size controller (dt, t0/t1, initial step and the
+    # interpolation abscissa are tensors with history, misc.py:84-170); autograd_path.py keeps those paths, so the
+    # gradient must equal the oracle's full autograd - not merely the frozen-grid one (3 % away at rtol 1e-6,
+    # 35 % at 1e-3, measured).
     assert rel(x.grad.cpu(), xc.grad) < tol
     assert rel(f.wt.weight.grad.cpu(), W.grad) < tol
     assert rel(f.wt.bias.grad.cpu(), b.grad) < tol
