@@ -1,15 +1,112 @@
-"""`odeint_adjoint` - O(1)-memory backward (reference: torchdiffeq/_impl/adjoint.py:105-133).
+"""`odeint_adjoint` - O(1)-memory backward by integrating the adjoint system backwards in time
+(reference: torchdiffeq/_impl/adjoint.py:7-133).
 
-SURVEY.md 8(f) rank 1, a "next" row: the reference parses `--adjoint` but never enables it
-(heat_dynamics.py:43; neural_dynamics.py:145-147).  The signature and argument checks are mirrored; the
-backward itself is not built yet and says so loudly.
+Forward: this package's `odeint` without autograd history (device-resident HIP solver when `func` is ODEFunc).
+Backward: for every tick interval [t_i, t_{i-1}], the augmented state (y, a_y, a_t, a_theta) is integrated
+backwards with the same solver settings; its right-hand side evaluates func once and takes one vector-Jacobian
+product of it (HIP SpMM with the transposed operator / MFMA Linear through autograd_ops).  Only the saved
+trajectory (T x N x H) is kept between the two passes.
 """
+import torch
 import torch.nn as nn
+
+from .odeint import odeint
+
+
+def _flat(tensors, like=None):
+    if like is None:
+        parts = [p.contiguous().view(-1) for p in tensors]
+    else:
+        parts = [p.contiguous().view(-1) if p is not None else torch.zeros_like(q).view(-1) for p, q in zip(tensors, like)]
+    return torch.cat(parts) if parts else torch.tensor([])
+
+
+class _TupleFunc(nn.Module):
+    def __init__(self, base_func):
+        super().__init__()
+        self.base_func = base_func
+        self.ndcn_autonomous = bool(getattr(base_func, 'ndcn_autonomous', False))
+
+    def forward(self, t, y):
+        return (self.base_func(t, y[0]),)
+
+
+class _AdjointMethod(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, func, user_func, n_state, t, flat_params, rtol, atol, method, options, *y0):
+        ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options, ctx.n_state = func, rtol, atol, method, options, n_state
+        with torch.no_grad():
+            if user_func is not None:                      # single-tensor state: let the fast path see ODEFunc itself
+                ans = (odeint(user_func, y0[0], t, rtol=rtol, atol=atol, method=method, options=options),)
+            else:
+                ans = odeint(func, tuple(y0), t, rtol=rtol, atol=atol, method=method, options=options)
+        ctx.save_for_backward(t, flat_params, *ans)
+        return ans
+
+    @staticmethod
+    def backward(ctx, *grad_output):
+        t, flat_params, *ans = ctx.saved_tensors
+        func, rtol, atol, method, options = ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options
+        n = ctx.n_state
+        f_params = tuple(func.parameters())
+
+        def augmented(tt, y_aug):
+            # d/dt (y, a_y, a_t, a_theta) = (f, -a_y^T df/dy, -a_y^T df/dt, -a_y^T df/dtheta)   adjoint.py:34-59
+            y, adj_y = y_aug[:n], y_aug[n:2 * n]
+            with torch.enable_grad():
+                tt = tt.to(y[0].device).detach().requires_grad_(True)
+                y = tuple(v.detach().requires_grad_(True) for v in y)
+                f_eval = func(tt, y)
+                vjp_t, *rest = torch.autograd.grad(f_eval, (tt,) + y + f_params, tuple(-a for a in adj_y),
+                                                   allow_unused=True, retain_graph=True)
+            vjp_y, vjp_p = rest[:n], rest[n:]
+            vjp_t = torch.zeros_like(tt) if vjp_t is None else vjp_t
+            vjp_y = tuple(torch.zeros_like(v) if g is None else g for g, v in zip(vjp_y, y))
+            vjp_p = _flat(vjp_p, f_params)
+            if len(f_params) == 0:
+                vjp_p = torch.tensor(0.).to(vjp_y[0])
+            return (*[f.detach() for f in f_eval], *vjp_y, vjp_t, vjp_p)
+
+        T = ans[0].shape[0]
+        with torch.no_grad():
+            adj_y = tuple(g[-1] for g in grad_output)
+            adj_params = torch.zeros_like(flat_params)
+            adj_time = torch.tensor(0.).to(t)
+            time_vjps = []
+            for i in range(T - 1, 0, -1):
+                ans_i = tuple(a[i] for a in ans)
+                grad_i = tuple(g[i] for g in grad_output)
+                f_i = func(t[i], ans_i)
+                # effect of moving the measurement time                               adjoint.py:72-77
+                dLd_t = sum(torch.dot(f.reshape(-1), g.reshape(-1)).view(1) for f, g in zip(f_i, grad_i))
+                adj_time = adj_time - dLd_t
+                time_vjps.append(dLd_t)
+                if adj_params.numel() == 0:
+                    adj_params = torch.tensor(0.).to(adj_y[0])
+                aug0 = (*ans_i, *adj_y, adj_time, adj_params)
+                aug = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=rtol, atol=atol, method=method,
+                             options=options)
+                adj_y = tuple(a[1] for a in aug[n:2 * n])
+                adj_time = aug[2 * n][1]
+                adj_params = aug[2 * n + 1][1]
+                adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
+                del aug0, aug
+            time_vjps.append(adj_time.reshape(1))
+            time_vjps = torch.cat([v.reshape(1) for v in time_vjps[::-1]])
+        return (None, None, None, time_vjps, adj_params, None, None, None, None) + tuple(adj_y)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
-    # adjoint.py:109-110
+    """Same signature, defaults and errors as the reference (adjoint.py:105-133)."""
     if not isinstance(func, nn.Module):
         raise ValueError('func is required to be an instance of nn.Module.')
-    raise NotImplementedError('odeint_adjoint: the adjoint backward is not part of this build yet '
-                              '(SURVEY.md 8f rank 1); use odeint, which backpropagates through the solver')
+    tensor_input = torch.is_tensor(y0)
+    user_func = None
+    if tensor_input:
+        user_func = func
+        func = _TupleFunc(func)
+        y0 = (y0,)
+    flat_params = _flat(func.parameters())
+    ys = _AdjointMethod.apply(func, user_func, len(y0), t, flat_params, rtol, atol, method, options, *y0)
+    return ys[0] if tensor_input else ys

@@ -63,4 +63,4 @@ def test_argument_errors_match_reference():
     with pytest.raises(AssertionError):
         ode.odeint(f, [y0], torch.tensor([0., 1.]), method='euler')
     with pytest.raises(ValueError):
-        ode.odeint_adjoint(f, y0, torch.tensor([0., 1.]))
+        ode.odeint_adjoint(f, y0, torch.tensor([0., 1.]))          # func must be an nn.Module (adjoint.py:109-110)

@@ -126,3 +126,30 @@ def test_forward_only_kernels_are_not_used_silently(dev):
     f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
     y = ode.odeint(f, T(d['x0']).to(dev), torch.tensor([0., .1, .2]).to(dev), method='dopri5', rtol=1e-3, atol=1e-4)
     assert y.requires_grad and y.grad_fn is not None
+
+
+@pytest.mark.parametrize('method', ['dopri5', 'rk4'])
+def test_odeint_adjoint_against_reference_gradients(dev, method):
+    """odeint_adjoint (O(1)-memory backward) vs the gradients the REFERENCE's odeint_adjoint produced on the same
+    inputs (fixture adjoint_*.npz, tools/gen_golden.py G9)."""
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('adjoint_' + method)
+    f = ODEFunc(8, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
+    f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+    x0 = T(d['x0']).to(dev).requires_grad_(True)
+    kw = dict(method=method) if method == 'rk4' else dict(method=method, rtol=float(d['rtol']), atol=float(d['atol']))
+    y = ode.odeint_adjoint(f, x0, T(d['t']).to(dev), **kw)
+    assert np.abs(y.detach().cpu().numpy() - d['traj']).max() < 1e-5
+    loss = torch.nn.functional.l1_loss(y, T(d['target']).to(dev))
+    assert abs(float(loss.detach()) - float(d['loss'])) < 1e-6
+    loss.backward()
+    assert rel(x0.grad.cpu(), T(d['g_x0'])) < 2e-3
+    assert rel(f.wt.weight.grad.cpu(), T(d['g_W'])) < 2e-3
+    assert rel(f.wt.bias.grad.cpu(), T(d['g_b'])) < 2e-3
+    # ODEBlock(adjoint=True) routes here (neural_dynamics.py:72-74)
+    from ndcn_amd.neural_dynamics import ODEBlock
+    blk = ODEBlock(f, rtol=1e-3, atol=1e-4, method='dopri5', adjoint=True, terminal=True)
+    out = blk(T(d['t']).to(dev), T(d['x0']).to(dev))
+    assert out.requires_grad and out.shape == (144, 8)

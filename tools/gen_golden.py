@@ -364,7 +364,27 @@ def gen_dataset():
          idx_val=np.arange(len(y), len(y) + 500, dtype=np.int32), idx_test=test_idx_range.astype(np.int32))
 
 
+# ----------------------------------------------------------------------------- G9
+def gen_adjoint():
+    """Gradients of the reference's odeint_adjoint (torchdiffeq/_impl/adjoint.py:105-133) on a small case."""
+    _, OM = grid_operator(12)
+    OMs = ref_u.torch_sensor_to_torch_sparse_tensor(OM)
+    for method, rtol, atol in (('dopri5', 1e-5, 1e-7), ('rk4', 0.0, 0.0)):
+        torch.manual_seed(41)
+        f = ref_nd.ODEFunc(8, OMs, dropout=0.0)
+        x0 = torch.rand(144, 8, requires_grad=True)
+        t = torch.linspace(0., 1., 5 if method == 'dopri5' else 21)
+        target = torch.rand(len(t), 144, 8)
+        kw = dict(method=method) if method == 'rk4' else dict(method=method, rtol=rtol, atol=atol)
+        y = ref_ode.odeint_adjoint(f, x0, t, **kw)
+        loss = torch.nn.functional.l1_loss(y, target)
+        loss.backward()
+        save('adjoint_%s' % method, x0=x0.detach(), t=t, target=target, W=f.wt.weight.detach(), b=f.wt.bias.detach(),
+             traj=y.detach(), loss=loss.detach(), g_x0=x0.grad, g_W=f.wt.weight.grad, g_b=f.wt.bias.grad,
+             rtol=rtol, atol=atol, **csr_of(OM))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset']
+    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint']
     for w in which:
         globals()['gen_' + w]()
