@@ -32,6 +32,30 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+KERNEL_FAMILY = {'rhs_fused': 'rhs_fused', 'spmm': 'spmm_', 'combine': 'combine_kernel', 'linear': 'linear_',
+                 'error': 'rk_error_kernel'}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (profiles/*traffic_pmc.json,
+    produced by tools/gpu_final.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted mean over the family's kernels; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic_pmc.json')))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))['kernels']
+    except Exception:
+        return None, None
+    num = den = 0
+    for name, v in d.items():
+        if family in name and 'finish' not in name:
+            num += v['hbm_bytes_per_launch'] * v['launches']
+            den += v['launches']
+    return (int(num / den), os.path.relpath(files[-1], ROOT)) if den else (None, None)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -184,17 +208,23 @@ def main():
             dom = max(breakdown, key=lambda k: breakdown[k]['ms_total'])
             i = _lib.PROF_KINDS.index(dom)
             cnt, ms, byt, fl = buf[4 * i:4 * i + 4]
-            mfma_bound = dom in ('linear', 'rhs_fused')
-            if mfma_bound:
+            # which roof is nearer: time the launch would take at the HBM peak vs at the fp32 MFMA peak
+            t_hbm = byt / cnt / (HBM_PEAK_GBS * 1e9)
+            t_mfma = fl / cnt / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            if t_mfma > t_hbm:
                 ach = fl / ms / 1e9
                 roofline = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None}
+                            'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
             else:
                 ach = byt / ms / 1e6
                 roofline = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None}
-            roofline.update({'kernel': dom, 'launches': int(cnt), 'avg_ms': round(ms / cnt, 4),
-                             'alg_bytes_per_launch': round(byt / cnt), 'alg_flops_per_launch': round(fl / cnt),
+                            'frac': round(ach / HBM_PEAK_GBS, 4)}
+            traffic, src = pmc_traffic(KERNEL_FAMILY.get(dom, dom))
+            roofline.update({'traffic': traffic, 'traffic_source': src, 'kernel': dom, 'launches': int(cnt),
+                             'avg_ms': round(ms / cnt, 4), 'alg_bytes_per_launch': round(byt / cnt),
+                             'alg_flops_per_launch': round(fl / cnt),
+                             'ms_at_hbm_peak': round(1e3 * t_hbm, 4), 'ms_at_mfma_peak': round(1e3 * t_mfma, 4),
+                             'achieved_GBps': round(byt / ms / 1e6, 1), 'achieved_TFLOPs': round(fl / ms / 1e9, 2),
                              'share_of_kernel_time': round(breakdown[dom]['ms_total'] / tot_ms, 3)})
 
     if rank != 0:
