@@ -46,9 +46,8 @@ constexpr int kRowsPerProd = kTile2 / kProd;
 constexpr int kMaxPrev = 5;              // dopri5 needs at most 5 earlier stages with a non-zero coefficient
 
 struct Fused2Args {
-    const int *rowptr, *colidx;
-    const float *val;
     const float *X, *Xh;
+    int x_bytes, xh_bytes;                  // sizes of the gathered panels (buffer descriptors: < 2^31)
     int n_own;
     const float *Wp, *bias;
     float *K;                               // relu(...) output panel
@@ -61,6 +60,7 @@ struct Fused2Args {
     float *y_next;
     float rtol, atol;
     double *partials;                       // ERROR: [gridDim.x * kProd][2]
+    unsigned long long *dbg_cycles;         // NDCN_FUSED_TIMING: per (block, wave) {work cycles, barrier-wait cycles}
     int dbg;                                // timing experiments only (NDCN_FUSED_DBG): 1 skip MFMA, 2 skip gather, 4 skip epilogue
 };
 
@@ -70,17 +70,26 @@ __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 a) {
     return (f32x4){fmaf(s, x.x, a.x), fmaf(s, x.y, a.y), fmaf(s, x.z, a.z), fmaf(s, x.w, a.w)};
 }
 
-// issue U neighbour-row fetches of one output row (entries i .. i+U-1 of the lane-held (col, val) pairs)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Issue U neighbour-row fetches of one output row: entries j .. j+U-1 of the CSR arrays.
+// The gather waves share their SIMD with an MFMA wave, and on gfx950 the fp32 MFMA keeps the SIMD's VALU busy
+// (measured: the same gather code takes 2x the cycles while the MFMA waves run, independent of memory traffic
+// and of wave priorities).  So the per-neighbour work is kept OFF the VALU: column index and value arrive by
+// scalar loads (the CSR arrays are __restrict__ kernel arguments, j is wave-uniform), the row address is a
+// buffer-load SGPR offset (col << 10) on top of a fixed per-lane offset - the only VALU work left per
+// neighbour is the two packed FMAs.
 template <int U, bool HALO>
-__device__ __forceinline__ void g_issue(int c, float v, int i, const f32x4 *__restrict__ X, const f32x4 *__restrict__ Xh,
-                                        int n_own, int lane, f32x4 (&x)[8], float (&vv)[8]) {
+__device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j,
+                                        __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
+                                        f32x4 (&x)[8], float (&vv)[8]) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-        int cc = __builtin_amdgcn_readlane(c, i + q);
-        vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i + q));
-        const f32x4 *pp = X;
-        if (HALO && cc >= n_own) { pp = Xh; cc -= n_own; }
-        x[q] = pp[(size_t)cc * 64 + lane];
+        int cc = colidx[j + q];
+        vv[q] = val[j + q];
+        __amdgpu_buffer_rsrc_t rs = rsX;
+        if (HALO && cc >= n_own) { rs = rsH; cc -= n_own; }
+        x[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, cc << 10, 0));
     }
 }
 template <int U>
@@ -89,20 +98,23 @@ __device__ __forceinline__ void g_accum(const f32x4 (&x)[8], const float (&vv)[8
     for (int q = 0; q < U; ++q) acc = fma4(vv[q], x[q], acc);
 }
 
-// remaining entries [i, cnt) of a row in batches of 8 / 4 / 2 / 1
+// entries [j, j1) of a row in batches of 8 / 4 / 2 / 1
 template <bool HALO>
-__device__ __forceinline__ void g_rest(int c, float v, int i, int cnt, const f32x4 *__restrict__ X,
-                                       const f32x4 *__restrict__ Xh, int n_own, int lane, f32x4 &acc) {
+__device__ __forceinline__ void g_rest(const int *__restrict__ colidx, const float *__restrict__ val, int j, int j1,
+                                       __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
+                                       f32x4 &acc) {
     f32x4 x[8];
     float vv[8];
-    for (; i + 8 <= cnt; i += 8) { g_issue<8, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<8>(x, vv, acc); }
-    if (i + 4 <= cnt) { g_issue<4, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<4>(x, vv, acc); i += 4; }
-    if (i + 2 <= cnt) { g_issue<2, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<2>(x, vv, acc); i += 2; }
-    if (i < cnt) { g_issue<1, HALO>(c, v, i, X, Xh, n_own, lane, x, vv); g_accum<1>(x, vv, acc); }
+    for (; j + 8 <= j1; j += 8) { g_issue<8, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<8>(x, vv, acc); }
+    if (j + 4 <= j1) { g_issue<4, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<4>(x, vv, acc); j += 4; }
+    if (j + 2 <= j1) { g_issue<2, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<2>(x, vv, acc); j += 2; }
+    if (j < j1) { g_issue<1, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<1>(x, vv, acc); }
 }
 
-template <bool HALO, int MODE>
-__global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args a) {
+template <bool HALO, int MODE, int RING>
+__global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int *__restrict__ rowptr,
+                                                                      const int *__restrict__ colidx,
+                                                                      const float *__restrict__ val, Fused2Args a) {
     __shared__ __attribute__((aligned(16))) float s_tile[2 * kTileFloats2];
 
     const int lane = threadIdx.x & 63;
@@ -110,8 +122,12 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
     const bool producer = wave >= 4;
     const int p = wave - 4;                                   // producer index 0..7
     const f32x4 *X = reinterpret_cast<const f32x4 *>(a.X);
-    const f32x4 *Xh = reinterpret_cast<const f32x4 *>(a.Xh);
     const f32x4 *Wp = reinterpret_cast<const f32x4 *>(a.Wp);
+    // buffer descriptors of the gathered panels (wave-uniform; byte sizes < 2^31 checked by the launcher)
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HALO ? a.Xh : a.X), 0,
+                                                                          HALO ? a.xh_bytes : a.x_bytes, 0x00020000);
+    const int lane_off = lane * 16;
 
     // tiles of this workgroup: XCD x owns a contiguous chunk; its workgroups take tiles round-robin
     const int xcd = blockIdx.x % kXcds;
@@ -131,61 +147,41 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
 
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 
-    // ---- producer: index data of the wave's 8 rows of a tile, fetched one tile ahead ------------------
-    // (rowptr pairs by one vector load, then the first <= 64 (col, val) pairs of each row: nothing but the
-    // neighbour-row fetches themselves is left on the critical path of gather_tile)
-    int ix_j0[kRowsPerProd], ix_j1[kRowsPerProd], ix_c[kRowsPerProd];
-    float ix_v[kRowsPerProd];
+    // ---- producer: row extents of the wave's 8 rows of a tile by one vector load ---------------------------
+    int ix_j0[kRowsPerProd], ix_j1[kRowsPerProd];
     auto prefetch_index = [&](int t) {
         int rp = 0;
         if (lane < 2 * kRowsPerProd) {
             int r = t * kTile2 + p + kProd * (lane >> 1) + (lane & 1);
-            rp = a.rowptr[min(r, a.n_rows)];
+            rp = rowptr[min(r, a.n_rows)];
         }
 #pragma unroll
         for (int k = 0; k < kRowsPerProd; ++k) {
             ix_j0[k] = __builtin_amdgcn_readlane(rp, 2 * k);
             ix_j1[k] = __builtin_amdgcn_readlane(rp, 2 * k + 1);
             if (t * kTile2 + p + kProd * k >= a.n_rows) ix_j1[k] = ix_j0[k];
-            ix_c[k] = 0; ix_v[k] = 0.f;
-            if (lane < ix_j1[k] - ix_j0[k]) { ix_c[k] = a.colidx[ix_j0[k] + lane]; ix_v[k] = a.val[ix_j0[k] + lane]; }
         }
     };
 
-    // ---- producer: gather the tile whose index data was prefetched into LDS tile dst; two rows in flight ----
+    // ---- producer: gather the tile whose row extents were prefetched into LDS tile dst; two rows in flight ----
     auto gather_tile = [&](float *dst) {
 #pragma unroll
         for (int k = 0; k < kRowsPerProd; k += 2) {
             const int lrA = p + kProd * k, lrB = lrA + kProd;
-            const int jA0 = ix_j0[k], jA1 = ix_j1[k], jB0 = ix_j0[k + 1], jB1 = ix_j1[k + 1];
-            const int cntA = min(64, jA1 - jA0), cntB = min(64, jB1 - jB0);
-            const int cA = ix_c[k], cB = ix_c[k + 1];
-            const float vA = ix_v[k], vB = ix_v[k + 1];
+            int jA = ix_j0[k], jB = ix_j0[k + 1];
+            const int jA1 = ix_j1[k], jB1 = ix_j1[k + 1];
             f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
-            int iA = 0, iB = 0;
             {   // first batches of both rows in flight together (16 x 1 KiB per wave)
                 f32x4 xA[8], xB[8];
                 float wA[8], wB[8];
-                const bool fa = cntA >= 8, fb = cntB >= 8;
-                if (fa) g_issue<8, HALO>(cA, vA, 0, X, Xh, a.n_own, lane, xA, wA);
-                if (fb) g_issue<8, HALO>(cB, vB, 0, X, Xh, a.n_own, lane, xB, wB);
-                if (fa) { g_accum<8>(xA, wA, accA); iA = 8; }
-                if (fb) { g_accum<8>(xB, wB, accB); iB = 8; }
+                const bool fa = jA + 8 <= jA1, fb = jB + 8 <= jB1;
+                if (fa) g_issue<8, HALO>(colidx, val, jA, rsX, rsH, a.n_own, lane_off, xA, wA);
+                if (fb) g_issue<8, HALO>(colidx, val, jB, rsX, rsH, a.n_own, lane_off, xB, wB);
+                if (fa) { g_accum<8>(xA, wA, accA); jA += 8; }
+                if (fb) { g_accum<8>(xB, wB, accB); jB += 8; }
             }
-            g_rest<HALO>(cA, vA, iA, cntA, X, Xh, a.n_own, lane, accA);
-            g_rest<HALO>(cB, vB, iB, cntB, X, Xh, a.n_own, lane, accB);
-            for (int jb = jA0 + 64; jb < jA1; jb += 64) {      // rows longer than 64 entries
-                const int cnt = min(64, jA1 - jb);
-                int c = 0; float v = 0.f;
-                if (lane < cnt) { c = a.colidx[jb + lane]; v = a.val[jb + lane]; }
-                g_rest<HALO>(c, v, 0, cnt, X, Xh, a.n_own, lane, accA);
-            }
-            for (int jb = jB0 + 64; jb < jB1; jb += 64) {
-                const int cnt = min(64, jB1 - jb);
-                int c = 0; float v = 0.f;
-                if (lane < cnt) { c = a.colidx[jb + lane]; v = a.val[jb + lane]; }
-                g_rest<HALO>(c, v, 0, cnt, X, Xh, a.n_own, lane, accB);
-            }
+            g_rest<HALO>(colidx, val, jA, jA1, rsX, rsH, a.n_own, lane_off, accA);
+            g_rest<HALO>(colidx, val, jB, jB1, rsX, rsH, a.n_own, lane_off, accB);
             *reinterpret_cast<f32x4 *>(dst + lrA * kLd2 + 4 * lane) = accA;
             *reinterpret_cast<f32x4 *>(dst + lrB * kLd2 + 4 * lane) = accB;
         }
@@ -200,7 +196,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
         for (int m = 0; m < kMaxPrev; ++m)
             if (m < a.n_prev) e.km[m] = reinterpret_cast<const f32x4 *>(a.kprev[m])[off];
         e.y0v = reinterpret_cast<const f32x4 *>(a.y0)[off];
-        if (MODE == MODE_ERROR) e.y1v = X[off];                // the input of this evaluation is y1
+        if (MODE == MODE_ERROR) e.y1v = X[off];                // the input of this evaluation is y1 (own rows)
     };
     auto epi_finish = [&](int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
@@ -257,7 +253,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
     f32x16 acc00, acc01, acc10, acc11;
     // Ring of weight operands, kRing deep: slot u holds k-quad q with q % kRing == u.  The weights are the same
     // for every tile, so the ring simply wraps around - it is already full when the next tile starts.
-    constexpr int kRing = 4;
+    constexpr int kRing = RING;
     const f32x4 *b0p = Wp + (size_t)(2 * (wave & 3)) * 32 * 64 + lane;
     const f32x4 *b1p = b0p + 32 * 64;
     f32x4 r0[kRing], r1[kRing];
@@ -282,7 +278,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
                     a1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
                 }
                 // the refill wraps into the next tile's first quads (dbg bit 8 = do not wrap: A/B switch)
-                if (!(a.dbg & 8) || q + kRing < 32) {
+                if ((!(a.dbg & 8) || q + kRing < 32) && !(a.dbg & 64)) {       // dbg 64: no weight refills (timing experiment)
                     const int qn = (q + kRing) & 31;
                     r0[u] = b0p[qn * 64];
                     r1[u] = b1p[qn * 64];
@@ -317,19 +313,28 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
 
     // Role-specialised loops (both execute the same sequence of workgroup barriers), so the accumulators of the
     // MFMA waves and the fetch registers of the gather waves never share a live range.
+    unsigned long long cyc_work = 0, cyc_wait = 0;
     if (producer) {
+        if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);         // timing experiment: gather waves win issue arbitration
         prefetch_index(t_first);
         gather_tile(s_tile);
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             const int t = t_first + it * wgs_per_xcd;
             float *oth = s_tile + ((it & 1) ^ 1) * kTileFloats2;
+            const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             if (it > 0 && !(a.dbg & 4)) epilogue_tile(t - wgs_per_xcd, oth);
             if (it + 1 < my_tiles && !(a.dbg & 2)) { prefetch_index(t + wgs_per_xcd); gather_tile(oth); }
+            const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
             __syncthreads();
+            if (a.dbg_cycles) { cyc_work += c1 - c0; cyc_wait += __builtin_readcyclecounter() - c1; }
+        }
+        if (a.dbg_cycles && lane == 0) {
+            a.dbg_cycles[2 * (blockIdx.x * 12 + wave)] = cyc_work;
+            a.dbg_cycles[2 * (blockIdx.x * 12 + wave) + 1] = cyc_wait;
         }
         const int t_last = t_first + (my_tiles - 1) * wgs_per_xcd;
         epilogue_tile(t_last, s_tile + ((my_tiles - 1) & 1) * kTileFloats2);
@@ -345,15 +350,25 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(Fused2Args
             }
         }
     } else {
+        if (a.dbg & 128) __builtin_amdgcn_s_setprio(3);        // timing experiment: MFMA waves win issue arbitration
         ring_fill();                                           // weight fetches fly while the first tile is gathered
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             float *cur = s_tile + (it & 1) * kTileFloats2;
+            const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             if ((a.dbg & 8) && it > 0) ring_fill();
             if (!(a.dbg & 1)) mfma_tile(cur);
+            const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();                                   // every consumer is done reading `cur`
+            const unsigned long long c2 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             dump_tile(cur);
+            const unsigned long long c3 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
+            if (a.dbg_cycles) { cyc_work += (c1 - c0) + (c3 - c2); cyc_wait += (c2 - c1) + (__builtin_readcyclecounter() - c3); }
+        }
+        if (a.dbg_cycles && lane == 0) {
+            a.dbg_cycles[2 * (blockIdx.x * 12 + wave)] = cyc_work;
+            a.dbg_cycles[2 * (blockIdx.x * 12 + wave) + 1] = cyc_wait;
         }
     }
 }
@@ -381,7 +396,7 @@ int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags) {
     static const int enabled = env_int3("NDCN_RHS_FUSED2", 1);
     if (!enabled || H != kH2 || !A) return 0;
     if (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) return 0;
-    return 1;
+    return A->n_cols * (int64_t)kH2 * 4 < (1ll << 31) ? 1 : 0;       // gathered panel must fit a buffer descriptor
 }
 
 int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kProd * 2 * sizeof(double); }
@@ -394,13 +409,22 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (n_rows == 0) return NDCN_OK;
     if (n_prev < 0 || n_prev > kMaxPrev) { set_error("rhs_fused2: at most %d previous stages", kMaxPrev); return NDCN_EINVAL; }
     Fused2Args a;
-    a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val;
-    a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wp = Wp; a.bias = b; a.K = K;
+    const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;
+    if (xb >= (1ll << 31) || xhb >= (1ll << 31)) {
+        set_error("rhs_fused2: panel of %lld bytes exceeds the 2 GiB buffer-descriptor range", (long long)(xb > xhb ? xb : xhb));
+        return NDCN_EINVAL;
+    }
+    a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (int)xb; a.xh_bytes = (int)xhb; a.Wp = Wp; a.bias = b; a.K = K;
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     a.y0 = y0; a.n_prev = n_prev; a.y_next = y_next; a.rtol = rtol; a.atol = atol;
     a.partials = static_cast<double *>(d_ws);
     static const int dbg = env_int3("NDCN_FUSED_DBG", 0);
     a.dbg = dbg;
+    static const int timing = env_int3("NDCN_FUSED_TIMING", 0);
+    static unsigned long long *d_cyc = nullptr;
+    static int timing_prints = 0;
+    if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * 12 * 2 * sizeof(unsigned long long));
+    a.dbg_cycles = timing ? d_cyc : nullptr;
     for (int m = 0; m < kMaxPrev; ++m) a.kprev[m] = (m < n_prev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kMaxPrev; ++m) a.c[m] = (mode != MODE_PLAIN && m <= n_prev) ? h_c[m] : 0.f;
     int per_xcd = kCus / kXcds;
@@ -412,7 +436,14 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
     if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * kH2 + 2.0 * (double)A->n_rows * kH2 * kH2);
-#define NDCN_F2(HALO_, MODE_) hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_>), grid, block, 0, st, a)
+    static const int ring = env_int3("NDCN_FUSED_RING", 4);
+#define NDCN_F2(HALO_, MODE_)                                                                              \
+    do {                                                                                                   \
+        if (ring >= 8)                                                                                     \
+            hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, 8>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a); \
+        else                                                                                               \
+            hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, 4>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a); \
+    } while (0)
     if (Xh) {
         if (mode == MODE_PLAIN) NDCN_F2(true, MODE_PLAIN);
         else if (mode == MODE_COMBINE) NDCN_F2(true, MODE_COMBINE);
@@ -426,6 +457,18 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (mode == MODE_ERROR)
         hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, a.partials, (int)grid.x * kProd, d_out);
     NDCN_LAUNCH_CHECK();
+    if (timing && timing_prints < 3) {                          // debugging aid: s_memtime accounting of block 0 and 100
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[2 * 12 * 2];
+        for (int bi = 0; bi < 2; ++bi) {
+            const int blk = bi == 0 ? 0 : 100;
+            (void)hipMemcpy(h, d_cyc + (size_t)blk * 24, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[fused2 timing] block %d:", blk);
+            for (int w = 0; w < 12; ++w) fprintf(stderr, " w%d work=%llu wait=%llu |", w, h[2 * w], h[2 * w + 1]);
+            fprintf(stderr, "\n");
+        }
+        ++timing_prints;
+    }
     return NDCN_OK;
 }
 

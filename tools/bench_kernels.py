@@ -13,10 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'rhs_fused2_wrap': {},
-    'rhs_fused2_nowrap': {'NDCN_FUSED_DBG': '8'},
-    'rhs_fused2_wrap_b': {},
-    'rhs_fused2_nowrap_b': {'NDCN_FUSED_DBG': '8'},
+    'rhs_fused2_scalarIdx': {'NDCN_FUSED_TIMING': '1'},
+    'rhs_fused2_scalarIdx_b': {},
+    'rhs_fused_v1': {'NDCN_RHS_FUSED2': '0'},
 }
 
 
