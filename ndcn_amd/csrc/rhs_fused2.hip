@@ -190,18 +190,30 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     // ---- producer: stream K rows of tile `t` out of LDS tile src (+ RK algebra) ----------------------
     // The row-local panels of row k+1 are requested before row k is finished (one row of fetches always in flight).
     struct EpiRow { f32x4 km[kMaxPrev]; f32x4 y0v, y1v; };
+    // Row-local panels go through buffer descriptors built on the scalar unit: address = descriptor base + SGPR row
+    // offset (r << 10) + the fixed per-lane offset - no VALU address arithmetic per panel (the producers' VALU time
+    // is what the MFMA waves squeeze).  Panels are < 2 GiB (launcher check).
+    const int panel_bytes = a.n_rows << 10;
+    auto ldp = [&](const float *base, int row_off) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, panel_bytes, 0x00020000);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, row_off, 0));
+    };
+    auto stp = [&](float *base, int row_off, f32x4 v) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, panel_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, row_off, 2 /* nt */);
+    };
     auto epi_load = [&](int r, EpiRow &e) {
-        const size_t off = (size_t)r * 64 + lane;
+        const int off = r << 10;
 #pragma unroll
         for (int m = 0; m < kMaxPrev; ++m)
-            if (m < a.n_prev) e.km[m] = reinterpret_cast<const f32x4 *>(a.kprev[m])[off];
-        e.y0v = reinterpret_cast<const f32x4 *>(a.y0)[off];
-        if (MODE == MODE_ERROR) e.y1v = X[off];                // the input of this evaluation is y1 (own rows)
+            if (m < a.n_prev) e.km[m] = ldp(a.kprev[m], off);
+        e.y0v = ldp(a.y0, off);
+        if (MODE == MODE_ERROR) e.y1v = ldp(a.X, off);         // the input of this evaluation is y1 (own rows)
     };
     auto epi_finish = [&](int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
-        const size_t off = (size_t)r * 64 + lane;
-        __builtin_nontemporal_store(kn, reinterpret_cast<f32x4 *>(a.K) + off);
+        const int off = r << 10;
+        stp(a.K, off, kn);
         if (MODE == MODE_PLAIN) return;
         f32x4 s = kn * a.c[a.n_prev];                          // only term when n_prev == 0
         if (a.n_prev > 0) {
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             s = s + kn * a.c[a.n_prev];                        // the new stage is the last term of the sum
         }
         if (MODE == MODE_COMBINE) {
-            __builtin_nontemporal_store(e.y0v + s, reinterpret_cast<f32x4 *>(a.y_next) + off);
+            stp(a.y_next, off, e.y0v + s);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -457,13 +469,13 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (mode == MODE_ERROR)
         hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, a.partials, (int)grid.x * kProd, d_out);
     NDCN_LAUNCH_CHECK();
-    if (timing && timing_prints < 3) {                          // debugging aid: s_memtime accounting of block 0 and 100
+    if (timing && timing_prints < timing) {                          // debugging aid: s_memtime accounting of block 0 and 100
         (void)hipStreamSynchronize(st);
         unsigned long long h[2 * 12 * 2];
         for (int bi = 0; bi < 2; ++bi) {
             const int blk = bi == 0 ? 0 : 100;
             (void)hipMemcpy(h, d_cyc + (size_t)blk * 24, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[fused2 timing] block %d:", blk);
+            fprintf(stderr, "[fused2 timing] mode %d n_prev %d block %d:", mode, n_prev, blk);
             for (int w = 0; w < 12; ++w) fprintf(stderr, " w%d work=%llu wait=%llu |", w, h[2 * w], h[2 * w + 1]);
             fprintf(stderr, "\n");
         }

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 VARIANTS = {
     'rhs_fused2_scalarIdx': {'NDCN_FUSED_TIMING': '1'},
     'rhs_fused2_scalarIdx_b': {},
-    'rhs_fused_v1': {'NDCN_RHS_FUSED2': '0'},
+
 }
 
 
