@@ -152,6 +152,11 @@ NDCN_API int64_t ndcn_reduce_ws_bytes(void);
 NDCN_API int ndcn_dopri5_interp_fit_f32(const float *y0, const float *y1, const float *const *h_k /*7*/,
                                const float *h_cmid /*7*/, float dt, float *a, float *b, float *c, float *d,
                                int64_t n_elem, void *stream);
+/* Fit and evaluate in one pass without storing the coefficients (same arithmetic as the pair above): for a step
+ * that is sampled at a single tick this reads 9 panels and writes 1 instead of 13 + 6.                  */
+NDCN_API int ndcn_dopri5_interp_direct_f32(const float *y0, const float *y1, const float *const *h_k /*7*/,
+                                           const float *h_cmid /*7*/, float dt, const float h_xpow[5], float *out,
+                                           int64_t n_elem, void *stream);
 /* out = a x^4 + b x^3 + c x^2 + d x + e with h_xpow = {x^4, x^3, x^2, x, 1} formed by the caller in fp32
  * (interp.py:59-65).                                                                                  */
 NDCN_API int ndcn_interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e,

@@ -66,6 +66,7 @@ SIGNATURES = {
     'ndcn_scaled_sumsq_f32': (_I, [_P, _P, _P, _F, _F, _L, _P, _P, _P]),
     'ndcn_reduce_ws_bytes': (_L, []),
     'ndcn_dopri5_interp_fit_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _F, _P, _P, _P, _P, _L, _P]),
+    'ndcn_dopri5_interp_direct_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _F, ctypes.POINTER(_F), _P, _L, _P]),
     'ndcn_interp_eval_f32': (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(_F), _P, _L, _P]),
     'ndcn_fixed_stage_f32': (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _L, _P]),
     'ndcn_gene_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _P]),

@@ -146,6 +146,13 @@ int ndcn_dopri5_interp_fit_f32(const float *y0, const float *y1, const float *co
     return interp_fit_f32(y0, y1, h_k, h_cmid, dt, a, b, c, d, n_elem, ST(stream));
 }
 
+int ndcn_dopri5_interp_direct_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                                  const float h_xpow[5], float *out, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && h_k && h_cmid && h_xpow, "bad argument");
+    NDCN_CHECK_ARG(n_elem == 0 || (y0 && y1 && out), "null panel");
+    return interp_direct_f32(y0, y1, h_k, h_cmid, dt, h_xpow, out, n_elem, ST(stream));
+}
+
 int ndcn_interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e,
                          const float h_xpow[5], float *out, int64_t n_elem, void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && h_xpow, "bad argument");

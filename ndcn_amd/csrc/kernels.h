@@ -37,6 +37,8 @@ int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol,
 int64_t reduce_ws_bytes();
 int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt, float *a,
                    float *b, float *c, float *d, int64_t n, hipStream_t st);
+int interp_direct_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                      const float xp[5], float *out, int64_t n, hipStream_t st);
 int interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e, const float xp[5],
                     float *out, int64_t n, hipStream_t st);
 int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,

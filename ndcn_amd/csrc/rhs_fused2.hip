@@ -10,9 +10,10 @@
 // LDS = S[2][64][260] fp32 (133 120 B).
 //
 //   phase A(t): consumers  MFMA on S[t&1]                            -> K_t in registers
-//               producers  epilogue of K_{t-1} (sits in S[(t-1)&1]): whole 1 KiB rows of K (and of the RK
-//                          algebra: y0 / earlier stages are row-local) streamed to HBM;
-//                          then gather S_{t+1} = (A X)[tile t+1] into S[(t-1)&1]
+//               producers  per pair of rows: request the row-local RK panels of K_{t-1}'s rows (K_{t-1} sits in
+//                          S[(t-1)&1]), gather the same two rows of S_{t+1} = (A X)[tile t+1] into registers,
+//                          then finish the epilogue (K rows + RK algebra streamed to HBM as whole 1 KiB rows)
+//                          and drop the gathered rows into S[(t-1)&1]
 //   barrier
 //   phase B(t): consumers  K_t (+bias, relu) -> S[t&1], row-major
 //   barrier
@@ -45,6 +46,22 @@ constexpr int kProd = 8;
 constexpr int kRowsPerProd = kTile2 / kProd;
 constexpr int kMaxPrev = 5;              // dopri5 needs at most 5 earlier stages with a non-zero coefficient
 
+// Arguments of the RK epilogue.  They are NOT read through the kernel-parameter object: the compiler would keep
+// all of them (8 pointers + 8 scalars) live in SGPRs across the gather loops, whose scalar CSR loads already
+// fill the SGPR file - the COMBINE / ERROR variants then spilled 79 SGPRs into VGPR lanes (v_writelane /
+// v_readlane = VALU work inside the loops that share a SIMD with the fp32 MFMA wave: +1.0 M cycles per launch,
+// measured with every epilogue operation disabled).  The epilogue re-reads them from the kernarg segment once
+// per tile instead (a handful of s_loads), through a laundered pointer the compiler cannot hoist.
+struct EpiArgs {
+    const float *y0;
+    const float *kprev[kMaxPrev];
+    float *y_next;
+    double *partials;                       // ERROR: [gridDim.x * kProd][2]
+    float c[kMaxPrev + 1];                  // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K
+    int n_prev;
+    float rtol, atol;
+};
+
 struct Fused2Args {
     const float *X, *Xh;
     int x_bytes, xh_bytes;                  // sizes of the gathered panels (buffer descriptors: < 2^31)
@@ -52,17 +69,12 @@ struct Fused2Args {
     const float *Wp, *bias;
     float *K;                               // relu(...) output panel
     int n_rows, n_tiles, relu;
-    // epilogue
-    const float *y0;
-    const float *kprev[kMaxPrev];
-    float c[kMaxPrev + 1];                  // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K
-    int n_prev;
-    float *y_next;
-    float rtol, atol;
-    double *partials;                       // ERROR: [gridDim.x * kProd][2]
     unsigned long long *dbg_cycles;         // NDCN_FUSED_TIMING: per (block, wave) {work cycles, barrier-wait cycles}
     int dbg;                                // timing experiments only (NDCN_FUSED_DBG): 1 skip MFMA, 2 skip gather, 4 skip epilogue
 };
+typedef const __attribute__((address_space(4))) EpiArgs *EpiPtr;
+// kernel parameters: rowptr, colidx, val (3 x 8 bytes), Fused2Args, EpiArgs - both structs are 8-aligned
+constexpr int kEpiKernargOffset = 24 + (int)((sizeof(Fused2Args) + 7) / 8 * 8);
 
 enum { MODE_PLAIN = 0, MODE_COMBINE = 1, MODE_ERROR = 2 };
 
@@ -111,10 +123,18 @@ __device__ __forceinline__ void g_rest(const int *__restrict__ colidx, const flo
     if (j < j1) { g_issue<1, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<1>(x, vv, acc); }
 }
 
-template <bool HALO, int MODE, int RING>
+template <bool HALO, int MODE>
 __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int *__restrict__ rowptr,
                                                                       const int *__restrict__ colidx,
-                                                                      const float *__restrict__ val, Fused2Args a) {
+                                                                      const float *__restrict__ val, Fused2Args a,
+                                                                      EpiArgs epi_by_kernarg_only) {
+    (void)epi_by_kernarg_only;
+    auto epi_args = [&]() -> EpiPtr {
+        auto base = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        EpiPtr e = (EpiPtr)(base + kEpiKernargOffset);
+        asm volatile("" : "+s"(e));                           // a fresh pointer per call: loads stay where they are used
+        return e;
+    };
     __shared__ __attribute__((aligned(16))) float s_tile[2 * kTileFloats2];
 
     const int lane = threadIdx.x & 63;
@@ -139,51 +159,23 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     const int my_tiles = t_first < t_hi ? (t_hi - t_first + wgs_per_xcd - 1) / wgs_per_xcd : 0;
     if (my_tiles == 0) {                                      // uniform per workgroup
         if (MODE == MODE_ERROR && producer && lane == 0) {    // the finish kernel sums EVERY slot
-            a.partials[2 * (blockIdx.x * kProd + p)] = 0.0;
-            a.partials[2 * (blockIdx.x * kProd + p) + 1] = 0.0;
+            double *partials = epi_args()->partials;
+            partials[2 * (blockIdx.x * kProd + p)] = 0.0;
+            partials[2 * (blockIdx.x * kProd + p) + 1] = 0.0;
         }
         return;
     }
 
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 
-    // ---- producer: row extents of the wave's 8 rows of a tile by one vector load ---------------------------
-    int ix_j0[kRowsPerProd], ix_j1[kRowsPerProd];
+    // ---- producer: row extents of the wave's 8 rows of a tile by one vector load; they stay in that VGPR (lane
+    // 2k / 2k+1 = begin / end of row k) and are read out per row pair - 16 resident SGPRs less
+    int ix_rp = 0;
     auto prefetch_index = [&](int t) {
-        int rp = 0;
+        ix_rp = 0;
         if (lane < 2 * kRowsPerProd) {
             int r = t * kTile2 + p + kProd * (lane >> 1) + (lane & 1);
-            rp = rowptr[min(r, a.n_rows)];
-        }
-#pragma unroll
-        for (int k = 0; k < kRowsPerProd; ++k) {
-            ix_j0[k] = __builtin_amdgcn_readlane(rp, 2 * k);
-            ix_j1[k] = __builtin_amdgcn_readlane(rp, 2 * k + 1);
-            if (t * kTile2 + p + kProd * k >= a.n_rows) ix_j1[k] = ix_j0[k];
-        }
-    };
-
-    // ---- producer: gather the tile whose row extents were prefetched into LDS tile dst; two rows in flight ----
-    auto gather_tile = [&](float *dst) {
-#pragma unroll
-        for (int k = 0; k < kRowsPerProd; k += 2) {
-            const int lrA = p + kProd * k, lrB = lrA + kProd;
-            int jA = ix_j0[k], jB = ix_j0[k + 1];
-            const int jA1 = ix_j1[k], jB1 = ix_j1[k + 1];
-            f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
-            {   // first batches of both rows in flight together (16 x 1 KiB per wave)
-                f32x4 xA[8], xB[8];
-                float wA[8], wB[8];
-                const bool fa = jA + 8 <= jA1, fb = jB + 8 <= jB1;
-                if (fa) g_issue<8, HALO>(colidx, val, jA, rsX, rsH, a.n_own, lane_off, xA, wA);
-                if (fb) g_issue<8, HALO>(colidx, val, jB, rsX, rsH, a.n_own, lane_off, xB, wB);
-                if (fa) { g_accum<8>(xA, wA, accA); jA += 8; }
-                if (fb) { g_accum<8>(xB, wB, accB); jB += 8; }
-            }
-            g_rest<HALO>(colidx, val, jA, jA1, rsX, rsH, a.n_own, lane_off, accA);
-            g_rest<HALO>(colidx, val, jB, jB1, rsX, rsH, a.n_own, lane_off, accB);
-            *reinterpret_cast<f32x4 *>(dst + lrA * kLd2 + 4 * lane) = accA;
-            *reinterpret_cast<f32x4 *>(dst + lrB * kLd2 + 4 * lane) = accB;
+            ix_rp = rowptr[min(r, a.n_rows)];       // rows past the end: begin == end == rowptr[n_rows]
         }
     };
 
@@ -195,68 +187,130 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     // is what the MFMA waves squeeze).  Panels are < 2 GiB (launcher check).
     const int panel_bytes = a.n_rows << 10;
     auto ldp = [&](const float *base, int row_off) {
+        asm volatile("" : "+s"(base));      // keep the 4-SGPR descriptor transient: hoisted descriptors for 8 panels spill
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, panel_bytes, 0x00020000);
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, row_off, 0));
     };
     auto stp = [&](float *base, int row_off, f32x4 v) {
+        asm volatile("" : "+s"(base));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, panel_bytes, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, row_off, 2 /* nt */);
     };
     auto epi_load = [&](int r, EpiRow &e) {
         const int off = r << 10;
+        if (a.dbg & 256) {                                     // timing experiment: no row-local fetches
+#pragma unroll
+            for (int m = 0; m < kMaxPrev; ++m) e.km[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            e.y0v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+        const EpiPtr ea = epi_args();
+        const int n_prev = ea->n_prev;
 #pragma unroll
         for (int m = 0; m < kMaxPrev; ++m)
-            if (m < a.n_prev) e.km[m] = ldp(a.kprev[m], off);
-        e.y0v = ldp(a.y0, off);
-        if (MODE == MODE_ERROR) e.y1v = ldp(a.X, off);         // the input of this evaluation is y1 (own rows)
+            if (m < n_prev) e.km[m] = ldp(ea->kprev[m], off);
+        e.y0v = ldp(ea->y0, off);
+    };
+    // sum of the earlier stages (left to right, as misc.py:22-25 accumulates), into km[0]: frees the fetch registers
+    auto epi_reduce = [&](int r, EpiRow &e) {
+        const EpiPtr ea = epi_args();
+        const int n_prev = ea->n_prev;
+        if (n_prev > 0) {
+            f32x4 s = e.km[0] * ea->c[0];
+#pragma unroll
+            for (int m = 1; m < kMaxPrev; ++m)
+                if (m < n_prev) s = s + e.km[m] * ea->c[m];
+            e.km[0] = s;
+        }
+        // ERROR: the input of this evaluation is y1 (own rows); requested only now that the stage registers are free
+        if (MODE == MODE_ERROR) e.y1v = (a.dbg & 256) ? e.y0v : ldp(a.X, r << 10);
     };
     auto epi_finish = [&](int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
         const int off = r << 10;
         stp(a.K, off, kn);
         if (MODE == MODE_PLAIN) return;
-        f32x4 s = kn * a.c[a.n_prev];                          // only term when n_prev == 0
-        if (a.n_prev > 0) {
-            s = e.km[0] * a.c[0];
-#pragma unroll
-            for (int m = 1; m < kMaxPrev; ++m)
-                if (m < a.n_prev) s = s + e.km[m] * a.c[m];
-            s = s + kn * a.c[a.n_prev];                        // the new stage is the last term of the sum
-        }
+        const EpiPtr ea = epi_args();
+        if (a.dbg & 1024) { if (MODE == MODE_COMBINE) stp(ea->y_next, off, kn); return; }   // timing experiment: no algebra
+        const int n_prev = ea->n_prev;
+        f32x4 s = kn * ea->c[n_prev];                          // the new stage is the last term of the sum
+        if (n_prev > 0) s = e.km[0] + s;
         if (MODE == MODE_COMBINE) {
-            stp(a.y_next, off, e.y0v + s);
+            if (!(a.dbg & 512)) stp(ea->y_next, off, e.y0v + s);
+            else if (s[0] == 1.2345e-30f) stp(ea->y_next, off, e.y0v + s);    // timing experiment: store never taken
         } else {
+            const float rtol = ea->rtol, atol = ea->atol;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float tol = a.atol + a.rtol * fmaxf(fabsf(e.y0v[q]), fabsf(e.y1v[q]));
+                const float tol = atol + rtol * fmaxf(fabsf(e.y0v[q]), fabsf(e.y1v[q]));
                 const float z = s[q] / tol;
                 err_sum += (double)(z * z);
                 err_bad += (double)(int)(!(fabsf(e.y1v[q]) <= 3.402823466e38f));
             }
         }
     };
-    auto epilogue_tile = [&](int t, const float *src) {
-        const int r0 = t * kTile2 + p;
-        if (MODE == MODE_PLAIN) {
-#pragma unroll
-            for (int k = 0; k < kRowsPerProd; ++k) {
-                const int r = r0 + kProd * k;
-                if (r < a.n_rows) {
-                    EpiRow dummy;
-                    epi_finish(r, src + (p + kProd * k) * kLd2, dummy);
-                }
-            }
-            return;
-        }
-        EpiRow ea, eb;
-        if (r0 < a.n_rows) epi_load(r0, ea);
+    // ---- producer phase A: per pair of the wave's rows -----------------------------------------------------
+    //   1. request the row-local panels (y0, earlier stages) of rows (A, B) of tile t_epi, whose K sits in `buf`
+    //   2. gather rows (A, B) of the NEXT tile (extents prefetched) into registers - ~10k cycles, which is what
+    //      hides the latency of (1): with the epilogue run as its own loop that latency was exposed once per row
+    //      (measured 2.3k cycles per row, +1.2..1.7 M cycles per launch); the panels of (1) are folded into one
+    //      partial sum per row as soon as the first gather batch has landed (they are older, so they have too)
+    //   3. finish the epilogue of rows (A, B): K out of `buf`, RK algebra, stores
+    //   4. drop the gathered rows into the same two rows of `buf`
+    // A producer wave owns the same rows of every tile, so no producer-to-producer synchronisation is needed.
+    auto producer_phase = [&](float *buf, int t_epi, bool do_epi, bool do_gather) {
+        const int r0 = t_epi * kTile2 + p;
 #pragma unroll
         for (int k = 0; k < kRowsPerProd; k += 2) {
-            const int rA = r0 + kProd * k, rB = rA + kProd, rC = rB + kProd;
-            if (rB < a.n_rows) epi_load(rB, eb);
-            if (rA < a.n_rows) epi_finish(rA, src + (p + kProd * k) * kLd2, ea);
-            if (k + 2 < kRowsPerProd && rC < a.n_rows) epi_load(rC, ea);
-            if (rB < a.n_rows) epi_finish(rB, src + (p + kProd * (k + 1)) * kLd2, eb);
+            const int lrA = p + kProd * k, lrB = lrA + kProd;
+            const int rA = r0 + kProd * k, rB = rA + kProd;
+            const bool epA = do_epi && rA < a.n_rows, epB = do_epi && rB < a.n_rows;
+            EpiRow eA, eB;
+            // ERROR carries y1 and the fp64 partial sums on top: row B's panels are requested only after row A's
+            // have been folded (they then overlap the tail of the gather), which keeps the variant free of spills
+            constexpr bool kDeferB = MODE == MODE_ERROR;
+            if (MODE != MODE_PLAIN) {
+                if (epA) epi_load(rA, eA);
+                if (epB && !kDeferB) epi_load(rB, eB);
+            }
+            f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
+            int jA = 0, jB = 0, jA1 = 0, jB1 = 0;
+            if (do_gather) {
+                jA = __builtin_amdgcn_readlane(ix_rp, 2 * k);
+                jA1 = __builtin_amdgcn_readlane(ix_rp, 2 * k + 1);
+                jB = __builtin_amdgcn_readlane(ix_rp, 2 * k + 2);
+                jB1 = __builtin_amdgcn_readlane(ix_rp, 2 * k + 3);
+                // first batches of both rows in flight together (16 x 1 KiB per wave)
+                f32x4 xA[8], xB[8];
+                float wA[8], wB[8];
+                const bool fa = jA + 8 <= jA1, fb = jB + 8 <= jB1;
+                if (fa) g_issue<8, HALO>(colidx, val, jA, rsX, rsH, a.n_own, lane_off, xA, wA);
+                if (kDeferB) {                 // ERROR: one row's batch at a time (register budget, see above)
+                    if (fa) { g_accum<8>(xA, wA, accA); jA += 8; }
+                    if (fb) g_issue<8, HALO>(colidx, val, jB, rsX, rsH, a.n_own, lane_off, xA, wA);
+                    if (fb) { g_accum<8>(xA, wA, accB); jB += 8; }
+                } else {
+                    if (fb) g_issue<8, HALO>(colidx, val, jB, rsX, rsH, a.n_own, lane_off, xB, wB);
+                    if (fa) { g_accum<8>(xA, wA, accA); jA += 8; }
+                    if (fb) { g_accum<8>(xB, wB, accB); jB += 8; }
+                }
+            }
+            if (MODE != MODE_PLAIN) {
+                if (epA) epi_reduce(rA, eA);
+                if (epB && !kDeferB) epi_reduce(rB, eB);
+                if (epB && kDeferB) epi_load(rB, eB);
+            }
+            if (do_gather) {
+                g_rest<HALO>(colidx, val, jA, jA1, rsX, rsH, a.n_own, lane_off, accA);
+                g_rest<HALO>(colidx, val, jB, jB1, rsX, rsH, a.n_own, lane_off, accB);
+            }
+            if (MODE != MODE_PLAIN && kDeferB && epB) epi_reduce(rB, eB);
+            if (epA) epi_finish(rA, buf + lrA * kLd2, eA);
+            if (epB) epi_finish(rB, buf + lrB * kLd2, eB);
+            if (do_gather) {
+                *reinterpret_cast<f32x4 *>(buf + lrA * kLd2 + 4 * lane) = accA;
+                *reinterpret_cast<f32x4 *>(buf + lrB * kLd2 + 4 * lane) = accB;
+            }
         }
     };
 
@@ -265,7 +319,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     f32x16 acc00, acc01, acc10, acc11;
     // Ring of weight operands, kRing deep: slot u holds k-quad q with q % kRing == u.  The weights are the same
     // for every tile, so the ring simply wraps around - it is already full when the next tile starts.
-    constexpr int kRing = RING;
+    constexpr int kRing = 4;
     const f32x4 *b0p = Wp + (size_t)(2 * (wave & 3)) * 32 * 64 + lane;
     const f32x4 *b1p = b0p + 32 * 64;
     f32x4 r0[kRing], r1[kRing];
@@ -329,15 +383,16 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     if (producer) {
         if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);         // timing experiment: gather waves win issue arbitration
         prefetch_index(t_first);
-        gather_tile(s_tile);
+        producer_phase(s_tile, 0, false, true);
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             const int t = t_first + it * wgs_per_xcd;
             float *oth = s_tile + ((it & 1) ^ 1) * kTileFloats2;
             const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
-            if (it > 0 && !(a.dbg & 4)) epilogue_tile(t - wgs_per_xcd, oth);
-            if (it + 1 < my_tiles && !(a.dbg & 2)) { prefetch_index(t + wgs_per_xcd); gather_tile(oth); }
+            const bool do_gather = it + 1 < my_tiles && !(a.dbg & 2);
+            if (do_gather) prefetch_index(t + wgs_per_xcd);
+            producer_phase(oth, t - wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
@@ -349,7 +404,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             a.dbg_cycles[2 * (blockIdx.x * 12 + wave) + 1] = cyc_wait;
         }
         const int t_last = t_first + (my_tiles - 1) * wgs_per_xcd;
-        epilogue_tile(t_last, s_tile + ((my_tiles - 1) & 1) * kTileFloats2);
+        producer_phase(s_tile + ((my_tiles - 1) & 1) * kTileFloats2, t_last, true, false);
         if (MODE == MODE_ERROR) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -357,8 +412,9 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
                 err_bad += __shfl_down(err_bad, off, 64);
             }
             if (lane == 0) {
-                a.partials[2 * (blockIdx.x * kProd + p)] = err_sum;
-                a.partials[2 * (blockIdx.x * kProd + p) + 1] = err_bad;
+                double *partials = epi_args()->partials;
+                partials[2 * (blockIdx.x * kProd + p)] = err_sum;
+                partials[2 * (blockIdx.x * kProd + p) + 1] = err_bad;
             }
         }
     } else {
@@ -428,8 +484,9 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     }
     a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (int)xb; a.xh_bytes = (int)xhb; a.Wp = Wp; a.bias = b; a.K = K;
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
-    a.y0 = y0; a.n_prev = n_prev; a.y_next = y_next; a.rtol = rtol; a.atol = atol;
-    a.partials = static_cast<double *>(d_ws);
+    EpiArgs ea;
+    ea.y0 = y0; ea.n_prev = n_prev; ea.y_next = y_next; ea.rtol = rtol; ea.atol = atol;
+    ea.partials = static_cast<double *>(d_ws);
     static const int dbg = env_int3("NDCN_FUSED_DBG", 0);
     a.dbg = dbg;
     static const int timing = env_int3("NDCN_FUSED_TIMING", 0);
@@ -437,8 +494,8 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     static int timing_prints = 0;
     if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * 12 * 2 * sizeof(unsigned long long));
     a.dbg_cycles = timing ? d_cyc : nullptr;
-    for (int m = 0; m < kMaxPrev; ++m) a.kprev[m] = (m < n_prev) ? h_kprev[m] : nullptr;
-    for (int m = 0; m <= kMaxPrev; ++m) a.c[m] = (mode != MODE_PLAIN && m <= n_prev) ? h_c[m] : 0.f;
+    for (int m = 0; m < kMaxPrev; ++m) ea.kprev[m] = (m < n_prev) ? h_kprev[m] : nullptr;
+    for (int m = 0; m <= kMaxPrev; ++m) ea.c[m] = (mode != MODE_PLAIN && m <= n_prev) ? h_c[m] : 0.f;
     int per_xcd = kCus / kXcds;
     const int need = (a.n_tiles + kXcds - 1) / kXcds;
     if (per_xcd > need) per_xcd = need;
@@ -448,14 +505,8 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
     if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * kH2 + 2.0 * (double)A->n_rows * kH2 * kH2);
-    static const int ring = env_int3("NDCN_FUSED_RING", 4);
-#define NDCN_F2(HALO_, MODE_)                                                                              \
-    do {                                                                                                   \
-        if (ring >= 8)                                                                                     \
-            hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, 8>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a); \
-        else                                                                                               \
-            hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, 4>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a); \
-    } while (0)
+#define NDCN_F2(HALO_, MODE_) \
+    hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a, ea)
     if (Xh) {
         if (mode == MODE_PLAIN) NDCN_F2(true, MODE_PLAIN);
         else if (mode == MODE_COMBINE) NDCN_F2(true, MODE_COMBINE);
@@ -467,7 +518,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     }
 #undef NDCN_F2
     if (mode == MODE_ERROR)
-        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, a.partials, (int)grid.x * kProd, d_out);
+        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, ea.partials, (int)grid.x * kProd, d_out);
     NDCN_LAUNCH_CHECK();
     if (timing && timing_prints < timing) {                          // debugging aid: s_memtime accounting of block 0 and 100
         (void)hipStreamSynchronize(st);
@@ -475,9 +526,11 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         for (int bi = 0; bi < 2; ++bi) {
             const int blk = bi == 0 ? 0 : 100;
             (void)hipMemcpy(h, d_cyc + (size_t)blk * 24, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[fused2 timing] mode %d n_prev %d block %d:", mode, n_prev, blk);
-            for (int w = 0; w < 12; ++w) fprintf(stderr, " w%d work=%llu wait=%llu |", w, h[2 * w], h[2 * w + 1]);
-            fprintf(stderr, "\n");
+            double cw = 0, cq = 0, pw = 0, pq = 0;
+            for (int w = 0; w < 4; ++w) { cw += h[2 * w] / 4.0; cq += h[2 * w + 1] / 4.0; }
+            for (int w = 4; w < 12; ++w) { pw += h[2 * w] / 8.0; pq += h[2 * w + 1] / 8.0; }
+            fprintf(stderr, "[fused2 timing] mode %d n_prev %d block %3d: mfma waves work %.0f wait %.0f | gather waves work %.0f wait %.0f\n",
+                    mode, n_prev, blk, cw, cq, pw, pq);
         }
         ++timing_prints;
     }

@@ -232,6 +232,33 @@ __global__ __launch_bounds__(256) void interp_eval_kernel(EvalArgs p, int64_t n_
     }
 }
 
+// fit + evaluate in one pass, nothing stored: for the (common) step that is sampled at a single tick
+struct DirectArgs {
+    FitArgs f;                      // a, b, c, d unused
+    float x4, x3, x2, x1, x0;
+    float *out;
+};
+
+__device__ __forceinline__ float direct1(float y0, float y1, float ms, float f0, float f1, const DirectArgs &p) {
+    float a, b, c, d;
+    fit1(y0, y1, ms, f0, f1, p.f.dt, a, b, c, d);
+    return (((a * p.x4 + b * p.x3) + c * p.x2) + d * p.x1) + y0 * p.x0;     // interp.py:65, e = y0
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void interp_direct_kernel(DirectArgs p, int64_t n_items) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 ms = wsum4(p.f.mid, i);
+            const float4 y0 = ld4(p.f.y0, i), y1 = ld4(p.f.y1, i), f0 = ld4(p.f.f0, i), f1 = ld4(p.f.f1, i);
+            st4(p.out, i, make_float4(direct1(y0.x, y1.x, ms.x, f0.x, f1.x, p), direct1(y0.y, y1.y, ms.y, f0.y, f1.y, p),
+                                      direct1(y0.z, y1.z, ms.z, f0.z, f1.z, p), direct1(y0.w, y1.w, ms.w, f0.w, f1.w, p)));
+        } else {
+            p.out[i] = direct1(p.f.y0[i], p.f.y1[i], wsum1(p.f.mid, i), p.f.f0[i], p.f.f1[i], p);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------- fixed-grid stages
 template <int OP>
 __device__ __forceinline__ float stage1(float y, float k1, float k2, float k3, float k4, float dt) {
@@ -357,6 +384,33 @@ int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, co
     ProfScope prof(PROF_FIT, st, 4.0 * n * (2 + m + 4), 2.0 * n * (m + 16));
     if (vec) hipLaunchKernelGGL((interp_fit_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
     else hipLaunchKernelGGL((interp_fit_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int interp_direct_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                      const float xp[5], float *out, int64_t n, hipStream_t st) {
+    DirectArgs p;
+    bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1) && aligned16(out);
+    const float *kk[kMaxTerms];
+    float cc[kMaxTerms];
+    int m = 0;
+    for (int j = 0; j < 7; ++j) {
+        if (!h_k[j]) { set_error("interp_direct: null stage pointer"); return NDCN_EINVAL; }
+        vec = vec && aligned16(h_k[j]);
+        if (h_cmid[j] != 0.f) { kk[m] = h_k[j]; cc[m] = h_cmid[j]; ++m; }
+    }
+    if (m == 0) { kk[0] = h_k[0]; cc[0] = 0.f; m = 1; }
+    bool dummy = true;
+    fill_terms(p.f.mid, kk, cc, m, dummy);
+    p.f.y0 = y0; p.f.y1 = y1; p.f.f0 = h_k[0]; p.f.f1 = h_k[6]; p.f.dt = dt;
+    p.f.a = p.f.b = p.f.c = p.f.d = nullptr;
+    p.x4 = xp[0]; p.x3 = xp[1]; p.x2 = xp[2]; p.x1 = xp[3]; p.x0 = xp[4];
+    p.out = out;
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_EVAL, st, 4.0 * n * (2 + m + 1), 2.0 * n * (m + 24));
+    if (vec) hipLaunchKernelGGL((interp_direct_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_direct_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

@@ -70,6 +70,7 @@ struct ndcn_solver {
     float tf = 0;                  // fixed grid: current time in the state dtype
     bool fit_pending = false;      // last accepted step not yet fitted
     bool fit_valid = false;
+    int evals_in_step = 0;         // ticks already evaluated inside the current accepted step
     float fit_dt = 0;
     bool cur_is_borrowed = false;  // ycur points into a caller buffer (fixed grid)
     float *ycur_own = nullptr;
@@ -300,6 +301,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
         // keep {y0, y1, k[0..6]} of this step intact for a lazy dense-output fit; rotate the state
         s->fit_pending = true;
         s->fit_valid = false;
+        s->evals_in_step = 0;
         s->fit_dt = dt32;
         s->t0 = t_start;
         s->t1 = t_start + dt;
@@ -605,13 +607,6 @@ int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hi
         ++n_here;
     }
     if (!out) return NDCN_OK;
-    if (!s->fit_valid) {
-        if (!s->fit_pending) { set_error("no accepted step covers t=%g", next_t); return NDCN_ESTATE; }
-        int rc = do_fit(s, st);
-        if (rc) return rc;
-        s->ce = s->ycur;               // y0 of the fitted step; becomes yold at the rotation
-        s->fit_valid = true;
-    }
     // interp.py:51-65: abscissa and its powers in the state dtype
     const float a0 = (float)s->t0, a1 = (float)s->t1, at = (float)next_t;
     if (!(a0 <= at && at <= a1)) {
@@ -621,6 +616,20 @@ int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hi
     const float x = (at - a0) / (a1 - a0);
     float xp[5];
     xp[4] = 1.f; xp[3] = x; xp[2] = xp[3] * x; xp[1] = xp[2] * x; xp[0] = xp[1] * x;
+    if (!s->fit_valid) {
+        if (!s->fit_pending) { set_error("no accepted step covers t=%g", next_t); return NDCN_ESTATE; }
+        if (s->evals_in_step++ == 0) {
+            // first tick inside this step: fit + evaluate in one pass, coefficients not materialised (most steps
+            // are sampled at most once); a second tick in the same step pays for the stored fit below
+            float cm[7];
+            for (int j = 0; j < 7; ++j) cm[j] = s->fit_dt * (float)kCMid[j];
+            return interp_direct_f32(s->ycur, s->ynext, s->k, cm, s->fit_dt, xp, out, s->n_elem, st);
+        }
+        int rc = do_fit(s, st);
+        if (rc) return rc;
+        s->ce = s->ycur;               // y0 of the fitted step; becomes yold at the rotation
+        s->fit_valid = true;
+    }
     return interp_eval_f32(s->ca, s->cb, s->cc, s->cd, s->ce, xp, out, s->n_elem, st);
 }
 

@@ -234,6 +234,21 @@ class HipOps:
         return a, b, c, d
 
     @staticmethod
+    def interp_direct(y0, y1, ks, cmid, dt, xpow, out=None):
+        """interp_fit + interp_eval in one pass, coefficients not stored (same arithmetic, bit-identical)."""
+        y0, y1 = _panel(y0), _panel(y1)
+        ks = [_panel(k) for k in ks]
+        assert len(ks) == 7
+        if out is None:
+            out = torch.empty_like(y0)
+        arr_k, arr_c, _ = _terms(ks, cmid)
+        xp = (_F * 5)(*[float(v) for v in xpow])
+        with torch.cuda.device(y0.device):
+            check(_lib.load().ndcn_dopri5_interp_direct_f32(ptr(y0), ptr(y1), arr_k, arr_c, float(dt), xp, ptr(out),
+                                                            y0.numel(), stream_ptr()))
+        return out
+
+    @staticmethod
     def interp_eval(fit, e, xpow, out=None):
         """`fit` = the (a, b, c, d) panels interp_fit returned; e = y at the start of the fitted step."""
         a, b, c, d = fit

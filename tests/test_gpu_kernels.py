@@ -211,6 +211,9 @@ def test_rk_kernels_bitwise_vs_reference_op_order(dev, shape):
     xp = (np.float32(x * x * x * x), np.float32(x * x * x), np.float32(x * x), x, np.float32(1))
     got = hip.interp_eval(tuple(g(v) for v in ref), g(y0), xp).cpu()
     assert torch.equal(got, OracleOps.interp_eval(ref, y0, xp))
+    # single-pass variant (what the device solver uses for the first tick inside a step)
+    direct = hip.interp_direct(g(y0), g(y1), [g(k) for k in ks], cmid, dt, xp).cpu()
+    assert torch.equal(direct, got)
     for op in range(6):
         got = hip.fixed_stage(op, g(y0), g(ks[0]), g(ks[1]), g(ks[2]), g(ks[3]), dt=dt).cpu()
         assert torch.equal(got, OracleOps.fixed_stage(op, y0, ks[0], ks[1], ks[2], ks[3], dt=dt)), op
