@@ -42,7 +42,10 @@ constexpr int kH2 = 256;
 constexpr int kTile2 = 64;
 constexpr int kLd2 = kH2 + 4;              // +4 floats: row m starts on 16-byte slot (4 m) mod 64 -> conflict-free b128
 constexpr int kTileFloats2 = kTile2 * kLd2;
-constexpr int kProd = 8;
+#ifndef NDCN_KPROD
+#define NDCN_KPROD 8
+#endif
+constexpr int kProd = NDCN_KPROD;
 constexpr int kRowsPerProd = kTile2 / kProd;
 constexpr int kMaxPrev = 5;              // dopri5 needs at most 5 earlier stages with a non-zero coefficient
 
@@ -91,36 +94,50 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // scalar loads (the CSR arrays are __restrict__ kernel arguments, j is wave-uniform), the row address is a
 // buffer-load SGPR offset (col << 10) on top of a fixed per-lane offset - the only VALU work left per
 // neighbour is the two packed FMAs.
-template <int U, bool HALO>
+template <int U, bool HALO, int O = 0>
 __device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j,
                                         __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
                                         f32x4 (&x)[8], float (&vv)[8]) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
         int cc = colidx[j + q];
-        vv[q] = val[j + q];
+        vv[O + q] = val[j + q];
         __amdgpu_buffer_rsrc_t rs = rsX;
         if (HALO && cc >= n_own) { rs = rsH; cc -= n_own; }
-        x[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, cc << 10, 0));
+        x[O + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, cc << 10, 0));
     }
 }
-template <int U>
+template <int U, int O = 0>
 __device__ __forceinline__ void g_accum(const f32x4 (&x)[8], const float (&vv)[8], f32x4 &acc) {
 #pragma unroll
-    for (int q = 0; q < U; ++q) acc = fma4(vv[q], x[q], acc);
+    for (int q = 0; q < U; ++q) acc = fma4(vv[O + q], x[O + q], acc);
 }
 
-// entries [j, j1) of a row in batches of 8 / 4 / 2 / 1
+// tails of two rows (fewer than 8 entries left each): pieces of 4 / 2 / 1, the same-size pieces of both rows in
+// flight together (one fetch latency per piece size instead of one per row and size); entries are folded in
+// ascending order within each row, so the sums round exactly as a row-at-a-time loop would
+template <int U, bool HALO>
+__device__ __forceinline__ void g_piece2(const int *__restrict__ colidx, const float *__restrict__ val, int &jA, int nA,
+                                         int &jB, int nB, __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own,
+                                         int lane_off, f32x4 &accA, f32x4 &accB) {
+    f32x4 xA[8], xB[8];
+    float wA[8], wB[8];
+    const bool hA = nA & U, hB = nB & U;
+    if (hA) g_issue<U, HALO>(colidx, val, jA, rsX, rsH, n_own, lane_off, xA, wA);
+    if (hB) g_issue<U, HALO>(colidx, val, jB, rsX, rsH, n_own, lane_off, xB, wB);
+    if (hA) { g_accum<U>(xA, wA, accA); jA += U; }
+    if (hB) { g_accum<U>(xB, wB, accB); jB += U; }
+}
+
+// whole batches of 8 of the entries [j, j1) of a row; returns the first entry of the tail
 template <bool HALO>
-__device__ __forceinline__ void g_rest(const int *__restrict__ colidx, const float *__restrict__ val, int j, int j1,
-                                       __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
-                                       f32x4 &acc) {
+__device__ __forceinline__ int g_batches(const int *__restrict__ colidx, const float *__restrict__ val, int j, int j1,
+                                         __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
+                                         f32x4 &acc) {
     f32x4 x[8];
     float vv[8];
     for (; j + 8 <= j1; j += 8) { g_issue<8, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<8>(x, vv, acc); }
-    if (j + 4 <= j1) { g_issue<4, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<4>(x, vv, acc); j += 4; }
-    if (j + 2 <= j1) { g_issue<2, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<2>(x, vv, acc); j += 2; }
-    if (j < j1) { g_issue<1, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<1>(x, vv, acc); }
+    return j;
 }
 
 template <bool HALO, int MODE>
@@ -196,15 +213,14 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, panel_bytes, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, row_off, 2 /* nt */);
     };
-    auto epi_load = [&](int r, EpiRow &e) {
-        const int off = r << 10;
+    auto epi_load = [&](EpiPtr ea, int r, EpiRow &e) {
+        const int off = (a.dbg & 2048) ? ((r & 63) << 10) : (r << 10);      // timing experiment: cache-resident panels
         if (a.dbg & 256) {                                     // timing experiment: no row-local fetches
 #pragma unroll
             for (int m = 0; m < kMaxPrev; ++m) e.km[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             e.y0v = (f32x4){0.f, 0.f, 0.f, 0.f};
             return;
         }
-        const EpiPtr ea = epi_args();
         const int n_prev = ea->n_prev;
 #pragma unroll
         for (int m = 0; m < kMaxPrev; ++m)
@@ -212,8 +228,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
         e.y0v = ldp(ea->y0, off);
     };
     // sum of the earlier stages (left to right, as misc.py:22-25 accumulates), into km[0]: frees the fetch registers
-    auto epi_reduce = [&](int r, EpiRow &e) {
-        const EpiPtr ea = epi_args();
+    auto epi_reduce = [&](EpiPtr ea, int r, EpiRow &e) {
         const int n_prev = ea->n_prev;
         if (n_prev > 0) {
             f32x4 s = e.km[0] * ea->c[0];
@@ -225,12 +240,11 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
         // ERROR: the input of this evaluation is y1 (own rows); requested only now that the stage registers are free
         if (MODE == MODE_ERROR) e.y1v = (a.dbg & 256) ? e.y0v : ldp(a.X, r << 10);
     };
-    auto epi_finish = [&](int r, const float *src_row, const EpiRow &e) {
+    auto epi_finish = [&](EpiPtr ea, int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
         const int off = r << 10;
         stp(a.K, off, kn);
         if (MODE == MODE_PLAIN) return;
-        const EpiPtr ea = epi_args();
         if (a.dbg & 1024) { if (MODE == MODE_COMBINE) stp(ea->y_next, off, kn); return; }   // timing experiment: no algebra
         const int n_prev = ea->n_prev;
         f32x4 s = kn * ea->c[n_prev];                          // the new stage is the last term of the sum
@@ -259,6 +273,10 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     //   4. drop the gathered rows into the same two rows of `buf`
     // A producer wave owns the same rows of every tile, so no producer-to-producer synchronisation is needed.
     auto producer_phase = [&](float *buf, int t_epi, bool do_epi, bool do_gather) {
+        // one (laundered) read of the epilogue arguments per tile: re-reading them at every use cost 11 scalar
+        // loads + waits per row (SQ_INSTS_SMEM 15.7 M vs 4.0 M per launch)
+        EpiPtr ea = nullptr;
+        if (MODE != MODE_PLAIN) ea = epi_args();
         const int r0 = t_epi * kTile2 + p;
 #pragma unroll
         for (int k = 0; k < kRowsPerProd; k += 2) {
@@ -270,8 +288,8 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             // have been folded (they then overlap the tail of the gather), which keeps the variant free of spills
             constexpr bool kDeferB = MODE == MODE_ERROR;
             if (MODE != MODE_PLAIN) {
-                if (epA) epi_load(rA, eA);
-                if (epB && !kDeferB) epi_load(rB, eB);
+                if (epA) epi_load(ea, rA, eA);
+                if (epB && !kDeferB) epi_load(ea, rB, eB);
             }
             f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
             int jA = 0, jB = 0, jA1 = 0, jB1 = 0;
@@ -296,17 +314,21 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
                 }
             }
             if (MODE != MODE_PLAIN) {
-                if (epA) epi_reduce(rA, eA);
-                if (epB && !kDeferB) epi_reduce(rB, eB);
-                if (epB && kDeferB) epi_load(rB, eB);
+                if (epA) epi_reduce(ea, rA, eA);
+                if (epB && !kDeferB) epi_reduce(ea, rB, eB);
+                if (epB && kDeferB) epi_load(ea, rB, eB);
             }
             if (do_gather) {
-                g_rest<HALO>(colidx, val, jA, jA1, rsX, rsH, a.n_own, lane_off, accA);
-                g_rest<HALO>(colidx, val, jB, jB1, rsX, rsH, a.n_own, lane_off, accB);
+                jA = g_batches<HALO>(colidx, val, jA, jA1, rsX, rsH, a.n_own, lane_off, accA);     // rows > 16 entries
+                jB = g_batches<HALO>(colidx, val, jB, jB1, rsX, rsH, a.n_own, lane_off, accB);
+                const int nA = jA1 - jA, nB = jB1 - jB;
+                g_piece2<4, HALO>(colidx, val, jA, nA, jB, nB, rsX, rsH, a.n_own, lane_off, accA, accB);
+                g_piece2<2, HALO>(colidx, val, jA, nA, jB, nB, rsX, rsH, a.n_own, lane_off, accA, accB);
+                g_piece2<1, HALO>(colidx, val, jA, nA, jB, nB, rsX, rsH, a.n_own, lane_off, accA, accB);
             }
-            if (MODE != MODE_PLAIN && kDeferB && epB) epi_reduce(rB, eB);
-            if (epA) epi_finish(rA, buf + lrA * kLd2, eA);
-            if (epB) epi_finish(rB, buf + lrB * kLd2, eB);
+            if (MODE != MODE_PLAIN && kDeferB && epB) epi_reduce(ea, rB, eB);
+            if (epA) epi_finish(ea, rA, buf + lrA * kLd2, eA);
+            if (epB) epi_finish(ea, rB, buf + lrB * kLd2, eB);
             if (do_gather) {
                 *reinterpret_cast<f32x4 *>(buf + lrA * kLd2 + 4 * lane) = accA;
                 *reinterpret_cast<f32x4 *>(buf + lrB * kLd2 + 4 * lane) = accB;
@@ -332,29 +354,37 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
         for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
         const float *a0p = src + (lane & 31) * kLd2 + 128 * (lane >> 5);
         const float *a1p = a0p + 32 * kLd2;
-        f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p), a1 = *reinterpret_cast<const f32x4 *>(a1p);
+        // A operands ping-pong between an even-quad and an odd-quad register set, and a weight slot is refilled
+        // AFTER the MFMAs that read it: no value ever has to be copied to free its register (the first version
+        // rotated through temporaries - 116 v_mov per 64 MFMAs, issued on the VALU port the gather waves need)
+        f32x4 aE0 = *reinterpret_cast<const f32x4 *>(a0p), aE1 = *reinterpret_cast<const f32x4 *>(a1p);
+        f32x4 aO0 = aE0, aO1 = aE1;
 #pragma unroll 1
         for (int q0 = 0; q0 < 32; q0 += kRing) {
 #pragma unroll
             for (int u = 0; u < kRing; ++u) {
                 const int q = q0 + u;
-                const f32x4 c0 = r0[u], c1 = r1[u], x0 = a0, x1 = a1;
-                if (q + 1 < 32) {
-                    a0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
-                    a1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
+                if ((u & 1) == 0) {
+                    aO0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
+                    aO1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
+                } else if (q + 1 < 32) {
+                    aE0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
+                    aE1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = (u & 1) ? aO0[e] : aE0[e], x1 = (u & 1) ? aO1[e] : aE1[e];
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, r0[u][e], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, r1[u][e], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, r0[u][e], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, r1[u][e], acc11, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 // the refill wraps into the next tile's first quads (dbg bit 8 = do not wrap: A/B switch)
                 if ((!(a.dbg & 8) || q + kRing < 32) && !(a.dbg & 64)) {       // dbg 64: no weight refills (timing experiment)
                     const int qn = (q + kRing) & 31;
                     r0[u] = b0p[qn * 64];
                     r1[u] = b1p[qn * 64];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], c0[e], acc00, 0, 0, 0);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], c1[e], acc01, 0, 0, 0);
-                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], c0[e], acc10, 0, 0, 0);
-                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], c1[e], acc11, 0, 0, 0);
                 }
             }
         }
@@ -392,7 +422,8 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             const bool do_gather = it + 1 < my_tiles && !(a.dbg & 2);
             if (do_gather) prefetch_index(t + wgs_per_xcd);
-            producer_phase(oth, t - wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
+            if (!((a.dbg & 4096) && p >= 4))                   // timing experiment: only half of the gather waves work
+                producer_phase(oth, t - wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
@@ -528,7 +559,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
             (void)hipMemcpy(h, d_cyc + (size_t)blk * 24, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost);
             double cw = 0, cq = 0, pw = 0, pq = 0;
             for (int w = 0; w < 4; ++w) { cw += h[2 * w] / 4.0; cq += h[2 * w + 1] / 4.0; }
-            for (int w = 4; w < 12; ++w) { pw += h[2 * w] / 8.0; pq += h[2 * w + 1] / 8.0; }
+            for (int w = 4; w < 4 + kProd; ++w) { pw += h[2 * w] / (double)kProd; pq += h[2 * w + 1] / (double)kProd; }
             fprintf(stderr, "[fused2 timing] mode %d n_prev %d block %3d: mfma waves work %.0f wait %.0f | gather waves work %.0f wait %.0f\n",
                     mode, n_prev, blk, cw, cq, pw, pq);
         }

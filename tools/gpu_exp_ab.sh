@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of two builds of the library inside one box: default vs gpurun_in_*.so
+mkdir -p gpurun_out
+run() {
+  NDCN_FUSED_TIMING=9 python bench.py --steps 2 --warmup 0 --no-cpu-baseline 2>&1 | grep -E "fused2 timing" | grep -v "block   0" | cut -c1-200
+  python bench.py --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+}
+{
+  echo "=== default"; run
+  for f in gpurun_in_*.so; do cp $f ndcn_amd/libndcn_hip.so; echo "=== $f"; run; done
+} > gpurun_out/exp_ab.log 2>&1

@@ -1,0 +1,36 @@
+#!/bin/bash
+# SQ issue/stall counters of the fused RHS kernel (one --pmc group per pass; kernel-trace only)
+export TMPDIR=/tmp
+mkdir -p gpurun_out/sq
+(cd /tmp && rocprofv3 --list-avail 2>/dev/null | grep -oE "SQ_[A-Z0-9_]+" | sort -u > "$GRAFT_REPO_ROOT/gpurun_out/sq/avail.txt")
+groups=(
+ "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU"
+ "SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS"
+ "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
+ "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_IFETCH"
+ "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_THREAD_CYCLES_VALU SQ_WAVE32_INSTS SQ_INST_LEVEL_VMEM"
+)
+i=0
+for g in "${groups[@]}"; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/sq/g$i" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-profile-pass --steps 2 --warmup 0 > "$GRAFT_REPO_ROOT/gpurun_out/sq/g$i.log" 2>&1)
+  i=$((i+1))
+done
+python - <<'PY'
+import csv, glob, collections
+out = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('gpurun_out/sq/g*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if 'rhs_fused2_kernel' not in k: continue
+        mode = k.split('ILb')[1][:8]
+        out[mode][r['Counter_Name']].append(float(r['Counter_Value']))
+with open('gpurun_out/sq/summary.txt', 'w') as fh:
+    for mode in sorted(out):
+        fh.write('== %s\n' % mode)
+        for c in sorted(out[mode]):
+            v = out[mode][c]
+            fh.write('  %-32s n=%3d mean=%.4g\n' % (c, len(v), sum(v) / len(v)))
+PY
+tail -5 gpurun_out/sq/g0.log
