@@ -20,6 +20,7 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
 int rhs_fused_supported(int H, uint32_t flags);
 int pack_weight_256(const float *W, float *Wp, hipStream_t st);
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);
+int rhs_fused2_variant(int mode, int n_prev);
 int64_t rhs_fused2_partials_bytes();
 // mode 0: K only; 1: also y_next = y0 + sum c_m kprev_m + c_new K; 2: also the dopri5 error record into d_out
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,

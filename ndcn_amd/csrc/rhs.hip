@@ -65,7 +65,7 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
     if (rk_mode == 0) return rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
     if (n_prev < 0 || n_prev > 5) { set_error("rhs_rk: n_prev must be 0..5"); return NDCN_EINVAL; }
     const bool both = !(flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
-    if (both && rhs_fused2_supported(A, H, flags)) {
+    if (both && rhs_fused2_supported(A, H, flags) && rhs_fused2_variant(rk_mode, n_prev)) {
         if (!work) { set_error("rhs_rk: scratch of ndcn_rhs_work_bytes() bytes required"); return NDCN_EINVAL; }
         int rc = pack_weight_256(W, work, st);
         if (rc) return rc;

@@ -42,11 +42,9 @@ constexpr int kH2 = 256;
 constexpr int kTile2 = 64;
 constexpr int kLd2 = kH2 + 4;              // +4 floats: row m starts on 16-byte slot (4 m) mod 64 -> conflict-free b128
 constexpr int kTileFloats2 = kTile2 * kLd2;
-#ifndef NDCN_KPROD
-#define NDCN_KPROD 8
-#endif
-constexpr int kProd = NDCN_KPROD;
-constexpr int kRowsPerProd = kTile2 / kProd;
+constexpr int kProd = 12;                                   // gather waves (3 per SIMD, next to one MFMA wave)
+constexpr int kWaves = 4 + kProd;
+constexpr int kRowsPerProd = (kTile2 + kProd - 1) / kProd;  // rows p, p+12, ... < 64 of every tile: 6 (p < 4) or 5
 constexpr int kMaxPrev = 5;              // dopri5 needs at most 5 earlier stages with a non-zero coefficient
 
 // Arguments of the RK epilogue.  They are NOT read through the kernel-parameter object: the compiler would keep
@@ -97,7 +95,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int U, bool HALO, int O = 0>
 __device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j,
                                         __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
-                                        f32x4 (&x)[8], float (&vv)[8]) {
+                                        f32x4 (&x)[16], float (&vv)[16]) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
         int cc = colidx[j + q];
@@ -108,40 +106,34 @@ __device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const fl
     }
 }
 template <int U, int O = 0>
-__device__ __forceinline__ void g_accum(const f32x4 (&x)[8], const float (&vv)[8], f32x4 &acc) {
+__device__ __forceinline__ void g_accum(const f32x4 (&x)[16], const float (&vv)[16], f32x4 &acc) {
 #pragma unroll
     for (int q = 0; q < U; ++q) acc = fma4(vv[O + q], x[O + q], acc);
 }
 
-// tails of two rows (fewer than 8 entries left each): pieces of 4 / 2 / 1, the same-size pieces of both rows in
-// flight together (one fetch latency per piece size instead of one per row and size); entries are folded in
-// ascending order within each row, so the sums round exactly as a row-at-a-time loop would
-template <int U, bool HALO>
-__device__ __forceinline__ void g_piece2(const int *__restrict__ colidx, const float *__restrict__ val, int &jA, int nA,
-                                         int &jB, int nB, __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own,
-                                         int lane_off, f32x4 &accA, f32x4 &accB) {
-    f32x4 xA[8], xB[8];
-    float wA[8], wB[8];
-    const bool hA = nA & U, hB = nB & U;
-    if (hA) g_issue<U, HALO>(colidx, val, jA, rsX, rsH, n_own, lane_off, xA, wA);
-    if (hB) g_issue<U, HALO>(colidx, val, jB, rsX, rsH, n_own, lane_off, xB, wB);
-    if (hA) { g_accum<U>(xA, wA, accA); jA += U; }
-    if (hB) { g_accum<U>(xB, wB, accB); jB += U; }
-}
-
-// whole batches of 8 of the entries [j, j1) of a row; returns the first entry of the tail
+// The last m < 16 entries of a row in ONE round: pieces of 8 / 4 / 2 / 1 in slots 0-7 / 8-11 / 12-13 / 14, all
+// issued before any is awaited (a 9-entry grid row is one fetch latency, not two); g_row_accum folds them in
+// ascending entry order, so the sum rounds exactly like a sequential loop over the row.
 template <bool HALO>
-__device__ __forceinline__ int g_batches(const int *__restrict__ colidx, const float *__restrict__ val, int j, int j1,
-                                         __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
-                                         f32x4 &acc) {
-    f32x4 x[8];
-    float vv[8];
-    for (; j + 8 <= j1; j += 8) { g_issue<8, HALO>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); g_accum<8>(x, vv, acc); }
-    return j;
+__device__ __forceinline__ void g_row_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j, int m,
+                                            __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
+                                            f32x4 (&x)[16], float (&vv)[16]) {
+    if (m & 8) { g_issue<8, HALO, 0>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); j += 8; }
+    if (m & 4) { g_issue<4, HALO, 8>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); j += 4; }
+    if (m & 2) { g_issue<2, HALO, 12>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); j += 2; }
+    if (m & 1) { g_issue<1, HALO, 14>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); }
+}
+__device__ __forceinline__ void g_row_accum(int m, const f32x4 (&x)[16], const float (&vv)[16], f32x4 &acc) {
+    if (m & 8) g_accum<8, 0>(x, vv, acc);
+    if (m & 4) g_accum<4, 8>(x, vv, acc);
+    if (m & 2) g_accum<2, 12>(x, vv, acc);
+    if (m & 1) g_accum<1, 14>(x, vv, acc);
 }
 
-template <bool HALO, int MODE>
-__global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int *__restrict__ rowptr,
+// NP = number of earlier stages in the RK sum (compile-time: the number of fetches in flight must be known for the
+// waits on the gathered rows not to include the younger, slower row-local fetches)
+template <bool HALO, int MODE, int NP>
+__global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__restrict__ rowptr,
                                                                       const int *__restrict__ colidx,
                                                                       const float *__restrict__ val, Fused2Args a,
                                                                       EpiArgs epi_by_kernarg_only) {
@@ -157,7 +149,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool producer = wave >= 4;
-    const int p = wave - 4;                                   // producer index 0..7
+    const int p = wave - 4;                                   // producer index 0..11
     const f32x4 *X = reinterpret_cast<const f32x4 *>(a.X);
     const f32x4 *Wp = reinterpret_cast<const f32x4 *>(a.Wp);
     // buffer descriptors of the gathered panels (wave-uniform; byte sizes < 2^31 checked by the launcher)
@@ -185,23 +177,23 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
 
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 
-    // ---- producer: row extents of the wave's 8 rows of a tile by one vector load; they stay in that VGPR (lane
-    // 2k / 2k+1 = begin / end of row k) and are read out per row pair - 16 resident SGPRs less
+    // ---- producer: row extents of the wave's rows of a tile by one vector load; they stay in that VGPR (lane
+    // 2k / 2k+1 = begin / end of row k) and are read out row by row
     int ix_rp = 0;
     auto prefetch_index = [&](int t) {
         ix_rp = 0;
-        if (lane < 2 * kRowsPerProd) {
-            int r = t * kTile2 + p + kProd * (lane >> 1) + (lane & 1);
+        const int lr = p + kProd * (lane >> 1);
+        if (lane < 2 * kRowsPerProd && lr < kTile2) {
+            const int r = t * kTile2 + lr + (lane & 1);
             ix_rp = rowptr[min(r, a.n_rows)];       // rows past the end: begin == end == rowptr[n_rows]
         }
     };
 
-    // ---- producer: stream K rows of tile `t` out of LDS tile src (+ RK algebra) ----------------------
-    // The row-local panels of row k+1 are requested before row k is finished (one row of fetches always in flight).
-    struct EpiRow { f32x4 km[kMaxPrev]; f32x4 y0v, y1v; };
+    // ---- producer: RK epilogue of one K row ----------------------------------------------------------
     // Row-local panels go through buffer descriptors built on the scalar unit: address = descriptor base + SGPR row
     // offset (r << 10) + the fixed per-lane offset - no VALU address arithmetic per panel (the producers' VALU time
     // is what the MFMA waves squeeze).  Panels are < 2 GiB (launcher check).
+    struct EpiRow { f32x4 km[NP > 0 ? NP : 1]; f32x4 y0v, y1v; };
     const int panel_bytes = a.n_rows << 10;
     auto ldp = [&](const float *base, int row_off) {
         asm volatile("" : "+s"(base));      // keep the 4-SGPR descriptor transient: hoisted descriptors for 8 panels spill
@@ -215,43 +207,26 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
     };
     auto epi_load = [&](EpiPtr ea, int r, EpiRow &e) {
         const int off = (a.dbg & 2048) ? ((r & 63) << 10) : (r << 10);      // timing experiment: cache-resident panels
-        if (a.dbg & 256) {                                     // timing experiment: no row-local fetches
 #pragma unroll
-            for (int m = 0; m < kMaxPrev; ++m) e.km[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            e.y0v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            return;
-        }
-        const int n_prev = ea->n_prev;
-#pragma unroll
-        for (int m = 0; m < kMaxPrev; ++m)
-            if (m < n_prev) e.km[m] = ldp(ea->kprev[m], off);
+        for (int m = 0; m < NP; ++m) e.km[m] = ldp(ea->kprev[m], off);
         e.y0v = ldp(ea->y0, off);
-    };
-    // sum of the earlier stages (left to right, as misc.py:22-25 accumulates), into km[0]: frees the fetch registers
-    auto epi_reduce = [&](EpiPtr ea, int r, EpiRow &e) {
-        const int n_prev = ea->n_prev;
-        if (n_prev > 0) {
-            f32x4 s = e.km[0] * ea->c[0];
-#pragma unroll
-            for (int m = 1; m < kMaxPrev; ++m)
-                if (m < n_prev) s = s + e.km[m] * ea->c[m];
-            e.km[0] = s;
-        }
-        // ERROR: the input of this evaluation is y1 (own rows); requested only now that the stage registers are free
-        if (MODE == MODE_ERROR) e.y1v = (a.dbg & 256) ? e.y0v : ldp(a.X, r << 10);
+        if (MODE == MODE_ERROR) e.y1v = ldp(a.X, off);         // the input of this evaluation is y1 (own rows)
     };
     auto epi_finish = [&](EpiPtr ea, int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
         const int off = r << 10;
         stp(a.K, off, kn);
         if (MODE == MODE_PLAIN) return;
-        if (a.dbg & 1024) { if (MODE == MODE_COMBINE) stp(ea->y_next, off, kn); return; }   // timing experiment: no algebra
-        const int n_prev = ea->n_prev;
-        f32x4 s = kn * ea->c[n_prev];                          // the new stage is the last term of the sum
-        if (n_prev > 0) s = e.km[0] + s;
+        // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
+        f32x4 s = kn * ea->c[NP];
+        if (NP > 0) {
+            f32x4 u = e.km[0] * ea->c[0];
+#pragma unroll
+            for (int m = 1; m < NP; ++m) u = u + e.km[m] * ea->c[m];
+            s = u + s;
+        }
         if (MODE == MODE_COMBINE) {
             if (!(a.dbg & 512)) stp(ea->y_next, off, e.y0v + s);
-            else if (s[0] == 1.2345e-30f) stp(ea->y_next, off, e.y0v + s);    // timing experiment: store never taken
         } else {
             const float rtol = ea->rtol, atol = ea->atol;
 #pragma unroll
@@ -263,76 +238,48 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             }
         }
     };
-    // ---- producer phase A: per pair of the wave's rows -----------------------------------------------------
-    //   1. request the row-local panels (y0, earlier stages) of rows (A, B) of tile t_epi, whose K sits in `buf`
-    //   2. gather rows (A, B) of the NEXT tile (extents prefetched) into registers - ~10k cycles, which is what
-    //      hides the latency of (1): with the epilogue run as its own loop that latency was exposed once per row
-    //      (measured 2.3k cycles per row, +1.2..1.7 M cycles per launch); the panels of (1) are folded into one
-    //      partial sum per row as soon as the first gather batch has landed (they are older, so they have too)
-    //   3. finish the epilogue of rows (A, B): K out of `buf`, RK algebra, stores
-    //   4. drop the gathered rows into the same two rows of `buf`
-    // A producer wave owns the same rows of every tile, so no producer-to-producer synchronisation is needed.
+    // ---- producer phase A, one row at a time -------------------------------------------------------------
+    //   1. issue the neighbour-row fetches of row k of the NEXT tile (extents prefetched): the whole row if it
+    //      has < 16 entries, after whole batches of 8 otherwise
+    //   2. request the row-local panels (y0, earlier stages) of row k of tile t_epi, whose K sits in `buf`; they
+    //      are YOUNGER than (1), so the wait for the gathered rows (vector memory returns in order) does not
+    //      include their HBM latency - they land while (3) runs
+    //   3. fold the gathered rows (2 packed FMAs per neighbour)
+    //   4. epilogue of the row: K out of `buf`, RK algebra, stores
+    //   5. drop the gathered row into the same row of `buf`
+    // A gather wave owns the same rows of every tile, so no producer-to-producer synchronisation is needed.
+    // Twelve waves work like this per CU: a wave's chain (scalar index load -> fetches -> FMAs under MFMA
+    // contention -> stores) is latency-bound - with half of the 8 waves of the previous version switched off the
+    // others were not a cycle faster - so throughput comes from the number of chains in flight.
     auto producer_phase = [&](float *buf, int t_epi, bool do_epi, bool do_gather) {
-        // one (laundered) read of the epilogue arguments per tile: re-reading them at every use cost 11 scalar
-        // loads + waits per row (SQ_INSTS_SMEM 15.7 M vs 4.0 M per launch)
         EpiPtr ea = nullptr;
-        if (MODE != MODE_PLAIN) ea = epi_args();
+        if (MODE != MODE_PLAIN) ea = epi_args();               // one (laundered) read of the epilogue arguments per tile
         const int r0 = t_epi * kTile2 + p;
 #pragma unroll
-        for (int k = 0; k < kRowsPerProd; k += 2) {
-            const int lrA = p + kProd * k, lrB = lrA + kProd;
-            const int rA = r0 + kProd * k, rB = rA + kProd;
-            const bool epA = do_epi && rA < a.n_rows, epB = do_epi && rB < a.n_rows;
-            EpiRow eA, eB;
-            // ERROR carries y1 and the fp64 partial sums on top: row B's panels are requested only after row A's
-            // have been folded (they then overlap the tail of the gather), which keeps the variant free of spills
-            constexpr bool kDeferB = MODE == MODE_ERROR;
-            if (MODE != MODE_PLAIN) {
-                if (epA) epi_load(ea, rA, eA);
-                if (epB && !kDeferB) epi_load(ea, rB, eB);
-            }
-            f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accB = accA;
-            int jA = 0, jB = 0, jA1 = 0, jB1 = 0;
+        for (int k = 0; k < kRowsPerProd; ++k) {
+            const int lr = p + kProd * k;
+            if (lr >= kTile2) break;                           // wave-uniform: waves 4.. own one row less
+            const int r = r0 + kProd * k;
+            const bool ep = do_epi && r < a.n_rows;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 x[16];
+            float w[16];
+            int m = 0;
             if (do_gather) {
-                jA = __builtin_amdgcn_readlane(ix_rp, 2 * k);
-                jA1 = __builtin_amdgcn_readlane(ix_rp, 2 * k + 1);
-                jB = __builtin_amdgcn_readlane(ix_rp, 2 * k + 2);
-                jB1 = __builtin_amdgcn_readlane(ix_rp, 2 * k + 3);
-                // first batches of both rows in flight together (16 x 1 KiB per wave)
-                f32x4 xA[8], xB[8];
-                float wA[8], wB[8];
-                const bool fa = jA + 8 <= jA1, fb = jB + 8 <= jB1;
-                if (fa) g_issue<8, HALO>(colidx, val, jA, rsX, rsH, a.n_own, lane_off, xA, wA);
-                if (kDeferB) {                 // ERROR: one row's batch at a time (register budget, see above)
-                    if (fa) { g_accum<8>(xA, wA, accA); jA += 8; }
-                    if (fb) g_issue<8, HALO>(colidx, val, jB, rsX, rsH, a.n_own, lane_off, xA, wA);
-                    if (fb) { g_accum<8>(xA, wA, accB); jB += 8; }
-                } else {
-                    if (fb) g_issue<8, HALO>(colidx, val, jB, rsX, rsH, a.n_own, lane_off, xB, wB);
-                    if (fa) { g_accum<8>(xA, wA, accA); jA += 8; }
-                    if (fb) { g_accum<8>(xB, wB, accB); jB += 8; }
+                int j = __builtin_amdgcn_readlane(ix_rp, 2 * k);
+                const int j1 = __builtin_amdgcn_readlane(ix_rp, 2 * k + 1);
+                for (; j1 - j >= 16; j += 8) {                 // long rows: whole batches first
+                    g_issue<8, HALO>(colidx, val, j, rsX, rsH, a.n_own, lane_off, x, w);
+                    g_accum<8>(x, w, acc);
                 }
+                m = j1 - j;
+                g_row_issue<HALO>(colidx, val, j, m, rsX, rsH, a.n_own, lane_off, x, w);
             }
-            if (MODE != MODE_PLAIN) {
-                if (epA) epi_reduce(ea, rA, eA);
-                if (epB && !kDeferB) epi_reduce(ea, rB, eB);
-                if (epB && kDeferB) epi_load(ea, rB, eB);
-            }
-            if (do_gather) {
-                jA = g_batches<HALO>(colidx, val, jA, jA1, rsX, rsH, a.n_own, lane_off, accA);     // rows > 16 entries
-                jB = g_batches<HALO>(colidx, val, jB, jB1, rsX, rsH, a.n_own, lane_off, accB);
-                const int nA = jA1 - jA, nB = jB1 - jB;
-                g_piece2<4, HALO>(colidx, val, jA, nA, jB, nB, rsX, rsH, a.n_own, lane_off, accA, accB);
-                g_piece2<2, HALO>(colidx, val, jA, nA, jB, nB, rsX, rsH, a.n_own, lane_off, accA, accB);
-                g_piece2<1, HALO>(colidx, val, jA, nA, jB, nB, rsX, rsH, a.n_own, lane_off, accA, accB);
-            }
-            if (MODE != MODE_PLAIN && kDeferB && epB) epi_reduce(ea, rB, eB);
-            if (epA) epi_finish(ea, rA, buf + lrA * kLd2, eA);
-            if (epB) epi_finish(ea, rB, buf + lrB * kLd2, eB);
-            if (do_gather) {
-                *reinterpret_cast<f32x4 *>(buf + lrA * kLd2 + 4 * lane) = accA;
-                *reinterpret_cast<f32x4 *>(buf + lrB * kLd2 + 4 * lane) = accB;
-            }
+            EpiRow e;
+            if (MODE != MODE_PLAIN && ep) epi_load(ea, r, e);
+            if (do_gather) g_row_accum(m, x, w, acc);
+            if (ep) epi_finish(ea, r, buf + lr * kLd2, e);
+            if (do_gather) *reinterpret_cast<f32x4 *>(buf + lr * kLd2 + 4 * lane) = acc;
         }
     };
 
@@ -380,8 +327,8 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
                     acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, r1[u][e], acc11, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // the refill wraps into the next tile's first quads (dbg bit 8 = do not wrap: A/B switch)
-                if ((!(a.dbg & 8) || q + kRing < 32) && !(a.dbg & 64)) {       // dbg 64: no weight refills (timing experiment)
+                // the refill wraps into the next tile's first quads
+                if (!(a.dbg & 64)) {                                             // dbg 64: no weight refills (timing experiment)
                     const int qn = (q + kRing) & 31;
                     r0[u] = b0p[qn * 64];
                     r1[u] = b1p[qn * 64];
@@ -422,7 +369,7 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             const bool do_gather = it + 1 < my_tiles && !(a.dbg & 2);
             if (do_gather) prefetch_index(t + wgs_per_xcd);
-            if (!((a.dbg & 4096) && p >= 4))                   // timing experiment: only half of the gather waves work
+            if (!((a.dbg & 4096) && (p & 1)))                  // timing experiment: only half of the gather waves work
                 producer_phase(oth, t - wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
@@ -431,8 +378,8 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             if (a.dbg_cycles) { cyc_work += c1 - c0; cyc_wait += __builtin_readcyclecounter() - c1; }
         }
         if (a.dbg_cycles && lane == 0) {
-            a.dbg_cycles[2 * (blockIdx.x * 12 + wave)] = cyc_work;
-            a.dbg_cycles[2 * (blockIdx.x * 12 + wave) + 1] = cyc_wait;
+            a.dbg_cycles[2 * (blockIdx.x * kWaves + wave)] = cyc_work;
+            a.dbg_cycles[2 * (blockIdx.x * kWaves + wave) + 1] = cyc_wait;
         }
         const int t_last = t_first + (my_tiles - 1) * wgs_per_xcd;
         producer_phase(s_tile + ((my_tiles - 1) & 1) * kTileFloats2, t_last, true, false);
@@ -455,7 +402,6 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
         for (int it = 0; it < my_tiles; ++it) {
             float *cur = s_tile + (it & 1) * kTileFloats2;
             const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
-            if ((a.dbg & 8) && it > 0) ring_fill();
             if (!(a.dbg & 1)) mfma_tile(cur);
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();                                   // every consumer is done reading `cur`
@@ -463,11 +409,14 @@ __global__ __launch_bounds__(256 + 64 * kProd) void rhs_fused2_kernel(const int 
             dump_tile(cur);
             const unsigned long long c3 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
-            if (a.dbg_cycles) { cyc_work += (c1 - c0) + (c3 - c2); cyc_wait += (c2 - c1) + (__builtin_readcyclecounter() - c3); }
+            if (a.dbg_cycles) {
+                if (a.dbg & 8192) { cyc_work += c1 - c0; cyc_wait += c3 - c2; }     // split: MFMA loop | accumulator dump
+                else { cyc_work += (c1 - c0) + (c3 - c2); cyc_wait += (c2 - c1) + (__builtin_readcyclecounter() - c3); }
+            }
         }
         if (a.dbg_cycles && lane == 0) {
-            a.dbg_cycles[2 * (blockIdx.x * 12 + wave)] = cyc_work;
-            a.dbg_cycles[2 * (blockIdx.x * 12 + wave) + 1] = cyc_wait;
+            a.dbg_cycles[2 * (blockIdx.x * kWaves + wave)] = cyc_work;
+            a.dbg_cycles[2 * (blockIdx.x * kWaves + wave) + 1] = cyc_wait;
         }
     }
 }
@@ -498,6 +447,14 @@ int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags) {
     return A->n_cols * (int64_t)kH2 * 4 < (1ll << 31) ? 1 : 0;       // gathered panel must fit a buffer descriptor
 }
 
+// compiled (mode, n_prev) variants: plain; COMBINE with 0..5 earlier stages; ERROR with dopri5's 5.  Anything else
+// is served by the composition path of rhs_rk_f32 (same term order).
+int rhs_fused2_variant(int mode, int n_prev) {
+    if (mode == MODE_PLAIN) return 1;
+    if (mode == MODE_COMBINE) return n_prev >= 0 && n_prev <= kMaxPrev;
+    return mode == MODE_ERROR && n_prev == kMaxPrev;
+}
+
 int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kProd * 2 * sizeof(double); }
 
 // mode: 0 plain; 1 combine (y_next = y0 + sum c_m k_m, new K last); 2 error (d_out[0..1], d_ws scratch)
@@ -506,7 +463,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
                    int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
     const int n_rows = (int)A->n_rows;
     if (n_rows == 0) return NDCN_OK;
-    if (n_prev < 0 || n_prev > kMaxPrev) { set_error("rhs_fused2: at most %d previous stages", kMaxPrev); return NDCN_EINVAL; }
+    if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;
     const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;
     if (xb >= (1ll << 31) || xhb >= (1ll << 31)) {
@@ -523,40 +480,47 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     static const int timing = env_int3("NDCN_FUSED_TIMING", 0);
     static unsigned long long *d_cyc = nullptr;
     static int timing_prints = 0;
-    if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * 12 * 2 * sizeof(unsigned long long));
+    if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * kWaves * 2 * sizeof(unsigned long long));
     a.dbg_cycles = timing ? d_cyc : nullptr;
     for (int m = 0; m < kMaxPrev; ++m) ea.kprev[m] = (m < n_prev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kMaxPrev; ++m) ea.c[m] = (mode != MODE_PLAIN && m <= n_prev) ? h_c[m] : 0.f;
     int per_xcd = kCus / kXcds;
     const int need = (a.n_tiles + kXcds - 1) / kXcds;
     if (per_xcd > need) per_xcd = need;
-    const dim3 grid(per_xcd * kXcds), block(256 + 64 * kProd);
+    const dim3 grid(per_xcd * kXcds), block(64 * kWaves);
     const double P = 4.0 * kH2 * (double)A->n_rows;
     double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * kH2 * (double)(A->n_rows + A->n_cols) + 4.0 * kH2 * kH2;
     if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
     if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * kH2 + 2.0 * (double)A->n_rows * kH2 * kH2);
-#define NDCN_F2(HALO_, MODE_) \
-    hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a, ea)
-    if (Xh) {
-        if (mode == MODE_PLAIN) NDCN_F2(true, MODE_PLAIN);
-        else if (mode == MODE_COMBINE) NDCN_F2(true, MODE_COMBINE);
-        else NDCN_F2(true, MODE_ERROR);
-    } else {
-        if (mode == MODE_PLAIN) NDCN_F2(false, MODE_PLAIN);
-        else if (mode == MODE_COMBINE) NDCN_F2(false, MODE_COMBINE);
-        else NDCN_F2(false, MODE_ERROR);
-    }
+#define NDCN_F2(HALO_, MODE_, NP_) \
+    hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, NP_>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a, ea)
+#define NDCN_F2_DISPATCH(HALO_)                                      \
+    do {                                                             \
+        if (mode == MODE_PLAIN) NDCN_F2(HALO_, MODE_PLAIN, 0);       \
+        else if (mode == MODE_ERROR) NDCN_F2(HALO_, MODE_ERROR, 5);  \
+        else switch (n_prev) {                                       \
+            case 0: NDCN_F2(HALO_, MODE_COMBINE, 0); break;          \
+            case 1: NDCN_F2(HALO_, MODE_COMBINE, 1); break;          \
+            case 2: NDCN_F2(HALO_, MODE_COMBINE, 2); break;          \
+            case 3: NDCN_F2(HALO_, MODE_COMBINE, 3); break;          \
+            case 4: NDCN_F2(HALO_, MODE_COMBINE, 4); break;          \
+            default: NDCN_F2(HALO_, MODE_COMBINE, 5); break;         \
+        }                                                            \
+    } while (0)
+    if (Xh) NDCN_F2_DISPATCH(true);
+    else NDCN_F2_DISPATCH(false);
+#undef NDCN_F2_DISPATCH
 #undef NDCN_F2
     if (mode == MODE_ERROR)
         hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, ea.partials, (int)grid.x * kProd, d_out);
     NDCN_LAUNCH_CHECK();
     if (timing && timing_prints < timing) {                          // debugging aid: s_memtime accounting of block 0 and 100
         (void)hipStreamSynchronize(st);
-        unsigned long long h[2 * 12 * 2];
+        unsigned long long h[2 * kWaves];
         for (int bi = 0; bi < 2; ++bi) {
             const int blk = bi == 0 ? 0 : 100;
-            (void)hipMemcpy(h, d_cyc + (size_t)blk * 24, sizeof(unsigned long long) * 24, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h, d_cyc + (size_t)blk * 2 * kWaves, sizeof(unsigned long long) * 2 * kWaves, hipMemcpyDeviceToHost);
             double cw = 0, cq = 0, pw = 0, pq = 0;
             for (int w = 0; w < 4; ++w) { cw += h[2 * w] / 4.0; cq += h[2 * w + 1] / 4.0; }
             for (int w = 4; w < 4 + kProd; ++w) { pw += h[2 * w] / (double)kProd; pq += h[2 * w + 1] / (double)kProd; }
