@@ -37,6 +37,7 @@ namespace ndcn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kH2 = 256;
 constexpr int kTile2 = 64;
@@ -83,7 +84,34 @@ __device__ __forceinline__ f32x4 fma4(float s, f32x4 x, f32x4 a) {
     return (f32x4){fmaf(s, x.x, a.x), fmaf(s, x.y, a.y), fmaf(s, x.z, a.z), fmaf(s, x.w, a.w)};
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- vector-memory fetches with hand-placed waits ---------------------------------------------------------
+// A gather wave has three classes of fetches in flight: neighbour rows (L2 hits, needed first), the row-local RK
+// panels of the epilogue (HBM, needed later) and its stores.  Vector memory returns in order, so the wait for the
+// neighbour rows is exact only as "all but the E youngest fetches" - but how many neighbour fetches a row issues is
+// a run-time number, and hipcc's waitcnt insertion then falls back to vmcnt(0), i.e. it also waits for the HBM
+// panels (and, with extents read by v_readlane, for the previous row's stores).  The fetches below are therefore
+// issued from inline asm (invisible to that pass) and awaited by hand: wait_vmcnt<E>() + tie() of the destination
+// registers (an empty asm with the register as in/out operand, ordered after the wait because volatile asms keep
+// their order: the first use of the data cannot be scheduled above the wait).
+__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    return (u32x4){(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ f32x4 fetch128(u32x4 rs, int voff, int soff) {
+    f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff));
+    return v;
+}
+// streaming (nt) store; issued from asm as well: hipcc guards the data registers of stores it knows about with
+// vmcnt waits that - not counting the asm fetches - would drain those instead.  s_nop: the data registers of a
+// 16-byte store must not be written in the next wait state.
+__device__ __forceinline__ void store128(f32x4 v, u32x4 rs, int voff, int soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void tie(f32x4 &v) { asm volatile("" : "+v"(v)); }
 
 // Issue U neighbour-row fetches of one output row: entries j .. j+U-1 of the CSR arrays.
 // The gather waves share their SIMD with an MFMA wave, and on gfx950 the fp32 MFMA keeps the SIMD's VALU busy
@@ -93,22 +121,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // buffer-load SGPR offset (col << 10) on top of a fixed per-lane offset - the only VALU work left per
 // neighbour is the two packed FMAs.
 template <int U, bool HALO, int O = 0>
-__device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j,
-                                        __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
-                                        f32x4 (&x)[16], float (&vv)[16]) {
+__device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j, u32x4 rsX,
+                                        u32x4 rsH, int n_own, int lane_off, f32x4 (&x)[16], float (&vv)[16]) {
+    // all scalar loads first: a volatile asm is a scheduling barrier, and U separate s_load_dword + waits (instead of
+    // one s_load_dwordx8) would serialise a scalar-cache round trip per neighbour
+    int cc[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) { cc[q] = colidx[j + q]; vv[O + q] = val[j + q]; }
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-        int cc = colidx[j + q];
-        vv[O + q] = val[j + q];
-        __amdgpu_buffer_rsrc_t rs = rsX;
-        if (HALO && cc >= n_own) { rs = rsH; cc -= n_own; }
-        x[O + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, cc << 10, 0));
+        u32x4 rs = rsX;
+        int c = cc[q];
+        if (HALO && c >= n_own) { rs = rsH; c -= n_own; }
+        x[O + q] = fetch128(rs, lane_off, c << 10);
     }
 }
 template <int U, int O = 0>
-__device__ __forceinline__ void g_accum(const f32x4 (&x)[16], const float (&vv)[16], f32x4 &acc) {
+__device__ __forceinline__ void g_accum(f32x4 (&x)[16], const float (&vv)[16], f32x4 &acc) {
 #pragma unroll
-    for (int q = 0; q < U; ++q) acc = fma4(vv[O + q], x[O + q], acc);
+    for (int q = 0; q < U; ++q) { tie(x[O + q]); acc = fma4(vv[O + q], x[O + q], acc); }
 }
 
 // The last m < 16 entries of a row in ONE round: pieces of 8 / 4 / 2 / 1 in slots 0-7 / 8-11 / 12-13 / 14, all
@@ -116,14 +147,14 @@ __device__ __forceinline__ void g_accum(const f32x4 (&x)[16], const float (&vv)[
 // ascending entry order, so the sum rounds exactly like a sequential loop over the row.
 template <bool HALO>
 __device__ __forceinline__ void g_row_issue(const int *__restrict__ colidx, const float *__restrict__ val, int j, int m,
-                                            __amdgpu_buffer_rsrc_t rsX, __amdgpu_buffer_rsrc_t rsH, int n_own, int lane_off,
-                                            f32x4 (&x)[16], float (&vv)[16]) {
+                                            u32x4 rsX, u32x4 rsH, int n_own, int lane_off, f32x4 (&x)[16], float (&vv)[16]) {
     if (m & 8) { g_issue<8, HALO, 0>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); j += 8; }
     if (m & 4) { g_issue<4, HALO, 8>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); j += 4; }
     if (m & 2) { g_issue<2, HALO, 12>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); j += 2; }
     if (m & 1) { g_issue<1, HALO, 14>(colidx, val, j, rsX, rsH, n_own, lane_off, x, vv); }
 }
-__device__ __forceinline__ void g_row_accum(int m, const f32x4 (&x)[16], const float (&vv)[16], f32x4 &acc) {
+// caller has waited for the fetches
+__device__ __forceinline__ void g_row_accum(int m, f32x4 (&x)[16], const float (&vv)[16], f32x4 &acc) {
     if (m & 8) g_accum<8, 0>(x, vv, acc);
     if (m & 4) g_accum<4, 8>(x, vv, acc);
     if (m & 2) g_accum<2, 12>(x, vv, acc);
@@ -153,9 +184,8 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     const f32x4 *X = reinterpret_cast<const f32x4 *>(a.X);
     const f32x4 *Wp = reinterpret_cast<const f32x4 *>(a.Wp);
     // buffer descriptors of the gathered panels (wave-uniform; byte sizes < 2^31 checked by the launcher)
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HALO ? a.Xh : a.X), 0,
-                                                                          HALO ? a.xh_bytes : a.x_bytes, 0x00020000);
+    const u32x4 rsX = make_rsrc(a.X, a.x_bytes);
+    const u32x4 rsH = make_rsrc(HALO ? a.Xh : a.X, HALO ? a.xh_bytes : a.x_bytes);
     const int lane_off = lane * 16;
 
     // tiles of this workgroup: XCD x owns a contiguous chunk; its workgroups take tiles round-robin
@@ -177,16 +207,14 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
 
     double err_sum = 0.0, err_bad = 0.0;                      // MODE_ERROR, producers
 
-    // ---- producer: row extents of the wave's rows of a tile by one vector load; they stay in that VGPR (lane
-    // 2k / 2k+1 = begin / end of row k) and are read out row by row
-    int ix_rp = 0;
-    auto prefetch_index = [&](int t) {
-        ix_rp = 0;
-        const int lr = p + kProd * (lane >> 1);
-        if (lane < 2 * kRowsPerProd && lr < kTile2) {
-            const int r = t * kTile2 + lr + (lane & 1);
-            ix_rp = rowptr[min(r, a.n_rows)];       // rows past the end: begin == end == rowptr[n_rows]
-        }
+    // ---- producer: row extents by scalar loads, one row ahead (row r of the CSR: entries [rowptr[r], rowptr[r+1])).
+    // They used to come from one vector load per tile read out with v_readlane: hipcc then put s_waitcnt vmcnt(0) in
+    // front of every row - i.e. each row first waited for the previous row's STORES to be acknowledged.
+    struct RowExt { int j, j1; };
+    auto row_ext = [&](int r) -> RowExt {
+        RowExt e{0, 0};
+        if (r < a.n_rows) { e.j = rowptr[r]; e.j1 = rowptr[r + 1]; }
+        return e;
     };
 
     // ---- producer: RK epilogue of one K row ----------------------------------------------------------
@@ -197,13 +225,11 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     const int panel_bytes = a.n_rows << 10;
     auto ldp = [&](const float *base, int row_off) {
         asm volatile("" : "+s"(base));      // keep the 4-SGPR descriptor transient: hoisted descriptors for 8 panels spill
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, panel_bytes, 0x00020000);
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, row_off, 0));
+        return fetch128(make_rsrc(base, panel_bytes), lane_off, row_off);
     };
     auto stp = [&](float *base, int row_off, f32x4 v) {
         asm volatile("" : "+s"(base));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, panel_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, lane_off, row_off, 2 /* nt */);
+        store128(v, make_rsrc(base, panel_bytes), lane_off, row_off);
     };
     auto epi_load = [&](EpiPtr ea, int r, EpiRow &e) {
         const int off = (a.dbg & 2048) ? ((r & 63) << 10) : (r << 10);      // timing experiment: cache-resident panels
@@ -251,34 +277,51 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     // Twelve waves work like this per CU: a wave's chain (scalar index load -> fetches -> FMAs under MFMA
     // contention -> stores) is latency-bound - with half of the 8 waves of the previous version switched off the
     // others were not a cycle faster - so throughput comes from the number of chains in flight.
-    auto producer_phase = [&](float *buf, int t_epi, bool do_epi, bool do_gather) {
+    auto producer_phase = [&](float *buf, int t_epi, int t_next, bool do_epi, bool do_gather) {
         EpiPtr ea = nullptr;
         if (MODE != MODE_PLAIN) ea = epi_args();               // one (laundered) read of the epilogue arguments per tile
-        const int r0 = t_epi * kTile2 + p;
+        const int r0 = t_epi * kTile2 + p, g0 = t_next * kTile2 + p;
+        RowExt ext = do_gather ? row_ext(g0) : RowExt{0, 0};
 #pragma unroll
         for (int k = 0; k < kRowsPerProd; ++k) {
             const int lr = p + kProd * k;
             if (lr >= kTile2) break;                           // wave-uniform: waves 4.. own one row less
             const int r = r0 + kProd * k;
+            const RowExt cur = ext;
+            if (do_gather && lr + kProd < kTile2) ext = row_ext(g0 + kProd * (k + 1));
             const bool ep = do_epi && r < a.n_rows;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 x[16];
             float w[16];
             int m = 0;
             if (do_gather) {
-                int j = __builtin_amdgcn_readlane(ix_rp, 2 * k);
-                const int j1 = __builtin_amdgcn_readlane(ix_rp, 2 * k + 1);
+                int j = cur.j;
+                const int j1 = cur.j1;
                 for (; j1 - j >= 16; j += 8) {                 // long rows: whole batches first
                     g_issue<8, HALO>(colidx, val, j, rsX, rsH, a.n_own, lane_off, x, w);
+                    wait_vmcnt<0>();
                     g_accum<8>(x, w, acc);
                 }
                 m = j1 - j;
                 g_row_issue<HALO>(colidx, val, j, m, rsX, rsH, a.n_own, lane_off, x, w);
             }
             EpiRow e;
-            if (MODE != MODE_PLAIN && ep) epi_load(ea, r, e);
+            // the row-local panels are the kEpiFetches youngest fetches: the neighbour rows are complete when at most
+            // that many are outstanding
+            constexpr int kEpiFetches = MODE == MODE_PLAIN ? 0 : NP + 1 + (MODE == MODE_ERROR ? 1 : 0);
+            if (MODE != MODE_PLAIN && ep) { epi_load(ea, r, e); wait_vmcnt<kEpiFetches>(); }
+            else wait_vmcnt<0>();
             if (do_gather) g_row_accum(m, x, w, acc);
-            if (ep) epi_finish(ea, r, buf + lr * kLd2, e);
+            if (ep) {
+                if (MODE != MODE_PLAIN) {
+                    wait_vmcnt<0>();
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) tie(e.km[i]);
+                    tie(e.y0v);
+                    if (MODE == MODE_ERROR) tie(e.y1v);
+                }
+                epi_finish(ea, r, buf + lr * kLd2, e);
+            }
             if (do_gather) *reinterpret_cast<f32x4 *>(buf + lr * kLd2 + 4 * lane) = acc;
         }
     };
@@ -286,53 +329,73 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     // ---- consumer -----------------------------------------------------------------------------------
     // wave w owns output columns [64 w, 64 w + 64) (n-tiles 2w, 2w+1) for both 32-row m-tiles
     f32x16 acc00, acc01, acc10, acc11;
-    // Ring of weight operands, kRing deep: slot u holds k-quad q with q % kRing == u.  The weights are the same
-    // for every tile, so the ring simply wraps around - it is already full when the next tile starts.
-    constexpr int kRing = 4;
-    const f32x4 *b0p = Wp + (size_t)(2 * (wave & 3)) * 32 * 64 + lane;
-    const f32x4 *b1p = b0p + 32 * 64;
+    // Ring of weight operands, kRing deep: slot u holds the k-quads q with q % kRing == u.  The weights are the same
+    // for every tile, so the ring runs on across tiles: after the MFMAs of quad q its slot is refilled with quad
+    // q + kRing of the same tile or, for the last kRing quads, with quad (q % kRing) of the next tile (kRing need not
+    // divide 32: the 32 quads are fully unrolled, every slot index is static).
+#ifndef NDCN_RING
+#define NDCN_RING 4
+#endif
+    constexpr int kRing = NDCN_RING;
+    // packed weights through a buffer descriptor: per-lane offset in one VGPR, the (n-tile, k-quad) block offset on
+    // the scalar unit - 64 distinct block addresses per tile would otherwise each cost a 64-bit VGPR pair
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Wp), 0, kH2 * kH2 * 4, 0x00020000);
+    const int w_slab = (2 * (wave & 3)) * 32 * 1024;           // bytes; n-tiles 2w, 2w+1 of this wave
+    auto ldw = [&](int ntile, int quad) {
+        int ws = w_slab;
+        asm volatile("" : "+s"(ws));        // one s_add at the use instead of 64 hoisted (and spilled) block offsets
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane_off, ws + (ntile * 32 + quad) * 1024, 0));
+    };
     f32x4 r0[kRing], r1[kRing];
     auto ring_fill = [&]() {
 #pragma unroll
-        for (int u = 0; u < kRing; ++u) { r0[u] = b0p[u * 64]; r1[u] = b1p[u * 64]; }
+        for (int u = 0; u < kRing; ++u) { r0[u] = ldw(0, u); r1[u] = ldw(1, u); }
     };
     auto mfma_tile = [&](const float *src) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
         const float *a0p = src + (lane & 31) * kLd2 + 128 * (lane >> 5);
         const float *a1p = a0p + 32 * kLd2;
-        // A operands ping-pong between an even-quad and an odd-quad register set, and a weight slot is refilled
-        // AFTER the MFMAs that read it: no value ever has to be copied to free its register (the first version
-        // rotated through temporaries - 116 v_mov per 64 MFMAs, issued on the VALU port the gather waves need)
-        f32x4 aE0 = *reinterpret_cast<const f32x4 *>(a0p), aE1 = *reinterpret_cast<const f32x4 *>(a1p);
-        f32x4 aO0 = aE0, aO1 = aE1;
-#pragma unroll 1
-        for (int q0 = 0; q0 < 32; q0 += kRing) {
+        // A operands (LDS) are fetched half a k-quad (2 k-steps = 8 MFMAs = 512 cycles) ahead and ping-pong between two
+        // 8-byte register pairs per m-tile.  A weight slot is refilled right AFTER the MFMAs that read it (no operand
+        // is ever copied aside), i.e. kRing - 1 quads = 4096 MFMA cycles before it is needed: with twelve gather waves
+        // queueing on the same texture path the L2 latency of a weight fetch averaged ~3600 cycles (measured: the
+        // MFMA loop ran at 2.09 M cycles per launch without refills, 3.3-3.5 M with a three-quad lead).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 aX0 = *reinterpret_cast<const f32x2 *>(a0p), aX1 = *reinterpret_cast<const f32x2 *>(a1p);
+        f32x2 aY0 = aX0, aY1 = aX1;
 #pragma unroll
-            for (int u = 0; u < kRing; ++u) {
-                const int q = q0 + u;
-                if ((u & 1) == 0) {
-                    aO0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
-                    aO1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
-                } else if (q + 1 < 32) {
-                    aE0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (q + 1));
-                    aE1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (q + 1));
-                }
+        for (int q = 0; q < 32; ++q) {
+            constexpr int dummy = 0; (void)dummy;
+            const int u = q % kRing;
+            // first half of the quad on aX while aY (second half) is fetched
+            __builtin_amdgcn_sched_barrier(0);      // straight-line code: keep hipcc from hoisting later fetches up here
+            aY0 = *reinterpret_cast<const f32x2 *>(a0p + 4 * q + 2);
+            aY1 = *reinterpret_cast<const f32x2 *>(a1p + 4 * q + 2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = (u & 1) ? aO0[e] : aE0[e], x1 = (u & 1) ? aO1[e] : aE1[e];
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, r0[u][e], acc00, 0, 0, 0);
-                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, r1[u][e], acc01, 0, 0, 0);
-                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, r0[u][e], acc10, 0, 0, 0);
-                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, r1[u][e], acc11, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // the refill wraps into the next tile's first quads
-                if (!(a.dbg & 64)) {                                             // dbg 64: no weight refills (timing experiment)
-                    const int qn = (q + kRing) & 31;
-                    r0[u] = b0p[qn * 64];
-                    r1[u] = b1p[qn * 64];
-                }
+            for (int e = 0; e < 2; ++e) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(aX0[e], r0[u][e], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(aX0[e], r1[u][e], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(aX1[e], r0[u][e], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(aX1[e], r1[u][e], acc11, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < 32) {
+                aX0 = *reinterpret_cast<const f32x2 *>(a0p + 4 * (q + 1));
+                aX1 = *reinterpret_cast<const f32x2 *>(a1p + 4 * (q + 1));
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(aY0[e], r0[u][2 + e], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(aY0[e], r1[u][2 + e], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(aY1[e], r0[u][2 + e], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(aY1[e], r1[u][2 + e], acc11, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(a.dbg & 64)) {                                                 // dbg 64: no weight refills (timing experiment)
+                const int qn = q + kRing < 32 ? q + kRing : u;                   // next tile's quad for this slot
+                r0[u] = ldw(0, qn);
+                r1[u] = ldw(1, qn);
             }
         }
     };
@@ -359,8 +422,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     unsigned long long cyc_work = 0, cyc_wait = 0;
     if (producer) {
         if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);         // timing experiment: gather waves win issue arbitration
-        prefetch_index(t_first);
-        producer_phase(s_tile, 0, false, true);
+        producer_phase(s_tile, 0, t_first, false, true);
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             const int t = t_first + it * wgs_per_xcd;
@@ -368,9 +430,8 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             const bool do_gather = it + 1 < my_tiles && !(a.dbg & 2);
-            if (do_gather) prefetch_index(t + wgs_per_xcd);
             if (!((a.dbg & 4096) && (p & 1)))                  // timing experiment: only half of the gather waves work
-                producer_phase(oth, t - wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
+                producer_phase(oth, t - wgs_per_xcd, t + wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
@@ -382,7 +443,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             a.dbg_cycles[2 * (blockIdx.x * kWaves + wave) + 1] = cyc_wait;
         }
         const int t_last = t_first + (my_tiles - 1) * wgs_per_xcd;
-        producer_phase(s_tile + ((my_tiles - 1) & 1) * kTileFloats2, t_last, true, false);
+        producer_phase(s_tile + ((my_tiles - 1) & 1) * kTileFloats2, t_last, 0, true, false);
         if (MODE == MODE_ERROR) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -414,6 +475,11 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
                 else { cyc_work += (c1 - c0) + (c3 - c2); cyc_wait += (c2 - c1) + (__builtin_readcyclecounter() - c3); }
             }
         }
+        // The last refills of the weight ring (they wrap into a tile that does not exist) are still in flight here.
+        // hipcc lays the gather-wave region out after this one and merges the two paths' waitcnt state: without this
+        // explicit wait it "protects" v64-v95 in the gather code with vmcnt waits that - not counting the asm fetches
+        // there - drain those instead.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
         if (a.dbg_cycles && lane == 0) {
             a.dbg_cycles[2 * (blockIdx.x * kWaves + wave)] = cyc_work;
             a.dbg_cycles[2 * (blockIdx.x * kWaves + wave) + 1] = cyc_wait;
