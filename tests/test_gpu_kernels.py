@@ -188,6 +188,62 @@ def test_rhs_module_matches_reference_semantics(dev):
     assert np.abs(out - d['out']).max() <= 2e-5
 
 
+def _shard(m, lo, hi):
+    """Rows [lo, hi) of a square scipy CSR with columns remapped to [own | halo] the way sharding.HaloPlan does."""
+    blk = m[lo:hi].tocoo()
+    own = (blk.col >= lo) & (blk.col < hi)
+    halo_cols = np.unique(blk.col[~own])
+    col = np.where(own, blk.col - lo, (hi - lo) + np.searchsorted(halo_cols, blk.col))
+    out = sp.csr_matrix((blk.data, (blk.row, col)), shape=(hi - lo, hi - lo + halo_cols.size))
+    out.sort_indices()
+    return out, halo_cols
+
+
+@pytest.mark.parametrize('side,cut', [(40, 800), (33, 500)])
+def test_fused_rhs_rk_with_halo_panel_equals_unsharded(dev, side, cut):
+    """Every compiled (mode, stage-count) variant of the fused RHS kernel with the operand split into an own panel
+    and a halo panel - the multi-GPU form - against the one-panel launch on the whole graph (what the N>1 bench runs
+    but a 1-GPU box cannot: both shards are evaluated here on one device)."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H, n = 256, side * side
+    m = graphs.make_operator(graphs.grid_8_neighbor(side), 'norm_lap').tocsr()
+    g = torch.Generator().manual_seed(side)
+    X = torch.rand(n, H, generator=g)
+    y0 = torch.rand(n, H, generator=g)
+    ks = [torch.randn(n, H, generator=g) for _ in range(5)]
+    W = (torch.rand(H, H, generator=g) - 0.5) / 8
+    b = (torch.rand(H, generator=g) - 0.5) / 8
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    A = CsrOperator.from_scipy(m, dev)
+    d = lambda t: t.to(dev)
+    Xd, y0d, ksd, Wd, bd = d(X), d(y0), [d(k) for k in ks], d(W), d(b)
+    shards = []
+    for lo, hi in ((0, cut), (cut, n)):
+        blk, halo_cols = _shard(m, lo, hi)
+        shards.append((lo, hi, CsrOperator.from_scipy(blk, dev), Xd[torch.from_numpy(halo_cols).to(dev)].contiguous()))
+    full = hip.rhs(A, Xd, Wd, bd)
+    for lo, hi, As, Xh in shards:
+        got = hip.rhs(As, Xd[lo:hi].contiguous(), Wd, bd, X_halo=Xh)
+        assert torch.allclose(got, full[lo:hi], rtol=1e-5, atol=1e-6)
+    for n_prev in range(6):
+        c = cs[:n_prev] + [cs[5]]
+        K, ynext = hip.rhs_rk(A, Xd, Wd, bd, 'combine', y0d, ksd[:n_prev], c)
+        for lo, hi, As, Xh in shards:
+            Ks, ys = hip.rhs_rk(As, Xd[lo:hi].contiguous(), Wd, bd, 'combine', y0d[lo:hi].contiguous(),
+                                [k[lo:hi].contiguous() for k in ksd[:n_prev]], c, X_halo=Xh)
+            assert torch.allclose(Ks, K[lo:hi], rtol=1e-5, atol=1e-6)
+            assert torch.allclose(ys, ynext[lo:hi], rtol=1e-5, atol=1e-6)
+    K, (ss, bad) = hip.rhs_rk(A, Xd, Wd, bd, 'error', y0d, ksd, cs, rtol=1e-2, atol=1e-3)
+    tot = 0.0
+    for lo, hi, As, Xh in shards:
+        Ks, (s1, b1) = hip.rhs_rk(As, Xd[lo:hi].contiguous(), Wd, bd, 'error', y0d[lo:hi].contiguous(),
+                                  [k[lo:hi].contiguous() for k in ksd], cs, rtol=1e-2, atol=1e-3, X_halo=Xh)
+        assert torch.allclose(Ks, K[lo:hi], rtol=1e-5, atol=1e-6)
+        assert float(b1) == 0.0
+        tot += float(s1)
+    assert abs(tot - float(ss)) <= 1e-6 * abs(float(ss)) and float(bad) == 0.0
+
+
 # ------------------------------------------------------------------------------------------- RK bookkeeping
 @pytest.mark.parametrize('shape', [(400, 20), (1001, 1), (257, 3), (4096, 256)])
 def test_rk_kernels_bitwise_vs_reference_op_order(dev, shape):
