@@ -238,6 +238,7 @@ class Dopri5:
         self.dt = h
         self.pending_bad = bad
         self.fit = None               # (a, b, c, d, e) tuples-of-tensors of the last fitted step
+        self.ticks_in_step = 0        # dense-output evaluations already served from the current accepted step
         self.stage = None             # (y0, y1, k) of the last accepted, not yet fitted step
 
     def _count(self, tt, yy):
@@ -283,6 +284,7 @@ class Dopri5:
         if accept:
             self.stage = (y0, y1, k, dt32)
             self.fit = None
+            self.ticks_in_step = 0
             self.y = y1
             self.f = tuple(k_[-1] for k_ in k)
             self.t0, self.t1 = t0, t0 + dt
@@ -327,12 +329,6 @@ class Dopri5:
                 return None
             self.step()
             n_steps += 1
-        if self.fit is None:
-            y0, y1, k, dt32 = self.stage
-            cmid = [f32(dt32 * f32(c)) for c in DP_C_MID]
-            fits = [self.ops.interp_fit(a_, b_, k_, cmid, dt32) for a_, b_, k_ in zip(y0, y1, k)]
-            self.fit = (fits, y0)
-        fits, e = self.fit
         # interp.py:51-65: abscissa and powers in the state dtype
         a0, a1, at = f32(self.t0), f32(self.t1), f32(next_t)
         assert (a0 <= at) and (at <= a1), 'invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}'.format(a0, at, a1)
@@ -341,6 +337,17 @@ class Dopri5:
         x3 = f32(x2 * x)
         x4 = f32(x3 * x)
         xp = (x4, x3, x2, x, f32(1))
+        if self.fit is None:
+            y0, y1, k, dt32 = self.stage
+            cmid = [f32(dt32 * f32(c)) for c in DP_C_MID]
+            self.ticks_in_step += 1
+            if self.ticks_in_step == 1 and hasattr(self.ops, 'interp_direct'):
+                # first tick inside this step: fit + evaluate in one pass, coefficients not stored (most steps are
+                # sampled at most once); a second tick pays for the stored fit
+                return tuple(self.ops.interp_direct(a_, b_, k_, cmid, dt32, xp) for a_, b_, k_ in zip(y0, y1, k))
+            fits = [self.ops.interp_fit(a_, b_, k_, cmid, dt32) for a_, b_, k_ in zip(y0, y1, k)]
+            self.fit = (fits, y0)
+        fits, e = self.fit
         return tuple(self.ops.interp_eval(fit, e_, xp) for fit, e_ in zip(fits, e))
 
 
