@@ -227,6 +227,28 @@ def main():
                              'achieved_GBps': round(byt / ms / 1e6, 1), 'achieved_TFLOPs': round(fl / ms / 1e9, 2),
                              'share_of_kernel_time': round(breakdown[dom]['ms_total'] / tot_ms, 3)})
 
+    # device-to-device copy of one panel: the HBM rate this box actually sustains (report the fraction of
+    # the spec AND of the measured copy)
+    if roofline is not None:
+        src_p = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+        dst_p = torch.empty_like(src_p)
+        dst_p.copy_(src_p)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst_p.copy_(src_p)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src_p.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        roofline['measured_copy_GBps'] = round(copy_gbps, 1)
+        roofline['frac_of_measured_copy'] = round(roofline['achieved_GBps'] / copy_gbps, 4)
+        del src_p, dst_p
+    halo = None
+    if world > 1 and hasattr(runner, 'plan'):
+        hb = int(runner.plan.bytes_per_exchange(H))
+        halo = {'bytes_received_per_rhs_per_gpu': hb, 'exchanges_per_step': 6,
+                'xgmi_peak_GBps_per_gpu': 7 * 153}
+
     if rank != 0:
         return
     out = {
@@ -253,6 +275,7 @@ def main():
         'roofline': roofline,
         'kernels': breakdown,
         'device': device_info(),
+        'halo_exchange': halo,
     }
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.cpu_side, H, args.T, args.rtol, args.atol, args.cpu_threads)
