@@ -184,6 +184,11 @@ NDCN_API int ndcn_gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, fl
 NDCN_API int ndcn_mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d,
                         float e, float h, void *stream);
 
+/* Row-wise L1 normalisation: Y[r,:] = X[r,:] / max(sum_j |X[r,j]|, 1e-12), infinities zeroed.  Replaces
+ * `row_normalization` / `RowNorm.forward` (ode_gcn.py:9-26; used by ResBlock(normalize=True) ode_gcn.py:50-57 and the
+ * odeGCN input stack dgnn.py:152).  Y may alias X.                                                                   */
+NDCN_API int ndcn_row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows, int H, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Device-resident integrator for the ODEFunc RHS (state, stage derivatives and dense-output coefficients
  * stay in HBM across steps; the host only reads the 16-byte error record per adaptive step).

@@ -69,6 +69,7 @@ SIGNATURES = {
     'ndcn_dopri5_interp_direct_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _F, ctypes.POINTER(_F), _P, _L, _P]),
     'ndcn_interp_eval_f32': (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(_F), _P, _L, _P]),
     'ndcn_fixed_stage_f32': (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _L, _P]),
+    'ndcn_row_l1_normalize_f32': (_I, [_P, _P, _L, _I, _P]),
     'ndcn_gene_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _P]),
     'ndcn_mutual_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     'ndcn_solver_workspace_bytes': (_L, [ctypes.POINTER(SolverDesc)]),

@@ -167,6 +167,12 @@ int ndcn_fixed_stage_f32(int op, float *out, const float *y, const float *k1, co
     return fixed_stage_f32(op, out, y, k1, k2, k3, k4, dt, n_elem, ST(stream));
 }
 
+int ndcn_row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows, int H, void *stream) {
+    NDCN_CHECK_ARG(n_rows >= 0 && H >= 0, "negative size");
+    NDCN_CHECK_ARG(n_rows == 0 || H == 0 || (X && Y), "null panel");
+    return row_l1_normalize_f32(X, Y, n_rows, H, ST(stream));
+}
+
 int ndcn_gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, void *stream) {
     int rc = check_csr(A, __func__);
     if (rc) return rc;

@@ -45,6 +45,7 @@ int interp_eval_f32(const float *a, const float *b, const float *c, const float 
 int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
                     const float *k4, float dt, int64_t n, hipStream_t st, const float *dt_dev = nullptr);
 
+int row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows, int H, hipStream_t st);
 int gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, hipStream_t st);
 int mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d, float e, float h,
                    hipStream_t st);

@@ -3,7 +3,8 @@ with Linear+Tanh -> ODEBlock2(ODEFunc) terminal -> Linear, trained by backprop t
 
 Kept: the flags of dgnn.py:24-70 that the differential model reads, cross-entropy on the training nodes, Adam
 (lr, weight decay), the per-epoch log line and the test report (dgnn.py:192-237), the README command
-(README.md:64).  The other --model choices (GCN / DeepGCN* / resGCN / odeGCN) are static baselines outside
+(README.md:64); `--model resGCN` (dgnn.py:129-140) stacks ndcn_amd.ode_gcn.ResBlock.  The other
+--model choices (GCN / DeepGCN* / odeGCN) are static baselines outside
 the accelerated path.
 
     python -m ndcn_amd.drivers.dgnn --dataset cora --model differential_gcn --iter 5 --dropout 0 --hidden 256 \\
@@ -43,6 +44,9 @@ def build_parser():
     p.add_argument('--method', type=str, default='dopri5', choices=['dopri5', 'euler', 'midpoint', 'rk4'])
     p.add_argument('--alpha', type=float, default=0.5, help='Tuning Matrix Operator')
     p.add_argument('--data_dir', type=str, default='data')
+    p.add_argument('-nhl', '--nHiddenLayers', type=int, default=0, help='Number of Hidden layers.')
+    p.add_argument('--normalize', action='store_true', default=False, help='Row normalize the feature in residual block')
+    p.add_argument('--Euler', action='store_true', default=False, help='Euler step in forward method')
     return p
 
 
@@ -52,8 +56,10 @@ def accuracy(output, labels):
 
 def main(argv=None, data=None, quiet=False):
     args = build_parser().parse_args(argv)
-    if args.model != 'differential_gcn':
-        raise NotImplementedError('only --model differential_gcn runs on the accelerated path')
+    if args.model not in ('differential_gcn', 'resGCN'):
+        # GCN / DeepGCN* are static baselines outside SURVEY 8; `odeGCN` and `GCN` cannot run in the reference's own
+        # dgnn.py either (its train() calls model(features) without the operator / time vector they need)
+        raise NotImplementedError('--model differential_gcn and resGCN run on the accelerated path')
     assert torch.cuda.is_available() and not args.no_cuda, 'ndcn_amd runs on a ROCm device; there is no CPU path'
     device = torch.device('cuda:0')
     if args.seed >= 0:
@@ -70,11 +76,19 @@ def main(argv=None, data=None, quiet=False):
         num_classes = int(labels.max().item()) + 1
         say('T : {}, time tick: {}'.format(args.T, args.time_tick))
         t = torch.linspace(0, args.T, args.time_tick).float().to(device)
-        model = nn.Sequential(
-            nn.Linear(features.shape[1], args.hidden, bias=True), nn.Tanh(),
-            ODEBlock2(ODEFunc(args.hidden, adj, dropout=args.dropout, no_control=args.no_control), t,
-                      rtol=args.rtol, atol=args.atol, method=args.method, terminal=True),
-            nn.Linear(args.hidden, num_classes, bias=True)).to(device)
+        if args.model == 'resGCN':                                # dgnn.py:129-140
+            from ..ode_gcn import ResBlock
+            model = nn.Sequential(
+                nn.Linear(features.shape[1], args.hidden, bias=True), nn.ReLU(inplace=True),
+                *[ResBlock(args.hidden, adj, dropout=args.dropout, normalize=args.normalize, Euler=args.Euler)
+                  for _ in range(args.nHiddenLayers)],
+                nn.Linear(args.hidden, num_classes, bias=True)).to(device)
+        else:
+            model = nn.Sequential(
+                nn.Linear(features.shape[1], args.hidden, bias=True), nn.Tanh(),
+                ODEBlock2(ODEFunc(args.hidden, adj, dropout=args.dropout, no_control=args.no_control), t,
+                          rtol=args.rtol, atol=args.atol, method=args.method, terminal=True),
+                nn.Linear(args.hidden, num_classes, bias=True)).to(device)
         optimizer = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
         t_start = time.time()
         for epoch in range(args.epochs):

@@ -1,6 +1,8 @@
-"""Drop-in for the sparse GraphConvolution of the reference's models.py:8-20 (Linear first, then SpMM).
-The GCN / DeepGCN baseline model classes of that file are out of scope."""
+"""Drop-in for the sparse GraphConvolution of the reference's models.py:8-20 (Linear first, then SpMM) and the
+GCN stack built from it (models.py:22-47).  The DeepGCN* baseline classes of that file are out
+of scope."""
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .neural_dynamics import _HipLinear, _needs_grad
 from .ops import hip
@@ -18,3 +20,31 @@ class GraphConvolution(nn.Module):
             from .autograd_ops import spmm
             return spmm(propagation_adj, support)
         return hip.spmm(propagation_adj, support)
+
+
+class GCN(nn.Module):
+    """models.py:22-47: gc1 -> relu -> [conv_middle -> relu]* -> gc2 with dropout in front of every layer."""
+
+    def __init__(self, input_size, hidden_size, num_classes, dropout=0, num_middle_layers=0):
+        super(GCN, self).__init__()
+
+        self.gc1 = GraphConvolution(input_size, hidden_size)
+        self.gc2 = GraphConvolution(hidden_size, num_classes)
+        self.dropout = dropout
+
+        self.conv_middle = nn.ModuleList([GraphConvolution(hidden_size, hidden_size) for i in range(num_middle_layers)])
+
+    def forward(self, x, propagation_adj):
+        x = F.dropout(x, self.dropout, training=self.training)  # drop out for input
+        x = self.gc1.forward(x, propagation_adj)
+        x = F.relu(x)
+
+        for conv_middle in self.conv_middle:
+            x = F.dropout(x, self.dropout, training=self.training)  # drop out for input
+            x = conv_middle.forward(x, propagation_adj)
+            x = F.relu(x)
+
+        x = F.dropout(x, self.dropout, training=self.training)  # drop out for hidden layers
+        x = self.gc2.forward(x, propagation_adj)
+
+        return x

@@ -274,6 +274,16 @@ class HipOps:
 
     # ---------------------------------------------------------------- truth dynamics (N x 1 state)
     @staticmethod
+    def row_l1_normalize(X, out=None):
+        """F.normalize(X, p=1, dim=1) with infinities zeroed (ode_gcn.py:9-26)."""
+        X = _panel(X)
+        if out is None:
+            out = torch.empty_like(X)
+        with torch.cuda.device(X.device):
+            check(_lib.load().ndcn_row_l1_normalize_f32(ptr(X), ptr(out), X.shape[0], X.shape[1], stream_ptr()))
+        return out
+
+    @staticmethod
     def gene_rhs(A, x, b=1.0, f=1.0, h=2.0):
         A = as_csr(A)
         x = _panel(x)

@@ -94,12 +94,43 @@ def gcn_layer(A, x, W, b):
     return apply_operator(A, F.linear(x, W, b))
 
 
-def resblock(A, x, W=None, b=None, time_step=1.0):
-    """ode_gcn.py:48-60 with normalize=False, dropout 0: x + relu([W](A x)) * time_step."""
+def row_normalization(X):
+    """ode_gcn.py:9-16 / RowNorm ode_gcn.py:19-26: each row divided by max(its L1 norm, 1e-12), infinities zeroed."""
+    X = F.normalize(X.float(), 1, 1)
+    X[torch.isinf(X)] = 0
+    return X
+
+
+def resblock(A, x, W=None, b=None, time_step=1.0, normalize=False):
+    """ResBlock.forward ode_gcn.py:48-60, dropout 0: x + relu([rownorm]([W]((A [rownorm]x)))) * time_step."""
+    shortcut = x
+    if normalize:
+        x = row_normalization(x)
     f = torch.sparse.mm(A, x) if A.is_sparse else torch.mm(A, x)
     if W is not None:
         f = F.linear(f, W, b)
-    return x + F.relu(f) * time_step
+    if normalize:
+        f = row_normalization(f)
+    return shortcut + F.relu(f) * time_step
+
+
+def gcn_forward(sd, A, x, n_middle=0):
+    """models.GCN.forward (models.py:33-47) in eval mode: gc1 -> relu -> [middle -> relu]* -> gc2, every layer
+    A (x W^T + b) (models.py:14-18).  `sd` = the reference state_dict."""
+    x = F.relu(gcn_layer(A, x, sd['gc1.fc.weight'], sd['gc1.fc.bias']))
+    for i in range(n_middle):
+        x = F.relu(gcn_layer(A, x, sd['conv_middle.%d.fc.weight' % i], sd['conv_middle.%d.fc.bias' % i]))
+    return gcn_layer(A, x, sd['gc2.fc.weight'], sd['gc2.fc.bias'])
+
+
+def resgcn_forward(sd, A, x, n_blocks, normalize=False):
+    """dgnn.py:129-140 `resGCN` Sequential in eval mode: Linear -> ReLU -> ResBlock x n -> Linear."""
+    x = F.relu(F.linear(x, sd['0.weight'], sd['0.bias']))
+    for i in range(n_blocks):
+        ts = sd.get('%d.time_step' % (2 + i))
+        x = resblock(A, x, time_step=1.0 if ts is None else ts, normalize=normalize)
+    k = 2 + n_blocks
+    return F.linear(x, sd['%d.weight' % k], sd['%d.bias' % k])
 
 
 # ------------------------------------------------------------------------------------------------

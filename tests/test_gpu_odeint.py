@@ -145,6 +145,45 @@ def test_dgnn_block_golden(dev, name, H):
     check_traj(y.cpu().numpy(), d['out'], l1=1e-5, mx=2e-4)
 
 
+def test_rownorm_resblock_gcn_resgcn_golden(dev):
+    """RowNorm, ResBlock (all four configurations), models.GCN and dgnn's resGCN Sequential on the
+    Cora topology - reference outputs (fixtures G10) vs the drop-in modules on the HIP kernels, reference state_dicts
+    loaded by key."""
+    import torch.nn as nn
+    from ndcn_amd import CsrOperator
+    from ndcn_amd.ode_gcn import RowNorm, ResBlock
+    from ndcn_amd.models import GCN
+    d0 = load_golden('resgcn_rownorm')
+    x = T(d0['x']).to(dev)
+    with torch.no_grad():
+        assert (RowNorm()(x).cpu() - T(d0['out'])).abs().max() <= 1e-6
+        for tag in ('plain', 'norm', 'tv', 'euler', 'norm_tv'):
+            d = load_golden('resgcn_block_' + tag)
+            A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)
+            blk = ResBlock(32, A, normalize='norm' in tag, time_varying='tv' in tag, Euler=tag == 'euler').to(dev).eval()
+            sd = {}
+            if 'W' in d:
+                sd.update({'linear.weight': T(d['W']), 'linear.bias': T(d['b'])})
+            if 'time_step' in d:
+                sd['time_step'] = T(d['time_step'])
+            blk.load_state_dict(sd)
+            assert (blk(x).cpu() - T(d['out'])).abs().max() <= 2e-5, tag
+        d = load_golden('resgcn_gcn')
+        A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)
+        gcn = GCN(32, 16, 7, dropout=0.5, num_middle_layers=1).to(dev).eval()
+        gcn.load_state_dict({k[3:]: T(v) for k, v in d.items() if k.startswith('sd_')})
+        assert (gcn(T(d['x']).to(dev), A).cpu() - T(d['out'])).abs().max() <= 2e-5
+        for tag, norm, euler in (('model', False, False), ('model_norm_euler', True, True)):
+            d = load_golden('resgcn_' + tag)
+            A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)
+            from ndcn_amd.neural_dynamics import _HipLinear
+            model = nn.Sequential(_HipLinear(32, 32), nn.ReLU(inplace=True),
+                                  *[ResBlock(32, A, dropout=0.5, normalize=norm, Euler=euler) for _ in range(2)],
+                                  _HipLinear(32, 7)).to(dev).eval()
+            model.load_state_dict({k[3:]: T(v) for k, v in d.items() if k.startswith('sd_')})
+            assert (model(T(d['x']).to(dev)).cpu() - T(d['out'])).abs().max() <= 2e-5, tag
+
+
 @pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])
 def test_hipgraph_replay_equals_eager(dev, method):
     """Fixed-grid steps replayed from one captured hipGraph (dt read from device memory) give bit-identical
@@ -347,6 +386,28 @@ def test_irregular_graphs_fused_path_vs_oracle(dev, network, n):
     assert [r[2] for r in log[:-1]] == [r[2] for r in lo]
     check_traj(y.cpu().numpy(), ref.numpy(), l1=1e-5, mx=3e-4)
     check_traj(yr.cpu().numpy(), orc.odeint(fo, x0, t, method='rk4').numpy(), l1=1e-5, mx=3e-4)
+
+
+def _cora(dev):
+    from ndcn_amd import CsrOperator
+    import scipy.sparse as sp
+    d = load_golden('dataset_cora')
+    g = load_golden('operators_cora')
+    n = int(g['n'])
+    adj = CsrOperator.from_arrays(g['alpha00_indptr'], g['alpha00_indices'], g['alpha00_data'], (n, n), dev)
+    feats = sp.csr_matrix((d['feat_data'], d['feat_indices'].astype(np.int64), d['feat_indptr']), shape=tuple(d['feat_shape']))
+    return (adj, torch.from_numpy(feats.toarray()).to(dev), torch.from_numpy(d['labels'].astype(np.int64)).to(dev),
+            torch.from_numpy(d['idx_train'].astype(np.int64)).to(dev), torch.from_numpy(d['idx_val'].astype(np.int64)).to(dev),
+            torch.from_numpy(d['idx_test'].astype(np.int64)).to(dev))
+
+
+def test_dgnn_resgcn_trains_on_cora(dev):
+    """dgnn.py --model resGCN (dgnn.py:129-140): Linear -> ReLU -> 2 x ResBlock -> Linear with dropout .5, trained on
+    the HIP SpMM (forward) / SpMM with A^T (backward).  A two-hop residual GCN on Cora lands in the high 70s."""
+    from ndcn_amd.drivers import dgnn
+    accs = dgnn.main(['--dataset', 'cora', '--model', 'resGCN', '-nhl', '2', '--hidden', '64', '--dropout', '0.5',
+                      '--epochs', '100', '--weight_decay', '5e-4', '--alpha', '0', '--seed', '0'], data=_cora(dev), quiet=True)
+    assert accs.mean() >= 0.72, accs
 
 
 def test_dgnn_cora_accuracy_parity(dev):

@@ -160,6 +160,24 @@ def test_dgnn_block(name, H):
     assert np.abs(y.numpy() - d['out']).max() <= 1e-5
 
 
+def test_rownorm_resblock_gcn_resgcn():
+    """G10: RowNorm, ResBlock in its four configurations, models.GCN and dgnn's resGCN Sequential (eval mode)."""
+    x = T(load_golden('resgcn_rownorm')['x'])
+    assert torch.equal(orc.row_normalization(x.clone()), T(load_golden('resgcn_rownorm')['out']))
+    for tag in ('plain', 'norm', 'tv', 'euler', 'norm_tv'):
+        d = load_golden('resgcn_block_' + tag)
+        out = orc.resblock(op_from(d), x.clone(), T(d['W']) if 'W' in d else None, T(d['b']) if 'b' in d else None,
+                           time_step=T(d['time_step']) if 'time_step' in d else 1.0, normalize='norm' in tag)
+        assert (out - T(d['out'])).abs().max() <= TOL, tag
+    d = load_golden('resgcn_gcn')
+    sd = {k[3:]: T(v) for k, v in d.items() if k.startswith('sd_')}
+    assert (orc.gcn_forward(sd, op_from(d), T(d['x']), n_middle=1) - T(d['out'])).abs().max() <= TOL
+    for tag, norm in (('model', False), ('model_norm_euler', True)):
+        d = load_golden('resgcn_' + tag)
+        sd = {k[3:]: T(v) for k, v in d.items() if k.startswith('sd_')}
+        assert (orc.resgcn_forward(sd, op_from(d), T(d['x']), 2, normalize=norm) - T(d['out'])).abs().max() <= TOL, tag
+
+
 def test_input_checks():
     f = lambda t, x: -x
     y0 = torch.ones(3)

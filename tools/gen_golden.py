@@ -16,6 +16,7 @@ Fixture families:
   G5 truth_*.npz      heat / gene / mutualistic truth       {heat,gene,mutualistic}_dynamics.py:186-232
   G6 operators_*.npz  dense operator builders, zipf alpha   utils_in_learn_dynamics.py:80-157, propagation.py:91-103
   G7 dgnn_*.npz       ODEBlock2(no_control, terminal)       dgnn.py:173-182 on the Planetoid topologies
+  G10 resgcn_*.npz    RowNorm / ResBlock / GCN / resGCN     ode_gcn.py:9-60, models.py:8-47, dgnn.py:129-140
 """
 import os
 import sys
@@ -384,7 +385,48 @@ def gen_adjoint():
              rtol=rtol, atol=atol, **csr_of(OM))
 
 
+# ----------------------------------------------------------------------------- G10
+def gen_resgcn():
+    import utils as ref_utils
+    import ode_gcn as ref_og
+    import models as ref_models
+    adj = load_planetoid_adj('cora')
+    with contextlib.redirect_stdout(io.StringIO()):
+        op = sp.csr_matrix(ref_prop.Propagation(adj).zipf_smoothing_alpha(0.0))
+    A = ref_utils.sparse_csr_matrix_to_torch_sparse_tensor(op)
+    op.sort_indices()
+    csr = dict(indptr=op.indptr.astype(np.int32), indices=op.indices.astype(np.int32), data=op.data.astype(np.float32),
+               shape=np.array(op.shape, dtype=np.int64))
+    n, H = adj.shape[0], 32
+    torch.manual_seed(11)
+    x = torch.randn(n, H)
+    x[17] = 0                                                  # an all-zero row: 0 / max(0, eps)
+    with torch.no_grad():
+        save('resgcn_rownorm', x=x, out=ref_og.RowNorm()(x.clone()))
+        for tag, kw in (('plain', {}), ('norm', dict(normalize=True)), ('tv', dict(time_varying=True)),
+                        ('euler', dict(Euler=True)), ('norm_tv', dict(normalize=True, time_varying=True))):
+            torch.manual_seed(3)
+            blk = ref_og.ResBlock(H, A, **kw).eval()
+            extra = {}
+            if kw.get('time_varying'):
+                extra.update(W=blk.linear.weight, b=blk.linear.bias)
+            if kw.get('Euler'):
+                extra.update(time_step=blk.time_step)
+            save('resgcn_block_%s' % tag, out=blk(x.clone()), **extra, **csr)     # input: x of resgcn_rownorm.npz
+        feat = torch.rand(n, 32)
+        torch.manual_seed(4)
+        gcn = ref_models.GCN(32, 16, 7, dropout=0.5, num_middle_layers=1).eval()
+        save('resgcn_gcn', x=feat, out=gcn(feat, A), **{'sd_' + k: v for k, v in gcn.state_dict().items()}, **csr)
+        for tag, norm, euler in (('model', False, False), ('model_norm_euler', True, True)):
+            torch.manual_seed(5)
+            layers = [torch.nn.Linear(32, H), torch.nn.ReLU(inplace=True)]
+            layers += [ref_og.ResBlock(H, A, dropout=0.5, normalize=norm, Euler=euler) for _ in range(2)]
+            layers += [torch.nn.Linear(H, 7)]
+            model = torch.nn.Sequential(*layers).eval()
+            save('resgcn_%s' % tag, x=feat, out=model(feat), **{'sd_' + k: v for k, v in model.state_dict().items()}, **csr)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint']
+    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint', 'resgcn']
     for w in which:
         globals()['gen_' + w]()
