@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 3
+#define NDCN_ABI_VERSION 4
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -71,6 +71,31 @@ typedef struct ndcn_csr {
     const int32_t *ug_ptr;    /* [n_groups + 1] */
     const int32_t *ug_cols;   /* [ug_ptr[n_groups]] */
     const uint16_t *ug_lidx;  /* [nnz] */
+    /* Optional long-row plan (hub_n = 0 when absent), built once per operator by the host
+     * (ndcn_amd/csr.py:build_hub_plan) for graphs with a skewed degree distribution.  Rows with more than the
+     * plan's threshold of entries ("hubs": a 3900-entry row of a 10^6-node Barabasi-Albert graph is otherwise
+     * one wave's sequential work inside the fused RHS kernel) are evaluated ahead of that kernel:
+     *   hub_seg_* : CSR over SEGMENTS of the hub rows (<= 256 entries each; columns as in colidx),
+     *               S_seg = hub_seg x X                         -> hub_Sseg [hub_nseg][H]
+     *   hub_cmb_* : CSR [hub_n x hub_nseg] of ones, row h = the segments of hub h in order,
+     *               S_hub = hub_cmb x S_seg                     -> hub_S [hub_n][H]
+     *   lt_*      : the operator with every hub row replaced by ONE entry (column n_cols + h, value 1): the
+     *               fused kernel reads S_hub as its second ("halo") panel.
+     * hub_S / hub_Sseg are scratch owned by the operator (one launch stream at a time).  Used by ndcn_rhs_f32 /
+     * ndcn_rhs_rk_f32 / the solver when H == hub_H and no halo panel is passed.                              */
+    int32_t        hub_n, hub_nseg, hub_H;
+    int64_t        hub_nnz, lt_nnz;
+    const int32_t *hub_seg_rowptr;  /* [hub_nseg + 1] */
+    const int32_t *hub_colidx;      /* [hub_nnz] */
+    const float   *hub_val;         /* [hub_nnz] */
+    const int32_t *hub_cmb_rowptr;  /* [hub_n + 1] */
+    const int32_t *hub_cmb_colidx;  /* [hub_nseg] = 0 .. hub_nseg-1 */
+    const float   *hub_cmb_val;     /* [hub_nseg] ones */
+    const int32_t *lt_rowptr;       /* [n_rows + 1] */
+    const int32_t *lt_colidx;       /* [lt_nnz] */
+    const float   *lt_val;          /* [lt_nnz] */
+    float         *hub_Sseg;        /* [hub_nseg][hub_H] */
+    float         *hub_S;           /* [hub_n][hub_H] */
 } ndcn_csr;
 
 NDCN_API int         ndcn_abi_version(void);

@@ -27,6 +27,7 @@ class CsrOperator:
         self._t = None
         self.row_order = None        # optional int32 permutation: the order in which kernels walk the rows
         self.union = None            # optional row-group union plan (build_union_plan)
+        self.hub = None              # optional long-row plan (build_hub_plan)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -141,12 +142,82 @@ class CsrOperator:
         self._view = None
         return staged_nnz / max(self.nnz, 1)
 
+    def build_hub_plan(self, H, threshold=64, seg=256):
+        """Long-row plan (see include/ndcn_hip.h, struct ndcn_csr): rows with more than `threshold` entries are cut
+        into segments of <= `seg` entries that a separate SpMM evaluates with one wave per segment; the fused RHS
+        kernel then reads each hub's finished (A X) row as ONE entry of a second panel.  One-off numpy
+        preprocessing.  Returns the number of hub rows (0 = no plan attached)."""
+        rp = self.rowptr.cpu().numpy().astype(np.int64)
+        deg = np.diff(rp)
+        hubs = np.nonzero(deg > threshold)[0]
+        self.hub = None
+        self._view = None
+        if hubs.size == 0:
+            return 0
+        dev = self.device
+        ci, va = self.colidx.cpu().numpy(), self.val.cpu().numpy()
+        n, n_cols = self.shape
+        hub_deg = deg[hubs]
+        # compact copy of the hub rows' entries, in hub order
+        take = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in hubs])
+        nseg_per = (hub_deg + seg - 1) // seg
+        seg_len = np.concatenate([np.minimum(seg, d - seg * np.arange(k)) for d, k in zip(hub_deg, nseg_per)])
+        seg_rowptr = np.zeros(seg_len.size + 1, dtype=np.int64)
+        np.cumsum(seg_len, out=seg_rowptr[1:])
+        cmb_rowptr = np.zeros(hubs.size + 1, dtype=np.int64)
+        np.cumsum(nseg_per, out=cmb_rowptr[1:])
+        # light operator: hub row h -> one entry (n_cols + h, 1.0)
+        is_hub = np.zeros(n, dtype=bool)
+        is_hub[hubs] = True
+        lt_deg = np.where(is_hub, 1, deg)
+        lt_rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lt_deg, out=lt_rowptr[1:])
+        keep = np.ones(ci.size, dtype=bool)
+        keep[take] = False
+        lt_ci = np.empty(int(lt_rowptr[-1]), dtype=np.int32)
+        lt_va = np.empty(int(lt_rowptr[-1]), dtype=np.float32)
+        rows_of = np.repeat(np.arange(n), deg)
+        pos_in_row = np.arange(ci.size) - rp[rows_of]
+        dst = lt_rowptr[rows_of[keep]] + pos_in_row[keep]
+        lt_ci[dst] = ci[keep]
+        lt_va[dst] = va[keep]
+        lt_ci[lt_rowptr[hubs]] = n_cols + np.arange(hubs.size)
+        lt_va[lt_rowptr[hubs]] = 1.0
+        t32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).to(dev)
+        self.hub = {
+            'n': int(hubs.size), 'nseg': int(seg_len.size), 'H': int(H), 'nnz': int(take.size), 'lt_nnz': int(lt_rowptr[-1]),
+            'threshold': int(threshold), 'rows': hubs,
+            'seg_rowptr': t32(seg_rowptr), 'colidx': t32(ci[take]), 'val': torch.from_numpy(va[take].astype(np.float32)).to(dev),
+            'cmb_rowptr': t32(cmb_rowptr), 'cmb_colidx': t32(np.arange(seg_len.size)),
+            'cmb_val': torch.ones(seg_len.size, dtype=torch.float32, device=dev),
+            'lt_rowptr': t32(lt_rowptr), 'lt_colidx': torch.from_numpy(lt_ci).to(dev), 'lt_val': torch.from_numpy(lt_va).to(dev),
+            'Sseg': torch.empty(seg_len.size, H, dtype=torch.float32, device=dev),
+            'S': torch.empty(hubs.size, H, dtype=torch.float32, device=dev),
+        }
+        return int(hubs.size)
+
     def ensure_plans(self, H):
         """One-off, lazy: attach the row-group union plan when the panel width has a kernel that uses it
         (H = 256) and the graph has enough neighbour sharing between consecutive rows for it to pay."""
         if H != 256 or self.union is not None or getattr(self, '_union_tried', False) or self.device.type != 'cuda':
             return self
         self._union_tried = True
+        # Long-row plan: rows longer than the threshold leave the fused kernel.  Worth it only when such rows are the
+        # exception (measured, 10^6 nodes: Barabasi-Albert m=5 36.8 -> 24.5 ms/step at threshold 32; G(n,p) with mean
+        # degree 41, where a threshold of 32 moves nearly every row, 53 -> 57 ms/step): take the lowest threshold
+        # that moves at most 5 % of the rows.
+        if self.nnz and getattr(self, 'hub', None) is None:
+            env = os.environ.get('NDCN_HUB_THRESHOLD')
+            deg = (self.rowptr[1:] - self.rowptr[:-1])
+            for thr in ([int(env)] if env else [32, 64, 128]):
+                if thr <= 0:
+                    break
+                n_hub = int((deg > thr).sum())
+                if n_hub == 0:
+                    break
+                if env or n_hub <= 0.05 * self.shape[0]:
+                    self.build_hub_plan(H, thr)
+                    break
         rows = int(os.environ.get('NDCN_UNION_ROWS', '8'))       # = the fused RHS kernel's row group
         cap = int(os.environ.get('NDCN_UNION_CAP', '30'))        # LDS rows per staged group
         if rows <= 0 or self.nnz == 0:
@@ -171,6 +242,15 @@ class CsrOperator:
                 self._view.ug_rows, self._view.ug_cap = u['rows'], u['cap']
                 self._view.ug_ptr, self._view.ug_cols = u['ptr'].data_ptr(), u['cols'].data_ptr()
                 self._view.ug_lidx = u['lidx'].data_ptr()
+            h = getattr(self, 'hub', None)
+            if h is not None:
+                v = self._view
+                v.hub_n, v.hub_nseg, v.hub_H, v.hub_nnz, v.lt_nnz = h['n'], h['nseg'], h['H'], h['nnz'], h['lt_nnz']
+                v.hub_seg_rowptr, v.hub_colidx, v.hub_val = h['seg_rowptr'].data_ptr(), h['colidx'].data_ptr(), h['val'].data_ptr()
+                v.hub_cmb_rowptr, v.hub_cmb_colidx, v.hub_cmb_val = (h['cmb_rowptr'].data_ptr(), h['cmb_colidx'].data_ptr(),
+                                                                       h['cmb_val'].data_ptr())
+                v.lt_rowptr, v.lt_colidx, v.lt_val = h['lt_rowptr'].data_ptr(), h['lt_colidx'].data_ptr(), h['lt_val'].data_ptr()
+                v.hub_Sseg, v.hub_S = h['Sseg'].data_ptr(), h['S'].data_ptr()
         return self._view
 
     def view_ref(self):

@@ -297,10 +297,12 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             if (do_gather) {
                 int j = cur.j;
                 const int j1 = cur.j1;
-                for (; j1 - j >= 16; j += 8) {                 // long rows: whole batches first
-                    g_issue<8, HALO>(colidx, val, j, rsX, rsH, a.n_own, lane_off, x, w);
+                for (; j1 - j >= 16; j += 16) {                // long rows: whole rounds of 16 fetches first
+                    g_issue<8, HALO, 0>(colidx, val, j, rsX, rsH, a.n_own, lane_off, x, w);
+                    g_issue<8, HALO, 8>(colidx, val, j + 8, rsX, rsH, a.n_own, lane_off, x, w);
                     wait_vmcnt<0>();
-                    g_accum<8>(x, w, acc);
+                    g_accum<8, 0>(x, w, acc);
+                    g_accum<8, 8>(x, w, acc);
                 }
                 m = j1 - j;
                 g_row_issue<HALO>(colidx, val, j, m, rsX, rsH, a.n_own, lane_off, x, w);
@@ -529,6 +531,28 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
                    int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
     const int n_rows = (int)A->n_rows;
     if (n_rows == 0) return NDCN_OK;
+    // Long-row plan: the hub rows' (A X) rows are formed ahead by two small SpMMs (segments, then their sums) and the
+    // kernel runs on the "light" operator that reads them as its second panel (include/ndcn_hip.h, struct ndcn_csr).
+    ndcn_csr light;
+    const ndcn_csr *A_full = A;
+    if (A->hub_n > 0 && !Xh && A->hub_H == kH2 && A->hub_S && A->hub_Sseg) {
+        ndcn_csr seg = {};
+        seg.n_rows = A->hub_nseg; seg.n_cols = A->n_cols; seg.nnz = A->hub_nnz;
+        seg.rowptr = A->hub_seg_rowptr; seg.colidx = A->hub_colidx; seg.val = A->hub_val;
+        int rc = spmm_f32(&seg, X, nullptr, A->n_cols, A->hub_Sseg, kH2, 1.f, 0, st);
+        if (rc) return rc;
+        ndcn_csr cmb = {};
+        cmb.n_rows = A->hub_n; cmb.n_cols = A->hub_nseg; cmb.nnz = A->hub_nseg;
+        cmb.rowptr = A->hub_cmb_rowptr; cmb.colidx = A->hub_cmb_colidx; cmb.val = A->hub_cmb_val;
+        rc = spmm_f32(&cmb, A->hub_Sseg, nullptr, A->hub_nseg, A->hub_S, kH2, 1.f, 0, st);
+        if (rc) return rc;
+        light = ndcn_csr{};
+        light.n_rows = A->n_rows; light.n_cols = A->n_cols + A->hub_n; light.nnz = A->lt_nnz;
+        light.rowptr = A->lt_rowptr; light.colidx = A->lt_colidx; light.val = A->lt_val;
+        n_own = A->n_cols;
+        Xh = A->hub_S;
+        A = &light;
+    }
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;
     const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;
@@ -555,10 +579,10 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (per_xcd > need) per_xcd = need;
     const dim3 grid(per_xcd * kXcds), block(64 * kWaves);
     const double P = 4.0 * kH2 * (double)A->n_rows;
-    double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * kH2 * (double)(A->n_rows + A->n_cols) + 4.0 * kH2 * kH2;
+    double bytes = 8.0 * A_full->nnz + 4.0 * (A_full->n_rows + 1) + 4.0 * kH2 * (double)(A_full->n_rows + A_full->n_cols) + 4.0 * kH2 * kH2;
     if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
     if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
-    ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * kH2 + 2.0 * (double)A->n_rows * kH2 * kH2);
+    ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A_full->nnz * kH2 + 2.0 * (double)A_full->n_rows * kH2 * kH2);
 #define NDCN_F2(HALO_, MODE_, NP_) \
     hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, NP_>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a, ea)
 #define NDCN_F2_DISPATCH(HALO_)                                      \

@@ -244,6 +244,37 @@ def test_fused_rhs_rk_with_halo_panel_equals_unsharded(dev, side, cut):
     assert abs(tot - float(ss)) <= 1e-6 * abs(float(ss)) and float(bad) == 0.0
 
 
+def test_long_row_plan_equals_in_kernel_gather(dev):
+    """Power-law graph: rows longer than the plan's threshold are evaluated by the segment SpMMs ahead of the fused
+    kernel and enter it as one entry of a second panel - same results as gathering them inside the kernel."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H, n = 256, 6000
+    m = graphs.normalized_laplacian(graphs.make_graph('power_law', n, seed=1)).tocsr()
+    deg = np.diff(m.indptr)
+    assert deg.max() > 300                                     # hubs spanning several 256-entry segments
+    g = torch.Generator().manual_seed(0)
+    X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+    W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    A_plan = CsrOperator.from_scipy(m, dev)
+    A_plan.ensure_plans(H)
+    assert A_plan.hub is not None and A_plan.hub['n'] == int((deg > A_plan.hub['threshold']).sum()) > 0
+    assert A_plan.hub['nseg'] > A_plan.hub['n']                # at least one hub spans several segments
+    A_ref = CsrOperator.from_scipy(m, dev)
+    A_ref._union_tried = True                                  # no plans: every row is gathered inside the kernel
+    ref = hip.rhs(A_ref, X, W, b)
+    assert torch.allclose(hip.rhs(A_plan, X, W, b), ref, rtol=1e-5, atol=1e-6)
+    exact = torch.relu(torch.from_numpy((m.astype(np.float64) @ X.cpu().double().numpy())).to(dev) @ W.double().T + b.double())
+    assert (ref.double() - exact).abs().max() < 2e-5 and (hip.rhs(A_plan, X, W, b).double() - exact).abs().max() < 2e-5
+    K1, y1 = hip.rhs_rk(A_plan, X, W, b, 'combine', y0, ks[:4], cs[:4] + [cs[5]])
+    K2, y2 = hip.rhs_rk(A_ref, X, W, b, 'combine', y0, ks[:4], cs[:4] + [cs[5]])
+    assert torch.allclose(K1, K2, rtol=1e-5, atol=1e-6) and torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)
+    _, (s1, b1) = hip.rhs_rk(A_plan, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
+    _, (s2, b2) = hip.rhs_rk(A_ref, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
+    assert abs(float(s1) - float(s2)) <= 1e-6 * abs(float(s2)) and float(b1) == float(b2) == 0.0
+
+
 # ------------------------------------------------------------------------------------------- RK bookkeeping
 @pytest.mark.parametrize('shape', [(400, 20), (1001, 1), (257, 3), (4096, 256)])
 def test_rk_kernels_bitwise_vs_reference_op_order(dev, shape):
