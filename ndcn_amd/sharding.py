@@ -79,6 +79,13 @@ class HaloPlan:
         if self.world == 1:
             return halo
         packed = ops.gather_rows(X, self.send_idx) if self.send_idx.numel() else X[:0]
+        if X.is_cuda and dist.get_backend(self.group) != 'nccl':
+            # gloo moves host memory only: stage through the host (the 2-rank GPU test runs both ranks on one device,
+            # which RCCL refuses; production is nccl = RCCL, device to device over xGMI)
+            h = torch.empty((self.n_halo, H), dtype=X.dtype)
+            dist.all_to_all_single(h, packed.cpu(), self.recv_counts, self.send_counts, group=self.group)
+            halo.copy_(h)
+            return halo
         dist.all_to_all_single(halo, packed, self.recv_counts, self.send_counts, group=self.group)
         return halo
 

@@ -9,6 +9,8 @@ import pytest
 import torch
 
 from conftest import GOLDEN, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import ndcn_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -270,6 +272,67 @@ def test_sharded_path_single_rank_equals_device_solver(dev):
         assert runner.run_steps(3) == 3 and runner.nfe() >= 2 + 18
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ndcn_amd import graphs, sharding, hip
+        from ndcn_amd.neural_dynamics import ODEFunc
+        dev = torch.device('cuda:0')
+        H, R, C = 256, 60, 40                                  # 2400 nodes, 30 lattice rows per rank
+        torch.manual_seed(0)
+        f = ODEFunc(H, None).to(dev)
+        bounds = [(R * r // world) * C for r in range(world + 1)]
+        block = graphs.grid_operator_row_block(R, C, bounds[rank] // C, bounds[rank + 1] // C)
+        plan = sharding.HaloPlan(block, bounds, rank, dev)
+        x = torch.rand(R * C, H, generator=torch.Generator().manual_seed(1))
+        xl = x[bounds[rank]:bounds[rank + 1]].contiguous().to(dev)
+        t = torch.linspace(0., 1.5, 4).to(dev)
+        out = {'halo': plan.n_halo}
+        with torch.no_grad():
+            for method in ('rk4', 'dopri5'):
+                log = []
+                y = sharding.sharded_odeint(hip, f, plan, R * C, xl, t, rtol=1e-3, atol=1e-4, method=method, step_log=log)
+                out[method] = y.cpu().numpy()
+                out[method + '_log'] = [r for r in log if r[0] != 'nfe']
+        out['W'], out['b'] = f.wt.weight.detach().cpu().numpy(), f.wt.bias.detach().cpu().numpy()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_hip_path_equals_device_solver(dev):
+    """The N > 1 product path with world size 2 ON THE GPU: two processes (both on cuda:0, gloo with host staging
+    because RCCL refuses two ranks on one device) run HaloPlan + halo exchange + the HALO variants of the fused
+    RHS+RK kernel + the global error reduction; the stitched trajectory must equal the single-process
+    device-resident solver on the whole graph, with the same accept / reject sequence on both ranks."""
+    import torch.multiprocessing as mp
+    from ndcn_amd import graphs, CsrOperator
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq import odeint
+    world, port = 2, 29900 + os.getpid() % 90
+    ret = mp.Manager().dict()
+    mp.spawn(_two_rank_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world and ret[0]['halo'] > 0 and ret[1]['halo'] > 0
+    H, R, C = 256, 60, 40
+    full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(R, C))
+    f = ODEFunc(H, CsrOperator.from_scipy(full, dev)).to(dev)
+    f.load_state_dict({'wt.weight': torch.from_numpy(ret[0]['W']), 'wt.bias': torch.from_numpy(ret[0]['b'])})
+    x = torch.rand(R * C, H, generator=torch.Generator().manual_seed(1)).to(dev)
+    t = torch.linspace(0., 1.5, 4).to(dev)
+    assert ret[0]['dopri5_log'] == ret[1]['dopri5_log'] and len(ret[0]['dopri5_log']) >= 3
+    with torch.no_grad():
+        for method in ('rk4', 'dopri5'):
+            ref = odeint(f, x, t, rtol=1e-3, atol=1e-4, method=method).cpu().numpy()
+            got = np.concatenate([ret[r][method] for r in range(world)], axis=1)
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() < 2e-5, method
 
 
 def test_tuple_state_generic_path(dev):
