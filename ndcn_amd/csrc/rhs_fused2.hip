@@ -66,13 +66,14 @@ struct EpiArgs {
 
 struct Fused2Args {
     const float *X, *Xh;
-    int x_bytes, xh_bytes;                  // sizes of the gathered panels (buffer descriptors: < 2^31)
+    unsigned x_bytes, xh_bytes;             // sizes of the gathered panels (buffer descriptors: < 2^32)
     int n_own;
     const float *Wp, *bias;
     float *K;                               // relu(...) output panel
     int n_rows, n_tiles, relu;
     unsigned long long *dbg_cycles;         // NDCN_FUSED_TIMING: per (block, wave) {work cycles, barrier-wait cycles}
-    int dbg;                                // timing experiments only (NDCN_FUSED_DBG): 1 skip MFMA, 2 skip gather, 4 skip epilogue
+    int dbg;                                // cycle-accounting experiments only (NDCN_FUSED_DBG): 1 skip MFMA, 2 skip gather,
+                                            // 4 skip epilogue, 64 no weight refills, 8192 report MFMA loop | dump separately
 };
 typedef const __attribute__((address_space(4))) EpiArgs *EpiPtr;
 // kernel parameters: rowptr, colidx, val (3 x 8 bytes), Fused2Args, EpiArgs - both structs are 8-aligned
@@ -98,7 +99,7 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
     const unsigned long long b = (unsigned long long)base;
     return (u32x4){(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
 }
-__device__ __forceinline__ f32x4 fetch128(u32x4 rs, int voff, int soff) {
+__device__ __forceinline__ f32x4 fetch128(u32x4 rs, int voff, unsigned soff) {
     f32x4 v;
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff));
     return v;
@@ -106,7 +107,7 @@ __device__ __forceinline__ f32x4 fetch128(u32x4 rs, int voff, int soff) {
 // streaming (nt) store; issued from asm as well: hipcc guards the data registers of stores it knows about with
 // vmcnt waits that - not counting the asm fetches - would drain those instead.  s_nop: the data registers of a
 // 16-byte store must not be written in the next wait state.
-__device__ __forceinline__ void store128(f32x4 v, u32x4 rs, int voff, int soff) {
+__device__ __forceinline__ void store128(f32x4 v, u32x4 rs, int voff, unsigned soff) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 template <int N>
@@ -133,7 +134,7 @@ __device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const fl
         u32x4 rs = rsX;
         int c = cc[q];
         if (HALO && c >= n_own) { rs = rsH; c -= n_own; }
-        x[O + q] = fetch128(rs, lane_off, c << 10);
+        x[O + q] = fetch128(rs, lane_off, (unsigned)c << 10);
     }
 }
 template <int U, int O = 0>
@@ -222,17 +223,17 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     // offset (r << 10) + the fixed per-lane offset - no VALU address arithmetic per panel (the producers' VALU time
     // is what the MFMA waves squeeze).  Panels are < 2 GiB (launcher check).
     struct EpiRow { f32x4 km[NP > 0 ? NP : 1]; f32x4 y0v, y1v; };
-    const int panel_bytes = a.n_rows << 10;
-    auto ldp = [&](const float *base, int row_off) {
+    const unsigned panel_bytes = (unsigned)a.n_rows << 10;         // panels < 4 GiB (launcher check)
+    auto ldp = [&](const float *base, unsigned row_off) {
         asm volatile("" : "+s"(base));      // keep the 4-SGPR descriptor transient: hoisted descriptors for 8 panels spill
         return fetch128(make_rsrc(base, panel_bytes), lane_off, row_off);
     };
-    auto stp = [&](float *base, int row_off, f32x4 v) {
+    auto stp = [&](float *base, unsigned row_off, f32x4 v) {
         asm volatile("" : "+s"(base));
         store128(v, make_rsrc(base, panel_bytes), lane_off, row_off);
     };
     auto epi_load = [&](EpiPtr ea, int r, EpiRow &e) {
-        const int off = (a.dbg & 2048) ? ((r & 63) << 10) : (r << 10);      // timing experiment: cache-resident panels
+        const unsigned off = (unsigned)r << 10;
 #pragma unroll
         for (int m = 0; m < NP; ++m) e.km[m] = ldp(ea->kprev[m], off);
         e.y0v = ldp(ea->y0, off);
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     };
     auto epi_finish = [&](EpiPtr ea, int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
-        const int off = r << 10;
+        const unsigned off = (unsigned)r << 10;
         stp(a.K, off, kn);
         if (MODE == MODE_PLAIN) return;
         // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             s = u + s;
         }
         if (MODE == MODE_COMBINE) {
-            if (!(a.dbg & 512)) stp(ea->y_next, off, e.y0v + s);
+            stp(ea->y_next, off, e.y0v + s);
         } else {
             const float rtol = ea->rtol, atol = ea->atol;
 #pragma unroll
@@ -423,7 +424,6 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     // MFMA waves and the fetch registers of the gather waves never share a live range.
     unsigned long long cyc_work = 0, cyc_wait = 0;
     if (producer) {
-        if (a.dbg & 32) __builtin_amdgcn_s_setprio(3);         // timing experiment: gather waves win issue arbitration
         producer_phase(s_tile, 0, t_first, false, true);
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
@@ -432,8 +432,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             // phase A: K of the previous tile sits in `oth`; stream it out, then refill `oth` with the next S
             const bool do_gather = it + 1 < my_tiles && !(a.dbg & 2);
-            if (!((a.dbg & 4096) && (p & 1)))                  // timing experiment: only half of the gather waves work
-                producer_phase(oth, t - wgs_per_xcd, t + wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
+            producer_phase(oth, t - wgs_per_xcd, t + wgs_per_xcd, it > 0 && !(a.dbg & 4), do_gather);
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             // phase B: consumers drop K_t into the tile they consumed
@@ -459,7 +458,6 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             }
         }
     } else {
-        if (a.dbg & 128) __builtin_amdgcn_s_setprio(3);        // timing experiment: MFMA waves win issue arbitration
         ring_fill();                                           // weight fetches fly while the first tile is gathered
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
@@ -512,7 +510,8 @@ int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags) {
     static const int enabled = env_int3("NDCN_RHS_FUSED2", 1);
     if (!enabled || H != kH2 || !A) return 0;
     if (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) return 0;
-    return A->n_cols * (int64_t)kH2 * 4 < (1ll << 31) ? 1 : 0;       // gathered panel must fit a buffer descriptor
+    // every panel must fit a buffer descriptor with a 32-bit row offset: < 4 GiB, i.e. < 4 Mi rows of 1 KiB
+    return (A->n_cols * (int64_t)kH2 * 4 < (1ll << 32) && A->n_rows * (int64_t)kH2 * 4 < (1ll << 32)) ? 1 : 0;
 }
 
 // compiled (mode, n_prev) variants: plain; COMBINE with 0..5 earlier stages; ERROR with dopri5's 5.  Anything else
@@ -556,11 +555,11 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;
     const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;
-    if (xb >= (1ll << 31) || xhb >= (1ll << 31)) {
-        set_error("rhs_fused2: panel of %lld bytes exceeds the 2 GiB buffer-descriptor range", (long long)(xb > xhb ? xb : xhb));
+    if (xb >= (1ll << 32) || xhb >= (1ll << 32) || (int64_t)n_rows * kH2 * 4 >= (1ll << 32)) {
+        set_error("rhs_fused2: panel of %lld bytes exceeds the 4 GiB buffer-descriptor range", (long long)(xb > xhb ? xb : xhb));
         return NDCN_EINVAL;
     }
-    a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (int)xb; a.xh_bytes = (int)xhb; a.Wp = Wp; a.bias = b; a.K = K;
+    a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (unsigned)xb; a.xh_bytes = (unsigned)xhb; a.Wp = Wp; a.bias = b; a.K = K;
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     EpiArgs ea;
     ea.y0 = y0; ea.n_prev = n_prev; ea.y_next = y_next; ea.rtol = rtol; ea.atol = atol;

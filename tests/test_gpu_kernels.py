@@ -12,6 +12,7 @@ from conftest import GOLDEN, load_golden
 from oracle import ndcn_oracle as orc
 from _oracle_ops import OracleOps
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -273,6 +274,55 @@ def test_long_row_plan_equals_in_kernel_gather(dev):
     _, (s1, b1) = hip.rhs_rk(A_plan, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
     _, (s2, b2) = hip.rhs_rk(A_ref, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
     assert abs(float(s1) - float(s2)) <= 1e-6 * abs(float(s2)) and float(b1) == float(b2) == 0.0
+
+
+def test_fused_rhs_panel_beyond_2_gib(dev):
+    """2.2 M nodes x 256 floats = 2.25 GB per panel: row offsets of the fused kernel's buffer accesses pass 2^31
+    (they are unsigned 32-bit: the kernel serves panels < 4 GiB).  Checked on row samples against fp64."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H, R, C = 256, 2200, 1000
+    m = graphs.grid_operator_row_block(R, C, 0, R, 'norm_lap').tocsr()
+    n = R * C
+    assert n * H * 4 > 2 ** 31
+    A = CsrOperator.from_scipy(m, dev)
+    g = torch.Generator().manual_seed(0)
+    W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    X = torch.rand(n, H, device=dev)
+    y0 = torch.rand(n, H, device=dev)
+    k1 = torch.rand(n, H, device=dev)
+    c = [np.float32(0.3), np.float32(-0.2)]
+    K, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, [k1], c)
+    rows = torch.tensor([0, 1, 999, 1000, 1048575, 2097151, 2097152, 2150000, n - 1001, n - 1], device=dev)
+    sub = m[rows.cpu().numpy()].tocsr()
+    cols = np.unique(sub.indices)
+    small = sp.csr_matrix((sub.data.astype(np.float64), np.searchsorted(cols, sub.indices), sub.indptr), shape=(sub.shape[0], cols.size))
+    S = torch.from_numpy(small @ X[torch.from_numpy(cols).to(dev)].cpu().double().numpy()).to(dev)
+    exact = torch.relu(S @ W.double().T + b.double())
+    assert (K[rows].double() - exact).abs().max() < 2e-5
+    want = y0[rows] + (k1[rows] * float(c[0]) + K[rows] * float(c[1]))
+    assert torch.equal(yn[rows], want)
+
+
+def test_first_generation_fused_kernel_still_serves_as_fallback(dev):
+    """NDCN_RHS_FUSED2=0 (what panels >= 4 GiB fall back to): rhs golden + a dopri5 golden in a fresh process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_golden\n"
+        "from ndcn_amd import hip, CsrOperator\n"
+        "d = load_golden('rhs_grid400_H256_default_coo'); dev = torch.device('cuda:0')\n"
+        "A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)\n"
+        "T = lambda a: torch.from_numpy(np.asarray(a)).to(dev)\n"
+        "out = hip.rhs(A, T(d['x']), T(d['W']), T(d['b'])).cpu().numpy()\n"
+        "assert np.abs(out - d['out']).max() <= 2e-5\n"
+        "K, yn = hip.rhs_rk(A, T(d['x']), T(d['W']), T(d['b']), 'combine', T(d['x']), [], [np.float32(0.5)])\n"
+        "assert np.abs(K.cpu().numpy() - d['out']).max() <= 2e-5\n"
+        "assert torch.equal(yn, T(d['x']) + K * 0.5)\n"
+        "print('fallback ok')\n") % (ROOT, os.path.join(ROOT, 'tests'))
+    env = dict(os.environ, NDCN_RHS_FUSED2='0')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'fallback ok' in r.stdout, r.stderr[-2000:]
 
 
 # ------------------------------------------------------------------------------------------- RK bookkeeping
