@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "kernels.h"
 
 namespace ndcn {
 

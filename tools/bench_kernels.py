@@ -13,9 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'rhs_fused2_scalarIdx': {'NDCN_FUSED_TIMING': '1'},
-    'rhs_fused2_scalarIdx_b': {},
-
+    'spmm_union': {},                                              # row-group union plan (default on the lattice)
+    'spmm_wide': {'NDCN_SPMM_UNION': '0'},                         # direct gather, one row per wave (v_readlane broadcast)
+    'spmm_blocked': {'NDCN_SPMM_UNION': '0', 'NDCN_SPMM_WIDE': '0'},
+    'rhs_fused': {},
+    'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
 }
 
 
