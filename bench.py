@@ -242,6 +242,12 @@ def main():
         copy_gbps = 5 * 2 * src_p.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         roofline['measured_copy_GBps'] = round(copy_gbps, 1)
         roofline['frac_of_measured_copy'] = round(roofline['achieved_GBps'] / copy_gbps, 4)
+        if roofline.get('traffic'):
+            # what the HBM actually moved per launch (PMC), over the launch time: how close the kernel runs to the rate
+            # a plain device copy sustains on this box
+            tg = roofline['traffic'] / (roofline['avg_ms'] * 1e-3) / 1e9
+            roofline['traffic_GBps'] = round(tg, 1)
+            roofline['traffic_frac_of_measured_copy'] = round(tg / copy_gbps, 4)
         del src_p, dst_p
     halo = None
     if world > 1 and hasattr(runner, 'plan'):

@@ -8,9 +8,11 @@ groups=(
  "SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS"
  "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY"
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
- "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU"
- "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_IFETCH"
- "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_THREAD_CYCLES_VALU SQ_WAVE32_INSTS SQ_INST_LEVEL_VMEM"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH"
+ "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_BANK_CONFLICT"
+ "SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE"
+ "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS"
+ "SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM"
 )
 i=0
 for g in "${groups[@]}"; do
@@ -24,7 +26,9 @@ for f in glob.glob('gpurun_out/sq/g*/**/*counter_collection.csv', recursive=True
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'rhs_fused2_kernel' not in k: continue
-        mode = k.split('ILb')[1][:8]
+        import re
+        m_ = re.search(r'rhs_fused2_kernel<([^>]*)>', k)
+        mode = m_.group(1) if m_ else k[:60]
         out[mode][r['Counter_Name']].append(float(r['Counter_Value']))
 with open('gpurun_out/sq/summary.txt', 'w') as fh:
     for mode in sorted(out):
