@@ -37,6 +37,13 @@ __device__ __forceinline__ f32x4 fetch128(u32x4 rs, int voff, unsigned soff) {
 __device__ __forceinline__ void store128(f32x4 v, u32x4 rs, int voff, unsigned soff) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+// fetch of data that is read exactly once (row-local RK panels): non-temporal, so the stream does not push the
+// gathered panel's lines (re-read up to 9 times) out of the XCD's 4 MiB L2
+__device__ __forceinline__ f32x4 fetch128_stream(u32x4 rs, int voff, unsigned soff) {
+    f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff));
+    return v;
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N)); }
 __device__ __forceinline__ void tie(f32x4 &v) { asm volatile("" : "+v"(v)); }

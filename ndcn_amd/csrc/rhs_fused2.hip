@@ -146,7 +146,8 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     const unsigned panel_bytes = (unsigned)a.n_rows << 10;         // panels < 4 GiB (launcher check)
     auto ldp = [&](const float *base, unsigned row_off) {
         asm volatile("" : "+s"(base));      // keep the 4-SGPR descriptor transient: hoisted descriptors for 8 panels spill
-        return fetch128(make_rsrc(base, panel_bytes), lane_off, row_off);
+        // read once: non-temporal (measured: 7.46 -> 6.77 GB read per 4-stage COMBINE launch, 12.36 -> 12.18 ms/step)
+        return fetch128_stream(make_rsrc(base, panel_bytes), lane_off, row_off);
     };
     auto stp = [&](float *base, unsigned row_off, f32x4 v) {
         asm volatile("" : "+s"(base));
