@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
 #pragma unroll
         for (int m = 0; m < NP; ++m) e.km[m] = ldp(ea->kprev[m], off);
         e.y0v = ldp(ea->y0, off);
-        if (MODE == MODE_ERROR) e.y1v = ldp(a.X, off);         // the input of this evaluation is y1 (own rows)
+        if (MODE == MODE_ERROR) e.y1v = ldp(a.X, off);         // the input of this evaluation is y1 (own rows); measured:
+                                                               // non-temporal here too reads less (8.69 vs 9.01 GB)
     };
     auto epi_finish = [&](EpiPtr ea, int r, const float *src_row, const EpiRow &e) {
         const f32x4 kn = *reinterpret_cast<const f32x4 *>(src_row + 4 * lane);
