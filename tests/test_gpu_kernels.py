@@ -325,6 +325,27 @@ def test_first_generation_fused_kernel_still_serves_as_fallback(dev):
     assert r.returncode == 0 and 'fallback ok' in r.stdout, r.stderr[-2000:]
 
 
+def test_integration_stub_runs(dev):
+    """the ~40-line ctypes stub a reference maintainer would add (examples/ndcn_hip_binding.py,
+    no ndcn_amd import) against the reference's own expression on a torch COO operator."""
+    import importlib.util
+    from ndcn_amd import _lib
+    os.environ['NDCN_HIP_LIB'] = _lib.LIB_PATH
+    spec = importlib.util.spec_from_file_location('ndcn_hip_binding', os.path.join(ROOT, 'examples', 'ndcn_hip_binding.py'))
+    stub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stub)
+    d = load_golden('rhs_grid400_H256_default_coo')
+    A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape']).to(dev)
+    csr, keep = stub.to_csr(A)
+    out = stub.odefunc_forward(csr, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev))
+    assert np.abs(out.cpu().numpy() - d['out']).max() <= 2e-5
+    d = load_golden('rhs_grid400_H20_no_control_coo')
+    A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape']).to(dev)
+    csr, keep = stub.to_csr(A)
+    out = stub.odefunc_forward(csr, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev), no_control=True)
+    assert np.abs(out.cpu().numpy() - d['out']).max() <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------- RK bookkeeping
 @pytest.mark.parametrize('shape', [(400, 20), (1001, 1), (257, 3), (4096, 256)])
 def test_rk_kernels_bitwise_vs_reference_op_order(dev, shape):
