@@ -136,10 +136,17 @@ NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
  *   rk_mode NDCN_RK_ERROR      also d_out = {sum ((sum_m h_c[m] k_m) / (atol + rtol max(|y0|, |X|)))^2,
  *                              non-finite count of X}: the dopri5 error record, X being y1 (rk_common.py:60,
  *                              misc.py:146-157, dopri5.py:101-102); d_ws: ndcn_reduce_ws_bytes() bytes
+ *   rk_mode NDCN_RK_RK4        also y_next = the input of the next stage of the 3/8-rule RK4 step - or, for the last
+ *                              stage, the step's result - in the reference's operator order (rk_common.py:72-78,
+ *                              solvers.py:92); n_prev = stage index 0..3, kprev = the earlier stages, h_c[0] = dt:
+ *                                0: y0 + dt K / 3            1: y0 + dt (K - k1 / 3)
+ *                                2: y0 + dt (k1 - k2 + K)    3: y0 + (k1 + 3 k2 + 3 k3 + K) dt / 8
+ *                              (y_next may alias y0 here: both are row-local to the epilogue)
  * h_kprev / h_c are HOST arrays (n_prev <= 5 device pointers; n_prev + 1 coefficients, already dt * beta in
  * fp32).  X, K, y_next, y0 and the kprev panels must not alias each other.                              */
 #define NDCN_RK_COMBINE 1
 #define NDCN_RK_ERROR   2
+#define NDCN_RK_RK4     3
 NDCN_API int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
                              const float *W, const float *b, float *K, float *work, int H, uint32_t flags,
                              int rk_mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,

@@ -17,7 +17,7 @@ OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
 
 F_RELU, F_NO_GRAPH, F_NO_CONTROL = 1, 2, 4
-RK_NONE, RK_COMBINE, RK_ERROR = 0, 1, 2
+RK_NONE, RK_COMBINE, RK_ERROR, RK_RK4 = 0, 1, 2, 3
 M_EULER, M_MIDPOINT, M_RK4, M_DOPRI5 = 0, 1, 2, 3
 METHODS = {'euler': M_EULER, 'midpoint': M_MIDPOINT, 'rk4': M_RK4, 'dopri5': M_DOPRI5}
 PROF_KINDS = ('spmm', 'linear', 'rhs_fused', 'combine', 'error', 'sumsq', 'interp_fit', 'interp_eval',

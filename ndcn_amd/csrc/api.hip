@@ -92,7 +92,7 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
                     double *d_out, void *d_ws, void *stream) {
     NDCN_CHECK_ARG(A, "null operator descriptor");
     NDCN_CHECK_ARG(H > 0, "H must be positive");
-    NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 2, "rk_mode must be 0, NDCN_RK_COMBINE or NDCN_RK_ERROR");
+    NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 3, "rk_mode must be 0, NDCN_RK_COMBINE, NDCN_RK_ERROR or NDCN_RK_RK4");
     if (!(flags & NDCN_F_NO_GRAPH)) {
         int rc = check_csr(A, __func__);
         if (rc) return rc;
@@ -105,6 +105,8 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
         NDCN_CHECK_ARG(y0 && h_c && (n_prev == 0 || h_kprev), "rk arguments missing");
         NDCN_CHECK_ARG(rk_mode != NDCN_RK_COMBINE || (y_next && y_next != X && y_next != K), "y_next missing or aliased");
         NDCN_CHECK_ARG(rk_mode != NDCN_RK_ERROR || (d_out && d_ws), "error record / scratch missing");
+        NDCN_CHECK_ARG(rk_mode != NDCN_RK_RK4 || (y_next && y_next != X && y_next != K && n_prev >= 0 && n_prev <= 3),
+                       "rk4 stage: y_next missing / aliased or stage index outside 0..3");
     }
     return rhs_rk_f32(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                       d_out, d_ws, ST(stream));

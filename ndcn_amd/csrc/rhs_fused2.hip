@@ -5,6 +5,8 @@
 //       COMBINE :  y_next = y0 + sum_m c_m k_m   (k_new last)      [rk_common.py:51 / misc.py:22-25]
 //       ERROR   :  sum ((sum_m c_m k_m) / (atol + rtol max(|y0|, |y1|)))^2 and the non-finite count of y1
 //                                                                  [rk_common.py:60, misc.py:146-157, dopri5.py:101]
+//       RK4     :  the input of the next stage of the 3/8-rule step, or the step itself, in the reference's operator
+//                  order (stage index = number of earlier stages)  [rk_common.py:72-78, solvers.py:92]
 //
 // One persistent workgroup per CU: 4 consumer waves (one per SIMD, fp32 MFMA) + 8 producer waves; 64-row tiles;
 // LDS = S[2][64][260] fp32 (133 120 B).
@@ -78,7 +80,7 @@ typedef const __attribute__((address_space(4))) EpiArgs *EpiPtr;
 // kernel parameters: rowptr, colidx, val (3 x 8 bytes), Fused2Args, EpiArgs - both structs are 8-aligned
 constexpr int kEpiKernargOffset = 24 + (int)((sizeof(Fused2Args) + 7) / 8 * 8);
 
-enum { MODE_PLAIN = 0, MODE_COMBINE = 1, MODE_ERROR = 2 };
+enum { MODE_PLAIN = 0, MODE_COMBINE = 1, MODE_ERROR = 2, MODE_RK4 = 3 };
 
 
 
@@ -166,6 +168,17 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
         const unsigned off = (unsigned)r << 10;
         stp(a.K, off, kn);
         if (MODE == MODE_PLAIN) return;
+        if (MODE == MODE_RK4) {
+            // rk4_alt_step_func (rk_common.py:72-78), same operator order as fixed_stage_kernel ops 2-5
+            const float dt = ea->c[0];
+            f32x4 s;
+            if (NP == 0) s = (kn * dt) / 3.f;                                            // y + dt*k1/3
+            else if (NP == 1) s = (e.km[0] / -3.f + kn) * dt;                            // y + dt*(k2 - k1/3)
+            else if (NP == 2) s = ((e.km[0] - e.km[1]) + kn) * dt;                       // y + dt*(k1 - k2 + k3)
+            else s = (((e.km[0] + e.km[1] * 3.f) + e.km[2] * 3.f) + kn) * (dt / 8.f);    // y + (k1+3k2+3k3+k4)*dt/8
+            stp(ea->y_next, off, e.y0v + s);
+            return;
+        }
         // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
         f32x4 s = kn * ea->c[NP];
         if (NP > 0) {
@@ -441,6 +454,7 @@ int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags) {
 int rhs_fused2_variant(int mode, int n_prev) {
     if (mode == MODE_PLAIN) return 1;
     if (mode == MODE_COMBINE) return n_prev >= 0 && n_prev <= kMaxPrev;
+    if (mode == MODE_RK4) return n_prev >= 0 && n_prev <= 3;
     return mode == MODE_ERROR && n_prev == kMaxPrev;
 }
 
@@ -494,7 +508,8 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * kWaves * 2 * sizeof(unsigned long long));
     a.dbg_cycles = timing ? d_cyc : nullptr;
     for (int m = 0; m < kMaxPrev; ++m) ea.kprev[m] = (m < n_prev) ? h_kprev[m] : nullptr;
-    for (int m = 0; m <= kMaxPrev; ++m) ea.c[m] = (mode != MODE_PLAIN && m <= n_prev) ? h_c[m] : 0.f;
+    for (int m = 0; m <= kMaxPrev; ++m) ea.c[m] = (mode != MODE_PLAIN && mode != MODE_RK4 && m <= n_prev) ? h_c[m] : 0.f;
+    if (mode == MODE_RK4) ea.c[0] = h_c[0];                     // the step size
     int per_xcd = kCus / kXcds;
     const int need = (a.n_tiles + kXcds - 1) / kXcds;
     if (per_xcd > need) per_xcd = need;
@@ -503,6 +518,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     double bytes = 8.0 * A_full->nnz + 4.0 * (A_full->n_rows + 1) + 4.0 * kH2 * (double)(A_full->n_rows + A_full->n_cols) + 4.0 * kH2 * kH2;
     if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
     if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
+    if (mode == MODE_RK4) bytes += P * (n_prev + 2);            // y + earlier stages read, next input written
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A_full->nnz * kH2 + 2.0 * (double)A_full->n_rows * kH2 * kH2);
 #define NDCN_F2(HALO_, MODE_, NP_) \
     hipLaunchKernelGGL((rhs_fused2_kernel<HALO_, MODE_, NP_>), grid, block, 0, st, A->rowptr, A->colidx, A->val, a, ea)
@@ -510,6 +526,12 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     do {                                                             \
         if (mode == MODE_PLAIN) NDCN_F2(HALO_, MODE_PLAIN, 0);       \
         else if (mode == MODE_ERROR) NDCN_F2(HALO_, MODE_ERROR, 5);  \
+        else if (mode == MODE_RK4) switch (n_prev) {                 \
+            case 0: NDCN_F2(HALO_, MODE_RK4, 0); break;              \
+            case 1: NDCN_F2(HALO_, MODE_RK4, 1); break;              \
+            case 2: NDCN_F2(HALO_, MODE_RK4, 2); break;              \
+            default: NDCN_F2(HALO_, MODE_RK4, 3); break;             \
+        }                                                            \
         else switch (n_prev) {                                       \
             case 0: NDCN_F2(HALO_, MODE_COMBINE, 0); break;          \
             case 1: NDCN_F2(HALO_, MODE_COMBINE, 1); break;          \

@@ -554,6 +554,29 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
         s->n_accept++;
         return NDCN_OK;
     }
+    if (s->fused2 && s->d.method == NDCN_M_RK4) {
+        // the 3/8-rule stage algebra in the RHS epilogues (rk_common.py:72-78): 4 launches instead of 8, each stage
+        // input written by the launch that produced the stage it needs last
+        const float c1[1] = {dt};
+        const float *kp[3] = {s->k[0], s->k[1], s->k[2]};
+        const float *in = s->ycur;
+        for (int i = 0; i < 4; ++i) {
+            float *nxt = (i == 3) ? dst : (in == s->ytmp ? s->ytmp2 : s->ytmp);
+            s->n_rhs++;
+            rc = rhs_fused2_f32(&s->d.A, in, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[i], s->d.rhs_flags, 3, s->ycur, kp,
+                                c1, i, nxt, 0.f, 0.f, nullptr, nullptr, st);
+            if (rc) return rc;
+            in = nxt;
+        }
+        s->ycur = dst;
+        s->cur_is_borrowed = (dst != s->ycur_own);
+        s->tf = t1;
+        s->t0 = s->t1;
+        s->t1 = next_t;
+        s->n_attempt++;
+        s->n_accept++;
+        return NDCN_OK;
+    }
     if ((rc = rhs(s, s->ycur, s->k[0], st))) return rc;
     switch (s->d.method) {
         case NDCN_M_EULER:

@@ -139,7 +139,8 @@ class HipOps:
     def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
         mode 'combine': returns (K, y0 + sum cs[m] kprev[m] + cs[-1] K); mode 'error': returns
-        (K, (sum of squared error ratios, non-finite count of X)) - the dopri5 error record with X = y1."""
+        (K, (sum of squared error ratios, non-finite count of X)) - the dopri5 error record with X = y1;
+        mode 'rk4': stage len(kprev) of the 3/8-rule step, cs = [dt]: returns (K, next stage input / step result)."""
         X = _panel(X)
         H = X.shape[1]
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
@@ -157,7 +158,7 @@ class HipOps:
             b = _panel(b, 'bias') if b is not None else None
         y0 = _panel(y0)
         kprev = [_panel(k) for k in kprev]
-        assert len(cs) == len(kprev) + 1
+        assert len(cs) == (1 if mode == 'rk4' else len(kprev) + 1)
         if X_halo is not None:
             X_halo = _panel(X_halo, 'halo panel')
         K = torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
@@ -165,15 +166,15 @@ class HipOps:
         work = torch.empty(wbytes, dtype=torch.uint8, device=X.device) if wbytes else None
         arr_k = (_P * max(len(kprev), 1))(*[k.data_ptr() for k in kprev])
         arr_c = (_F * len(cs))(*[float(c) for c in cs])
-        rk = _lib.RK_COMBINE if mode == 'combine' else _lib.RK_ERROR
-        y_next = torch.empty_like(K) if mode == 'combine' else None
+        rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR, 'rk4': _lib.RK_RK4}[mode]
+        y_next = torch.empty_like(K) if mode in ('combine', 'rk4') else None
         red = _Reducer.get(X.device)
         with torch.cuda.device(X.device):
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                       ptr(None if no_control else b), ptr(K), ptr(work), H, flags, rk, ptr(y0), arr_k,
                                       arr_c, len(kprev), ptr(y_next), float(rtol), float(atol), ptr(red.out), ptr(red.ws),
                                       stream_ptr()))
-            if mode == 'combine':
+            if mode in ('combine', 'rk4'):
                 return K, y_next
             return K, red.fetch()
 

@@ -224,11 +224,14 @@ def test_fused_epilogue_solver_equals_generic_path(dev, side):
     f = ODEFunc(256, A).to(dev).eval()
     x0 = torch.rand(side * side, 256, device=dev)
     with torch.no_grad():
-        for method, t in (('euler', torch.linspace(0., 1., 5)), ('dopri5', torch.tensor([0., 0.4, 1.5, 3.0]))):
+        for method, t in (('euler', torch.linspace(0., 1., 5)), ('rk4', torch.linspace(0., 2., 5)),
+                          ('dopri5', torch.tensor([0., 0.4, 1.5, 3.0]))):
             la, lb = [], []
             ya = ode.odeint(f, x0, t.to(dev), rtol=.01, atol=.001, method=method, step_log=la)
             yb = ode.odeint(lambda tt, y: f(tt, y), x0, t.to(dev), rtol=.01, atol=.001, method=method, step_log=lb)
             assert float((ya - yb).abs().max()) <= 1e-5 * float(yb.abs().max())
+            if method == 'rk4':
+                assert torch.equal(ya, yb)        # stage algebra in the epilogue == the separate stage kernels, bit for bit
             if method == 'dopri5':
                 assert la[-1] == lb[-1]                                   # same number of RHS evaluations
                 assert [r[2] for r in la[:-1]] == [r[2] for r in lb[:-1]]
