@@ -276,6 +276,62 @@ def test_long_row_plan_equals_in_kernel_gather(dev):
     assert abs(float(s1) - float(s2)) <= 1e-6 * abs(float(s2)) and float(b1) == float(b2) == 0.0
 
 
+@pytest.mark.parametrize('plans', [False, True])
+def test_fused_rhs_every_row_length(dev, plans):
+    """Rows of 0, 1, 2, ... 70 entries (every split of the one-round gather: pieces 8/4/2/1, rounds of 16, rows past
+    the long-row threshold), ragged last tile, with and without the operator's plans - against fp64."""
+    from ndcn_amd import hip, CsrOperator
+    H, n = 256, 71 * 13 + 5
+    rng = np.random.RandomState(7)
+    deg = np.arange(n) % 71
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([rng.choice(n, size=d, replace=False) for d in deg])
+    m = sp.csr_matrix((rng.randn(rows.size).astype(np.float32) / 8, (rows, cols)), shape=(n, n))
+    m.sort_indices()
+    A = CsrOperator.from_scipy(m, dev)
+    if plans:
+        os.environ['NDCN_HUB_THRESHOLD'] = '32'
+        try:
+            A.ensure_plans(H)
+        finally:
+            del os.environ['NDCN_HUB_THRESHOLD']
+        assert A.hub is not None
+    else:
+        A._union_tried = True
+    g = torch.Generator().manual_seed(3)
+    X = torch.rand(n, H, generator=g).to(dev)
+    W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    S = torch.from_numpy(m.astype(np.float64) @ X.cpu().double().numpy()).to(dev)
+    exact = torch.relu(S @ W.double().T + b.double())
+    got = hip.rhs(A, X, W, b)
+    assert (got.double() - exact).abs().max() < 2e-5
+    y0 = torch.rand(n, H, generator=g).to(dev)
+    K, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, [X], [np.float32(0.25), np.float32(-0.5)])
+    assert torch.equal(K, got)
+    assert torch.equal(yn, y0 + (X * 0.25 + K * -0.5))
+
+
+def test_fused_rk4_stage_epilogues_bitwise_vs_separate_kernels(dev):
+    """ndcn_rhs_rk_f32 in NDCN_RK_RK4 mode (stage algebra of rk4_alt_step_func in the RHS epilogue) against
+    ODEFunc + ndcn_fixed_stage_f32 ops 2-5 (which are pinned to the reference's operator order)."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H, side = 256, 45
+    n = side * side
+    A = CsrOperator.from_scipy(graphs.normalized_laplacian(graphs.grid_8_neighbor(side)), dev)
+    g = torch.Generator().manual_seed(2)
+    X, y = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(3)]
+    W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    dt = np.float32(0.0505)
+    K = hip.rhs(A, X, W, b)
+    for i in range(4):
+        Ki, out = hip.rhs_rk(A, X, W, b, 'rk4', y, ks[:i], [dt])
+        assert torch.equal(Ki, K)
+        args = (ks[:i] + [K] + [None] * 3)[:4]
+        want = hip.fixed_stage(2 + i, y, args[0], args[1], args[2], args[3], dt=dt)
+        assert torch.equal(out, want), i
+
+
 def test_fused_rhs_panel_beyond_2_gib(dev):
     """2.2 M nodes x 256 floats = 2.25 GB per panel: row offsets of the fused kernel's buffer accesses pass 2^31
     (they are unsigned 32-bit: the kernel serves panels < 4 GiB).  Checked on row samples against fp64."""
