@@ -131,6 +131,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hook (tests/test_gpu_odeint.py): several ranks on ONE device over gloo, to exercise the N > 1 code path on a
+    # 1-GPU box; RCCL refuses two ranks per device, production is always nccl with one rank per GPU
+    backend = os.environ.get('NDCN_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = 0
     assert torch.cuda.is_available(), 'bench.py needs a ROCm device (there is no CPU path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -139,7 +144,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_PORT', '29655')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, '--gpus %d but WORLD_SIZE %d' % (args.gpus, world)
 
     from ndcn_amd import _lib, graphs, device_info
@@ -179,7 +187,7 @@ def main():
     assert done == args.steps
     nfe = runner.nfe() - nfe0
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     n_total = n_local * world

@@ -338,6 +338,25 @@ def test_two_rank_sharded_hip_path_equals_device_solver(dev):
             assert np.abs(got - ref).max() < 2e-5, method
 
 
+def test_bench_two_ranks_on_one_device(dev):
+    """bench.py's N > 1 flow end to end (torchrun, sharded runner, barriers, max over ranks, one JSON line from rank 0)
+    with two ranks on the one device of the test box (gloo hook); the driver runs it with nccl on 2/4/8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, NDCN_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29700 + os.getpid() % 200), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--side', '96',
+           '--steps', '6', '--warmup', '2']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 6 and out['value'] > 0 and out['scaling'] == 'weak'
+    assert out['halo_exchange']['bytes_received_per_rhs_per_gpu'] > 0 and out['cpu_baseline'] is None
+    assert out['roofline']['kernel'] == 'rhs_fused'
+
+
 def test_tuple_state_generic_path(dev):
     from ndcn_amd import torchdiffeq as ode
 
