@@ -8,27 +8,31 @@
 //       RK4     :  the input of the next stage of the 3/8-rule step, or the step itself, in the reference's operator
 //                  order (stage index = number of earlier stages)  [rk_common.py:72-78, solvers.py:92]
 //
-// One persistent workgroup per CU: 4 consumer waves (one per SIMD, fp32 MFMA) + 8 producer waves; 64-row tiles;
-// LDS = S[2][64][260] fp32 (133 120 B).
+// One persistent 1024-thread workgroup per CU: 4 MFMA waves (one per SIMD, fp32 MFMA) + 12 gather waves; 64-row
+// tiles; LDS = S[2][64][260] fp32 (133 120 B).
 //
-//   phase A(t): consumers  MFMA on S[t&1]                            -> K_t in registers
-//               producers  per pair of rows: request the row-local RK panels of K_{t-1}'s rows (K_{t-1} sits in
-//                          S[(t-1)&1]), gather the same two rows of S_{t+1} = (A X)[tile t+1] into registers,
-//                          then finish the epilogue (K rows + RK algebra streamed to HBM as whole 1 KiB rows)
-//                          and drop the gathered rows into S[(t-1)&1]
+//   phase A(t): MFMA waves    MFMA on S[t&1]                            -> K_t in registers
+//               gather waves  one row at a time: issue the neighbour-row fetches of a row of S_{t+1} = (A X)[tile t+1],
+//                             request the row-local RK panels of the same row of K_{t-1} (K_{t-1} sits in S[(t-1)&1]),
+//                             fold the gathered rows, finish the epilogue (K row + RK algebra streamed to HBM as whole
+//                             1 KiB rows) and drop the gathered row into S[(t-1)&1]
 //   barrier
-//   phase B(t): consumers  K_t (+bias, relu) -> S[t&1], row-major
+//   phase B(t): MFMA waves    K_t (+bias, relu) -> S[t&1], row-major
 //   barrier
-// A producer wave owns the same rows of every tile (p, p+8, ..., p+56): it first reads K out of them, then
-// overwrites them with the gathered S, so phase A needs no producer-to-producer synchronisation.
+// A gather wave owns the same rows of every tile (p, p+12, ... < 64): it first reads K out of them, then overwrites
+// them with the gathered S, so phase A needs no synchronisation among the gather waves.
 //
-// Measured lessons built in (1M-node grid, MI355X; profiles/r01*):
-//   * the first fused kernel ran its MFMA loop at ~50 % because hipcc scheduled the L2 weight fetch of step q+1
-//     late inside step q and then waited vmcnt(0): the weight operands now sit in a 4-deep register ring (a
-//     fetch is issued right after its slot is consumed, three steps = 3072 MFMA cycles before it is needed);
-//   * accumulators leave through LDS as full rows instead of 64 scattered 4-byte stores per lane;
-//   * a union-staged gather (fetch each distinct neighbour row of 8 rows once) needed a producer barrier per
-//     group and was latency-bound (2.1 ms vs 1.8 ms); the gather here is direct, two rows in flight per wave.
+// Measured lessons built in (1M-node grid, MI355X; profiles/r01*, DESIGN.md section 4):
+//   * fp32 MFMA waves slow every other wave on their SIMD (2x on the same gather code): per-neighbour work is kept
+//     off the VALU (scalar-loaded CSR entries, buffer SGPR offsets, descriptors built on the scalar unit);
+//   * a gather wave's chain is latency-bound, throughput comes from the number of chains: 12 gather waves, one row
+//     (one fetch round for rows < 16 entries) each;
+//   * vector memory returns in order and hipcc's waitcnt insertion cannot count fetches issued under run-time
+//     conditions: fetches / stores of the gather waves are issued from inline asm and awaited by hand (gather.h);
+//   * the weight operands sit in a 4-slot register ring refilled right after use (no operand copies), through a
+//     buffer descriptor; accumulators leave through LDS as full rows instead of scattered 4-byte stores;
+//   * launches with >= 3 earlier stages run at the HBM rate of a streaming kernel (texture-path FIFO full half of
+//     the time): the row-local panels are fetched non-temporal so that they do not evict the gathered panel.
 #include <stdlib.h>
 
 #include "kernels.h"
