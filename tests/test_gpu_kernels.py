@@ -311,6 +311,31 @@ def test_fused_rhs_every_row_length(dev, plans):
     assert torch.equal(yn, y0 + (X * 0.25 + K * -0.5))
 
 
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 127, 129, 2049])
+def test_fused_rhs_tiny_and_ragged_sizes(dev, n):
+    """Fewer rows than one tile, exactly one tile, one row into the next tile, fewer tiles than workgroups: plain,
+    COMBINE and ERROR launches against fp64 / the separate kernels."""
+    from ndcn_amd import hip, CsrOperator
+    H = 256
+    m = rand_csr(n, n, 6, seed=n)
+    A = CsrOperator.from_scipy(m, dev)
+    g = torch.Generator().manual_seed(n)
+    X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+    W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    S = torch.from_numpy(m.astype(np.float64) @ X.cpu().double().numpy()).to(dev)
+    exact = torch.relu(S @ W.double().T + b.double())
+    K = hip.rhs(A, X, W, b)
+    assert (K.double() - exact).abs().max() < 2e-5
+    K2, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:2], cs[:2] + [cs[5]])
+    assert torch.equal(K2, K) and torch.equal(yn, hip.combine(y0, ks[:2] + [K], cs[:2] + [cs[5]]))
+    K3, (ss, bad) = hip.rhs_rk(A, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
+    s_ref, bad_ref = hip.error(y0, X, ks + [K], cs, 1e-2, 1e-3)
+    assert torch.equal(K3, K) and float(bad) == float(bad_ref) == 0.0
+    assert abs(float(ss) - float(s_ref)) <= 1e-9 * max(abs(float(s_ref)), 1e-30)
+
+
 def test_fused_rk4_stage_epilogues_bitwise_vs_separate_kernels(dev):
     """ndcn_rhs_rk_f32 in NDCN_RK_RK4 mode (stage algebra of rk4_alt_step_func in the RHS epilogue) against
     ODEFunc + ndcn_fixed_stage_f32 ops 2-5 (which are pinned to the reference's operator order)."""
