@@ -1,5 +1,5 @@
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ndcn_amd import graphs, CsrOperator
 from ndcn_amd.neural_dynamics import ODEFunc
 from ndcn_amd.torchdiffeq import odeint
