@@ -277,7 +277,16 @@ def test_sharded_path_single_rank_equals_device_solver(dev):
         dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, world, port, ret):
+def _two_rank_graph(case):
+    from ndcn_amd import graphs
+    if case == 'grid':
+        R, C = 60, 40                                          # 2400 nodes, 30 lattice rows per rank
+        return graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(R, C)), [0, 30 * C, R * C]
+    full = graphs.normalized_laplacian(graphs.make_graph('small_world', 3000, seed=3))    # random shortcuts: wide halo
+    return full, [0, 1500, 3000]
+
+
+def _two_rank_worker(rank, world, port, case, ret):
     import sys
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -288,20 +297,20 @@ def _two_rank_worker(rank, world, port, ret):
         from ndcn_amd import graphs, sharding, hip
         from ndcn_amd.neural_dynamics import ODEFunc
         dev = torch.device('cuda:0')
-        H, R, C = 256, 60, 40                                  # 2400 nodes, 30 lattice rows per rank
+        H = 256
         torch.manual_seed(0)
         f = ODEFunc(H, None).to(dev)
-        bounds = [(R * r // world) * C for r in range(world + 1)]
-        block = graphs.grid_operator_row_block(R, C, bounds[rank] // C, bounds[rank + 1] // C)
-        plan = sharding.HaloPlan(block, bounds, rank, dev)
-        x = torch.rand(R * C, H, generator=torch.Generator().manual_seed(1))
+        full, bounds = _two_rank_graph(case)
+        n = full.shape[0]
+        plan = sharding.HaloPlan(full[bounds[rank]:bounds[rank + 1]], bounds, rank, dev)
+        x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
         xl = x[bounds[rank]:bounds[rank + 1]].contiguous().to(dev)
         t = torch.linspace(0., 1.5, 4).to(dev)
         out = {'halo': plan.n_halo}
         with torch.no_grad():
             for method in ('rk4', 'dopri5'):
                 log = []
-                y = sharding.sharded_odeint(hip, f, plan, R * C, xl, t, rtol=1e-3, atol=1e-4, method=method, step_log=log)
+                y = sharding.sharded_odeint(hip, f, plan, n, xl, t, rtol=1e-3, atol=1e-4, method=method, step_log=log)
                 out[method] = y.cpu().numpy()
                 out[method + '_log'] = [r for r in log if r[0] != 'nfe']
         out['W'], out['b'] = f.wt.weight.detach().cpu().numpy(), f.wt.bias.detach().cpu().numpy()
@@ -310,7 +319,8 @@ def _two_rank_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_hip_path_equals_device_solver(dev):
+@pytest.mark.parametrize('case', ['grid', 'small_world'])
+def test_two_rank_sharded_hip_path_equals_device_solver(dev, case):
     """The N > 1 product path with world size 2 ON THE GPU: two processes (both on cuda:0, gloo with host staging
     because RCCL refuses two ranks on one device) run HaloPlan + halo exchange + the HALO variants of the fused
     RHS+RK kernel + the global error reduction; the stitched trajectory must equal the single-process
@@ -319,15 +329,15 @@ def test_two_rank_sharded_hip_path_equals_device_solver(dev):
     from ndcn_amd import graphs, CsrOperator
     from ndcn_amd.neural_dynamics import ODEFunc
     from ndcn_amd.torchdiffeq import odeint
-    world, port = 2, 29900 + os.getpid() % 90
+    world, port = 2, 29900 + os.getpid() % 90 + (0 if case == 'grid' else 1)
     ret = mp.Manager().dict()
-    mp.spawn(_two_rank_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, port, case, ret), nprocs=world, join=True)
     assert len(ret) == world and ret[0]['halo'] > 0 and ret[1]['halo'] > 0
-    H, R, C = 256, 60, 40
-    full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(R, C))
+    H = 256
+    full, _ = _two_rank_graph(case)
     f = ODEFunc(H, CsrOperator.from_scipy(full, dev)).to(dev)
     f.load_state_dict({'wt.weight': torch.from_numpy(ret[0]['W']), 'wt.bias': torch.from_numpy(ret[0]['b'])})
-    x = torch.rand(R * C, H, generator=torch.Generator().manual_seed(1)).to(dev)
+    x = torch.rand(full.shape[0], H, generator=torch.Generator().manual_seed(1)).to(dev)
     t = torch.linspace(0., 1.5, 4).to(dev)
     assert ret[0]['dopri5_log'] == ret[1]['dopri5_log'] and len(ret[0]['dopri5_log']) >= 3
     with torch.no_grad():
