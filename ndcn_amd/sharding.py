@@ -171,9 +171,12 @@ def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, ato
     f = ShardedODEFunc(odefunc, plan, ops)
     dops = DistOps(ops, n_global_rows, x_local.shape[0], group)
     _, func, y0, tt = core.check_inputs(f, x_local, t)
+    # A decreasing grid is integrated as -f(-t, y) on -t (misc.py:184-189): the sign flip cannot ride in the ReLU
+    # epilogue of the fused RHS, so those solves step through the un-fused stage kernels.
+    decreasing = bool((t[1:] < t[:-1]).all())
     if method == 'dopri5':
         sol = core.integrate_dopri5(dops, func, y0, tt, rtol, atol, autonomous=True, step_log=step_log,
-                                    fused=f if fused else None)
+                                    fused=f if (fused and not decreasing) else None)
     else:
         sol = core.integrate_fixed(dops, func, y0, tt, method, autonomous=True)
     return torch.stack([s[0] for s in sol])

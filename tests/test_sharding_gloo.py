@@ -49,6 +49,9 @@ def _worker(rank, world, port, case, ret):
             y = sharding.sharded_odeint(OracleOps, f, plan, n, xl, t, rtol=1e-3, atol=1e-4, method=method, step_log=log)
             out[method] = y.detach().numpy()
             out[method + '_log'] = [r for r in log if r[0] != 'nfe']
+        # decreasing grid: the sign-flipped function must not take the fused (ReLU-epilogue) protocol
+        y = sharding.sharded_odeint(OracleOps, f, plan, n, xl, torch.flip(t, [0]), rtol=1e-3, atol=1e-4, method='dopri5')
+        out['dopri5_rev'] = y.detach().numpy()
         out['halo'] = plan.n_halo
         out['W'] = f.wt.weight.detach().numpy()
         out['b'] = f.wt.bias.detach().numpy()
@@ -89,3 +92,6 @@ def test_two_rank_sharded_solve_equals_single_process_oracle(case):
             assert ret[0]['dopri5_log'] == ret[1]['dopri5_log']            # identical decisions on every rank
             assert [r[2] for r in ret[0]['dopri5_log']] == [r[2] for r in log]
             assert np.allclose([r[1] for r in ret[0]['dopri5_log']], [r[1] for r in log], rtol=1e-5)
+    ref = orc.odeint(f, x, torch.flip(t, [0]), rtol=1e-3, atol=1e-4, method='dopri5').numpy()
+    got = np.concatenate([ret[r]['dopri5_rev'] for r in range(world)], axis=1)
+    assert np.abs(got - ref).max() < 5e-6

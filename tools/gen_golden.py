@@ -17,6 +17,8 @@ Fixture families:
   G6 operators_*.npz  dense operator builders, zipf alpha   utils_in_learn_dynamics.py:80-157, propagation.py:91-103
   G7 dgnn_*.npz       ODEBlock2(no_control, terminal)       dgnn.py:173-182 on the Planetoid topologies
   G10 resgcn_*.npz    RowNorm / ResBlock / GCN / resGCN     ode_gcn.py:9-60, models.py:8-47, dgnn.py:129-140
+  G11 layout_*.npz    generate_node_mapping degree/community utils_in_learn_dynamics.py:212-230 (+ the P A P^T of :233-247)
+  G12 gconv_dense.npz GraphConvolution (dense A, flattened)  neural_dynamics.py:163-176
 """
 import os
 import sys
@@ -426,7 +428,48 @@ def gen_resgcn():
             save('resgcn_%s' % tag, x=feat, out=model(feat), **{'sd_' + k: v for k, v in model.state_dict().items()}, **csr)
 
 
+def gen_layout():
+    """G11: the reference's node mapping on its own graph generators (heat_dynamics.py:87-109 at n = 400).
+    networkx_reorder_nodes itself calls nx.to_scipy_sparse_matrix, removed in networkx 3: the mapping
+    function is what still runs; the re-labelled adjacency new_A[map[i], map[j]] = A[i, j] is formed here with the
+    two calls' modern equivalents."""
+    import networkx as nx
+    n, seed = 400, 0
+    n1, n2, n3 = int(n / 3), int(n / 3), int(n / 4)
+    graphs = {
+        'random': nx.erdos_renyi_graph(n, 0.1, seed=seed),
+        'power_law': nx.barabasi_albert_graph(n, 5, seed=seed),
+        'small_world': nx.newman_watts_strogatz_graph(400, 5, 0.5, seed=seed),
+        'community': nx.random_partition_graph([n1, n2, n3, n - n1 - n2 - n3], .25, .01, seed=seed),
+    }
+    for name, G in graphs.items():
+        A = sp.csr_matrix(nx.to_scipy_sparse_array(G, nodelist=range(n), format='csr'))
+        A.sort_indices()
+        out = dict(indptr=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32))
+        for layout in ('degree', 'community'):
+            m = ref_u.generate_node_mapping(G, layout)
+            new = np.array([m[i] for i in range(n)], dtype=np.int32)
+            C = A.tocoo()
+            newA = sp.coo_matrix((C.data, (new[C.row], new[C.col])), shape=C.shape).tocsr()
+            newA.sort_indices()
+            out['map_' + layout] = new
+            out['new_indptr_' + layout] = newA.indptr.astype(np.int32)
+            out['new_indices_' + layout] = newA.indices.astype(np.int32)
+        save('layout_%s' % name, **out)
+
+
+def gen_gconv():
+    """G12: the dense-A GraphConvolution that dgnn.py's star import exposes (neural_dynamics.py:163-176)."""
+    A = grid_operator(12, 'norm_lap')
+    torch.manual_seed(21)
+    gc = ref_nd.GraphConvolution(7, 5, bias=True)
+    gc_nb = ref_nd.GraphConvolution(7, 5, bias=False)
+    x = torch.randn(A.shape[0], 7)
+    with torch.no_grad():
+        save('gconv_dense', A=A, x=x, W=gc.fc.weight, b=gc.fc.bias, out=gc(x, A), W_nb=gc_nb.fc.weight, out_nb=gc_nb(x, A))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint', 'resgcn']
+    which = sys.argv[1:] or ['layout', 'gconv', 'rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint', 'resgcn']
     for w in which:
         globals()['gen_' + w]()
