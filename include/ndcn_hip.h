@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 4
+#define NDCN_ABI_VERSION 5
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -60,17 +60,20 @@ typedef struct ndcn_csr {
     const int32_t *row_order; /* [n_rows] or NULL: a permutation of the rows giving the order in which the
                                  kernels WALK them (a cache-locality hint, e.g. lattice tiles); results are
                                  identical for any permutation                                              */
-    /* Optional "row-group union" plan (NULL / 0 when absent), built once per operator by the host
-     * (ndcn_amd/csr.py:build_union_plan): rows are cut into groups of `ug_rows`; for group g the DISTINCT
-     * columns its rows reference are ug_cols[ug_ptr[g] .. ug_ptr[g+1]) (ascending) and entry j of the CSR
-     * refers to ug_cols[ug_ptr[g] + ug_lidx[j]].  A kernel then fetches each distinct neighbour row of a group
-     * ONCE into LDS and serves the group's rows from there.  A group whose union exceeds the plan's cap has
-     * an empty range and ug_lidx unused: the kernel gathers it directly.                                    */
-    int32_t        ug_rows;
-    int32_t        ug_cap;    /* largest union size in the plan (LDS rows the kernel must provide)            */
-    const int32_t *ug_ptr;    /* [n_groups + 1] */
-    const int32_t *ug_cols;   /* [ug_ptr[n_groups]] */
-    const uint16_t *ug_lidx;  /* [nnz] */
+    /* Optional "group record" plan (rec = NULL when absent), built once per operator by the host
+     * (ndcn_amd/csr.py:build_rec_plan) for H = 256 panels.  The rows are cut into groups of rec_rows rows that are
+     * consecutive in the operator's walk order (row_order, or 0..n-1); group g owns the fixed-size record
+     * rec[g * rec_kib * 256 ...) of 32-bit words:
+     *   [0, rec_cap)                    the DISTINCT columns the group's rows reference, ascending, padded by repetition
+     *   [rec_cap, rec_cap + 2 rec_rows) per row {row id or -1, cnt | ofs << 16}; cnt = 0xffff flags a group the record
+     *                                   cannot hold (the kernel gathers its rows from rowptr / colidx / val directly)
+     *   [rec_cap + 2 rec_rows, ...)     the rows' entries as (index into the group's column list, fp32 value bits), row
+     *                                   after row in stored (column-ascending) order
+     * The SpMM kernel moves every record and every distinct neighbour row into LDS by DMA at addresses it can form
+     * without first loading streamed index data (ndcn_amd/csrc/spmm_rec.hip).  Supported shapes:
+     * {rec_rows, rec_cap, rec_kib} = {8, 32, 1} and {16, 40, 2}.                                             */
+    int32_t        rec_rows, rec_cap, rec_kib, rec_groups;
+    const int32_t *rec;       /* [rec_groups][rec_kib * 256] */
     /* Optional long-row plan (hub_n = 0 when absent), built once per operator by the host
      * (ndcn_amd/csr.py:build_hub_plan) for graphs with a skewed degree distribution.  Rows with more than the
      * plan's threshold of entries ("hubs": a 3900-entry row of a 10^6-node Barabasi-Albert graph is otherwise

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
@@ -35,14 +35,21 @@ class CsrView(ctypes.Structure):
     _fields_ = [('n_rows', ctypes.c_int64), ('n_cols', ctypes.c_int64), ('nnz', ctypes.c_int64),
                 ('rowptr', ctypes.c_void_p), ('colidx', ctypes.c_void_p), ('val', ctypes.c_void_p),
                 ('row_order', ctypes.c_void_p),
-                ('ug_rows', ctypes.c_int32), ('ug_cap', ctypes.c_int32), ('ug_ptr', ctypes.c_void_p),
-                ('ug_cols', ctypes.c_void_p), ('ug_lidx', ctypes.c_void_p),
+                ('rec_rows', ctypes.c_int32), ('rec_cap', ctypes.c_int32), ('rec_kib', ctypes.c_int32),
+                ('rec_groups', ctypes.c_int32), ('rec', ctypes.c_void_p),
                 ('hub_n', ctypes.c_int32), ('hub_nseg', ctypes.c_int32), ('hub_H', ctypes.c_int32),
                 ('hub_nnz', ctypes.c_int64), ('lt_nnz', ctypes.c_int64),
                 ('hub_seg_rowptr', ctypes.c_void_p), ('hub_colidx', ctypes.c_void_p), ('hub_val', ctypes.c_void_p),
                 ('hub_cmb_rowptr', ctypes.c_void_p), ('hub_cmb_colidx', ctypes.c_void_p), ('hub_cmb_val', ctypes.c_void_p),
                 ('lt_rowptr', ctypes.c_void_p), ('lt_colidx', ctypes.c_void_p), ('lt_val', ctypes.c_void_p),
                 ('hub_Sseg', ctypes.c_void_p), ('hub_S', ctypes.c_void_p)]
+
+
+def empty_csr(n_rows):
+    """struct ndcn_csr of an operator that is never applied (NDCN_F_NO_GRAPH): only n_rows is read."""
+    v = CsrView()
+    v.n_rows = v.n_cols = int(n_rows)
+    return v
 
 
 class SolverDesc(ctypes.Structure):

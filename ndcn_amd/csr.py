@@ -26,7 +26,8 @@ class CsrOperator:
         self._view = None
         self._t = None
         self.row_order = None        # optional int32 permutation: the order in which kernels walk the rows
-        self.union = None            # optional row-group union plan (build_union_plan)
+        self.rec = None              # optional group-record plan (build_rec_plan)
+        self.group_order = None      # optional int32 row ids (-1 = empty slot) in the order build_rec_plan groups them
         self.hub = None              # optional long-row plan (build_hub_plan)
 
     # ------------------------------------------------------------------ constructors
@@ -95,8 +96,10 @@ class CsrOperator:
         op = CsrOperator(self.rowptr.to(device), self.colidx.to(device), self.val.to(device), self.shape)
         if self.row_order is not None:
             op.row_order = self.row_order.to(device)
-        if self.union is not None:
-            op.union = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.union.items()}
+        if self.group_order is not None:
+            op.group_order = self.group_order.to(device)
+        if self.rec is not None:
+            op.rec = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.rec.items()}
         return op
 
     def set_row_order(self, order):
@@ -107,40 +110,123 @@ class CsrOperator:
         self._view = None
         return self
 
-    def build_union_plan(self, rows_per_group=8, cap=30):
-        """Row-group union plan (see include/ndcn_hip.h): per group of consecutive rows, the distinct columns
-        they reference and, per CSR entry, its index into that list.  One-off preprocessing with torch ops on
-        the operator's device; groups whose union exceeds `cap` get an empty range (the kernel gathers them
-        directly).  Returns the fraction of non-zeros served from a group union (0 = no reuse worth staging)."""
-        n, R = self.shape[0], int(rows_per_group)
+    REC_SHAPES = ((8, 32, 1), (16, 40, 2))       # {rows per group, column-list capacity, record KiB}: spmm_rec.hip
+
+    def build_rec_plan(self, rows_per_group=8, cap=32, kib=1):
+        """Group-record plan (include/ndcn_hip.h, struct ndcn_csr::rec): per group of rows that are consecutive in the
+        walk order (self.group_order - row ids with -1 padding -, self.row_order or 0..n-1) one fixed-size record = the group's distinct columns + per-row headers +
+        the rows' entries re-indexed into that column list.  One-off preprocessing with torch ops on the operator's
+        device, O(nnz log nnz).  Groups the record cannot hold (more than `cap` distinct columns, more entries than fit,
+        a row longer than 64) are flagged and gathered directly by the kernel.
+        Returns (fraction of non-zeros served from a staged group, rows staged into LDS per output row)."""
+        n, n_cols = self.shape
+        R, CAP, words = int(rows_per_group), int(cap), int(kib) * 256
+        E0 = CAP + 2 * R
+        ecap = (words - E0) // 2
         dev = self.device
-        ng = (n + R - 1) // R
-        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        i64 = torch.int64
+        if self.group_order is not None:                               # row ids, -1 = empty slot
+            order = self.group_order.to(i64)
+        elif self.row_order is not None:
+            order = self.row_order.to(i64)
+        else:
+            order = torch.arange(n, device=dev)
+        M = int(order.numel())
+        ng = (M + R - 1) // R
+        valid = order >= 0
+        pos = torch.empty(n, dtype=i64, device=dev)
+        pos[order[valid]] = torch.arange(M, device=dev)[valid]         # position of a row in the walk
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(i64)
         rows = torch.repeat_interleave(torch.arange(n, device=dev), counts)
-        grp = torch.div(rows, R, rounding_mode='floor')
-        key = grp * self.shape[1] + self.colidx.to(torch.int64)
+        e_pos = pos[rows]
+        e_grp = torch.div(e_pos, R, rounding_mode='floor')
+        e_i = e_pos - e_grp * R
+        # distinct columns per group, ascending
+        key = e_grp * n_cols + self.colidx.to(i64)
         uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
-        ugrp = torch.div(uniq, self.shape[1], rounding_mode='floor')
+        ugrp = torch.div(uniq, n_cols, rounding_mode='floor')
+        ucol = uniq - ugrp * n_cols
         usize = torch.bincount(ugrp, minlength=ng)
-        ok = usize <= cap                                   # groups that fit the LDS stage
-        uptr_all = torch.zeros(ng + 1, dtype=torch.int64, device=dev)
-        uptr_all[1:] = torch.cumsum(usize, 0)
-        keep_u = ok[ugrp]
-        kept_size = torch.where(ok, usize, torch.zeros_like(usize))
-        ptr = torch.zeros(ng + 1, dtype=torch.int64, device=dev)
-        ptr[1:] = torch.cumsum(kept_size, 0)
-        cols = (uniq - ugrp * self.shape[1])[keep_u]
-        lidx = inv - uptr_all[grp]                           # position of the entry's column inside its group
-        lidx = torch.where(ok[grp], lidx, torch.zeros_like(lidx))
-        staged_nnz = int(ok[grp].sum()) if self.nnz else 0
-        self.union = {'rows': R, 'cap': int(kept_size.max()) if ng else 0, 'ptr': ptr.to(torch.int32).contiguous(),
-                      'cols': cols.to(torch.int32).contiguous(),
-                      'lidx': lidx.to(torch.int16).contiguous(),       # < cap <= 65535; reinterpreted as uint16
-                      'loads_per_row': float(kept_size.sum() + (counts.sum() - staged_nnz)) / max(n, 1)}
-        if cols.numel() == 0:
-            self.union['cols'] = torch.zeros(1, dtype=torch.int32, device=dev)
+        ustart = torch.zeros(ng + 1, dtype=i64, device=dev)
+        ustart[1:] = torch.cumsum(usize, 0)
+        slot = inv - ustart[e_grp]
+        # per (group, row-in-group): row id, entry count, offset of its entries inside the group
+        grow = torch.full((ng * R,), -1, dtype=i64, device=dev)
+        grow[pos] = torch.arange(n, device=dev)
+        gcnt = torch.zeros(ng * R, dtype=i64, device=dev)
+        gcnt[pos] = counts
+        gcnt2 = gcnt.view(ng, R)
+        gofs = (torch.cumsum(gcnt2, 1) - gcnt2).reshape(-1)
+        gtot = gcnt2.sum(1)
+        fits = (usize <= CAP) & (gtot <= ecap) & (gcnt2.max(1).values <= 64)
+        rec = torch.zeros((ng, words), dtype=torch.int32, device=dev)
+        # column list, padded with the group's last column (an empty group reads row 0)
+        last = torch.where(usize > 0, ucol[(ustart[1:] - 1).clamp(min=0)], torch.zeros_like(usize))
+        rec[:, :CAP] = last.to(torch.int32).unsqueeze(1)
+        uslot = torch.arange(uniq.numel(), device=dev) - ustart[ugrp]
+        keep_u = fits[ugrp]
+        rec.view(-1)[(ugrp[keep_u] * words + uslot[keep_u])] = ucol[keep_u].to(torch.int32)
+        unfit_cols = ~fits
+        if bool(unfit_cols.any()):
+            rec[unfit_cols, :CAP] = 0
+        # headers
+        fit_row = fits.repeat_interleave(R)
+        meta = torch.where(fit_row, gcnt | (gofs << 16), torch.full_like(gcnt, 0xffff))
+        hdr = rec[:, CAP:E0].reshape(ng, R, 2)
+        hdr[:, :, 0] = grow.view(ng, R).to(torch.int32)
+        hdr[:, :, 1] = meta.view(ng, R).to(torch.int32)
+        # entries of the staged groups
+        keep_e = fits[e_grp]
+        q = torch.arange(self.nnz, device=dev) - self.rowptr.to(i64)[rows]
+        w = e_grp * words + E0 + 2 * (gofs[e_grp * R + e_i] + q)
+        flat = rec.view(-1)
+        flat[w[keep_e]] = slot[keep_e].to(torch.int32)
+        flat[w[keep_e] + 1] = self.val[keep_e].view(torch.int32)
+        staged_nnz = int(keep_e.sum()) if self.nnz else 0
+        loads = float(usize[fits].sum() + (self.nnz - staged_nnz)) / max(n, 1)
+        # the DMA waves read up to 2 D groups past the end of the walk of a workgroup only inside their own range, but
+        # keep one spare record so that a plan for zero groups still has an address
+        self.rec = {'rows': R, 'cap': CAP, 'kib': int(kib), 'groups': ng, 'rec': rec.contiguous(),
+                    'loads_per_row': loads, 'staged': staged_nnz / max(self.nnz, 1)}
         self._view = None
-        return staged_nnz / max(self.nnz, 1)
+        return self.rec['staged'], loads
+
+    def detect_stencil_order(self, px=4, py=4):
+        """If the operator is a 2-D lattice stencil in row-major node order (every entry's column is the row plus
+        a * S + b with |a|, |b| <= 2 for one stride S - the reference's grid graphs, utils_in_learn_dynamics.py:137-157,
+        handed over as plain tensors), return the group order that visits the lattice in px x py patches (the rows of a
+        patch share most of their neighbours: 36 distinct columns for 16 rows of the 8-neighbour grid instead of 54):
+        an int32 array of px * py slots per patch, -1 where a patch sticks out of the lattice.  None otherwise.  O(nnz)."""
+        n = self.shape[0]
+        if self.nnz == 0 or self.shape[0] != self.shape[1] or n < 64:
+            return None
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(n, device=self.device), counts)
+        off = torch.unique(self.colidx.to(torch.int64) - rows)
+        if off.numel() > 25:
+            return None
+        off = off.cpu().numpy()
+        big = off[off > 2]
+        if big.size == 0:
+            return None
+        # the smallest large offset is S - b_max with b_max <= 2: of the three strides that allows take the one that
+        # leaves the smallest in-row offsets
+        S, best_b = 0, 3
+        for cand in (int(big.min()), int(big.min()) + 1, int(big.min()) + 2):
+            a = np.rint(off / cand)
+            b = off - a * cand
+            if cand >= 8 and np.all(np.abs(a) <= 2) and np.abs(b).max() < best_b:
+                S, best_b = cand, int(np.abs(b).max())
+        if S == 0:
+            return None
+        # patches in row-major patch order, each padded to px * py slots (-1) so that groups never straddle patches
+        Rl = (n + S - 1) // S
+        PX, PY = (Rl + px - 1) // px, (S + py - 1) // py
+        x = (np.arange(PX)[:, None, None, None] * px + np.arange(px)[None, None, :, None])
+        y = (np.arange(PY)[None, :, None, None] * py + np.arange(py)[None, None, None, :])
+        node = x * S + y
+        node = np.where((x < Rl) & (y < S) & (node < n), node, -1)
+        return node.reshape(-1).astype(np.int32)
 
     def build_hub_plan(self, H, threshold=64, seg=256):
         """Long-row plan (see include/ndcn_hip.h, struct ndcn_csr): rows with more than `threshold` entries are cut
@@ -197,11 +283,11 @@ class CsrOperator:
         return int(hubs.size)
 
     def ensure_plans(self, H):
-        """One-off, lazy: attach the row-group union plan when the panel width has a kernel that uses it
-        (H = 256) and the graph has enough neighbour sharing between consecutive rows for it to pay."""
-        if H != 256 or self.union is not None or getattr(self, '_union_tried', False) or self.device.type != 'cuda':
+        """One-off, lazy: attach the operator plans the H = 256 kernels use - the long-row plan for skewed degree
+        distributions and the group-record plan when neighbouring rows share enough neighbours for staging to pay."""
+        if H != 256 or getattr(self, '_plans_tried', False) or self.device.type != 'cuda':
             return self
-        self._union_tried = True
+        self._plans_tried = True
         # Long-row plan: rows longer than the threshold leave the fused kernel.  Worth it only when such rows are the
         # exception (measured, 10^6 nodes: Barabasi-Albert m=5 36.8 -> 24.5 ms/step at threshold 32; G(n,p) with mean
         # degree 41, where a threshold of 32 moves nearly every row, 53 -> 57 ms/step): take the lowest threshold
@@ -218,15 +304,23 @@ class CsrOperator:
                 if env or n_hub <= 0.05 * self.shape[0]:
                     self.build_hub_plan(H, thr)
                     break
-        rows = int(os.environ.get('NDCN_UNION_ROWS', '8'))       # = the fused RHS kernel's row group
-        cap = int(os.environ.get('NDCN_UNION_CAP', '30'))        # LDS rows per staged group
-        if rows <= 0 or self.nnz == 0:
+        if os.environ.get('NDCN_REC_PLAN', '1') == '0' or self.nnz == 0:
             return self
-        self.build_union_plan(rows, cap)
+        # Group-record plan: with a lattice walk order (given by the caller or detected) 16-row patches, otherwise 8
+        # consecutive rows; kept when it covers the operator and stages clearly fewer rows than a direct gather fetches.
+        if self.group_order is None and self.row_order is None and os.environ.get('NDCN_REC_STENCIL', '1') != '0':
+            order = self.detect_stencil_order()
+            if order is not None:
+                self.group_order = torch.as_tensor(order, dtype=torch.int32).to(self.device)
         avg = self.nnz / max(self.shape[0], 1)
-        if self.union['loads_per_row'] > 0.75 * avg:        # < 25 % fewer fetches: not worth the LDS round trip
-            self.union = None
-            self._view = None
+        best = None
+        hinted = self.group_order is not None or self.row_order is not None
+        for shape in (self.REC_SHAPES[::-1] if hinted else self.REC_SHAPES[:1]):
+            staged, loads = self.build_rec_plan(*shape)
+            if staged >= 0.9 and loads <= 0.75 * avg and (best is None or loads < best[1]):
+                best = (self.rec, loads)
+        self.rec = best[0] if best is not None else None
+        self._view = None
         return self
 
     def view(self):
@@ -235,13 +329,11 @@ class CsrOperator:
             self._view = _lib.CsrView(self.shape[0], self.shape[1], self.nnz,
                                       self.rowptr.data_ptr(), self.colidx.data_ptr() if self.nnz else None,
                                       self.val.data_ptr() if self.nnz else None,
-                                      self.row_order.data_ptr() if self.row_order is not None else None,
-                                      0, 0, None, None, None)
-            if self.union is not None:
-                u = self.union
-                self._view.ug_rows, self._view.ug_cap = u['rows'], u['cap']
-                self._view.ug_ptr, self._view.ug_cols = u['ptr'].data_ptr(), u['cols'].data_ptr()
-                self._view.ug_lidx = u['lidx'].data_ptr()
+                                      self.row_order.data_ptr() if self.row_order is not None else None)
+            if self.rec is not None:
+                u = self.rec
+                self._view.rec_rows, self._view.rec_cap, self._view.rec_kib = u['rows'], u['cap'], u['kib']
+                self._view.rec_groups, self._view.rec = u['groups'], u['rec'].data_ptr()
             h = getattr(self, 'hub', None)
             if h is not None:
                 v = self._view

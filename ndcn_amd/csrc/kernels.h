@@ -26,6 +26,15 @@ int64_t rhs_fused2_partials_bytes();
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
                    float *K, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c,
                    int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
+// fixed-order sum of n {sum, bad} fp64 pairs into d_out[0..1] (one workgroup: deterministic accept / reject)
+int partials_finish(const double *partials, int n, double *d_out, hipStream_t st);
+int spmm_rec_supported(const ndcn_csr *A, int H);
+int spmm_rec_variant(int mode, int n_prev);
+int64_t spmm_rec_partials_bytes();
+// mode 0: Y = alpha (A X) [relu]; modes 1-3 (NDCN_RK_*): K = relu(A X) plus the RK algebra, as rhs_fused2_f32
+int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha, uint32_t flags,
+                 int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next,
+                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 

@@ -440,6 +440,12 @@ __global__ __launch_bounds__(256) void fused2_finish_kernel(const double *__rest
     if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
 }
 
+int partials_finish(const double *partials, int n, double *d_out, hipStream_t st) {
+    hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, partials, n, d_out);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 static int env_int3(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;

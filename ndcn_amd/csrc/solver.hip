@@ -64,7 +64,8 @@ struct ndcn_solver {
     // scalar state
     bool begun = false;
     bool fused = false;            // H = 256 fused RHS: `work` holds the packed weights
-    bool fused2 = false;           // ... and the operator has a union plan: RK algebra rides in the RHS epilogue
+    bool fused2 = false;           // the RK algebra rides in the epilogue of the RHS launches (rhs_epi)
+    bool rec_epi = false;          // ... of the group-record SpMM (no_control RHS) instead of the fused MFMA kernel
     float *ytmp2 = nullptr;        // second stage-input panel (fused2: a stage's input must outlive its epilogue)
     double t0 = 0, t1 = 0, dt = 0; // dopri5: last interval [t0, t1], next step size
     float tf = 0;                  // fixed grid: current time in the state dtype
@@ -127,12 +128,24 @@ int alloc_panel(ndcn_solver *s, float **p) {
 
 int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
     s->n_rhs++;
-    if (s->fused2)
+    if (s->fused2 && !s->rec_epi)
         return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, 0, nullptr,
                               nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st);
     if (s->fused)       // weights were packed once in solver_begin
         return rhs_fused_packed_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, st);
     return rhs_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, out, s->work, s->d.H, s->d.rhs_flags, st);
+}
+
+// right-hand side whose epilogue carries the stage algebra: the fused MFMA kernel (default RHS, H = 256) or the
+// group-record SpMM (no_control RHS)
+int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0, const float *const *kp, const float *cp,
+            int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
+    s->n_rhs++;
+    if (s->rec_epi)
+        return spmm_rec_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, 1.f, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next, rtol,
+                            atol, d_out, d_ws, st);
+    return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev,
+                          y_next, rtol, atol, d_out, d_ws, st);
 }
 
 // wait for the reduction record enqueued last on `st`
@@ -230,7 +243,6 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
         if (rc) return rc;
         float *in = s->ytmp;
         for (int i = 0; i < 6; ++i) {
-            s->n_rhs++;
             if (i < 5) {
                 float *out = (i == 4) ? s->ynext : (in == s->ytmp ? s->ytmp2 : s->ytmp);   // stage-6 input IS y1
                 int mp = 0;
@@ -242,8 +254,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
                     ++mp;
                 }
                 cp[mp] = dt32 * (float)kBeta[i + 1][i + 1];   // the K being produced, last term
-                rc = rhs_fused2_f32(&s->d.A, in, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[i + 1], s->d.rhs_flags, 1,
-                                    s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st);
+                rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st);
                 if (rc) return rc;
                 in = out;
             } else {
@@ -256,9 +267,8 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
                     ++mp;
                 }
                 cp[mp] = dt32 * (float)kCErr[6];
-                rc = rhs_fused2_f32(&s->d.A, in, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[6], s->d.rhs_flags, 2,
-                                    s->ycur, kp, cp, mp, nullptr, (float)s->d.rtol, (float)s->d.atol, s->d_red, s->d_ws2,
-                                    st);
+                rc = rhs_epi(s, in, s->k[6], 2, s->ycur, kp, cp, mp, nullptr, (float)s->d.rtol, (float)s->d.atol, s->d_red,
+                             s->d_ws2, st);
                 if (rc) return rc;
             }
         }
@@ -382,6 +392,10 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         const bool both = !(desc->rhs_flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
         s->fused = both && rhs_fused_supported(desc->H, desc->rhs_flags);
         s->fused2 = s->fused && rhs_fused2_supported(&desc->A, desc->H, desc->rhs_flags);
+        if (!no_graph && no_ctl && spmm_rec_supported(&desc->A, desc->H) && s->n_rows * (int64_t)1024 < (1ll << 32)) {
+            s->fused2 = true;                                   // same stepping, different launch (rhs_epi)
+            s->rec_epi = true;
+        }
     }
     const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;
     for (int j = 0; j < nk; ++j)
@@ -541,9 +555,7 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
     if (s->fused2 && s->d.method == NDCN_M_EULER && dst != s->ycur) {
         // y + dt * f in the RHS epilogue (one term: identical rounding to fixed_stage op 0)
         const float c1[1] = {dt};
-        s->n_rhs++;
-        rc = rhs_fused2_f32(&s->d.A, s->ycur, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[0], s->d.rhs_flags, 1, s->ycur,
-                            nullptr, c1, 0, dst, 0.f, 0.f, nullptr, nullptr, st);
+        rc = rhs_epi(s, s->ycur, s->k[0], 1, s->ycur, nullptr, c1, 0, dst, 0.f, 0.f, nullptr, nullptr, st);
         if (rc) return rc;
         s->ycur = dst;
         s->cur_is_borrowed = (dst != s->ycur_own);
@@ -562,9 +574,7 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
         const float *in = s->ycur;
         for (int i = 0; i < 4; ++i) {
             float *nxt = (i == 3) ? dst : (in == s->ytmp ? s->ytmp2 : s->ytmp);
-            s->n_rhs++;
-            rc = rhs_fused2_f32(&s->d.A, in, nullptr, s->d.A.n_cols, s->work, s->d.b, s->k[i], s->d.rhs_flags, 3, s->ycur, kp,
-                                c1, i, nxt, 0.f, 0.f, nullptr, nullptr, st);
+            rc = rhs_epi(s, in, s->k[i], 3, s->ycur, kp, c1, i, nxt, 0.f, 0.f, nullptr, nullptr, st);
             if (rc) return rc;
             in = nxt;
         }

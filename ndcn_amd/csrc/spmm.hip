@@ -245,140 +245,6 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Row-group union SpMM (H = 256): fetch each DISTINCT neighbour row of a group of consecutive rows once.
-//
-// Measured on MI355X (1M-node grid): the gather is bound by the CU's vector-memory pipe, not by HBM - a 1 KiB
-// wave load costs ~18 cycles of L1/TA time even when it hits, and every X row is loaded 9x (once per
-// neighbour): 0.36 ms of HBM time + 8 x 0.03 ms of L1 time + misses = 0.77 ms, with FETCH_SIZE already at
-// 1.2x the compulsory bytes.  Neighbouring rows share neighbours (a lattice row block of 16 rows references 54
-// distinct X rows for 144 non-zeros), so the plan in ndcn_csr::ug_* lets a workgroup stage the group's union in
-// LDS with 3.4 loads per row instead of 9 and serve the 9 reads per row from LDS (256 B/clk instead of 64).
-template <int U>
-__device__ __forceinline__ void lds_batch(int li, float v, int i, const f32x4 *s_x, int lane, f32x4 &acc) {
-    int ll[U];
-    float vv[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-        ll[q] = __builtin_amdgcn_readlane(li, i + q);
-        vv[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i + q));
-    }
-    f32x4 x[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q) x[q] = s_x[ll[q] * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < U; ++q) acc = vv[q] * x[q] + acc;
-}
-
-template <bool HALO, bool DMA>
-__global__ __launch_bounds__(256) void spmm_union_kernel(
-    const int *__restrict__ rowptr, const int *__restrict__ colidx, const float *__restrict__ val,
-    const int *__restrict__ ug_ptr, const int *__restrict__ ug_cols, const unsigned short *__restrict__ ug_lidx,
-    int ug_rows, const float *__restrict__ Xf, const float *__restrict__ Xhf, int n_own, float *__restrict__ Yf,
-    int n_rows, float alpha, int relu) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    f32x4 *s_x = reinterpret_cast<f32x4 *>(s_dyn);
-    const f32x4 *X = reinterpret_cast<const f32x4 *>(Xf);
-    const f32x4 *Xh = reinterpret_cast<const f32x4 *>(Xhf);
-    f32x4 *Y = reinterpret_cast<f32x4 *>(Yf);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = xcd_remap(blockIdx.x, gridDim.x);
-    const int u0 = ug_ptr[g];
-    const int nu = ug_ptr[g + 1] - u0;
-    const int r_lo = g * ug_rows;
-    const int r_hi = min(n_rows, r_lo + ug_rows);
-
-    if (nu > 0) {
-        // ---- index data of this wave's rows (2 per wave for 8-row groups) is requested first, so that after the
-        // barrier nothing but LDS reads stands between the wave and its stores
-        constexpr int kPre = 2;
-        int pj0[kPre], pj1[kPre], pli[kPre];
-        float pv[kPre];
-#pragma unroll
-        for (int i = 0; i < kPre; ++i) {
-            const int r = r_lo + wave + 4 * i;
-            pj0[i] = pj1[i] = 0; pli[i] = 0; pv[i] = 0.f;
-            if (r < r_hi) {
-                pj0[i] = rowptr[r]; pj1[i] = rowptr[r + 1];
-                if (lane < pj1[i] - pj0[i]) { pli[i] = ug_lidx[pj0[i] + lane]; pv[i] = val[pj0[i] + lane]; }
-            }
-        }
-        // ---- stage the union: wave w takes entries w, w+4, ...
-        if (DMA) {
-            // LDS-DMA: global -> LDS without a VGPR round trip; the LDS address is the wave-uniform row base,
-            // the hardware adds lane * 16
-            for (int u = wave; u < nu; u += 4) {
-                int c = ug_cols[u0 + u];
-                const f32x4 *p = X;
-                if (HALO && c >= n_own) { p = Xh; c -= n_own; }
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(p + (size_t)c * 64 + lane),
-                    (__attribute__((address_space(3))) void *)(s_x + u * 64), 16, 0, 0);
-            }
-        } else
-        // 8 fetches in flight per wave through registers
-        for (int base = wave; base < nu; base += 32) {
-            f32x4 x[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int u = base + 4 * q;
-                if (u < nu) {
-                    int c = ug_cols[u0 + u];
-                    const f32x4 *p = X;
-                    if (HALO && c >= n_own) { p = Xh; c -= n_own; }
-                    x[q] = p[(size_t)c * 64 + lane];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int u = base + 4 * q;
-                if (u < nu) s_x[u * 64 + lane] = x[q];
-            }
-        }
-        __syncthreads();
-        // ---- rows of the group from LDS
-        int slot = 0;
-        for (int r = r_lo + wave; r < r_hi; r += 4, ++slot) {
-            int j0, j1;
-            if (slot < kPre) { j0 = slot == 0 ? pj0[0] : pj0[1]; j1 = slot == 0 ? pj1[0] : pj1[1]; }
-            else { j0 = rowptr[r]; j1 = rowptr[r + 1]; }
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int jb = j0; jb < j1; jb += 64) {
-                const int cnt = min(64, j1 - jb);
-                int li = 0;
-                float v = 0.f;
-                if (slot < kPre && jb == j0) { li = slot == 0 ? pli[0] : pli[1]; v = slot == 0 ? pv[0] : pv[1]; }
-                else if (lane < cnt) { li = ug_lidx[jb + lane]; v = val[jb + lane]; }
-                int i = 0;
-                for (; i + 8 <= cnt; i += 8) lds_batch<8>(li, v, i, s_x, lane, acc);
-                if (i + 4 <= cnt) { lds_batch<4>(li, v, i, s_x, lane, acc); i += 4; }
-                if (i + 2 <= cnt) { lds_batch<2>(li, v, i, s_x, lane, acc); i += 2; }
-                if (i < cnt) lds_batch<1>(li, v, i, s_x, lane, acc);
-            }
-            f32x4 o = acc * alpha;
-            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            __builtin_nontemporal_store(o, &Y[(size_t)r * 64 + lane]);
-        }
-    } else {
-        // ---- union too large for the stage: gather this group directly
-        for (int r = r_lo + wave; r < r_hi; r += 4) {
-            const int j0 = rowptr[r], j1 = rowptr[r + 1];
-            f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-            for (int jb = j0; jb < j1; jb += 64) {
-                const int cnt = min(64, j1 - jb);
-                int c = 0;
-                float v = 0.f;
-                if (lane < cnt) { c = colidx[jb + lane]; v = val[jb + lane]; }
-                wide_chunk<1, HALO>(c, v, cnt, X, Xh, n_own, lane, acc);
-            }
-            f32x4 o = acc[0] * alpha;
-            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            __builtin_nontemporal_store(o, &Y[(size_t)r * 64 + lane]);
-        }
-    }
-}
-
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
@@ -445,28 +311,11 @@ static int dispatch_lpr(int slots, const ndcn_csr *A, const float *X, const floa
 int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
              uint32_t flags, hipStream_t st) {
     const bool vec = (H % 4 == 0) && aligned16(X) && aligned16(Y) && (Xh == nullptr || aligned16(Xh));
+    if (vec && spmm_rec_supported(A, H) && A->n_rows * (int64_t)1024 < (1ll << 32))     // operator carries a group-record plan
+        return spmm_rec_f32(A, X, Xh, n_own, Y, alpha, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr,
+                            nullptr, st);
     ProfScope prof(PROF_SPMM, st, 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * H * (double)(A->n_rows + A->n_cols),
                    2.0 * A->nnz * H);
-    if (vec && H == 256 && A->ug_ptr && A->ug_rows > 0 && A->ug_cap * 1024 <= 64 * 1024) {
-        static const int use_union = env_int("NDCN_SPMM_UNION", 1);
-        if (use_union) {
-            const int n_rows = (int)A->n_rows;
-            if (n_rows == 0) return NDCN_OK;
-            const int n_groups = (n_rows + A->ug_rows - 1) / A->ug_rows;
-            const size_t lds = (size_t)(A->ug_cap > 0 ? A->ug_cap : 1) * 1024;
-            const int relu = (flags & NDCN_F_RELU) ? 1 : 0;
-            static const int dma = env_int("NDCN_UNION_DMA", 0);
-#define NDCN_UNION(HALO_, DMA_)                                                                                       \
-    hipLaunchKernelGGL((spmm_union_kernel<HALO_, DMA_>), dim3(n_groups), dim3(256), lds, st, A->rowptr, A->colidx,    \
-                       A->val, A->ug_ptr, A->ug_cols, A->ug_lidx, (int)A->ug_rows, X, Xh, (int)n_own, Y, n_rows,      \
-                       alpha, relu)
-            if (Xh) { if (dma) NDCN_UNION(true, true); else NDCN_UNION(true, false); }
-            else { if (dma) NDCN_UNION(false, true); else NDCN_UNION(false, false); }
-#undef NDCN_UNION
-            NDCN_LAUNCH_CHECK();
-            return NDCN_OK;
-        }
-    }
     if (vec && H % 256 == 0 && H <= 1024) {
         static const int use_wide = env_int("NDCN_SPMM_WIDE", 1);
         if (use_wide) {

@@ -3,7 +3,7 @@ with Linear+Tanh -> ODEBlock2(ODEFunc) terminal -> Linear, trained by backprop t
 
 Kept: the flags of dgnn.py:24-70 that the differential model reads, cross-entropy on the training nodes, Adam
 (lr, weight decay), the per-epoch log line and the test report (dgnn.py:192-237), the README command
-(README.md:64); `--model resGCN` (dgnn.py:129-140) stacks ndcn_amd.ode_gcn.ResBlock.  The other
+(README.md:64), the `--dump` results file (dgnn.py:240-244,259-261); `--model resGCN` (dgnn.py:129-140) stacks ndcn_amd.ode_gcn.ResBlock.  The other
 --model choices (GCN / DeepGCN* / odeGCN) are static baselines outside
 the accelerated path.
 
@@ -11,6 +11,8 @@ the accelerated path.
         --T 1.2 --time_tick 16 --epochs 100 --weight_decay 0.024 --no_control --method dopri5 --alpha 0 --data_dir data
 """
 import argparse
+import datetime
+import os
 import time
 
 import numpy as np
@@ -71,25 +73,35 @@ def main(argv=None, data=None, quiet=False):
     adj, features, labels, idx_train, idx_val, idx_test = data
     say = (lambda *a, **k: None) if quiet else print
 
+    # model and optimiser are built ONCE, ahead of the --iter loop, as in the reference (dgnn.py:128-183): later
+    # iterations keep training the same model
+    num_classes = int(labels.max().item()) + 1
+    say('T : {}, time tick: {}'.format(args.T, args.time_tick))
+    t = torch.linspace(0, args.T, args.time_tick).float().to(device)
+    if args.model == 'resGCN':                                    # dgnn.py:129-140
+        from ..ode_gcn import ResBlock
+        model = nn.Sequential(
+            nn.Linear(features.shape[1], args.hidden, bias=True), nn.ReLU(inplace=True),
+            *[ResBlock(args.hidden, adj, dropout=args.dropout, normalize=args.normalize, Euler=args.Euler)
+              for _ in range(args.nHiddenLayers)],
+            nn.Linear(args.hidden, num_classes, bias=True)).to(device)
+    else:
+        model = nn.Sequential(
+            nn.Linear(features.shape[1], args.hidden, bias=True), nn.Tanh(),
+            ODEBlock2(ODEFunc(args.hidden, adj, dropout=args.dropout, no_control=args.no_control), t,
+                      rtol=args.rtol, atol=args.atol, method=args.method, terminal=True),
+            nn.Linear(args.hidden, num_classes, bias=True)).to(device)
+    optimizer = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    fout = None
+    if args.dump:                                                 # dgnn.py:240-244: one tab-separated line per iteration
+        os.makedirs('results', exist_ok=True)
+        fname = 'results/results_{}.txt'.format(datetime.datetime.now().__str__().replace(':', '-'))
+        fout = open(fname, 'w')
+        fout.write(vars(args).__str__() + '\n')
+        fout.write('Time\tLoss\tAccuracy\tStep\n')
+
     accs, t0 = [], time.time()
     for it in range(args.iter):
-        num_classes = int(labels.max().item()) + 1
-        say('T : {}, time tick: {}'.format(args.T, args.time_tick))
-        t = torch.linspace(0, args.T, args.time_tick).float().to(device)
-        if args.model == 'resGCN':                                # dgnn.py:129-140
-            from ..ode_gcn import ResBlock
-            model = nn.Sequential(
-                nn.Linear(features.shape[1], args.hidden, bias=True), nn.ReLU(inplace=True),
-                *[ResBlock(args.hidden, adj, dropout=args.dropout, normalize=args.normalize, Euler=args.Euler)
-                  for _ in range(args.nHiddenLayers)],
-                nn.Linear(args.hidden, num_classes, bias=True)).to(device)
-        else:
-            model = nn.Sequential(
-                nn.Linear(features.shape[1], args.hidden, bias=True), nn.Tanh(),
-                ODEBlock2(ODEFunc(args.hidden, adj, dropout=args.dropout, no_control=args.no_control), t,
-                          rtol=args.rtol, atol=args.atol, method=args.method, terminal=True),
-                nn.Linear(args.hidden, num_classes, bias=True)).to(device)
-        optimizer = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
         t_start = time.time()
         for epoch in range(args.epochs):
             te = time.time()
@@ -111,7 +123,8 @@ def main(argv=None, data=None, quiet=False):
                 'loss_val: {:.4f}'.format(loss_val.item()), 'acc_val: {:.4f}'.format(acc_val.item()),
                 'time: {:.4f}s'.format(time.time() - te))
         say('Optimization Finished!')
-        say('Total time elapsed: {:.4f}s'.format(time.time() - t_start))
+        t_total = time.time() - t_start
+        say('Total time elapsed: {:.4f}s'.format(t_total))
         model.eval()
         with torch.no_grad():
             output = model(features)
@@ -119,6 +132,12 @@ def main(argv=None, data=None, quiet=False):
             acc_test = accuracy(output[idx_test], labels[idx_test])
         print('Test set results:', 'loss= {:.4f}'.format(loss_test.item()), 'accuracy= {:.4f}'.format(acc_test.item()))
         accs.append(acc_test.item())
+        if fout is not None:                                      # dgnn.py:259-261 (its time_step column is the constant 0)
+            fout.write('{:.5f}\t{:.5f}\t{:.5f}\t{:.5f}\n'.format(t_total, loss_test.item(), acc_test.item(), 0))
+            fout.flush()
+    if fout is not None:
+        fout.close()
+        say('Dump results as: ' + fname)
     accs = np.array(accs)
     print('Total time: {:.4f}s;'.format(time.time() - t0))
     print('results: {:.3f}% (mean) +/- {:.3f}% (std), {:.3f}% (median);'.format(100 * accs.mean(), 100 * accs.std(), 100 * np.median(accs)))

@@ -171,8 +171,9 @@ def random_partition(sizes, p_in, p_out, seed=0):
     return _sym_csr(np.concatenate(us), np.concatenate(vs), n)
 
 
-def make_graph(network, n, seed=0, mean_degree=None):
-    """The five `--network` choices of the drivers (heat_dynamics.py:83-110) at arbitrary n.
+def make_graph(network, n, seed=0, mean_degree=None, layout=None):
+    """The five `--network` choices of the drivers (heat_dynamics.py:83-110) at arbitrary n; every network but the
+    grid is re-labelled by `layout` ('degree' / 'community' / None) as the reference does (:90,95,100,109).
 
     The reference's densities are quoted for n = 400 (ER p = 0.1, partition p = .25 / .01); at scale the
     same MEAN DEGREE is kept instead unless `mean_degree` is given."""
@@ -181,17 +182,71 @@ def make_graph(network, n, seed=0, mean_degree=None):
         return grid_8_neighbor(S)
     if network == 'random':
         deg = 39.9 if mean_degree is None else mean_degree
-        return erdos_renyi(n, min(1.0, deg / max(n - 1, 1)), seed)
-    if network == 'power_law':
-        return barabasi_albert(n, 5, seed)
-    if network == 'small_world':
-        return newman_watts_strogatz(n, 5, 0.5, seed)
-    if network == 'community':
+        G = erdos_renyi(n, min(1.0, deg / max(n - 1, 1)), seed)
+    elif network == 'power_law':
+        G = barabasi_albert(n, 5, seed)
+    elif network == 'small_world':
+        G = newman_watts_strogatz(n, 5, 0.5, seed)
+    elif network == 'community':
         n1, n2, n3 = int(n / 3), int(n / 3), int(n / 4)
         sizes = [n1, n2, n3, n - n1 - n2 - n3]
         scale = 400.0 / n
-        return random_partition(sizes, min(1.0, .25 * scale), min(1.0, .01 * scale), seed)
-    raise ValueError('unknown network %r' % network)
+        G = random_partition(sizes, min(1.0, .25 * scale), min(1.0, .01 * scale), seed)
+    else:
+        raise ValueError('unknown network %r' % network)
+    return reorder_nodes(G, layout)
+
+
+# ---------------------------------------------------------------------------------------------------
+# node layouts (the drivers' --layout)
+# ---------------------------------------------------------------------------------------------------
+
+def node_mapping(A, layout):
+    """new_index[old node] for the drivers' `--layout` choices (utils_in_learn_dynamics.py:212-230).
+
+    degree    : nodes ranked by degree, largest first; ties keep their original order (the reference's
+                `sorted(G.degree, key=deg, reverse=True)` is stable).  O(n log n) on the CSR row lengths.
+    community : the communities of networkx's greedy_modularity_communities (the reference's own dependency),
+                largest first, members in the order `list(frozenset)` yields - what the reference executes.  The
+                algorithm is networkx's pure-Python one: usable up to ~10^4..10^5 nodes, like the reference.
+    None      : identity (returns None)."""
+    if layout is None:
+        return None
+    A = A.tocsr()
+    n = A.shape[0]
+    if layout == 'degree':
+        deg = np.diff(A.indptr) + (A.diagonal() != 0)            # networkx counts a self loop twice
+        order = np.argsort(-deg.astype(np.int64), kind='stable')
+    elif layout == 'community':
+        import networkx as nx
+        from networkx.algorithms import community
+        G = nx.Graph()
+        G.add_nodes_from(range(n))
+        coo = A.tocoo()
+        keep = coo.row <= coo.col
+        G.add_edges_from(zip(coo.row[keep].tolist(), coo.col[keep].tolist()))
+        order = np.fromiter((v for c in community.greedy_modularity_communities(G) for v in list(c)), dtype=np.int64, count=n)
+    else:
+        raise ValueError('unknown layout %r' % (layout,))
+    new = np.empty(n, dtype=np.int64)
+    new[order] = np.arange(n, dtype=np.int64)
+    return new
+
+
+def reorder_nodes(A, layout):
+    """P A P^T for the node mapping of `layout`: new_A[map[i], map[j]] = A[i, j]
+    (networkx_reorder_nodes, utils_in_learn_dynamics.py:233-247).  O(nnz)."""
+    new = node_mapping(A, layout)
+    return A if new is None else permute_nodes(A, new)
+
+
+def permute_nodes(A, new_index):
+    """The matrix re-labelled by new_index[old] (rows and columns), as sorted CSR."""
+    new_index = np.asarray(new_index, dtype=np.int64)
+    coo = A.tocoo()
+    m = sp.csr_matrix((coo.data, (new_index[coo.row], new_index[coo.col])), shape=A.shape)
+    m.sort_indices()
+    return m
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -23,28 +23,19 @@ class GraphConvolution(nn.Module):
 
 
 class GCN(nn.Module):
-    """models.py:22-47: gc1 -> relu -> [conv_middle -> relu]* -> gc2 with dropout in front of every layer."""
+    """The GCN stack of models.py:22-47: dropout -> gc1 -> relu, `num_middle_layers` times dropout -> conv_middle[i] ->
+    relu, then dropout -> gc2 (logits, no activation).  Submodule names gc1 / gc2 / conv_middle are the reference's
+    state_dict keys."""
 
     def __init__(self, input_size, hidden_size, num_classes, dropout=0, num_middle_layers=0):
-        super(GCN, self).__init__()
-
+        super().__init__()
+        self.dropout = dropout
         self.gc1 = GraphConvolution(input_size, hidden_size)
         self.gc2 = GraphConvolution(hidden_size, num_classes)
-        self.dropout = dropout
-
-        self.conv_middle = nn.ModuleList([GraphConvolution(hidden_size, hidden_size) for i in range(num_middle_layers)])
+        self.conv_middle = nn.ModuleList(GraphConvolution(hidden_size, hidden_size) for _ in range(num_middle_layers))
 
     def forward(self, x, propagation_adj):
-        x = F.dropout(x, self.dropout, training=self.training)  # drop out for input
-        x = self.gc1.forward(x, propagation_adj)
-        x = F.relu(x)
-
-        for conv_middle in self.conv_middle:
-            x = F.dropout(x, self.dropout, training=self.training)  # drop out for input
-            x = conv_middle.forward(x, propagation_adj)
-            x = F.relu(x)
-
-        x = F.dropout(x, self.dropout, training=self.training)  # drop out for hidden layers
-        x = self.gc2.forward(x, propagation_adj)
-
-        return x
+        hidden_layers = [self.gc1] + list(self.conv_middle)
+        for layer in hidden_layers:
+            x = F.relu(layer(F.dropout(x, self.dropout, training=self.training), propagation_adj))
+        return self.gc2(F.dropout(x, self.dropout, training=self.training), propagation_adj)

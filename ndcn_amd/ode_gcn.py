@@ -43,23 +43,14 @@ class ResBlock(nn.Module):
     """ode_gcn.py:29-60."""
 
     def __init__(self, hidden_size, A, dropout=0, normalize=False, time_varying=False, Euler=False):
-        super(ResBlock, self).__init__()
-        self.hidden_size = hidden_size
-        self.dropout = dropout
-        self.dropout_layer = nn.Dropout(dropout)
-        self.A = A
-
-        #  Other tricks
-        self.normalize = normalize
-        self.time_varying = time_varying
-        if self.time_varying:
+        super().__init__()
+        self.hidden_size, self.A = hidden_size, A
+        self.dropout, self.dropout_layer = dropout, nn.Dropout(dropout)
+        self.normalize, self.time_varying, self.Euler = normalize, time_varying, Euler
+        if time_varying:                     # per-block weight: state_dict keys linear.weight / linear.bias
             self.linear = nn.Linear(hidden_size, hidden_size, bias=True)
-        self.Euler = Euler
-        if self.Euler:
-            self.time_step = nn.Parameter(torch.FloatTensor([0.1]))
-            nn.init.uniform_(self.time_step, 0, 1)
-        else:
-            self.time_step = 1
+        # learnable step of the residual update, drawn from U(0, 1) like the reference (ode_gcn.py:43-45); plain 1 otherwise
+        self.time_step = nn.Parameter(torch.empty(1).uniform_(0, 1)) if Euler else 1
 
     def forward(self, x):
         shortcut = x

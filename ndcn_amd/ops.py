@@ -109,7 +109,7 @@ class HipOps:
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
         lib = _lib.load()
         if no_graph:
-            view = _lib.CsrView(X.shape[0], X.shape[0], 0, None, None, None, None, 0, 0, None, None, None)
+            view = _lib.empty_csr(X.shape[0])
             view_ref = ctypes.byref(view)
             n_rows = X.shape[0]
         else:
@@ -146,7 +146,7 @@ class HipOps:
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
         lib = _lib.load()
         if no_graph:
-            view_ref = ctypes.byref(_lib.CsrView(X.shape[0], X.shape[0], 0, None, None, None, None, 0, 0, None, None, None))
+            view_ref = ctypes.byref(_lib.empty_csr(X.shape[0]))
             n_rows = X.shape[0]
         else:
             A = as_csr(A)

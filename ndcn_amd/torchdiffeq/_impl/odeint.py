@@ -109,7 +109,7 @@ class DeviceSolver:
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
         dev = odefunc.wt.weight.device
         if odefunc.no_graph:
-            view = _lib.CsrView(n_rows, n_rows, 0, None, None, None, None, 0, 0, None, None, None)
+            view = _lib.empty_csr(n_rows)
             self._keep = ()
         else:
             csr = as_csr(odefunc.A)

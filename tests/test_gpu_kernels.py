@@ -99,30 +99,99 @@ def test_spmm_dense_and_coo_inputs_match_reference_layouts(dev):
     assert np.abs(y_coo - d['out']).max() < 1e-5
 
 
-@pytest.mark.parametrize('rows,cap', [(16, 56), (8, 30), (4, 60)])
-def test_spmm_union_plan_kernel(dev, rows, cap):
-    """H = 256 with a row-group union plan: staged groups, fallback groups, long rows, halo - all must equal
-    the plain kernel bit for bit (same summation order)."""
+def _no_plan(A):
+    A._plans_tried = True                                         # keep the operator plan-free (direct-gather kernels)
+    return A
+
+
+@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2)])
+@pytest.mark.parametrize('side', [45, 64])
+def test_spmm_group_record_kernel(dev, shape, side):
+    """H = 256 with a group-record plan (spmm_rec.hip): staged groups, groups the record cannot hold (direct gather
+    inside the kernel), ragged last group, lattice patches sticking out of the grid, halo panel, alpha / relu - all
+    must equal the plan-free kernel bit for bit (same summation order)."""
     from ndcn_amd import hip, CsrOperator, graphs
-    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(45))                  # 2025 rows, staged
-    rnd = rand_csr(2025, 2025, 9, seed=5, hubs=2)                                    # no sharing -> fallback
+    n = side * side
+    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    rnd = rand_csr(n, n, 9, seed=5, hubs=2)                                          # no sharing, long rows -> direct
     mixed = sp.vstack([grid[:1000], rnd[1000:]]).tocsr()
-    X = torch.randn(2025, 256).to(dev)
-    for m in (grid, mixed, rnd):
+    X = torch.randn(n, 256).to(dev)
+    for m, hinted in ((grid, True), (grid, False), (mixed, False), (rnd, False)):
         m.sort_indices()
-        plain = CsrOperator.from_scipy(m, dev)
-        plain._union_tried = True                                                    # keep it plan-free
+        plain = _no_plan(CsrOperator.from_scipy(m, dev))
         ref = hip.spmm(plain, X)
-        A = CsrOperator.from_scipy(m, dev)
-        A._union_tried = True
-        A.build_union_plan(rows, cap)
+        A = _no_plan(CsrOperator.from_scipy(m, dev))
+        if hinted:
+            A.group_order = torch.as_tensor(A.detect_stencil_order(), dtype=torch.int32).to(dev)
+        staged, _ = A.build_rec_plan(*shape)
+        if m is grid and (hinted or shape[0] == 8):
+            assert staged == 1.0
+        if m is rnd:
+            assert staged < 0.05
+        assert A.view().rec_groups > 0
         assert torch.equal(hip.spmm(A, X), ref)
         assert torch.equal(hip.spmm(A, X, alpha=-1.5, relu=True), hip.spmm(plain, X, alpha=-1.5, relu=True))
-        # halo split
-        got = hip.spmm(A, X[:1200].contiguous(), X_halo=X[1200:].contiguous())
+        got = hip.spmm(A, X[:1200].contiguous(), X_halo=X[1200:].contiguous())      # halo split
         assert torch.equal(got, ref)
     ref64 = orc.spmm_f64(grid.indptr, grid.indices, grid.data, X.cpu().numpy())
-    assert np.abs(hip.spmm(A, X).cpu().numpy() - orc.spmm_f64(rnd.indptr, rnd.indices, rnd.data, X.cpu().numpy())).max() < 1e-3
+    assert np.abs(hip.spmm(CsrOperator.from_scipy(grid, dev), X).cpu().numpy() - ref64).max() < 1e-4
+
+
+def test_lattice_operator_gets_patch_plan_automatically(dev):
+    """A lattice operator handed over as a plain tensor (the reference's way) is recognised and gets the 16-row patch
+    plan; a random graph gets none."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(50))
+    A = CsrOperator.from_torch(torch.from_numpy(L.toarray()).to(dev))
+    A.ensure_plans(256)
+    assert A.rec is not None and A.rec['rows'] == 16 and A.rec['staged'] == 1.0 and A.rec['loads_per_row'] < 2.6
+    B = CsrOperator.from_scipy(rand_csr(2000, 2000, 9, seed=1), dev)
+    B.ensure_plans(256)
+    assert B.rec is None
+    X = torch.randn(2500, 256).to(dev)
+    assert torch.equal(hip.spmm(A, X), hip.spmm(_no_plan(CsrOperator.from_scipy(L, dev)), X))
+
+
+@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2)])
+def test_no_control_rhs_rk_epilogue_in_group_record_kernel(dev, shape):
+    """relu(A X) with the stage algebra in the SpMM's epilogue (the no_control RHS of the dgnn README command):
+    COMBINE with 0..5 earlier stages, ERROR, RK4 stages 0..3 - bit-identical to SpMM + the separate stage kernels."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    side, H = 41, 256
+    n = side * side
+    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    rnd = rand_csr(n, n, 7, seed=9)
+    for m in (grid, sp.vstack([grid[:800], rnd[800:]]).tocsr()):
+        m.sort_indices()
+        A = _no_plan(CsrOperator.from_scipy(m, dev))
+        A.group_order = torch.as_tensor(CsrOperator.from_scipy(grid, dev).detect_stencil_order(), dtype=torch.int32).to(dev)
+        A.build_rec_plan(*shape)
+        P = _no_plan(CsrOperator.from_scipy(m, dev))
+        g = torch.Generator().manual_seed(2)
+        X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+        ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+        cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+        K_ref = hip.rhs(P, X, None, None, no_control=True)
+        assert torch.equal(hip.rhs(A, X, None, None, no_control=True), K_ref)
+        for npv in range(6):
+            K, yn = hip.rhs_rk(A, X, None, None, 'combine', y0, ks[:npv], cs[:npv] + [cs[5]], no_control=True)
+            assert torch.equal(K, K_ref)
+            assert torch.equal(yn, hip.combine(y0, ks[:npv] + [K_ref], cs[:npv] + [cs[5]]))
+        for npv in (5, 3, 0) * 3:                                  # repeated: a premature read of a panel is a race
+            K, (s1, b1) = hip.rhs_rk(A, X, None, None, 'error', y0, ks[:npv], cs[:npv] + [cs[5]], rtol=1e-2, atol=1e-3,
+                                     no_control=True)
+            s2, b2 = hip.error(y0, X, ks[:npv] + [K_ref], cs[:npv] + [cs[5]], 1e-2, 1e-3)
+            assert torch.equal(K, K_ref) and abs(s1 - s2) <= 1e-9 * abs(s2) and b1 == b2 == 0.0
+        Xbad = X.clone()
+        Xbad[5, 7] = float('inf')
+        _, (_, bad) = hip.rhs_rk(A, Xbad, None, None, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3, no_control=True)
+        assert bad == 1.0
+        dt = np.float32(0.37)
+        for st in range(4):
+            K, yn = hip.rhs_rk(A, X, None, None, 'rk4', y0, ks[:st], [dt], no_control=True)
+            kk = ks[:st] + [K_ref]
+            want = hip.fixed_stage(2 + st, y0, *kk, dt=dt)
+            assert torch.equal(K, K_ref) and torch.equal(yn, want)
 
 
 def test_gather_rows(dev):
@@ -263,7 +332,7 @@ def test_long_row_plan_equals_in_kernel_gather(dev):
     assert A_plan.hub is not None and A_plan.hub['n'] == int((deg > A_plan.hub['threshold']).sum()) > 0
     assert A_plan.hub['nseg'] > A_plan.hub['n']                # at least one hub spans several segments
     A_ref = CsrOperator.from_scipy(m, dev)
-    A_ref._union_tried = True                                  # no plans: every row is gathered inside the kernel
+    _no_plan(A_ref)                                            # no plans: every row is gathered inside the kernel
     ref = hip.rhs(A_ref, X, W, b)
     assert torch.allclose(hip.rhs(A_plan, X, W, b), ref, rtol=1e-5, atol=1e-6)
     exact = torch.relu(torch.from_numpy((m.astype(np.float64) @ X.cpu().double().numpy())).to(dev) @ W.double().T + b.double())
@@ -297,7 +366,7 @@ def test_fused_rhs_every_row_length(dev, plans):
             del os.environ['NDCN_HUB_THRESHOLD']
         assert A.hub is not None
     else:
-        A._union_tried = True
+        _no_plan(A)
     g = torch.Generator().manual_seed(3)
     X = torch.rand(n, H, generator=g).to(dev)
     W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)

@@ -77,31 +77,66 @@ def test_algorithmic_bytes_of_the_metric_case():
     assert abs(graphs.spmm_bytes(10 ** 6, 8988004, 256) / 1e9 - 2.124) < 1e-3
 
 
-def test_union_plan_reconstructs_the_columns():
-    """CsrOperator.build_union_plan: ug_cols[ug_ptr[g] + ug_lidx[j]] == colidx[j] for every staged entry."""
+def _decode_rec(A):
+    """Rebuild (row -> columns, values) from a group-record plan; returns (rows seen, staged entries)."""
+    rec = A.rec['rec'].numpy()
+    R, CAP = A.rec['rows'], A.rec['cap']
+    E0 = CAP + 2 * R
+    rp, ci, va = A.rowptr.numpy(), A.colidx.numpy(), A.val.numpy()
+    seen, staged = [], 0
+    for g in range(rec.shape[0]):
+        r = rec[g]
+        cols = r[:CAP]
+        for i in range(R):
+            row, meta = int(r[CAP + 2 * i]), int(r[CAP + 2 * i + 1])
+            if row < 0:
+                continue
+            seen.append(row)
+            cnt, ofs = meta & 0xffff, meta >> 16
+            if cnt == 0xffff:                                   # group the record cannot hold: gathered from the CSR
+                continue
+            assert cnt == rp[row + 1] - rp[row] <= 64
+            e = r[E0 + 2 * ofs:E0 + 2 * (ofs + cnt)].reshape(-1, 2)
+            assert np.array_equal(cols[e[:, 0]], ci[rp[row]:rp[row + 1]])
+            assert np.array_equal(e[:, 1].view(np.float32), va[rp[row]:rp[row + 1]])
+            staged += cnt
+        live = np.unique(cols)
+        assert np.all(np.diff(cols[:live.size]) > 0) or live.size <= 1     # ascending, duplicate-free, then padding
+    return seen, staged
+
+
+def test_group_record_plan_reconstructs_the_operator():
+    """CsrOperator.build_rec_plan (include/ndcn_hip.h, ndcn_csr::rec): every row appears once, staged rows decode to
+    their CSR entries, groups that do not fit are flagged; lattice detection yields whole patches."""
     import torch
     from ndcn_amd import CsrOperator
     import scipy.sparse as sp
     rng = np.random.RandomState(0)
-    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(40))
-    rnd = sp.random(1600, 1600, density=0.01, random_state=rng, format='csr', dtype=np.float32)
+    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(37))          # side not a multiple of the patch
+    rnd = sp.random(1369, 1369, density=0.01, random_state=rng, format='csr', dtype=np.float32)
+    longrow = sp.vstack([grid[:500], sp.csr_matrix(np.ones((1, 1369), np.float32)), grid[501:]]).tocsr()
     mixed = sp.vstack([grid[:800], rnd[800:]]).tocsr()
-    for m, rows, cap in ((grid, 16, 56), (grid, 8, 30), (mixed, 16, 56), (rnd, 16, 56)):
+    for m, hinted in ((grid, True), (grid, False), (mixed, False), (rnd, False), (longrow, True)):
         m.sort_indices()
-        A = CsrOperator.from_scipy(m)
-        frac = A.build_union_plan(rows, cap)
-        u = A.union
-        ptr, cols, lidx = u['ptr'].numpy().astype(np.int64), u['cols'].numpy(), u['lidx'].numpy().astype(np.uint16).astype(np.int64)
-        r = np.repeat(np.arange(m.shape[0]), np.diff(m.indptr))
-        g = r // rows
-        staged = (ptr[g + 1] - ptr[g]) > 0
-        assert abs(staged.mean() - frac) < 1e-9
-        assert np.array_equal(cols[ptr[g[staged]] + lidx[staged]], m.indices[staged])
-        assert (ptr[1:] - ptr[:-1]).max() <= cap and u['cap'] == (ptr[1:] - ptr[:-1]).max()
-        for gi in np.unique(g[staged])[:50]:                      # union lists are ascending and duplicate-free
-            seg = cols[ptr[gi]:ptr[gi + 1]]
-            assert np.all(np.diff(seg) > 0)
-    assert frac == 0.0 or frac < 0.2          # the random matrix has (almost) no staged groups
+        for shape in CsrOperator.REC_SHAPES:
+            A = CsrOperator.from_scipy(m)
+            if hinted:
+                order = CsrOperator.from_scipy(grid).detect_stencil_order()
+                assert order is not None and order.size % 16 == 0 and sorted(order[order >= 0]) == list(range(1369))
+                A.group_order = torch.as_tensor(order)
+            frac, loads = A.build_rec_plan(*shape)
+            seen, staged = _decode_rec(A)
+            assert sorted(seen) == list(range(m.shape[0]))
+            assert abs(staged / m.nnz - frac) < 1e-9
+            if m is grid and (hinted or shape[0] == 8):
+                assert frac == 1.0 and loads < (2.3 if hinted and shape[0] == 16 else 4.1)
+            if m is rnd:
+                assert frac < 0.2
+            if m is longrow:
+                assert frac < 1.0                                   # the 1369-entry row's group is gathered directly
+    assert CsrOperator.from_scipy(rnd).detect_stencil_order() is None
+    five = sp.diags([1., 1., 1., 1., 1.], [-50, -1, 0, 1, 50], shape=(2500, 2500), format='csr', dtype=np.float32)
+    assert CsrOperator.from_scipy(five).detect_stencil_order() is not None    # 5-point stencil, stride 50
 
 
 def test_planetoid_loader_against_reference_steps():
@@ -124,3 +159,31 @@ def test_planetoid_loader_against_reference_steps():
     g = load_golden('operators_cora')
     ref_op = sp.csr_matrix((g['alpha00_data'], g['alpha00_indices'], g['alpha00_indptr']), shape=(2708, 2708))
     assert abs(adj.to_scipy() - ref_op).max() < 1e-7
+
+
+@pytest.mark.parametrize('net', ['random', 'power_law', 'small_world', 'community'])
+@pytest.mark.parametrize('layout', ['degree', 'community'])
+def test_node_layout_equals_reference_mapping(golden, net, layout):
+    """--layout (utils_in_learn_dynamics.py:212-247): fixture = the reference's generate_node_mapping on its own
+    networkx graphs at n = 400 and the re-labelled adjacency (tools/gen_golden.py gen_layout)."""
+    g = golden('layout_' + net)
+    n = g['indptr'].size - 1
+    A = sp.csr_matrix((np.ones(g['indices'].size, np.float32), g['indices'], g['indptr']), shape=(n, n))
+    new = graphs.node_mapping(A, layout)
+    assert np.array_equal(new, g['map_' + layout])
+    B = graphs.reorder_nodes(A, layout)
+    assert np.array_equal(B.indptr, g['new_indptr_' + layout]) and np.array_equal(B.indices, g['new_indices_' + layout])
+    # a relabelling: same degree multiset, symmetric, and undone by the inverse permutation
+    inv = np.empty(n, dtype=np.int64)
+    inv[new] = np.arange(n)
+    back = graphs.permute_nodes(B, inv)
+    assert (back != A).nnz == 0
+
+
+def test_make_graph_applies_layout():
+    A0 = graphs.make_graph('power_law', 300, seed=1)
+    A1 = graphs.make_graph('power_law', 300, seed=1, layout='degree')
+    deg = np.diff(A1.indptr)
+    assert np.all(deg[:-1] >= deg[1:])                       # degree layout: non-increasing degrees
+    assert sorted(np.diff(A0.indptr)) == sorted(deg)
+    assert graphs.make_graph('grid', 100, layout='degree').shape == (100, 100)   # the grid is never re-labelled

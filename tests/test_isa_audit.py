@@ -1,0 +1,26 @@
+"""ISA audit of the kernels that request vector memory from inline asm (hipcc does not know that the destination
+registers are written later): on every control-flow path from such a request to the first hand-placed wait no
+instruction may touch the destination registers (tools/audit_async_regs.py).  Cross-compiles on the CPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_group_record_kernels_never_touch_panels_in_flight(tmp_path):
+    asm = str(tmp_path / 'spmm_rec.s')
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', asm,
+                    os.path.join(ROOT, 'ndcn_amd', 'csrc', 'spmm_rec.hip')], check=True, stderr=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'audit_async_regs.py'), asm, 'spmm_rec_kernel'],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and 'TOTAL problems 0' in out.stdout, out.stdout[-2000:]
+    assert out.stdout.count('asm loads') == 16            # {8,16}-row shapes x halo x {plain, combine, error, rk4}
+    text = open(asm).read()
+    assert '.vgpr_spill_count: 0' in text and 'vgpr_spill_count:' in text
+    assert all(l.strip().endswith(' 0') for l in text.split('\n') if '.vgpr_spill_count:' in l)

@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    'spmm_union': {},                                              # row-group union plan (default on the lattice)
-    'spmm_wide': {'NDCN_SPMM_UNION': '0'},                         # direct gather, one row per wave (v_readlane broadcast)
-    'spmm_blocked': {'NDCN_SPMM_UNION': '0', 'NDCN_SPMM_WIDE': '0'},
+    'spmm_rec': {},                                                # group-record plan (default on lattices)
+    'spmm_rec_rows8': {'NDCN_REC_STENCIL': '0'},                   # ... without the lattice patch order
+    'spmm_wide': {'NDCN_REC_PLAN': '0'},                           # direct gather, one row per wave (v_readlane broadcast)
+    'spmm_blocked': {'NDCN_REC_PLAN': '0', 'NDCN_SPMM_WIDE': '0'},
     'rhs_fused': {},
     'rhs_unfused': {'NDCN_RHS_FUSED': '0'},
 }
@@ -68,7 +69,7 @@ def one(name, side=1000, H=256, reps=20):
         res.update(ms=ms, GBps=graphs.spmm_bytes(n, L.nnz, H) / ms / 1e6)
         if os.environ.get('NDCN_UNION_DMA'):
             plain = graphs.to_device(L, dev)
-            plain._union_tried = True
+            plain._plans_tried = True
             res['equal_to_plain'] = bool(torch.equal(hip.spmm(plain, X), Y))
         if os.environ.get('TILE'):       # order hint must not change the result
             Y0 = hip.spmm(graphs.to_device(L, dev), X)

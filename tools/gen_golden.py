@@ -442,7 +442,12 @@ def gen_layout():
         'small_world': nx.newman_watts_strogatz_graph(400, 5, 0.5, seed=seed),
         'community': nx.random_partition_graph([n1, n2, n3, n - n1 - n2 - n3], .25, .01, seed=seed),
     }
-    for name, G in graphs.items():
+    for name, G0 in graphs.items():
+        # canonical node order (labels ascending): nx.random_partition_graph inserts its nodes out of label order, and
+        # the reference's mapping breaks degree ties by insertion order - an adjacency matrix carries no such order
+        G = nx.Graph()
+        G.add_nodes_from(sorted(G0.nodes))
+        G.add_edges_from(sorted((min(u, v), max(u, v)) for u, v in G0.edges))
         A = sp.csr_matrix(nx.to_scipy_sparse_array(G, nodelist=range(n), format='csr'))
         A.sort_indices()
         out = dict(indptr=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32))
@@ -460,7 +465,7 @@ def gen_layout():
 
 def gen_gconv():
     """G12: the dense-A GraphConvolution that dgnn.py's star import exposes (neural_dynamics.py:163-176)."""
-    A = grid_operator(12, 'norm_lap')
+    _, A = grid_operator(12, 'norm_lap')
     torch.manual_seed(21)
     gc = ref_nd.GraphConvolution(7, 5, bias=True)
     gc_nb = ref_nd.GraphConvolution(7, 5, bias=False)

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ndcn_hip.h"
@@ -124,6 +125,119 @@ __global__ __launch_bounds__(64 * W) void spmm_pipe(const int *__restrict__ rowp
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Variant family "rec": every byte a group needs arrives by LDS-DMA at arithmetic addresses - no load of streamed
+// index data stands between a wave and its work.  Per group the plan holds one fixed-size RECORD
+//   words [0, CAP)            the union's column ids (padded by repetition)
+//   words [CAP, CAP + 2R)     per row {row id, cnt | ofs << 16}   (cnt 0xffff: the group does not fit - direct gather)
+//   words [CAP + 2R, ...)     the rows' entries as (slot, value) pairs, row after row
+// Roles: WD DMA waves (record of group it+2D, then the union rows of group it+D whose column ids they read out of the
+// record that landed earlier; their only waits are counted vmcnt on their own DMA) and WC compute waves (record +
+// rows out of LDS, plain stores; the compiler's own wait insertion is exact for them).  One barrier per group.
+template <int R, int WC, int WD, int CAP, int D, int RECW, int DBG>
+__global__ __launch_bounds__(64 * (WC + WD)) void spmm_rec(const int *__restrict__ rec, const float *__restrict__ Xf,
+                                                           float *__restrict__ Yf, int n_groups) {
+    constexpr int NBUF = D + 1, NREC = 2 * D + 1, CAPD = CAP / WD, RPW = R / WC, E0 = CAP + 2 * R;
+    static_assert(CAP % WD == 0 && R % WC == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane_off = lane * 16;
+    const unsigned lds_x = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)lds;
+    const unsigned lds_r = lds_x + NBUF * CAP * 1024;
+    const int *rbuf = reinterpret_cast<const int *>(lds) + NBUF * CAP * 256;
+
+    const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wpx = gridDim.x / kXcds;
+    const int chunk = (n_groups + kXcds - 1) / kXcds;
+    const int g_lo = xcd * chunk, g_hi = min(n_groups, g_lo + chunk);
+    const int g0 = g_lo + wg;
+    if (g0 >= g_hi) return;
+    const int my = (g_hi - g0 + wpx - 1) / wpx;
+
+    if (wave < WD) {
+        const int d = wave;
+        auto dma_rec = [&](int it) {
+            if (d < RECW && it < my)
+                dma_row(reinterpret_cast<const float *>(rec + ((size_t)(g0 + it * wpx) * RECW + d) * 256),
+                        lds_r + (unsigned)(((it % NREC) * RECW + d) * 1024), lane_off);
+        };
+        auto dma_x = [&](int it) {
+            const int *r = rbuf + (it % NREC) * RECW * 256 + d * CAPD;
+            int cc[CAPD];
+#pragma unroll
+            for (int k = 0; k < CAPD; ++k) cc[k] = __builtin_amdgcn_readfirstlane(r[k]);
+#pragma unroll
+            for (int k = 0; k < CAPD; ++k)
+                dma_row(Xf + (size_t)cc[k] * 256, lds_x + (unsigned)(((it % NBUF) * CAP + d * CAPD + k) * 1024), lane_off);
+        };
+        for (int it = 0; it < 2 * D; ++it) dma_rec(it);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it < D; ++it)
+            if (it < my) dma_x(it);
+        for (int it = 0; it < my; ++it) {
+            // the union rows of group `it` (and the record issued just ahead of them) must have landed; younger ops of
+            // this wave in steady state: D - 1 iterations of DMA
+            if (it >= D && it + 2 * D <= my) {
+                if (d < RECW) wait_vmcnt<(D - 1) * (CAPD + 1)>();
+                else wait_vmcnt<(D - 1) * CAPD>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            dma_rec(it + 2 * D);
+            if (it + D < my) dma_x(it + D);
+        }
+        wait_vmcnt<0>();
+    } else {
+        const int c = wave - WD;
+        f32x4 *Y = reinterpret_cast<f32x4 *>(Yf);
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it < my; ++it) {
+            __builtin_amdgcn_s_barrier();
+            const int *r = rbuf + (it % NREC) * RECW * 256;
+            const f32x4 *xb = reinterpret_cast<const f32x4 *>(lds) + (it % NBUF) * CAP * 64;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int i = c + WC * q;
+                const int row = __builtin_amdgcn_readfirstlane(r[CAP + 2 * i]);
+                const int meta = __builtin_amdgcn_readfirstlane(r[CAP + 2 * i + 1]);
+                const int cnt = meta & 0xffff, ofs = meta >> 16;
+                int es = 0;
+                float ev = 0.f;
+                if (lane < cnt) { es = r[E0 + 2 * (ofs + lane)]; ev = __builtin_bit_cast(float, r[E0 + 2 * (ofs + lane) + 1]); }
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                auto chunk_u = [&](auto U_, int base) {
+                    constexpr int U = decltype(U_)::value;
+                    int sl[U];
+                    float vv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        sl[u] = __builtin_amdgcn_readlane(es, base + u);
+                        vv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), base + u));
+                    }
+                    f32x4 x[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) x[u] = xb[sl[u] * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = fma4(vv[u], x[u], acc);
+                };
+                if (!(DBG & 4)) {
+                    int j = 0;
+                    for (; cnt - j >= 8; j += 8) chunk_u(std::integral_constant<int, 8>{}, j);
+                    const int m = cnt - j;
+                    if (m & 4) { chunk_u(std::integral_constant<int, 4>{}, j); j += 4; }
+                    if (m & 2) { chunk_u(std::integral_constant<int, 2>{}, j); j += 2; }
+                    if (m & 1) chunk_u(std::integral_constant<int, 1>{}, j);
+                }
+                if (!(DBG & 1)) __builtin_nontemporal_store(acc, &Y[(size_t)row * 64 + lane]);
+                else if (acc.x == 1.2345e-30f) Y[(size_t)row * 64 + lane] = acc;
+            }
+        }
+    }
+}
+
 // plain persistent row copy (one row per wave, 8 in flight): the ceiling of "read 1 KiB rows, write 1 KiB rows"
 __global__ __launch_bounds__(256) void row_copy(const f32x4 *__restrict__ X, f32x4 *__restrict__ Y, int n_rows) {
     const int lane = threadIdx.x & 63;
@@ -200,6 +314,46 @@ static bool build_plan(const Csr &A, const std::vector<int> &order, int R, int W
             const int r = P.grp_rows[(size_t)g * R + i];
             for (int j = A.rp[r]; j < A.rp[r + 1]; ++j)
                 P.lidx[j] = (int)(std::lower_bound(u.begin(), u.end(), A.ci[j]) - u.begin());
+        }
+    }
+    P.loads_per_row = (double)total / A.n;
+    return true;
+}
+
+
+struct RecPlan { int n_groups; std::vector<int> rec; double loads_per_row; int unfit; };
+static bool build_rec(const Csr &A, const std::vector<int> &order, int R, int CAP, int RECW, RecPlan &P) {
+    const int words = RECW * 256, E0 = CAP + 2 * R, ecap = (words - E0) / 2;
+    P.n_groups = (A.n + R - 1) / R;
+    P.rec.assign((size_t)P.n_groups * words, 0);
+    P.unfit = 0;
+    std::vector<int> u;
+    size_t total = 0;
+    for (int g = 0; g < P.n_groups; ++g) {
+        int *rec = &P.rec[(size_t)g * words];
+        u.clear();
+        int rows[64];
+        size_t ne = 0;
+        for (int i = 0; i < R; ++i) {
+            rows[i] = order[std::min(A.n - 1, g * R + i)];
+            for (int j = A.rp[rows[i]]; j < A.rp[rows[i] + 1]; ++j) u.push_back(A.ci[j]);
+            ne += A.rp[rows[i] + 1] - A.rp[rows[i]];
+        }
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        if ((int)u.size() > CAP || (int)ne > ecap) { fprintf(stderr, "group %d does not fit (union %zu, entries %zu)\n", g, u.size(), ne); ++P.unfit; return false; }
+        total += u.size();
+        for (int s = 0; s < CAP; ++s) rec[s] = u[std::min<size_t>(s, u.size() - 1)];
+        int ofs = 0;
+        for (int i = 0; i < R; ++i) {
+            const int r = rows[i], cnt = A.rp[r + 1] - A.rp[r];
+            rec[CAP + 2 * i] = r;
+            rec[CAP + 2 * i + 1] = cnt | (ofs << 16);
+            for (int j = A.rp[r]; j < A.rp[r + 1]; ++j) {
+                rec[E0 + 2 * (ofs + j - A.rp[r])] = (int)(std::lower_bound(u.begin(), u.end(), A.ci[j]) - u.begin());
+                memcpy(&rec[E0 + 2 * (ofs + j - A.rp[r]) + 1], &A.va[j], 4);
+            }
+            ofs += cnt;
         }
     }
     P.loads_per_row = (double)total / A.n;
@@ -349,6 +503,45 @@ int main(int argc, char **argv) {
         RUN_PIPE("pipe_p4x8", A, X, o, 32, 16, 4, 2, 0, 1, alg, "4x8 lattice patches, 16 waves (cap 64)");
         o = patch_order(2, 8);
         RUN_PIPE("pipe_p2x8w16", A, X, o, 16, 16, 3, 3, 0, 1, alg, "2x8 lattice patches, 16 waves (cap 48)");
+    }
+
+#define RUN_REC(NAME, CSR, ORDER, R_, WC_, WD_, CAP_, D_, RECW_, DBG_, BPC, BYTES, NOTE)                                      \
+    do {                                                                                                                       \
+        RecPlan P;                                                                                                             \
+        if (!build_rec(CSR, ORDER, R_, CAP_, RECW_, P)) break;                                                                 \
+        int *p_rec = dev(P.rec, 1024);                                                                                         \
+        const size_t ldsb = (size_t)((D_ + 1) * CAP_ + (2 * D_ + 1) * RECW_) * 1024;                                           \
+        auto kern = spmm_rec<R_, WC_, WD_, CAP_, D_, RECW_, DBG_>;                                                             \
+        HIPCHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));              \
+        HIPCHECK(hipMemset(dY, 0xff, (size_t)n * 1024));                                                                       \
+        float ms = timeit(reps, [&] { hipLaunchKernelGGL(kern, dim3(256 * BPC), dim3(64 * (WC_ + WD_)), ldsb, 0, p_rec, dX, dY, P.n_groups); }); \
+        char note[256];                                                                                                        \
+        snprintf(note, sizeof note, "%s; R %d WC %d WD %d CAP %d D %d RECW %d lds %zu KiB, %d WG/CU, %.2f staged rows per row", NOTE, R_, WC_, WD_, CAP_, D_, RECW_, ldsb >> 10, BPC, P.loads_per_row); \
+        report(NAME, ms, BYTES, DBG_ ? -1 : check(CSR, X, dY, NAME), note);                                                    \
+        (void)hipFree(p_rec);                                                                                                  \
+    } while (0)
+
+    RUN_REC("rec_identity", I, consec, 8, 8, 2, 8, 2, 1, 0, 1, 2048.0 * n, "identity (copy ceiling of this pipeline)");
+    RUN_REC("rec_identity_b2", I, consec, 8, 8, 2, 8, 2, 1, 0, 2, 2048.0 * n, "identity, 2 WG/CU");
+    RUN_REC("rec_identity_d4", I, consec, 8, 8, 2, 8, 4, 1, 0, 1, 2048.0 * n, "identity, depth 4");
+    RUN_REC("rec_r8_d2_wd2", A, consec, 8, 8, 2, 32, 2, 1, 0, 1, alg, "8 consecutive rows");
+    RUN_REC("rec_r8_d2_wd4", A, consec, 8, 8, 4, 32, 2, 1, 0, 1, alg, "8 consecutive rows");
+    RUN_REC("rec_r8_d3_wd4", A, consec, 8, 8, 4, 32, 3, 1, 0, 1, alg, "8 consecutive rows");
+    RUN_REC("rec_r8_d1_wd4_b2", A, consec, 8, 8, 4, 32, 1, 1, 0, 2, alg, "8 consecutive rows, 2 WG/CU");
+    RUN_REC("rec_r8_d2_wd4_nostore", A, consec, 8, 8, 4, 32, 2, 1, 1, 1, alg, "diagnostic: no stores");
+    RUN_REC("rec_r8_d2_wd4_nosum", A, consec, 8, 8, 4, 32, 2, 1, 4, 1, alg, "diagnostic: no LDS row reads / sums");
+    RUN_REC("rec_r16_d1", A, consec, 16, 8, 4, 56, 1, 2, 0, 1, alg, "16 consecutive rows");
+    {
+        std::vector<int> o = patch_order(2, 4);
+        RUN_REC("rec_p2x4_d2", A, o, 8, 8, 4, 24, 2, 1, 0, 1, alg, "2x4 patches");
+        RUN_REC("rec_p2x4_d2_b2", A, o, 8, 8, 4, 24, 2, 1, 0, 2, alg, "2x4 patches, 2 WG/CU");
+        RUN_REC("rec_p2x4_d3", A, o, 8, 8, 4, 24, 3, 1, 0, 1, alg, "2x4 patches");
+        RUN_REC("rec_p2x4_d4", A, o, 8, 8, 4, 24, 4, 1, 0, 1, alg, "2x4 patches");
+        o = patch_order(4, 4);
+        RUN_REC("rec_p4x4_d2", A, o, 16, 8, 4, 40, 2, 2, 0, 1, alg, "4x4 patches");
+        RUN_REC("rec_p4x4_d1_b2", A, o, 16, 8, 4, 36, 1, 2, 0, 2, alg, "4x4 patches, 2 WG/CU");
+        o = patch_order(4, 8);
+        RUN_REC("rec_p4x8_d1", A, o, 32, 8, 4, 60, 1, 3, 0, 1, alg, "4x8 patches");
     }
     return 0;
 }
