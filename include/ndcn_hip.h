@@ -245,6 +245,9 @@ typedef struct ndcn_solver_desc {
     const float *W, *b;       /* nullable under NO_CONTROL                                            */
     double   rtol, atol;      /* dopri5                                                               */
     int64_t  max_num_steps;   /* dopri5.py:61 (2^31-1 in the reference)                               */
+    double   safety, ifactor, dfactor;   /* dopri5 step-size controller (dopri5.py:60,72-74; misc.py:160-170); the
+                                            reference's defaults pass through a float32 tensor: (double)0.9f, 10, (double)0.2f.
+                                            Values <= 0 select those defaults.                                  */
 } ndcn_solver_desc;
 
 NDCN_API int64_t ndcn_solver_workspace_bytes(const ndcn_solver_desc *desc);

@@ -56,7 +56,8 @@ class SolverDesc(ctypes.Structure):
     """struct ndcn_solver_desc"""
     _fields_ = [('method', ctypes.c_int), ('H', ctypes.c_int), ('rhs_flags', ctypes.c_uint32),
                 ('use_graph', ctypes.c_int), ('A', CsrView), ('W', ctypes.c_void_p), ('b', ctypes.c_void_p),
-                ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('max_num_steps', ctypes.c_int64)]
+                ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('max_num_steps', ctypes.c_int64),
+                ('safety', ctypes.c_double), ('ifactor', ctypes.c_double), ('dfactor', ctypes.c_double)]
 
 
 _P, _I, _L, _F, _D, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_uint32

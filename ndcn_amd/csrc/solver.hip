@@ -292,14 +292,17 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
     const float ratio = (float)(sum / (double)s->n_elem);
     const bool accept = ratio <= 1.f;
     // misc.py:160-170.  safety / dfactor passed through a float32 tensor in the reference (dopri5.py:72-74)
+    const double safety = s->d.safety > 0 ? s->d.safety : (double)0.9f;
+    const double ifactor = s->d.ifactor > 0 ? s->d.ifactor : 10.0;
+    const double dfactor = s->d.dfactor > 0 ? s->d.dfactor : (double)0.2f;
     double dt_next;
     if (ratio == 0.f) {
-        dt_next = dt * 10.0;
+        dt_next = dt * ifactor;
     } else {
-        const double dfac = ratio < 1.f ? 1.0 : (double)0.2f;
+        const double dfac = ratio < 1.f ? 1.0 : dfactor;
         const double er = (double)sqrtf(ratio);
         const double expo = (double)0.2f;
-        const double factor = nan_max(1.0 / 10.0, nan_min(pow(er, expo) / (double)0.9f, 1.0 / dfac));
+        const double factor = nan_max(1.0 / ifactor, nan_min(pow(er, expo) / safety, 1.0 / dfac));
         dt_next = dt / factor;
     }
     s->n_attempt++;

@@ -3,7 +3,8 @@ mutualistic_dynamics.py - they differ only in the ground-truth dynamics) on the 
 
 Kept from the reference: flag names and defaults (heat_dynamics.py:19-64), the graph choices
 (:83-110), the equal / irregular time split (:121-147), the operator choices (:150-167), the three-block
-initial image (:178-182), the truth solve with dopri5 at odeint's default tolerances (:207-209), the model
+initial image (:178-182), the `--layout` node re-labelling of the non-grid networks (:90-109;
+utils_in_learn_dynamics.py:212-247), the truth solve with dopri5 at odeint's default tolerances (:207-209), the model
 variants (:245-268), Adam + L1 / relative-L1 (:295-321), the log line formats (:374-388), the dump dictionary
 keys and file naming (:300-311, :434-438).  Different by construction: graphs and operators are built in O(nnz)
 (ndcn_amd/graphs.py, so --n can be 10^6), everything runs on the ROCm device, `--seed` also seeds torch / numpy
@@ -96,7 +97,9 @@ def main(kind, argv=None):
 
     # ---- graph, operators, initial value
     print('Choose graph: ' + args.network)
-    A = graphs.make_graph(args.network, args.n, seed=args.seed)
+    # every network but the grid is re-labelled by --layout, as heat_dynamics.py:90,95,100,109 (the x0 image is indexed
+    # by node position, so the node order is part of the learning problem)
+    A = graphs.make_graph(args.network, args.n, seed=args.seed, layout=args.layout)
     n = A.shape[0]
     S = int(np.ceil(np.sqrt(n)))
     L = graphs.laplacian(A)

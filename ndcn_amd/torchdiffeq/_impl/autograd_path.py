@@ -24,9 +24,9 @@ from . import core
 f32 = np.float32
 
 
-def odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=False):
+def odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=False, step_log=None):
     if method == 'dopri5':
-        return integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=autonomous, **options)
+        return integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=autonomous, step_log=step_log, **options)
     if options:
         raise NotImplementedError('fixed-grid options %s: only the default grid (grid == t) is provided' % sorted(options))
     return core.integrate_fixed(autograd_ops, func, y0, t, method, autonomous=autonomous)
@@ -198,12 +198,16 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
     dtype = y0[0].dtype
     targ = core.TimeArg(y0[0], autonomous)
     tt = t.detach().to('cpu', torch.float64)
-    max_steps = options.get('max_num_steps', 2 ** 31 - 1)
-    safety = torch.tensor(core.SAFETY, dtype=torch.float64)
+    opt = core.dopri5_options(options, len(y0))                    # same validation / warnings as the inference path
+    max_steps = opt['max_num_steps']
+    safety = torch.tensor(opt['safety'], dtype=torch.float64)
+    ifactor, dfactor = opt['ifactor'], opt['dfactor']
+    rtols, atols = core.per_state_tolerance(rtol, len(y0)), core.per_state_tolerance(atol, len(y0))
+    rtol, atol = rtols[0], atols[0]                                # dopri5.py:80: the initial step uses the first pair
     bad = []
     f_cur = func(targ(f32(tt[0].item())), y0)
     nfe = 2
-    if options.get('first_step') is None:
+    if opt['first_step'] is None:
         dt = _initial_step(func, targ, tt[0].item(), y0, 4, rtol, atol, f_cur, bad).to(torch.float64)
     else:
         dt = torch.tensor(0.01, dtype=torch.float64)
@@ -233,18 +237,18 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             y1 = yi
             f1 = tuple(k_[-1] for k_ in k)
             bads = []
-            ratios = [_error_ratio(a_, b_, k_, [dts * c for c in core.DP_C_ERR], rtol, atol, bads)
-                      for a_, b_, k_ in zip(y_cur, y1, k)]
+            ratios = [_error_ratio(a_, b_, k_, [dts * c for c in core.DP_C_ERR], rt_, at_, bads)
+                      for a_, b_, k_, rt_, at_ in zip(y_cur, y1, k, rtols, atols)]
             accept = bool((torch.stack([r.detach() for r in ratios]) <= 1).all())      # dopri5.py:109
             worst = max(ratios)
             # misc.py:160-170
             if worst.item() == 0:
-                dt_next = dt * core.IFACTOR
+                dt_next = dt * ifactor
             else:
-                dfac = 1.0 if worst.item() < 1 else core.DFACTOR
+                dfac = 1.0 if worst.item() < 1 else dfactor
                 er = torch.sqrt(worst).to(torch.float64)
                 expo = torch.tensor(1 / 5).to(torch.float64)
-                factor = torch.max(torch.tensor(1 / core.IFACTOR, dtype=torch.float64),
+                factor = torch.max(torch.tensor(1 / ifactor, dtype=torch.float64),
                                    torch.min(er ** expo / safety, torch.tensor(1 / dfac, dtype=torch.float64)))
                 dt_next = dt / factor
             if step_log is not None:

@@ -193,29 +193,63 @@ def select_initial_step(ops, func, targ, t0, y0, order, rtol, atol, f0):
     return float(min(h100, h1)), bad0
 
 
-def optimal_step_size(dt, ratio32):
+def optimal_step_size(dt, ratio32, safety=SAFETY, ifactor=IFACTOR, dfactor=DFACTOR):
     """misc.py:160-170 in float64 with the reference's float32-born constants."""
     if ratio32 == 0:
-        return dt * IFACTOR
-    dfac = 1.0 if ratio32 < 1 else DFACTOR
+        return dt * ifactor
+    dfac = 1.0 if ratio32 < 1 else dfactor
     er = float(np.sqrt(f32(ratio32)))
     expo = float(f32(0.2))
-    factor = _nan_max(1.0 / IFACTOR, _nan_min(math.pow(er, expo) / SAFETY if er == er else float('nan'), 1.0 / dfac))
+    factor = _nan_max(1.0 / ifactor, _nan_min(math.pow(er, expo) / safety if er == er else float('nan'), 1.0 / dfac))
     return dt / factor
+
+
+DOPRI5_OPTIONS = ('first_step', 'safety', 'ifactor', 'dfactor', 'max_num_steps')
+
+
+def controller_constant(v):
+    """dopri5.py:72-74: `_convert_to_tensor(v, dtype=float64)` - a python number passes through torch.tensor (float32)
+    first, a tensor keeps its own precision."""
+    if torch.is_tensor(v):
+        return float(v.detach().to(torch.float64))
+    return float(f32(v))
+
+
+def dopri5_options(options, n_state):
+    """Validated solver options shared by every dopri5 path: warns about unknown names exactly as the reference
+    (`_handle_unused_kwargs`, misc.py:79-81) and returns the controller constants as float64 python floats."""
+    unused = {k: v for k, v in options.items() if k not in DOPRI5_OPTIONS}
+    if unused:
+        warnings.warn('Dopri5Solver: Unexpected arguments {}'.format(unused))
+    return {'first_step': options.get('first_step'),
+            'safety': controller_constant(options.get('safety', 0.9)),
+            'ifactor': controller_constant(options.get('ifactor', 10.0)),
+            'dfactor': controller_constant(options.get('dfactor', 0.2)),
+            'max_num_steps': int(options.get('max_num_steps', 2 ** 31 - 1))}
+
+
+def per_state_tolerance(tol, n_state):
+    """dopri5.py:69-70: a scalar tolerance applies to every state tensor, an iterable gives one per tensor."""
+    if isinstance(tol, (list, tuple)) or (torch.is_tensor(tol) and tol.dim() > 0):
+        tol = [float(v) for v in tol]
+        assert len(tol) == n_state, 'one tolerance per state tensor expected'
+        return tol
+    return [float(tol)] * n_state
 
 
 class Dopri5:
     """dopri5.py:58-122 as a resumable object: begin() = before_integrate, advance() = advance."""
 
     def __init__(self, ops, func, y0, rtol, atol, autonomous=False, max_num_steps=2 ** 31 - 1, first_step=None,
-                 fused=None):
+                 fused=None, safety=SAFETY, ifactor=IFACTOR, dfactor=DFACTOR):
         """`fused`: optional object with rhs_rk(x, mode, y0, kprev, cs, rtol, atol) -> (k, y_next | (sum, bad)):
         the right-hand side that also performs the stage algebra consuming its result (ndcn_rhs_rk_f32).
         Single-tensor states only; the step then costs 1 combine + 6 fused evaluations."""
         self.ops, self.func = ops, func
         self.fused = fused if len(y0) == 1 else None
         self.y = y0
-        self.rtol, self.atol = rtol, atol
+        self.rtol, self.atol = per_state_tolerance(rtol, len(y0)), per_state_tolerance(atol, len(y0))
+        self.safety, self.ifactor, self.dfactor = safety, ifactor, dfactor
         self.max_num_steps = max_num_steps
         self.first_step = first_step
         self.targ = TimeArg(y0[0], autonomous)
@@ -231,8 +265,9 @@ class Dopri5:
         self.t0 = self.t1 = float(t0)
         self.f = self._f(f32(t0), self.y)
         if self.first_step is None:
+            # dopri5.py:80: the initial step is chosen with the FIRST tensor's tolerances
             h, bad = select_initial_step(self.ops, lambda tt, yy: self._count(tt, yy), self.targ, t0, self.y, 4,
-                                         self.rtol, self.atol, self.f)
+                                         self.rtol[0], self.atol[0], self.f)
         else:
             h, bad = 0.01, 0          # dopri5.py:82: a supplied first_step is ignored, 0.01 is used
         self.dt = h
@@ -269,9 +304,9 @@ class Dopri5:
                 k_.append(f_)
         y1 = yi
         ratios, bad_total = [], 0
-        for y0_, y1_, k_, n in zip(y0, y1, k, self.n_elem):
+        for y0_, y1_, k_, n, rtol_, atol_ in zip(y0, y1, k, self.n_elem, self.rtol, self.atol):
             kk, cs = dt_terms(dt32, DP_C_ERR, k_)
-            s, bad = ops.error(y0_, y1_, kk, cs, self.rtol, self.atol)
+            s, bad = ops.error(y0_, y1_, kk, cs, rtol_, atol_)
             ratios.append(f32(s / n) if n else f32('nan'))        # misc.py:156: a float32 mean
             bad_total += bad
         return self._finish_step(t0, dt, dt32, y0, y1, k, ratios, bad_total)
@@ -279,7 +314,7 @@ class Dopri5:
     def _finish_step(self, t0, dt, dt32, y0, y1, k, ratios, bad_total):
         accept = all(bool(r <= 1) for r in ratios)                 # dopri5.py:109
         worst = f32('nan') if any(np.isnan(r) for r in ratios) else max(ratios)
-        dt_next = optimal_step_size(dt, worst)
+        dt_next = optimal_step_size(dt, worst, self.safety, self.ifactor, self.dfactor)
         self.log.append((t0, dt, 1.0 if accept else 0.0, float(worst), dt_next))
         if accept:
             self.stage = (y0, y1, k, dt32)
@@ -312,7 +347,7 @@ class Dopri5:
         prev, cp = dt_terms(dt32, DP_C_ERR[:6], k)
         c_new = f32(dt32 * f32(DP_C_ERR[6]))
         self.nfe += 1
-        k_new, (s, bad) = self.fused.rhs_rk(y1, 'error', y0, prev, cp + [c_new], self.rtol, self.atol)
+        k_new, (s, bad) = self.fused.rhs_rk(y1, 'error', y0, prev, cp + [c_new], self.rtol[0], self.atol[0])
         k.append(k_new)
         n = self.n_elem[0]
         ratios = [f32(s / n) if n else f32('nan')]
@@ -354,16 +389,11 @@ class Dopri5:
 def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=None, fused=None, **options):
     """solvers.py:25-33."""
     assert_increasing(t)
-    unused = {k: v for k, v in options.items() if k not in ('first_step', 'safety', 'ifactor', 'dfactor', 'max_num_steps')}
-    if unused:
-        warnings.warn('Dopri5Solver: Unexpected arguments {}'.format(unused))
-    for name in ('safety', 'ifactor', 'dfactor'):
-        if name in options:
-            raise NotImplementedError('dopri5 option `%s` is fixed at the reference default in this build' % name)
+    opt = dopri5_options(options, len(y0))
     tt = t.detach().to('cpu', torch.float64).numpy()
-    solver = Dopri5(ops, func, y0, rtol, atol, autonomous=autonomous,
-                    max_num_steps=options.get('max_num_steps', 2 ** 31 - 1), first_step=options.get('first_step'),
-                    fused=fused)
+    solver = Dopri5(ops, func, y0, rtol, atol, autonomous=autonomous, max_num_steps=opt['max_num_steps'],
+                    first_step=opt['first_step'], fused=fused, safety=opt['safety'], ifactor=opt['ifactor'],
+                    dfactor=opt['dfactor'])
     solver.begin(tt[0])
     sol = [y0]
     for i in range(1, len(tt)):

@@ -26,13 +26,19 @@ def _autonomous(func):
     return bool(getattr(func, 'ndcn_autonomous', False))
 
 
-def _needs_grad(func, y0):
+def _needs_grad(func, y0, probe=None):
+    """True when the solve must be differentiable: the state or the parameters of an nn.Module `func` require grad - or
+    `func` is a plain callable (lambda, bound method, closure over parameters) whose output carries autograd history:
+    the reference differentiates through any callable, so that case is detected by evaluating `probe()` = func(t0, y0)."""
     if not torch.is_grad_enabled():
         return False
     if any(y.requires_grad for y in y0):
         return True
     if isinstance(func, torch.nn.Module):
         return any(p.requires_grad for p in func.parameters())
+    if probe is not None:
+        out = probe()
+        return any(torch.is_tensor(o) and o.requires_grad for o in out)
     return False
 
 
@@ -62,9 +68,10 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
 
     for y in y0:
         _lib.require_device(y, 'state y0')
-    if _needs_grad(user_func, y0):
+    if _needs_grad(user_func, y0, probe=lambda: func(t[0].to(y0[0].dtype), y0)):
         from .autograd_path import odeint_with_grad
-        sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func))
+        sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func),
+                               step_log=step_log)
     elif _device_resident_ok(user_func, tensor_input, y0, t_user, method, options):
         return _device_resident(user_func, y0[0], t, rtol, atol, method, options, step_log)
     elif method == 'dopri5':
@@ -92,7 +99,9 @@ def _device_resident_ok(user_func, tensor_input, y0, t, method, options):
         return False
     if user_func.training and user_func.dropout > 0:
         return False
-    if set(options) - {'max_num_steps'}:
+    if set(options) - set(core.DOPRI5_OPTIONS) or (method != 'dopri5' and options):
+        return False
+    if options.get('first_step') is not None:                  # dopri5.py:82: then 0.01 is used; host logic handles it
         return False
     if bool((t[1:] < t[:-1]).any()):            # decreasing grids go through the generic sign flip
         return False
@@ -102,7 +111,8 @@ def _device_resident_ok(user_func, tensor_input, y0, t, method, options):
 class DeviceSolver:
     """RAII wrapper of ndcn_solver_* for one (ODEFunc, method) pair; the workspace is a torch allocation."""
 
-    def __init__(self, odefunc, n_rows, method, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1, use_graph=False):
+    def __init__(self, odefunc, n_rows, method, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1, use_graph=False,
+                 safety=core.SAFETY, ifactor=core.IFACTOR, dfactor=core.DFACTOR):
         from ...csr import as_csr
         self.lib = _lib.load()
         H = odefunc.hidden_size
@@ -125,7 +135,8 @@ class DeviceSolver:
         self._keep += (W, b)
         self.desc = _lib.SolverDesc(_lib.METHODS[method], H, flags, 1 if use_graph else 0, view,
                                     W.data_ptr(), b.data_ptr() if b is not None else None,
-                                    float(rtol), float(atol), int(max_num_steps))
+                                    float(rtol), float(atol), int(max_num_steps), float(safety), float(ifactor),
+                                    float(dfactor))
         self.device = dev
         self.shape = (n_rows, H)
         nbytes = int(self.lib.ndcn_solver_workspace_bytes(ctypes.byref(self.desc)))
@@ -180,8 +191,10 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
         tt = t.detach().to('cpu').to(y0.dtype).to(torch.float64).tolist()
     # launch-bound sizes replay one captured hipGraph per fixed-grid step (dt lives in device memory)
     use_graph = method != 'dopri5' and y0.numel() <= GRAPH_MAX_ELEMS and os.environ.get('NDCN_HIPGRAPH', '1') != '0'
-    solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, options.get('max_num_steps', 2 ** 31 - 1),
-                          use_graph=use_graph)
+    opt = core.dopri5_options(options, 1) if method == 'dopri5' else {}
+    solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, opt.get('max_num_steps', 2 ** 31 - 1),
+                          use_graph=use_graph, safety=opt.get('safety', core.SAFETY), ifactor=opt.get('ifactor', core.IFACTOR),
+                          dfactor=opt.get('dfactor', core.DFACTOR))
     try:
         out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         out[0].copy_(y0)

@@ -270,7 +270,8 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
         method = 'dopri5'
     assert bool((t[1:] > t[:-1]).all()), 't must be strictly increasing or decrasing'
     if method == 'dopri5':
-        sol = _dopri5(fn, state, t, rtol, atol, step_log)
+        sol = _dopri5(fn, state, t, rtol, atol, step_log, **{k: v for k, v in options.items()
+                                                             if k in ('safety', 'ifactor', 'dfactor')})
     elif method in ('euler', 'midpoint', 'rk4'):
         sol = _fixed_grid(fn, state, t, method)
     else:
@@ -326,8 +327,11 @@ def _is_finite(x):
     return not bool(((x == float('inf')) + (x == float('-inf')) + torch.isnan(x)).any())
 
 
-def _dopri5(fn, y_init, t, rtol, atol, step_log):
+def _dopri5(fn, y_init, t, rtol, atol, step_log, safety=0.9, ifactor=10.0, dfactor=0.2):
     dtype = y_init[0].dtype
+    # dopri5.py:72-74: python floats pass through torch.tensor (float32) before widening to float64
+    SAFETY, IFACTOR, DFACTOR = (float((v if torch.is_tensor(v) else torch.tensor(v)).type(torch.float64))
+                                for v in (safety, ifactor, dfactor))
     t = t.to(torch.float64)                                                   # solvers.py:28
     # dopri5.py:77-83
     f_cur = fn(t[0].type_as(y_init[0]), y_init)

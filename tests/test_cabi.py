@@ -64,3 +64,32 @@ def test_argument_errors_match_reference():
         ode.odeint(f, [y0], torch.tensor([0., 1.]), method='euler')
     with pytest.raises(ValueError):
         ode.odeint_adjoint(f, y0, torch.tensor([0., 1.]))          # func must be an nn.Module (adjoint.py:109-110)
+
+
+def test_dropin_install_redirects_the_reference_import_lines():
+    """after ndcn_amd.dropin.install() the reference drivers' own import lines
+    (heat_dynamics.py:12-14, dgnn.py:8,19,22) resolve to this package - checked in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = '''
+import sys
+sys.path.insert(0, %r)
+import ndcn_amd.dropin
+ndcn_amd.dropin.install(models=True)
+import torchdiffeq as ode
+from neural_dynamics import *
+from models import *
+import ndcn_amd.neural_dynamics as nd, ndcn_amd.torchdiffeq as td, ndcn_amd.models as md
+assert ode is td and ode.odeint is td.odeint and ode.odeint_adjoint is td.odeint_adjoint
+assert sys.modules['neural_dynamics'] is nd and sys.modules['models'] is md
+assert ODEFunc is nd.ODEFunc and ODEBlock is nd.ODEBlock and ODEBlock2 is nd.ODEBlock2 and NDCN is nd.NDCN
+assert GCN is md.GCN and GraphConvolution is md.GraphConvolution      # the later star import wins, as in Python
+import torch
+m = NDCN(input_size=1, hidden_size=4, A=torch.eye(3), num_classes=1)
+assert sorted(m.state_dict()) == sorted(['input_layer.0.weight', 'input_layer.0.bias', 'input_layer.2.weight',
+    'input_layer.2.bias', 'neural_dynamic_layer.odefunc.wt.weight', 'neural_dynamic_layer.odefunc.wt.bias',
+    'output_layer.weight', 'output_layer.bias'])
+print('ok')
+''' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]

@@ -72,9 +72,10 @@ def test_dopri5_golden(dev, name, as_module):
     d = load_golden(name)
     f = make_func(d, dev, as_module, no_control='no_control' in name)
     log = []
+    opts = {k[4:]: float(v) for k, v in d.items() if k.startswith('opt_')} or None
     with torch.no_grad():
         y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), rtol=float(d['rtol']), atol=float(d['atol']),
-                       method='dopri5', step_log=log)
+                       method='dopri5', step_log=log, options=opts)
     nfe = dict([log.pop()])['nfe']
     ref = d['steplog']
     log = np.array(log)
@@ -184,6 +185,28 @@ def test_rownorm_resblock_gcn_resgcn_golden(dev):
                                   _HipLinear(32, 7)).to(dev).eval()
             model.load_state_dict({k[3:]: T(v) for k, v in d.items() if k.startswith('sd_')})
             assert (model(T(d['x']).to(dev)).cpu() - T(d['out'])).abs().max() <= 2e-5, tag
+
+
+def test_dense_graph_convolution_golden(dev):
+    """The dense-A GraphConvolution that dgnn.py's star import exposes (neural_dynamics.py:163-176): A (x W^T + b)
+    flattened to 1 x (N * out), with and without bias - fixture from the reference (tools/gen_golden.py gen_gconv)."""
+    from ndcn_amd.neural_dynamics import GraphConvolution
+    d = load_golden('gconv_dense')
+    A, x = T(d['A']).to(dev), T(d['x']).to(dev)
+    for bias, wk, ok in ((True, 'W', 'out'), (False, 'W_nb', 'out_nb')):
+        gc = GraphConvolution(7, 5, bias=bias).to(dev)
+        sd = {'fc.weight': T(d[wk])}
+        if bias:
+            sd['fc.bias'] = T(d['b'])
+        gc.load_state_dict(sd)                                   # the reference's state_dict keys
+        with torch.no_grad():
+            out = gc(x, A)
+        assert tuple(out.shape) == tuple(d[ok].shape) == (1, A.shape[0] * 5)
+        assert np.abs(out.cpu().numpy() - d[ok]).max() <= 1e-5
+        out = gc(x, A)                                           # training path (autograd Functions): same values + grads
+        assert np.abs(out.detach().cpu().numpy() - d[ok]).max() <= 1e-5
+        out.sum().backward()
+        assert gc.fc.weight.grad is not None and torch.isfinite(gc.fc.weight.grad).all()
 
 
 @pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])

@@ -24,10 +24,10 @@ def names(pattern):
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern)))
 
 
-def run(func, y0, t, method, rtol=1e-7, atol=1e-9, log=None):
+def run(func, y0, t, method, rtol=1e-7, atol=1e-9, log=None, **options):
     tensor_input, f, y, tt = core.check_inputs(func, y0, t)
     if method == 'dopri5':
-        sol = core.integrate_dopri5(OracleOps, f, y, tt, rtol, atol, step_log=log)
+        sol = core.integrate_dopri5(OracleOps, f, y, tt, rtol, atol, step_log=log, **options)
     else:
         sol = core.integrate_fixed(OracleOps, f, y, tt, method)
     out = tuple(torch.stack([s[i] for s in sol]) for i in range(len(y)))
@@ -52,7 +52,8 @@ def test_dopri5_control_flow(name):
     d = load_golden(name)
     f = make_func(d, no_control='no_control' in name)
     log = []
-    y = run(f, T(d['x0']), T(d['t']), 'dopri5', float(d['rtol']), float(d['atol']), log)
+    opts = {k[4:]: float(v) for k, v in d.items() if k.startswith('opt_')}
+    y = run(f, T(d['x0']), T(d['t']), 'dopri5', float(d['rtol']), float(d['atol']), log, **opts)
     nfe = dict([log.pop()])['nfe']
     ref = d['steplog']
     log = np.array(log)
@@ -115,8 +116,15 @@ def test_rejected_steps_and_error_paths():
 def test_step_size_controller_matches_reference_formula():
     # misc.py:160-170 incl. the float32-born constants; fixtures give (dt, ratio) -> dt_next
     for name in names('dopri5_*.npz'):
-        for t0, dt, acc, ratio, dt_next in load_golden(name)['steplog']:
-            got = core.optimal_step_size(dt, np.float32(ratio))
+        d = load_golden(name)
+        k = {n[4:]: core.controller_constant(float(v)) for n, v in d.items() if n.startswith('opt_')}
+        for t0, dt, acc, ratio, dt_next in d['steplog']:
+            got = core.optimal_step_size(dt, np.float32(ratio), **k)
             assert abs(got - dt_next) <= 1e-6 * abs(dt_next), (name, dt, ratio)
+    d = load_golden('dopri5_options')                       # non-default safety / ifactor / dfactor, every branch
+    k = {n: core.controller_constant(float(d['opt_' + n])) for n in ('safety', 'ifactor', 'dfactor')}
+    for (dt, ratio), want in zip(d['ctl_in'], d['ctl_out']):
+        got = core.optimal_step_size(dt, np.float32(ratio), **k)
+        assert abs(got - want) <= 1e-12 * abs(want), (dt, ratio, got, want)
     assert core.optimal_step_size(0.5, np.float32(0)) == 5.0
     assert np.isnan(core.optimal_step_size(0.5, np.float32('nan')))

@@ -56,7 +56,9 @@ def test_dopri5(name):
     d = load_golden(name)
     f = orc.OracleODEFunc(op_from(d), T(d['W']), T(d['b']), no_control='no_control' in name)
     log = []
-    y = orc.odeint(f, T(d['x0']), T(d['t']), rtol=float(d['rtol']), atol=float(d['atol']), method='dopri5', step_log=log)
+    opts = {k[4:]: float(v) for k, v in d.items() if k.startswith('opt_')} or None
+    y = orc.odeint(f, T(d['x0']), T(d['t']), rtol=float(d['rtol']), atol=float(d['atol']), method='dopri5', step_log=log,
+                   options=opts)
     ref = d['steplog']
     assert f.nfe == int(d['nfe']) == 2 + 6 * len(ref)
     log = np.array(log)

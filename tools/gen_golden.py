@@ -201,6 +201,26 @@ def gen_dopri5():
             y = ref_ode.odeint(cf, x, t, rtol=rtol, atol=atol, method='dopri5')
         save('dopri5_%s' % name, x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, rtol=rtol, atol=atol,
              steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe, **csr_of(OM))
+    # non-default controller options (dopri5.py:60,72-74): small ifactor / large dfactor / tighter safety, tolerances
+    # that produce rejected steps
+    f, x = make_func(20, OMs, 37)
+    cf = CountingFunc(f)
+    log = StepLog()
+    t = torch.linspace(0., 4., 9)
+    opts = dict(safety=0.99, ifactor=20.0, dfactor=0.5)
+    with torch.no_grad(), log.attach():
+        y = ref_ode.odeint(cf, x, t, rtol=1e-3, atol=1e-4, method='dopri5', options=dict(opts))
+    # the controller itself on (dt, ratio) pairs that hit every branch (misc.py:160-170), with the solver's own
+    # conversion of the option values (dopri5.py:72-74)
+    import torchdiffeq._impl.misc as ref_misc
+    cv = lambda v: ref_misc._convert_to_tensor(v, dtype=torch.float64)
+    ctl_in = [(0.25, 0.0), (0.25, 1e-9), (0.25, 0.3), (0.25, 0.999), (0.25, 1.0), (0.25, 1.7), (0.25, 40.0), (0.25, 1e9)]
+    ctl_out = [float(ref_misc._optimal_step_size(torch.tensor(dt, dtype=torch.float64), [torch.tensor(r, dtype=torch.float32)],
+                                                 safety=cv(opts['safety']), ifactor=cv(opts['ifactor']), dfactor=cv(opts['dfactor'])))
+               for dt, r in ctl_in]
+    save('dopri5_options', x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, rtol=1e-3, atol=1e-4,
+         steplog=np.array(log.rows, dtype=np.float64), nfe=cf.nfe, ctl_in=np.array(ctl_in), ctl_out=np.array(ctl_out),
+         **{'opt_' + k: v for k, v in opts.items()}, **csr_of(OM))
     # no_control (pure SpMM+ReLU RHS) and a decreasing time vector
     f, x = make_func(20, OMs, 29, no_control=True)
     cf = CountingFunc(f)
