@@ -18,7 +18,18 @@ struct Terms {
     const float *k[kMaxTerms];
     float c[kMaxTerms];
     int n;
+    const float *dt_dev;      // nullable: the step size lives in device memory (hipGraph replay) and c[] holds the bare
+                              // tableau entries; the coefficient is then formed here as fl(dt * c) - the same single fp32
+                              // rounding the host applies when it passes dt * beta by value
 };
+
+__device__ __forceinline__ void apply_dt(Terms &t) {
+    if (t.dt_dev) {
+        const float dt = *t.dt_dev;
+#pragma unroll
+        for (int j = 0; j < kMaxTerms; ++j) t.c[j] = dt * t.c[j];
+    }
+}
 
 __device__ __forceinline__ float4 ld4(const float *p, int64_t i) { return reinterpret_cast<const float4 *>(p)[i]; }
 __device__ __forceinline__ void st4(float *p, int64_t i, float4 v) { reinterpret_cast<float4 *>(p)[i] = v; }
@@ -49,6 +60,7 @@ __device__ __forceinline__ float4 wsum4(const Terms &t, int64_t i) {
 template <bool VEC>
 __global__ __launch_bounds__(256) void combine_kernel(float *__restrict__ out, const float *__restrict__ y0, Terms t,
                                                       int64_t n_items) {
+    apply_dt(t);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         if (VEC) {
             const float4 s = wsum4(t, i);
@@ -94,6 +106,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void rk_error_kernel(const float *__restrict__ y0, const float *__restrict__ y1,
                                                        Terms t, float rtol, float atol, int64_t n_items,
                                                        double *__restrict__ partial) {
+    apply_dt(t);
     double s = 0.0, bad = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         if (VEC) {
@@ -308,8 +321,9 @@ static bool fill_terms(Terms &t, const float *const *h_k, const float *h_c, int 
 }
 
 int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n,
-                   hipStream_t st) {
+                   hipStream_t st, const float *dt_dev) {
     Terms t;
+    t.dt_dev = dt_dev;
     bool vec = (n % 4 == 0) && aligned16(out) && aligned16(y0);
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_combine: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
     if (n == 0) return NDCN_OK;
@@ -332,8 +346,9 @@ static int red_grid(int64_t items) {
 }
 
 int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
-                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st) {
+                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev) {
     Terms t;
+    t.dt_dev = dt_dev;
     bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1);
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_error: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
     double *partial = static_cast<double *>(d_ws);
