@@ -34,14 +34,19 @@ int64_t spmm_rec_partials_bytes();
 // mode 0: Y = alpha (A X) [relu]; modes 1-3 (NDCN_RK_*): K = relu(A X) plus the RK algebra, as rhs_fused2_f32
 int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha, uint32_t flags,
                  int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next,
-                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
+                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr);
+// out[i] = fl(dt[0] * beta[i]), i < n: the effective coefficients of a replayed adaptive step (device-resident step size)
+int scale_coef_f32(float *out, const float *beta, const float *dt, int n, hipStream_t st);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 
+// dt_dev (nullable, device): the step size is read from device memory and h_c holds the bare tableau entries - the
+// kernel forms fl(dt * c) itself (hipGraph replay of an adaptive step: one captured graph serves every step size)
 int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n,
-                   hipStream_t st);
+                   hipStream_t st, const float *dt_dev = nullptr);
 int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
-                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st);
+                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev = nullptr);
+void prof_pause(bool on);     // no launch timing while a stream is being captured
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st);
 int64_t reduce_ws_bytes();

@@ -11,6 +11,7 @@ namespace {
 struct Rec { int kind; hipEvent_t a, b; double bytes, flops; };
 struct Prof {
     bool on = false;
+    bool paused = false;
     bool overflow = false;
     std::vector<Rec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -21,7 +22,7 @@ constexpr size_t kMaxRecs = 1 << 16;
 }  // namespace
 
 ProfScope::ProfScope(int kind, hipStream_t s, double bytes, double flops) : slot(-1), st(s) {
-    if (!g_prof.on) return;
+    if (!g_prof.on || g_prof.paused) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (g_prof.recs.size() >= kMaxRecs) { g_prof.overflow = true; return; }
     Rec r;
@@ -42,6 +43,8 @@ ProfScope::~ProfScope() {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     (void)hipEventRecord(g_prof.recs[slot].b, st);
 }
+
+void prof_pause(bool on) { g_prof.paused = on; }
 
 }  // namespace ndcn
 

@@ -305,7 +305,19 @@ __global__ __launch_bounds__(256) void fixed_stage_kernel(float *out, const floa
     }
 }
 
+__global__ void scale_coef_kernel(float *__restrict__ out, const float *__restrict__ beta, const float *__restrict__ dt, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dt[0] * beta[i];
+}
+
 // -------------------------------------------------------------------------------- host wrappers
+int scale_coef_f32(float *out, const float *beta, const float *dt, int n, hipStream_t st) {
+    if (n <= 0) return NDCN_OK;
+    hipLaunchKernelGGL(scale_coef_kernel, dim3((n + 63) / 64), dim3(64), 0, st, out, beta, dt, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 static bool fill_terms(Terms &t, const float *const *h_k, const float *h_c, int n_k, bool &vec) {
     if (n_k < 1 || n_k > kMaxTerms) return false;
     t.n = n_k;

@@ -85,11 +85,17 @@ struct ndcn_solver {
     hipGraphExec_t gexec = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     float *d_dt = nullptr;         // device step size read by the captured stage kernels
+    float *d_coef = nullptr, *d_beta = nullptr;   // replayed adaptive step: tableau entries and their dt-scaled image
+    float h_beta[64] = {0};
+    int n_coef = 0;
     float *h_dt = nullptr;         // pinned ring of step sizes (async H2D source must stay untouched until consumed)
     int64_t g_step = 0;
 };
 
 namespace {
+
+constexpr int kDtRing = 4096;
+constexpr int kCoefCap = 64;
 
 inline size_t align_up(size_t v) { return (v + 255u) & ~(size_t)255u; }
 
@@ -104,7 +110,7 @@ size_t workspace_bytes(const ndcn_solver_desc *d) {
     const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
     const size_t work = align_up((size_t)rhs_work_bytes(d->A.n_rows, d->H, d->rhs_flags) + 16);
     return (size_t)n_panels(d) * panel + work + align_up((size_t)reduce_ws_bytes()) +
-           align_up((size_t)rhs_fused2_partials_bytes()) + 2048;
+           align_up((size_t)rhs_fused2_partials_bytes()) + 4096;
 }
 
 int carve(ndcn_solver *s, size_t bytes, void **p) {
@@ -139,11 +145,22 @@ int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
 // right-hand side whose epilogue carries the stage algebra: the fused MFMA kernel (default RHS, H = 256) or the
 // group-record SpMM (no_control RHS)
 int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0, const float *const *kp, const float *cp,
-            int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
+            int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st,
+            const float *dt_dev = nullptr) {
     s->n_rhs++;
-    if (s->rec_epi)
+    if (s->rec_epi) {
+        // replay: cp holds the bare tableau entries; they join the solver's coefficient table, whose scaled image
+        // (fl(dt * beta), written by the graph's first kernel) the launch reads instead of by-value coefficients
+        const float *c_dev = nullptr;
+        if (dt_dev) {
+            if (s->n_coef + n_prev + 1 > kCoefCap) { set_error("coefficient table full"); return NDCN_EINVAL; }
+            for (int m = 0; m <= n_prev; ++m) s->h_beta[s->n_coef + m] = cp[m];
+            c_dev = s->d_coef + s->n_coef;
+            s->n_coef += 8;                                   // slices stay 32-byte aligned
+        }
         return spmm_rec_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, 1.f, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next, rtol,
-                            atol, d_out, d_ws, st);
+                            atol, d_out, d_ws, st, c_dev);
+    }
     return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev,
                           y_next, rtol, atol, d_out, d_ws, st);
 }
@@ -220,18 +237,11 @@ void dt_coeffs(float dt32, const double *beta, int n, const float *const *kall, 
     }
 }
 
-// dopri5.py:94-122
-int dopri5_step(ndcn_solver *s, hipStream_t st) {
-    const double t_start = s->t1, dt = s->dt;
-    if (!(t_start + dt > t_start)) {
-        set_error("underflow in dt %g", dt);
-        return NDCN_EUNDERFLOW;
-    }
-    if (s->pending_bad > 0) {
-        set_error("non-finite values in state `y` (%lld elements)", (long long)s->pending_bad);
-        return NDCN_ENONFINITE;
-    }
-    const float dt32 = (float)dt;
+// The launches of one attempted step (rk_common.py:41-61): six stage inputs / evaluations and the error record.
+// dt_dev == nullptr: dt32 is the step size and rides in the kernel arguments.  dt_dev != nullptr (hipGraph capture):
+// dt32 must be 1 - the coefficients passed are the bare tableau entries and every kernel forms fl(dt * c) from the
+// device-resident step size, the same single rounding.
+int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_dev) {
     const float *kp[8];
     float cp[8];
     int m, rc;
@@ -239,7 +249,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
         // Stage algebra rides in the RHS epilogues: the evaluation that produces k[i+1] also forms the NEXT stage
         // input y0 + dt * sum_m beta[i+1][m] k[m] (its own K as the last term), the last one the error record.
         dt_coeffs(dt32, kBeta[0], 1, s->k, kp, cp, m);
-        rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st);
+        rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st, dt_dev);
         if (rc) return rc;
         float *in = s->ytmp;
         for (int i = 0; i < 6; ++i) {
@@ -254,7 +264,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
                     ++mp;
                 }
                 cp[mp] = dt32 * (float)kBeta[i + 1][i + 1];   // the K being produced, last term
-                rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st);
+                rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st, dt_dev);
                 if (rc) return rc;
                 in = out;
             } else {
@@ -268,22 +278,51 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
                 }
                 cp[mp] = dt32 * (float)kCErr[6];
                 rc = rhs_epi(s, in, s->k[6], 2, s->ycur, kp, cp, mp, nullptr, (float)s->d.rtol, (float)s->d.atol, s->d_red,
-                             s->d_ws2, st);
+                             s->d_ws2, st, dt_dev);
                 if (rc) return rc;
             }
         }
-    } else {
+        return NDCN_OK;
+    }
     for (int i = 0; i < 6; ++i) {
         dt_coeffs(dt32, kBeta[i], i + 1, s->k, kp, cp, m);
         float *dst = (i == 5) ? s->ynext : s->ytmp;          // the 6th stage input IS y1 (rk_common.py:54-58)
-        rc = rk_combine_f32(dst, s->ycur, kp, cp, m, s->n_elem, st);
+        rc = rk_combine_f32(dst, s->ycur, kp, cp, m, s->n_elem, st, dt_dev);
         if (rc) return rc;
         rc = rhs(s, dst, s->k[i + 1], st);
         if (rc) return rc;
     }
     dt_coeffs(dt32, kCErr, 7, s->k, kp, cp, m);
-    rc = rk_error_f32(s->ycur, s->ynext, kp, cp, m, (float)s->d.rtol, (float)s->d.atol, s->n_elem, s->d_red, s->d_ws, st);
-    if (rc) return rc;
+    return rk_error_f32(s->ycur, s->ynext, kp, cp, m, (float)s->d.rtol, (float)s->d.atol, s->n_elem, s->d_red, s->d_ws, st,
+                        dt_dev);
+}
+
+int graph_setup_dopri5(ndcn_solver *s);
+
+// dopri5.py:94-122
+int dopri5_step(ndcn_solver *s, hipStream_t st) {
+    const double t_start = s->t1, dt = s->dt;
+    if (!(t_start + dt > t_start)) {
+        set_error("underflow in dt %g", dt);
+        return NDCN_EUNDERFLOW;
+    }
+    if (s->pending_bad > 0) {
+        set_error("non-finite values in state `y` (%lld elements)", (long long)s->pending_bad);
+        return NDCN_ENONFINITE;
+    }
+    const float dt32 = (float)dt;
+    int rc;
+    if (s->graph_on) {
+        // one captured graph per attempt, the step size handed over through device memory
+        if (!s->gexec && (rc = graph_setup_dopri5(s))) return rc;
+        float *slot = s->h_dt + (s->g_step++ % kDtRing);
+        *slot = dt32;
+        NDCN_HIP(hipMemcpyAsync(s->d_dt, slot, sizeof(float), hipMemcpyHostToDevice, st));
+        NDCN_HIP(hipGraphLaunch(s->gexec, st));
+        s->n_rhs += 6;
+    } else {
+        rc = enqueue_attempt(s, st, dt32, nullptr);
+        if (rc) return rc;
     }
     double sum, bad;
     rc = fetch_record(s, st, sum, bad);
@@ -327,7 +366,19 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
 }
 
 // After an accepted step: y0 = ycur, y1 = ynext, f0 = k[0], f1 = k[6].  Rotate for the next step.
-void rotate_after_accept(ndcn_solver *s) {
+int rotate_after_accept(ndcn_solver *s, hipStream_t st) {
+    if (s->graph_on) {
+        // the captured graph holds fixed pointers: the state moves instead of the names (launch-bound sizes only, the
+        // three copies are a few microseconds)
+        const size_t bytes = (size_t)s->n_elem * sizeof(float);
+        if (s->fit_valid) {                 // the stored fit's "e" is the step's y0: keep it
+            NDCN_HIP(hipMemcpyAsync(s->yold, s->ycur, bytes, hipMemcpyDeviceToDevice, st));
+            s->ce = s->yold;
+        }
+        NDCN_HIP(hipMemcpyAsync(s->ycur, s->ynext, bytes, hipMemcpyDeviceToDevice, st));
+        NDCN_HIP(hipMemcpyAsync(s->k[0], s->k[6], bytes, hipMemcpyDeviceToDevice, st));   // FSAL
+        return NDCN_OK;
+    }
     float *old = s->yold;
     s->yold = s->ycur;       // becomes "e" if this step gets fitted
     s->ycur = s->ynext;
@@ -335,6 +386,7 @@ void rotate_after_accept(ndcn_solver *s) {
     float *f = s->k[0];
     s->k[0] = s->k[6];       // FSAL
     s->k[6] = f;
+    return NDCN_OK;
 }
 
 int do_fit(ndcn_solver *s, hipStream_t st) {
@@ -423,10 +475,22 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         return fail(NDCN_EHIP);
     }
     if (hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(NDCN_EHIP); }
-    if ((rc = carve(s, 256, &q))) return fail(rc);
+    if ((rc = carve(s, 256 + 2 * kCoefCap * sizeof(float), &q))) return fail(rc);
     s->d_dt = static_cast<float *>(q);
-    // hipGraph replay pays off where the step is launch-bound; the fused H = 256 path passes dt by value
-    s->graph_on = desc->use_graph && desc->method != NDCN_M_DOPRI5 && !s->fused2;
+    s->d_coef = s->d_dt + 64;
+    s->d_beta = s->d_coef + kCoefCap;
+    // hipGraph replay pays off where the step is launch-bound.  The fused MFMA kernel takes dt by value (large
+    // panels: never launch-bound); every other path reads it from device memory when replayed.
+    s->graph_on = desc->use_graph && !(s->fused2 && !s->rec_epi) &&
+                  !(s->rec_epi && desc->method != NDCN_M_DOPRI5);
+    if (s->graph_on) {
+        if (hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s->gev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->gev_out, hipEventDisableTiming) != hipSuccess) {
+            set_error("creating the replay stream failed");
+            return fail(NDCN_EHIP);
+        }
+    }
     *out = s;
     return NDCN_OK;
 }
@@ -474,8 +538,6 @@ int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st) {
     return NDCN_OK;
 }
 
-constexpr int kDtRing = 4096;
-
 // the kernel sequence of one fixed-grid step on the solver's own buffers (y updated in place), dt from d_dt
 static int enqueue_fixed_step(ndcn_solver *s, hipStream_t st) {
     const int64_t n = s->n_elem;
@@ -502,16 +564,16 @@ static int enqueue_fixed_step(ndcn_solver *s, hipStream_t st) {
 }
 
 static int graph_setup(ndcn_solver *s) {
-    NDCN_HIP(hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking));
-    NDCN_HIP(hipEventCreateWithFlags(&s->gev_in, hipEventDisableTiming));
-    NDCN_HIP(hipEventCreateWithFlags(&s->gev_out, hipEventDisableTiming));
     NDCN_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_dt), kDtRing * sizeof(float), hipHostMallocDefault));
     hipGraph_t graph = nullptr;
-    NDCN_HIP(hipStreamBeginCapture(s->gstream, hipStreamCaptureModeThreadLocal));
+    prof_pause(true);
+    hipError_t eb = hipStreamBeginCapture(s->gstream, hipStreamCaptureModeThreadLocal);
+    if (eb != hipSuccess) { prof_pause(false); set_error("hipStreamBeginCapture: %s", hipGetErrorString(eb)); return NDCN_EHIP; }
     const int64_t rhs_before = s->n_rhs;
     const int rc = enqueue_fixed_step(s, s->gstream);
     s->n_rhs = rhs_before;                                      // capturing is not evaluating
     hipError_t e = hipStreamEndCapture(s->gstream, &graph);
+    prof_pause(false);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return NDCN_EHIP; }
     e = hipGraphInstantiate(&s->gexec, graph, nullptr, nullptr, 0);
@@ -519,6 +581,33 @@ static int graph_setup(ndcn_solver *s) {
     if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return NDCN_EHIP; }
     return NDCN_OK;
 }
+
+}  // namespace ndcn
+namespace {
+int graph_setup_dopri5(ndcn_solver *s) {
+    NDCN_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_dt), kDtRing * sizeof(float), hipHostMallocDefault));
+    hipGraph_t graph = nullptr;
+    prof_pause(true);
+    hipError_t e = hipStreamBeginCapture(s->gstream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { prof_pause(false); set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return NDCN_EHIP; }
+    const int64_t rhs_before = s->n_rhs;
+    s->n_coef = 0;
+    int rc = scale_coef_f32(s->d_coef, s->d_beta, s->d_dt, kCoefCap, s->gstream);    // first node: fl(dt * beta) table
+    if (!rc) rc = enqueue_attempt(s, s->gstream, 1.f, s->d_dt);
+    s->n_rhs = rhs_before;                                      // capturing is not evaluating
+    e = hipStreamEndCapture(s->gstream, &graph);
+    prof_pause(false);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return NDCN_EHIP; }
+    // the tableau entries the captured launches refer to (constant for the life of the graph)
+    NDCN_HIP(hipMemcpy(s->d_beta, s->h_beta, sizeof(s->h_beta), hipMemcpyHostToDevice));
+    e = hipGraphInstantiate(&s->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return NDCN_EHIP; }
+    return NDCN_OK;
+}
+}  // namespace
+namespace ndcn {
 
 static int graph_advance(ndcn_solver *s, double next_t, float *out, hipStream_t st) {
     const float t1 = (float)next_t;
@@ -621,10 +710,18 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
     return NDCN_OK;
 }
 
+static int dopri5_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st);
+
 int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st) {
     NDCN_CHECK_ARG(s, "null solver");
     if (!s->begun) { set_error("ndcn_solver_advance before ndcn_solver_begin"); return NDCN_ESTATE; }
     if (s->d.method != NDCN_M_DOPRI5) return fixed_advance(s, next_t, out, st);
+    // replay mode: the captured attempt is launched into the caller's stream like any other work (capture needed a
+    // stream of its own, replay does not)
+    return dopri5_advance(s, next_t, out, budget, st);
+}
+
+static int dopri5_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st) {
     int64_t done = 0;
     int64_t n_here = 0;
     while (next_t > s->t1) {                                   // dopri5.py:88
@@ -634,7 +731,8 @@ int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hi
             return NDCN_EMAXSTEPS;
         }
         if (s->fit_pending) {          // previous accepted step is being left without ever being evaluated
-            rotate_after_accept(s);
+            int rcr = rotate_after_accept(s, st);
+            if (rcr) return rcr;
             s->fit_pending = false;
         }
         int rc = dopri5_step(s, st);

@@ -68,6 +68,8 @@ struct RecEpi {
     float c[kRecMaxPrev + 1];        // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K ; RK4: c[0] = dt
     int n_prev;
     float rtol, atol;
+    const float *c_dev;              // nullable: the coefficients live in device memory instead of c[] (hipGraph replay: one
+                                     // captured launch serves every step size; filled by scale_coef_kernel as fl(dt * c))
 };
 
 template <int N> __device__ __forceinline__ void rec_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
     const f32x4 *Xh = reinterpret_cast<const f32x4 *>(a.Xh);
     f32x4 *Y = reinterpret_cast<f32x4 *>(a.Y);
     const int np = MODE == REC_PLAIN ? 0 : e.n_prev;
+    auto coef = [&](int m) { return (MODE != REC_PLAIN && e.c_dev) ? e.c_dev[m] : e.c[m]; };    // wave-uniform (scalar loads)
 
     // Row-local RK panels are requested ONE GROUP AHEAD (the next group's row ids sit in its record, which landed D
     // iterations ago) from inline asm, so that hipcc's wait insertion - which cannot count requests issued under
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
         f32x4 *yn = reinterpret_cast<f32x4 *>(e.y_next);
         if (MODE == REC_RK4) {
             // rk4_alt_step_func (rk_common.py:72-78), same operator order as fixed_stage_kernel ops 2-5
-            const float dt = e.c[0];
+            const float dt = coef(0);
             f32x4 s;
             if (np == 0) s = (kn * dt) / 3.f;
             else if (np == 1) s = (p.km[0] / -3.f + kn) * dt;
@@ -258,12 +261,12 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
             return;
         }
         // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
-        f32x4 s = kn * e.c[np];
+        f32x4 s = kn * coef(np);
         if (np > 0) {
-            f32x4 u = p.km[0] * e.c[0];
+            f32x4 u = p.km[0] * coef(0);
 #pragma unroll
             for (int m = 1; m < MAXP; ++m)
-                if (m < np) u = u + p.km[m] * e.c[m];
+                if (m < np) u = u + p.km[m] * coef(m);
             s = u + s;
         }
         if (MODE == REC_COMBINE) {
@@ -442,7 +445,7 @@ static int launch_rec(const RecArgs &a, const RecEpi &e, int mode, bool halo, hi
 // mode 0: Y = alpha (A X) [relu];  modes 1-3: K = relu(A X) plus the RK algebra (see rhs_fused2_f32)
 int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha, uint32_t flags,
                  int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next,
-                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
+                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev) {
     if (A->n_rows == 0) return NDCN_OK;
     if (!spmm_rec_variant(mode, n_prev)) { set_error("spmm_rec: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     RecArgs a;
@@ -452,6 +455,7 @@ int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_o
     a.dbg = env_int_rec("NDCN_REC_DBG", 0);
     RecEpi e = {};
     e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
+    e.c_dev = c_dev;
     for (int m = 0; m < kRecMaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kRecMaxPrev; ++m) e.c[m] = (mode != REC_PLAIN && mode != REC_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == REC_RK4) e.c[0] = h_c[0];

@@ -19,7 +19,7 @@ from ...ops import hip
 from . import core
 
 SOLVERS = {m: m for m in core.METHODS}      # the in-scope subset of odeint.py:8-17
-GRAPH_MAX_ELEMS = 1 << 22                   # below ~4M state elements a step is launch-bound
+GRAPH_MAX_ELEMS = 1 << 23                   # below ~8M state elements (Pubmed x 256) a step is launch-bound
 
 
 def _autonomous(func):
@@ -189,8 +189,9 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     if method != 'dopri5':
         # solvers.py:81: the fixed grid is t in the state dtype
         tt = t.detach().to('cpu').to(y0.dtype).to(torch.float64).tolist()
-    # launch-bound sizes replay one captured hipGraph per fixed-grid step (dt lives in device memory)
-    use_graph = method != 'dopri5' and y0.numel() <= GRAPH_MAX_ELEMS and os.environ.get('NDCN_HIPGRAPH', '1') != '0'
+    # launch-bound sizes replay ONE captured hipGraph per step - a fixed-grid step, or one attempted dopri5 step - with the
+    # step size in device memory (the library declines where a path has no replayable form)
+    use_graph = y0.numel() <= GRAPH_MAX_ELEMS and os.environ.get('NDCN_HIPGRAPH', '1') != '0'
     opt = core.dopri5_options(options, 1) if method == 'dopri5' else {}
     solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, opt.get('max_num_steps', 2 ** 31 - 1),
                           use_graph=use_graph, safety=opt.get('safety', core.SAFETY), ifactor=opt.get('ifactor', core.IFACTOR),

@@ -234,6 +234,53 @@ def test_hipgraph_replay_equals_eager(dev, method):
     check_traj(outs[1].cpu().numpy(), d['traj'], l1=1e-5, mx=1e-4)
 
 
+@pytest.mark.parametrize('case', ['H20', 'no_control_rec', 'no_control_pubmed'])
+def test_dopri5_hipgraph_replay_equals_eager(dev, case):
+    """One attempted dopri5 step replayed from a captured hipGraph (step size and dt * beta in device memory): step log
+    and trajectory identical, bit for bit, to eager launches - generic kernels (H = 20), the group-record epilogue
+    kernels (no_control, H = 256, lattice) and the Pubmed topology (no plan: row SpMM + stage kernels)."""
+    from ndcn_amd import CsrOperator, graphs
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq._impl.odeint import DeviceSolver
+    if case == 'H20':
+        d = load_golden('dopri5_loose')
+        f = make_func(d, dev)
+        x0, t, rtol, atol = T(d['x0']).to(dev), T(d['t']), float(d['rtol']), float(d['atol'])
+    else:
+        if case == 'no_control_rec':
+            A = graphs.to_device(graphs.normalized_laplacian(graphs.grid_8_neighbor(60)), dev)
+            n = 3600
+        else:
+            g = load_golden('operators_pubmed')
+            n = int(g['n'])
+            A = CsrOperator.from_arrays(g['alpha00_indptr'], g['alpha00_indices'], g['alpha00_data'], (n, n), dev)
+        torch.manual_seed(1)
+        f = ODEFunc(256, A, no_control=True).to(dev).eval()
+        x0 = torch.rand(n, 256, device=dev)
+        t, rtol, atol = torch.linspace(0., 1.2, 16), .1, .1
+        if case == 'no_control_rec':
+            A.ensure_plans(256)
+            assert A.rec is not None
+            t, rtol, atol = torch.linspace(0., 3., 9), 1e-3, 1e-4       # a few dozen attempts
+    outs, logs = [], []
+    for use_graph in (False, True):
+        s = DeviceSolver(f, x0.shape[0], 'dopri5', rtol, atol, use_graph=use_graph)
+        s.begin(x0, float(t[0]))
+        traj = [x0.clone()]
+        for ti in t[1:].tolist():
+            o = torch.empty_like(x0)
+            s.advance(ti, o)
+            traj.append(o)
+        torch.cuda.synchronize()
+        logs.append((s.steplog(), s.stats()['nfe']))
+        s.close()
+        outs.append(torch.stack(traj))
+    assert logs[0] == logs[1] and len(logs[0][0]) >= 2
+    assert torch.equal(outs[0], outs[1])
+    if case == 'H20':
+        check_traj(outs[1].cpu().numpy(), d['traj'], l1=1e-5, mx=2e-4)
+
+
 @pytest.mark.parametrize('side', [48, 55, 64])       # 48: some workgroups of the persistent grid get no tile
 def test_fused_epilogue_solver_equals_generic_path(dev, side):
     """H = 256: the device-resident solver runs the stage algebra / error norm inside the fused RHS epilogue
@@ -460,6 +507,88 @@ def test_large_grid_properties(dev):
         yb = ode.odeint(lambda tt, y: f(tt, y), x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
     assert la[-1] == lb[-1]
     assert float((ya[-1] - yb[-1]).abs().max()) < 1e-4
+
+
+def _sampled_rhs_check(L, A, f, X, dev, rows):
+    """relu(W (A X) + b) on a sample of rows against fp64."""
+    from ndcn_amd import hip
+    sub = L[rows]
+    got = hip.rhs(A, X, f.wt.weight, f.wt.bias)[torch.from_numpy(rows).to(dev)].cpu().double().numpy()
+    S = orc.spmm_f64(sub.indptr, sub.indices, sub.data, X.cpu().numpy())
+    ref = np.maximum(S @ f.wt.weight.detach().cpu().double().numpy().T + f.wt.bias.detach().cpu().double().numpy(), 0)
+    assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('layout', [None, 'degree'])
+def test_config_c2_full_size_properties(dev, layout):
+    """BASELINE config 2 at full size (100k-node G(n,p), mean degree 39.9, H = 256, RK4 on linspace(0,5,100)), where the
+    oracle cannot run the solve in seconds: sampled RHS rows against fp64, SpMM linearity, the device-resident solver
+    (stage algebra in the RHS epilogues) bit-equal to the generic path (separate stage kernels) over the first steps, and
+    the --layout relabelling leaves the solution unchanged up to the permutation."""
+    from ndcn_amd import graphs, hip
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    n, H = 100000, 256
+    G0 = graphs.make_graph('random', n, seed=0)
+    G = graphs.reorder_nodes(G0, layout)
+    L = graphs.normalized_laplacian(G)
+    assert abs(L.nnz / n - 40.9) < 0.5
+    A = graphs.to_device(L, dev)
+    torch.manual_seed(0)
+    f = ODEFunc(H, A).to(dev).eval()
+    X = torch.rand(n, H, device=dev)
+    Z = torch.rand(n, H, device=dev)
+    assert float((hip.spmm(A, X + 2 * Z) - (hip.spmm(A, X) + 2 * hip.spmm(A, Z))).abs().max()) < 2e-4
+    _sampled_rhs_check(L, A, f, X, dev, np.r_[0:48, 50000:50048, n - 48:n])
+    t = torch.linspace(0., 5., 100)[:4].to(dev)
+    with torch.no_grad():
+        ya = ode.odeint(f, X, t, method='rk4')
+        yb = ode.odeint(lambda tt, y: f(tt, y), X, t, method='rk4')
+    assert torch.equal(ya, yb)
+    if layout is not None:                       # P A P^T on P x: the same trajectory, rows permuted
+        new = torch.from_numpy(graphs.node_mapping(G0, layout)).to(dev)
+        f0 = ODEFunc(H, graphs.to_device(graphs.normalized_laplacian(G0), dev)).to(dev).eval()
+        f0.load_state_dict(f.state_dict())
+        X0 = torch.empty_like(X)
+        X0[:] = X[new]                           # node i of the original graph sits at position new[i]
+        with torch.no_grad():
+            y0 = ode.odeint(f0, X0, t, method='rk4')
+        assert float((y0[-1] - ya[-1][new]).abs().max()) < 1e-4 * float(ya[-1].abs().max())
+
+
+def test_config_c3_full_size_properties(dev):
+    """BASELINE config 3 at full size (1M-node Barabasi-Albert m = 5, H = 256, dopri5): the long-row plan is active,
+    sampled RHS rows (hubs included) agree with fp64, the device-resident solver agrees with the generic path (same
+    accept / reject decisions), and the truth dynamics of the config (mutualistic, edge-wise kernel) run at this size."""
+    from ndcn_amd import graphs, hip
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    n, H = 1000000, 256
+    G = graphs.make_graph('power_law', n, seed=0)
+    L = graphs.normalized_laplacian(G)
+    deg = np.diff(L.indptr)
+    assert deg.max() > 1000 and abs(L.nnz - 11e6) < 1e5
+    A = graphs.to_device(L, dev)
+    torch.manual_seed(0)
+    f = ODEFunc(H, A).to(dev).eval()
+    X = torch.rand(n, H, device=dev)
+    hubs = np.argsort(-deg)[:16]
+    _sampled_rhs_check(L, A, f, X, dev, np.unique(np.r_[hubs, 0:32, 500000:500032, n - 32:n]))
+    assert A.hub is not None and A.hub['n'] > 1000
+    t = torch.tensor([0., 0.5], device=dev)
+    with torch.no_grad():
+        la, lb = [], []
+        ya = ode.odeint(f, X, t, rtol=.01, atol=.001, method='dopri5', step_log=la)
+        yb = ode.odeint(lambda tt, y: f(tt, y), X, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
+    assert la[-1] == lb[-1] and [r[2] for r in la[:-1]] == [r[2] for r in lb[:-1]]
+    assert float((ya[-1] - yb[-1]).abs().max()) < 1e-4 * max(1.0, float(yb[-1].abs().max()))
+    del ya, yb, X
+    # truth RHS of the config at full size: finite, and linear-response sanity of the edge-wise kernel on a constant state
+    Aadj = graphs.to_device(G, dev)
+    x = torch.full((n, 1), 2.0, device=dev)
+    out = hip.mutual_rhs(Aadj, x)
+    want = 0.1 + 2.0 * (1 - 2.0 / 5) * (2.0 / 1 - 1) + (deg - 1) * (2.0 * 2.0 / (5 + 0.9 * 2.0 + 0.1 * 2.0))
+    assert np.abs(out.cpu().numpy().reshape(-1) - want.astype(np.float32)).max() < 1e-3 * want.max()
 
 
 @pytest.mark.parametrize('kind', ['heat', 'gene', 'mutualistic'])

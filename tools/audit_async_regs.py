@@ -86,8 +86,8 @@ def main():
         name = m.group(1)
         if want not in name:
             continue
-        end = txt.index('s_endpgm', m.end())
-        nl, pr = audit(name, txt[m.end():end + 8].split('\n'))
+        end = txt.index('.Lfunc_end', m.end())                # a kernel may hold several s_endpgm
+        nl, pr = audit(name, txt[m.end():end].split('\n'))
         if nl:
             print('%-90s asm loads %3d  problems %d' % (name[:90], nl, pr))
             total += pr
