@@ -92,22 +92,35 @@ class SingleGpuRunner:
         self.out = torch.empty_like(x0)
         self.solver.begin(x0, self.ticks[0])
         self.pos = 1                                     # next tick to reach
+        self.solve_steps = 0                             # attempted steps of one whole solve (known after the first)
+        self.traj = torch.empty((len(self.ticks) - 1,) + tuple(x0.shape), device=x0.device) if len(self.ticks) > 2 and method == 'dopri5' else None
         self.restarts = 0
         self.nfe_done = 0
 
     def run_steps(self, k):
         done = 0
         while done < k:
-            before = self.solver.stats()['steps']
-            reached = self.solver.advance(self.ticks[self.pos], self.out, step_budget=k - done)
-            done += int(self.solver.stats()['steps'] - before)
-            if reached:
-                self.pos += 1
-                if self.pos == len(self.ticks):
-                    self.nfe_done += int(self.solver.stats()['nfe'])
-                    self.solver.begin(self.x0, self.ticks[0])    # resets the solver's own counters
-                    self.pos = 1
-                    self.restarts += 1
+            if (self.method == 'dopri5' and len(self.ticks) > 2 and self.pos == 1 and self.solve_steps
+                    and k - done >= self.solve_steps):
+                # a whole solve in ONE library call, as odeint() does it (ticks of a step are evaluated together); its
+                # step count is known from the previous solve of the same initial value
+                self.solver.advance_many(self.ticks[1:], self.traj)
+                done += int(self.solver.stats()['steps'])
+                reached_end = True
+            else:
+                before = self.solver.stats()['steps']
+                reached = self.solver.advance(self.ticks[self.pos], self.out, step_budget=k - done)
+                done += int(self.solver.stats()['steps'] - before)
+                reached_end = False
+                if reached:
+                    self.pos += 1
+                    reached_end = self.pos == len(self.ticks)
+            if reached_end:
+                self.solve_steps = int(self.solver.stats()['steps'])
+                self.nfe_done += int(self.solver.stats()['nfe'])
+                self.solver.begin(self.x0, self.ticks[0])        # resets the solver's own counters
+                self.pos = 1
+                self.restarts += 1
         return done
 
     def nfe(self):

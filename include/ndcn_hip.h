@@ -262,6 +262,12 @@ NDCN_API int ndcn_solver_begin(ndcn_solver *s, const float *y0, double t0, void 
  * dense-output evaluation (dopri5.py:85-92).  When the budget is exhausted first, returns 1 and leaves
  * `out` untouched; call again to continue.                                                            */
 NDCN_API int ndcn_solver_advance(ndcn_solver *s, double next_t, float *out, int64_t step_budget, void *stream);
+/* All of h_ticks (HOST array, increasing, the first one > the current time) in one call: out[i] = y(h_ticks[i]), n_ticks
+ * panels back to back.  dopri5: ticks that fall into the same accepted step are evaluated together, reading the step's
+ * panels once per <= 8 ticks instead of once per tick (the reference's drivers sample 16-120 ticks over a handful of
+ * steps: heat_dynamics.py:35,123; dgnn.py:173-182); same arithmetic per element as ndcn_solver_advance.  Fixed grid:
+ * one step per tick.                                                                                     */
+NDCN_API int ndcn_solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, float *out, void *stream);
 /* h_stats = {steps attempted, steps accepted, rhs evaluations, t1, dt_next, last mean_sq_error_ratio} */
 NDCN_API int ndcn_solver_stats(const ndcn_solver *s, double h_stats[6]);
 /* Copies up to `cap` rows {t0, dt, accepted, ratio, dt_next} of the per-attempt log; returns the count. */

@@ -91,6 +91,7 @@ SIGNATURES = {
     'ndcn_solver_destroy': (_I, [_P]),
     'ndcn_solver_begin': (_I, [_P, _P, _D, _P]),
     'ndcn_solver_advance': (_I, [_P, _D, _P, _L, _P]),
+    'ndcn_solver_advance_many': (_I, [_P, ctypes.POINTER(_D), _L, _P, _P]),
     'ndcn_solver_stats': (_I, [_P, ctypes.POINTER(_D)]),
     'ndcn_solver_steplog': (_L, [_P, ctypes.POINTER(_D), _L]),
     'ndcn_prof_enable': (_I, [_I]),

@@ -201,6 +201,9 @@ int ndcn_solver_begin(ndcn_solver *s, const float *y0, double t0, void *stream) 
 int ndcn_solver_advance(ndcn_solver *s, double next_t, float *out, int64_t step_budget, void *stream) {
     return solver_advance(s, next_t, out, step_budget, ST(stream));
 }
+int ndcn_solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, float *out, void *stream) {
+    return solver_advance_many(s, h_ticks, n_ticks, out, ST(stream));
+}
 int ndcn_solver_stats(const ndcn_solver *s, double h_stats[6]) { return solver_stats(s, h_stats); }
 int64_t ndcn_solver_steplog(const ndcn_solver *s, double *h_rows, int64_t cap) { return solver_steplog(s, h_rows, cap); }
 

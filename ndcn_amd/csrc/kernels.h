@@ -37,6 +37,10 @@ int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_o
                  float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr);
 // out[i] = fl(dt[0] * beta[i]), i < n: the effective coefficients of a replayed adaptive step (device-resident step size)
 int scale_coef_f32(float *out, const float *beta, const float *dt, int n, hipStream_t st);
+int spmm_wide_rk_supported(const ndcn_csr *A, int H);
+int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *K, uint32_t flags, int mode,
+                     const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, float rtol,
+                     float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 
@@ -54,6 +58,9 @@ int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, co
                    float *b, float *c, float *d, int64_t n, hipStream_t st);
 int interp_direct_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
                       const float xp[5], float *out, int64_t n, hipStream_t st);
+// fit + evaluate nt <= 8 ticks of ONE accepted step in one pass (h_xp: nt x {x^4, x^3, x^2, x, 1}; h_out: nt panels)
+int interp_direct_multi_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                            const float *h_xp, float *const *h_out, int nt, int64_t n, hipStream_t st);
 int interp_eval_f32(const float *a, const float *b, const float *c, const float *d, const float *e, const float xp[5],
                     float *out, int64_t n, hipStream_t st);
 int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,
@@ -69,6 +76,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
 int solver_destroy(ndcn_solver *s);
 int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st);
 int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st);
+int solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, float *out, hipStream_t st);
 int solver_stats(const ndcn_solver *s, double h[6]);
 int64_t solver_steplog(const ndcn_solver *s, double *rows, int64_t cap);
 

@@ -77,6 +77,8 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
     if (graph_only && spmm_rec_supported(A, H) && spmm_rec_variant(rk_mode, n_prev) && A->n_rows * (int64_t)1024 < (1ll << 32) &&
         aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))
         return spmm_rec_f32(A, X, Xh, n_own, K, 1.f, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st);
+    if (graph_only && spmm_wide_rk_supported(A, H) && aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))     // any other graph
+        return spmm_wide_rk_f32(A, X, Xh, n_own, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st);
     // composition with the same term order: K first, then the algebra over {kprev..., K}
     int rc = rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
     if (rc) return rc;

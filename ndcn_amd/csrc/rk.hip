@@ -18,7 +18,7 @@ struct Terms {
     const float *k[kMaxTerms];
     float c[kMaxTerms];
     int n;
-    const float *dt_dev;      // nullable: the step size lives in device memory (hipGraph replay) and c[] holds the bare
+    const float *dt_dev = nullptr;   // the step size lives in device memory (hipGraph replay) and c[] holds the bare
                               // tableau entries; the coefficient is then formed here as fl(dt * c) - the same single fp32
                               // rounding the host applies when it passes dt * beta by value
 };
@@ -272,6 +272,47 @@ __global__ __launch_bounds__(256) void interp_direct_kernel(DirectArgs p, int64_
     }
 }
 
+// the same for up to kMaxTicks ticks that fall into ONE accepted step: the step's panels are read once, one output
+// panel is written per tick ((2 + m) P + nt P of traffic instead of nt (3 + m) P)
+constexpr int kMaxTicks = 8;
+struct DirectMultiArgs {
+    FitArgs f;                      // a, b, c, d unused
+    float xp[kMaxTicks][5];         // {x^4, x^3, x^2, x, 1} per tick
+    float *out[kMaxTicks];
+    int nt;
+};
+
+__device__ __forceinline__ float poly1(float a, float b, float c, float d, float y0, const float *xp) {
+    return (((a * xp[0] + b * xp[1]) + c * xp[2]) + d * xp[3]) + y0 * xp[4];      // interp.py:65, e = y0
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void interp_direct_multi_kernel(DirectMultiArgs p, int64_t n_items) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 ms = wsum4(p.f.mid, i);
+            const float4 y0 = ld4(p.f.y0, i), y1 = ld4(p.f.y1, i), f0 = ld4(p.f.f0, i), f1 = ld4(p.f.f1, i);
+            float4 a, b, c, d;
+            fit1(y0.x, y1.x, ms.x, f0.x, f1.x, p.f.dt, a.x, b.x, c.x, d.x);
+            fit1(y0.y, y1.y, ms.y, f0.y, f1.y, p.f.dt, a.y, b.y, c.y, d.y);
+            fit1(y0.z, y1.z, ms.z, f0.z, f1.z, p.f.dt, a.z, b.z, c.z, d.z);
+            fit1(y0.w, y1.w, ms.w, f0.w, f1.w, p.f.dt, a.w, b.w, c.w, d.w);
+#pragma unroll
+            for (int t = 0; t < kMaxTicks; ++t)
+                if (t < p.nt)
+                    st4(p.out[t], i, make_float4(poly1(a.x, b.x, c.x, d.x, y0.x, p.xp[t]), poly1(a.y, b.y, c.y, d.y, y0.y, p.xp[t]),
+                                                 poly1(a.z, b.z, c.z, d.z, y0.z, p.xp[t]), poly1(a.w, b.w, c.w, d.w, y0.w, p.xp[t])));
+        } else {
+            const float y0 = p.f.y0[i];
+            float a, b, c, d;
+            fit1(y0, p.f.y1[i], wsum1(p.f.mid, i), p.f.f0[i], p.f.f1[i], p.f.dt, a, b, c, d);
+#pragma unroll
+            for (int t = 0; t < kMaxTicks; ++t)
+                if (t < p.nt) p.out[t][i] = poly1(a, b, c, d, y0, p.xp[t]);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------- fixed-grid stages
 template <int OP>
 __device__ __forceinline__ float stage1(float y, float k1, float k2, float k3, float k4, float dt) {
@@ -349,7 +390,9 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
 int64_t rhs_fused2_partials_bytes();
 int64_t reduce_ws_bytes() {
     const int64_t a = (int64_t)kRedBlocks * 2 * sizeof(double), b = rhs_fused2_partials_bytes();
-    return a > b ? a : b;      // one scratch serves the reductions of rk.hip and of the fused RHS epilogue
+    const int64_t c = (int64_t)kCus * 4 * 4 * 2 * sizeof(double);       // row SpMM with the ERROR epilogue: one slot per wave
+    const int64_t m = a > b ? a : b;
+    return m > c ? m : c;      // one scratch serves the reductions of rk.hip and of the RHS epilogues
 }
 
 static int red_grid(int64_t items) {
@@ -438,6 +481,38 @@ int interp_direct_f32(const float *y0, const float *y1, const float *const *h_k,
     ProfScope prof(PROF_EVAL, st, 4.0 * n * (2 + m + 1), 2.0 * n * (m + 24));
     if (vec) hipLaunchKernelGGL((interp_direct_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
     else hipLaunchKernelGGL((interp_direct_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int interp_direct_multi_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                            const float *h_xp /*nt x 5*/, float *const *h_out, int nt, int64_t n, hipStream_t st) {
+    if (nt < 1 || nt > kMaxTicks) { set_error("interp_direct_multi: 1..%d ticks per launch", kMaxTicks); return NDCN_EINVAL; }
+    DirectMultiArgs p;
+    bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1);
+    const float *kk[kMaxTerms];
+    float cc[kMaxTerms];
+    int m = 0;
+    for (int j = 0; j < 7; ++j) {
+        if (!h_k[j]) { set_error("interp_direct_multi: null stage pointer"); return NDCN_EINVAL; }
+        vec = vec && aligned16(h_k[j]);
+        if (h_cmid[j] != 0.f) { kk[m] = h_k[j]; cc[m] = h_cmid[j]; ++m; }
+    }
+    if (m == 0) { kk[0] = h_k[0]; cc[0] = 0.f; m = 1; }
+    bool dummy = true;
+    fill_terms(p.f.mid, kk, cc, m, dummy);
+    p.f.y0 = y0; p.f.y1 = y1; p.f.f0 = h_k[0]; p.f.f1 = h_k[6]; p.f.dt = dt;
+    p.f.a = p.f.b = p.f.c = p.f.d = nullptr;
+    p.nt = nt;
+    for (int t = 0; t < kMaxTicks; ++t) {
+        p.out[t] = h_out[t < nt ? t : 0];
+        vec = vec && aligned16(p.out[t]);
+        for (int q = 0; q < 5; ++q) p.xp[t][q] = h_xp[(t < nt ? t : 0) * 5 + q];
+    }
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_EVAL, st, 4.0 * n * (2 + m + nt), 2.0 * n * (m + 16 + 9 * nt));
+    if (vec) hipLaunchKernelGGL((interp_direct_multi_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_direct_multi_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

@@ -65,7 +65,8 @@ struct ndcn_solver {
     bool begun = false;
     bool fused = false;            // H = 256 fused RHS: `work` holds the packed weights
     bool fused2 = false;           // the RK algebra rides in the epilogue of the RHS launches (rhs_epi)
-    bool rec_epi = false;          // ... of the group-record SpMM (no_control RHS) instead of the fused MFMA kernel
+    bool rec_epi = false;          // ... of an SpMM kernel (no_control RHS) instead of the fused MFMA kernel:
+    bool wide_epi = false;         //     the group-record kernel, or (no plan) the row kernel
     float *ytmp2 = nullptr;        // second stage-input panel (fused2: a stage's input must outlive its epilogue)
     double t0 = 0, t1 = 0, dt = 0; // dopri5: last interval [t0, t1], next step size
     float tf = 0;                  // fixed grid: current time in the state dtype
@@ -109,8 +110,7 @@ int n_panels(const ndcn_solver_desc *d) {
 size_t workspace_bytes(const ndcn_solver_desc *d) {
     const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
     const size_t work = align_up((size_t)rhs_work_bytes(d->A.n_rows, d->H, d->rhs_flags) + 16);
-    return (size_t)n_panels(d) * panel + work + align_up((size_t)reduce_ws_bytes()) +
-           align_up((size_t)rhs_fused2_partials_bytes()) + 4096;
+    return (size_t)n_panels(d) * panel + work + 2 * align_up((size_t)reduce_ws_bytes()) + 4096;
 }
 
 int carve(ndcn_solver *s, size_t bytes, void **p) {
@@ -158,6 +158,9 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
             c_dev = s->d_coef + s->n_coef;
             s->n_coef += 8;                                   // slices stay 32-byte aligned
         }
+        if (s->wide_epi)
+            return spmm_wide_rk_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next,
+                                    rtol, atol, d_out, d_ws, st, c_dev);
         return spmm_rec_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, 1.f, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next, rtol,
                             atol, d_out, d_ws, st, c_dev);
     }
@@ -450,6 +453,8 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         if (!no_graph && no_ctl && spmm_rec_supported(&desc->A, desc->H) && s->n_rows * (int64_t)1024 < (1ll << 32)) {
             s->fused2 = true;                                   // same stepping, different launch (rhs_epi)
             s->rec_epi = true;
+        } else if (!no_graph && no_ctl && spmm_wide_rk_supported(&desc->A, desc->H)) {
+            s->fused2 = s->rec_epi = s->wide_epi = true;
         }
     }
     const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;
@@ -468,7 +473,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     s->d_red = static_cast<double *>(q);
     if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);
     s->d_ws = q;
-    if ((rc = carve(s, (size_t)rhs_fused2_partials_bytes(), &q))) return fail(rc);
+    if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);      // partials of any RHS epilogue
     s->d_ws2 = q;
     if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
@@ -765,6 +770,60 @@ static int dopri5_advance(ndcn_solver *s, double next_t, float *out, int64_t bud
         s->fit_valid = true;
     }
     return interp_eval_f32(s->ca, s->cb, s->cc, s->cd, s->ce, xp, out, s->n_elem, st);
+}
+
+// dopri5: all of `h_ticks` (increasing) in one call; out[i] = y(h_ticks[i]), panels back to back.  Ticks that fall
+// into the same accepted step are evaluated together: the step's panels are read once per <= 8 ticks
+// (interp_direct_multi_f32) instead of once per tick - the reference's drivers sample 16-120 ticks over a handful of
+// steps, where the dense output is most of the solve (dgnn.py:173-182: 15 ticks in 2 steps).  Same arithmetic per
+// element as the single-tick path (bit-identical).  Fixed-grid methods: one step per tick, as ndcn_solver_advance.
+int solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, float *out, hipStream_t st) {
+    NDCN_CHECK_ARG(s && (n_ticks == 0 || (h_ticks && out)), "null argument");
+    if (!s->begun) { set_error("ndcn_solver_advance_many before ndcn_solver_begin"); return NDCN_ESTATE; }
+    const size_t stride = (size_t)s->n_elem;
+    int64_t i = 0;
+    while (i < n_ticks) {
+        if (s->d.method != NDCN_M_DOPRI5) {
+            int rc = fixed_advance(s, h_ticks[i], out + i * stride, st);
+            if (rc) return rc;
+            ++i;
+            continue;
+        }
+        int rc = dopri5_advance(s, h_ticks[i], nullptr, 0, st);          // steps only (no evaluation)
+        if (rc) return rc;
+        if (s->fit_valid || !s->fit_pending) {                           // a stored fit / no fresh step: single-tick path
+            rc = dopri5_advance(s, h_ticks[i], out + i * stride, 0, st);
+            if (rc) return rc;
+            ++i;
+            continue;
+        }
+        int64_t j = i;
+        while (j < n_ticks && !(h_ticks[j] > s->t1)) ++j;                // the ticks this accepted step covers
+        const float a0 = (float)s->t0, a1 = (float)s->t1;
+        float cm[7];
+        for (int q = 0; q < 7; ++q) cm[q] = s->fit_dt * (float)kCMid[q];
+        while (i < j) {
+            const int nt = (int)((j - i) < 8 ? (j - i) : 8);
+            float xp[8][5];
+            float *outs[8];
+            for (int t = 0; t < nt; ++t) {
+                // interp.py:51-65: abscissa and its powers in the state dtype
+                const float at = (float)h_ticks[i + t];
+                if (!(a0 <= at && at <= a1)) {
+                    set_error("invalid interpolation, fails `t0 <= t <= t1`: %g, %g, %g", a0, at, a1);
+                    return NDCN_ESTATE;
+                }
+                const float x = (at - a0) / (a1 - a0);
+                xp[t][4] = 1.f; xp[t][3] = x; xp[t][2] = xp[t][3] * x; xp[t][1] = xp[t][2] * x; xp[t][0] = xp[t][1] * x;
+                outs[t] = out + (i + t) * stride;
+            }
+            rc = interp_direct_multi_f32(s->ycur, s->ynext, s->k, cm, s->fit_dt, &xp[0][0], outs, nt, s->n_elem, st);
+            if (rc) return rc;
+            s->evals_in_step += nt;
+            i += nt;
+        }
+    }
+    return NDCN_OK;
 }
 
 int solver_stats(const ndcn_solver *s, double h[6]) {

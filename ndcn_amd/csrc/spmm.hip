@@ -182,12 +182,32 @@ __device__ __forceinline__ void wide_chunk(int c, float v, int cnt, const f32x4 
     if (i < cnt) wide_batch<1, NV, HALO>(c, v, i, X, Xh, n_own, lane, acc);
 }
 
-template <int NV, bool HALO>
+// Runge-Kutta epilogue of the no_control right-hand side relu(A X) on operators without a group-record plan (any graph;
+// H = 256): the row-local panels are requested at the start of the row, ahead of its neighbour fetches, and consumed
+// after the sum - same term order and roundings as rk.hip / rhs_fused2.hip / spmm_rec.hip.
+constexpr int kWideMaxPrev = 5;
+struct WideEpi {
+    const float *y0;
+    const float *kprev[kWideMaxPrev];
+    float *y_next;
+    double *partials;                 // ERROR: [gridDim.x * 4][2]
+    float c[kWideMaxPrev + 1];
+    int n_prev;
+    float rtol, atol;
+    const float *c_dev;               // nullable: coefficients in device memory (hipGraph replay)
+};
+enum { WIDE_PLAIN = 0, WIDE_COMBINE = 1, WIDE_ERROR = 2, WIDE_RK4 = 3 };
+
+template <int NV, bool HALO, int MODE>
 __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ rowptr, const int *__restrict__ colidx,
                                                         const float *__restrict__ val, const int *__restrict__ order,
                                                         const float *__restrict__ Xf,
                                                         const float *__restrict__ Xhf, int n_own,
-                                                        float *__restrict__ Yf, int n_rows, float alpha, int relu) {
+                                                        float *__restrict__ Yf, int n_rows, float alpha, int relu, WideEpi e) {
+    static_assert(MODE == WIDE_PLAIN || NV == 1, "the RK epilogue is built for H = 256");
+    double err_sum = 0.0, err_bad = 0.0;
+    const int np = MODE == WIDE_PLAIN ? 0 : e.n_prev;
+    auto coef = [&](int m) { return (MODE != WIDE_PLAIN && e.c_dev) ? e.c_dev[m] : e.c[m]; };
     const int lane = threadIdx.x & 63;
     const int xcd = blockIdx.x % kXcds;
     const int waves_per_xcd = (gridDim.x / kXcds) * 4;
@@ -201,7 +221,13 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
     constexpr size_t stride = 64 * NV;                    // float4 slots per panel row
 
     int pos = __builtin_amdgcn_readfirstlane(row_lo + w);          // position in the walk order
-    if (pos >= row_hi) return;
+    if (pos >= row_hi) {
+        if (MODE == WIDE_ERROR && lane == 0) {                     // the finish kernel sums EVERY slot
+            e.partials[2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = 0.0;
+            e.partials[2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = 0.0;
+        }
+        return;
+    }
     int r = order ? order[pos] : pos;
     // software pipeline: the first <= 64 (col, val) pairs of the NEXT row are fetched while this row's
     // neighbour rows are in flight
@@ -217,6 +243,15 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
         f32x4 acc[NV];
 #pragma unroll
         for (int u = 0; u < NV; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 pk[kWideMaxPrev], py0, py1;
+        if (MODE != WIDE_PLAIN) {                                  // requested ahead of the neighbour rows
+            const size_t o = (size_t)r * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < kWideMaxPrev; ++m)
+                if (m < np) pk[m] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(e.kprev[m]) + o);
+            py0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(e.y0) + o);
+            if (MODE == WIDE_ERROR) py1 = __builtin_nontemporal_load(X + o);
+        }
         int nc = 0;
         float nv = 0.f;
         if (j1 - j0 <= 64) {
@@ -239,9 +274,56 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
             f32x4 o = acc[u] * alpha;
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             __builtin_nontemporal_store(o, &Y[(size_t)r * stride + lane + 64 * u]);
+            if (MODE != WIDE_PLAIN && u == 0) {
+#pragma clang fp contract(off)       // the RK algebra rounds like the reference's separate mul / add ops
+                const size_t oo = (size_t)r * 64 + lane;
+                f32x4 *yn = reinterpret_cast<f32x4 *>(e.y_next);
+                if (MODE == WIDE_RK4) {
+                    // rk4_alt_step_func (rk_common.py:72-78), same operator order as fixed_stage_kernel ops 2-5
+                    const float dt = coef(0);
+                    f32x4 sdt;
+                    if (np == 0) sdt = (o * dt) / 3.f;
+                    else if (np == 1) sdt = (pk[0] / -3.f + o) * dt;
+                    else if (np == 2) sdt = ((pk[0] - pk[1]) + o) * dt;
+                    else sdt = (((pk[0] + pk[1] * 3.f) + pk[2] * 3.f) + o) * (dt / 8.f);
+                    __builtin_nontemporal_store(py0 + sdt, yn + oo);
+                } else {
+                    // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
+                    f32x4 sm = o * coef(np);
+                    if (np > 0) {
+                        f32x4 uu = pk[0] * coef(0);
+#pragma unroll
+                        for (int m = 1; m < kWideMaxPrev; ++m)
+                            if (m < np) uu = uu + pk[m] * coef(m);
+                        sm = uu + sm;
+                    }
+                    if (MODE == WIDE_COMBINE) {
+                        __builtin_nontemporal_store(py0 + sm, yn + oo);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float tol = e.atol + e.rtol * fmaxf(fabsf(py0[q]), fabsf(py1[q]));
+                            const float z = sm[q] / tol;
+                            err_sum += (double)(z * z);
+                            err_bad += (double)(int)(!(fabsf(py1[q]) <= 3.402823466e38f));
+                        }
+                    }
+                }
+            }
         }
         if (!more) break;
         pos = pn; r = rn; j0 = nj0; j1 = nj1; c = nc; v = nv;
+    }
+    if (MODE == WIDE_ERROR) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            err_sum += __shfl_down(err_sum, off, 64);
+            err_bad += __shfl_down(err_bad, off, 64);
+        }
+        if (lane == 0) {
+            e.partials[2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = err_sum;
+            e.partials[2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = err_bad;
+        }
     }
 }
 
@@ -250,9 +332,9 @@ static int env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 
-template <int NV>
+template <int NV, int MODE = WIDE_PLAIN>
 static int launch_wide(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha,
-                       uint32_t flags, hipStream_t st) {
+                       uint32_t flags, hipStream_t st, const WideEpi *epi = nullptr, int *n_partials = nullptr) {
     const int n_rows = (int)A->n_rows;
     if (n_rows == 0) return NDCN_OK;
     static const int bpc = env_int("NDCN_SPMM_BLOCKS_PER_CU", 4);          // 4 waves each
@@ -261,13 +343,44 @@ static int launch_wide(const ndcn_csr *A, const float *X, const float *Xh, int64
     if (per_xcd > need) per_xcd = need < 1 ? 1 : need;
     const int relu = (flags & NDCN_F_RELU) ? 1 : 0;
     const dim3 grid(per_xcd * kXcds), block(256);
+    WideEpi e = {};
+    if (epi) e = *epi;
+    if (n_partials) *n_partials = (int)grid.x * 4;
     if (Xh)
-        hipLaunchKernelGGL((spmm_wide_kernel<NV, true>), grid, block, 0, st, A->rowptr, A->colidx, A->val,
-                           A->row_order, X, Xh, (int)n_own, Y, n_rows, alpha, relu);
+        hipLaunchKernelGGL((spmm_wide_kernel<NV, true, MODE>), grid, block, 0, st, A->rowptr, A->colidx, A->val,
+                           A->row_order, X, Xh, (int)n_own, Y, n_rows, alpha, relu, e);
     else
-        hipLaunchKernelGGL((spmm_wide_kernel<NV, false>), grid, block, 0, st, A->rowptr, A->colidx, A->val,
-                           A->row_order, X, Xh, (int)n_own, Y, n_rows, alpha, relu);
+        hipLaunchKernelGGL((spmm_wide_kernel<NV, false, MODE>), grid, block, 0, st, A->rowptr, A->colidx, A->val,
+                           A->row_order, X, Xh, (int)n_own, Y, n_rows, alpha, relu, e);
     NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int spmm_wide_rk_supported(const ndcn_csr *A, int H) {
+    static const int enabled = env_int("NDCN_SPMM_WIDE_RK", 1);
+    return enabled && A && H == 256 && A->n_rows > 0;
+}
+
+// K = relu(A X) plus the RK algebra in the row SpMM's epilogue (modes and arguments as spmm_rec_f32 / rhs_fused2_f32)
+int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *K, uint32_t flags, int mode,
+                     const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, float rtol,
+                     float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev) {
+    if (n_prev < 0 || n_prev > kWideMaxPrev || (mode == WIDE_RK4 && n_prev > 3)) { set_error("spmm_wide_rk: bad stage count"); return NDCN_EINVAL; }
+    WideEpi e = {};
+    e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
+    e.c_dev = c_dev;
+    for (int m = 0; m < kWideMaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
+    for (int m = 0; m <= kWideMaxPrev; ++m) e.c[m] = (mode != WIDE_RK4 && m <= n_prev) ? h_c[m] : 0.f;
+    if (mode == WIDE_RK4) e.c[0] = h_c[0];
+    const double P = 4.0 * 256 * (double)A->n_rows;
+    ProfScope prof(PROF_RHS_FUSED, st, 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * 256 * (double)(A->n_rows + A->n_cols) + P * (n_prev + 2),
+                   2.0 * A->nnz * 256);
+    int np = 0, rc;
+    if (mode == WIDE_COMBINE) rc = launch_wide<1, WIDE_COMBINE>(A, X, Xh, n_own, K, 1.f, flags, st, &e, &np);
+    else if (mode == WIDE_ERROR) rc = launch_wide<1, WIDE_ERROR>(A, X, Xh, n_own, K, 1.f, flags, st, &e, &np);
+    else rc = launch_wide<1, WIDE_RK4>(A, X, Xh, n_own, K, 1.f, flags, st, &e, &np);
+    if (rc) return rc;
+    if (mode == WIDE_ERROR) return partials_finish(e.partials, np, d_out, st);
     return NDCN_OK;
 }
 

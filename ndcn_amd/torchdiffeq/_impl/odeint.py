@@ -159,6 +159,13 @@ class DeviceSolver:
                                                          _lib.stream_ptr()))
         return rc == 0
 
+    def advance_many(self, ticks, out):
+        """All `ticks` in one library call; out: (len(ticks), n_rows, H) contiguous."""
+        assert out.is_contiguous() and tuple(out.shape) == (len(ticks),) + self.shape
+        arr = (ctypes.c_double * len(ticks))(*[float(v) for v in ticks])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ndcn_solver_advance_many(self.handle, arr, len(ticks), _lib.ptr(out), _lib.stream_ptr()))
+
     def stats(self):
         buf = (ctypes.c_double * 6)()
         _lib.check(self.lib.ndcn_solver_stats(self.handle, buf))
@@ -200,13 +207,13 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
         out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         out[0].copy_(y0)
         solver.begin(y0, tt[0])
-        for i in range(1, len(tt)):
-            try:
-                solver.advance(tt[i], out[i])
-            except _lib.NdcnHipError as e:
-                if e.code in (_lib.ENONFINITE, _lib.EUNDERFLOW, _lib.EMAXSTEPS, _lib.ESTATE):
-                    raise AssertionError(str(e)) from None     # the reference raises AssertionError here
-                raise
+        try:
+            if len(tt) > 1:
+                solver.advance_many(tt[1:], out[1:])               # one library call for the whole time vector
+        except _lib.NdcnHipError as e:
+            if e.code in (_lib.ENONFINITE, _lib.EUNDERFLOW, _lib.EMAXSTEPS, _lib.ESTATE):
+                raise AssertionError(str(e)) from None         # the reference raises AssertionError here
+            raise
         if step_log is not None:
             step_log.extend(solver.steplog())
             step_log.append(('nfe', int(solver.stats()['nfe'])))

@@ -152,10 +152,11 @@ def test_lattice_operator_gets_patch_plan_automatically(dev):
     assert torch.equal(hip.spmm(A, X), hip.spmm(_no_plan(CsrOperator.from_scipy(L, dev)), X))
 
 
-@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2)])
+@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2), None])
 def test_no_control_rhs_rk_epilogue_in_group_record_kernel(dev, shape):
     """relu(A X) with the stage algebra in the SpMM's epilogue (the no_control RHS of the dgnn README command):
-    COMBINE with 0..5 earlier stages, ERROR, RK4 stages 0..3 - bit-identical to SpMM + the separate stage kernels."""
+    COMBINE with 0..5 earlier stages, ERROR, RK4 stages 0..3 - bit-identical to SpMM + the separate stage kernels.
+    shape None: no plan - the row SpMM kernel carries the epilogue (any graph)."""
     from ndcn_amd import hip, CsrOperator, graphs
     side, H = 41, 256
     n = side * side
@@ -164,8 +165,9 @@ def test_no_control_rhs_rk_epilogue_in_group_record_kernel(dev, shape):
     for m in (grid, sp.vstack([grid[:800], rnd[800:]]).tocsr()):
         m.sort_indices()
         A = _no_plan(CsrOperator.from_scipy(m, dev))
-        A.group_order = torch.as_tensor(CsrOperator.from_scipy(grid, dev).detect_stencil_order(), dtype=torch.int32).to(dev)
-        A.build_rec_plan(*shape)
+        if shape is not None:
+            A.group_order = torch.as_tensor(CsrOperator.from_scipy(grid, dev).detect_stencil_order(), dtype=torch.int32).to(dev)
+            A.build_rec_plan(*shape)
         P = _no_plan(CsrOperator.from_scipy(m, dev))
         g = torch.Generator().manual_seed(2)
         X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)

@@ -277,6 +277,15 @@ def test_dopri5_hipgraph_replay_equals_eager(dev, case):
         outs.append(torch.stack(traj))
     assert logs[0] == logs[1] and len(logs[0][0]) >= 2
     assert torch.equal(outs[0], outs[1])
+    # the whole time vector in ONE call (ticks of a step evaluated together): bit-identical to tick-by-tick
+    s = DeviceSolver(f, x0.shape[0], 'dopri5', rtol, atol)
+    s.begin(x0, float(t[0]))
+    many = torch.empty((len(t) - 1,) + tuple(x0.shape), device=dev)
+    s.advance_many(t[1:].tolist(), many)
+    torch.cuda.synchronize()
+    assert (s.steplog(), s.stats()['nfe']) == logs[0]
+    s.close()
+    assert torch.equal(many, outs[0][1:])
     if case == 'H20':
         check_traj(outs[1].cpu().numpy(), d['traj'], l1=1e-5, mx=2e-4)
 

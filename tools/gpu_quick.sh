@@ -4,7 +4,8 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q ${1:-} > gpurun_out/pytest_quick.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_quick.log
+if [ -n "${1:-}" ]; then K=(-k "$1"); else K=(); fi
+timeout 1500 python -m pytest tests -m gpu -x -q "${K[@]}" > gpurun_out/pytest_quick.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_quick.log
 tail -15 gpurun_out/pytest_quick.log | cut -c1-300
 if [ -n "${2:-}" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kernels.log 2>&1
