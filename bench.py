@@ -373,10 +373,21 @@ def main():
             roofline['traffic_frac_of_measured_copy'] = round(tg / copy_gbps, 4)
         del src_p, dst_p
     halo = None
-    if world > 1 and hasattr(runner, 'plan'):
+    if hasattr(runner, 'plan') and (world > 1 or runner.plan.n_halo > 0):
         hb = int(runner.plan.bytes_per_exchange(H))
         halo = {'bytes_received_per_rhs_per_gpu': hb, 'exchanges_per_step': 6,
-                'xgmi_peak_GBps_per_gpu': 7 * 153}
+                'xgmi_peak_GBps_per_gpu': 7 * 153, 'overlapped_with_interior_rows': bool(runner.func.overlap)}
+        # a short instrumented pass: per exchange, its duration on the side stream, the interior launch it hides
+        # behind, and what the main stream still waited for (exposed)
+        runner.func.timing = {}
+        with torch.no_grad():
+            runner.run_steps(min(args.steps, 5))
+        torch.cuda.synchronize()
+        tm = runner.func.drain_timing() or {}
+        runner.func.timing = None
+        if tm.get('n'):
+            halo.update({'exchange_us': round(tm['exchange_us'] / tm['n'], 1), 'interior_us': round(tm['interior_us'] / tm['n'], 1),
+                         'exposed_us': round(tm['exposed_us'] / tm['n'], 1), 'timed_exchanges': tm['n']})
 
     if rank != 0:
         return

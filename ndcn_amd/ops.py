@@ -136,7 +136,8 @@ class HipOps:
         return Y
 
     @staticmethod
-    def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None):
+    def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
+               out_K=None, out_y=None):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
         mode 'combine': returns (K, y0 + sum cs[m] kprev[m] + cs[-1] K); mode 'error': returns
         (K, (sum of squared error ratios, non-finite count of X)) - the dopri5 error record with X = y1;
@@ -161,13 +162,14 @@ class HipOps:
         assert len(cs) == (1 if mode == 'rk4' else len(kprev) + 1)
         if X_halo is not None:
             X_halo = _panel(X_halo, 'halo panel')
-        K = torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
+        K = out_K if out_K is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
+        assert K.is_contiguous() and tuple(K.shape) == (n_rows, H)
         wbytes = int(lib.ndcn_rhs_work_bytes(n_rows, H, flags))
         work = torch.empty(wbytes, dtype=torch.uint8, device=X.device) if wbytes else None
         arr_k = (_P * max(len(kprev), 1))(*[k.data_ptr() for k in kprev])
         arr_c = (_F * len(cs))(*[float(c) for c in cs])
         rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR, 'rk4': _lib.RK_RK4}[mode]
-        y_next = torch.empty_like(K) if mode in ('combine', 'rk4') else None
+        y_next = (out_y if out_y is not None else torch.empty_like(K)) if mode in ('combine', 'rk4') else None
         red = _Reducer.get(X.device)
         with torch.cuda.device(X.device):
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),

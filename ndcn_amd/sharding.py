@@ -28,8 +28,11 @@ def even_bounds(n, world):
 class HaloPlan:
     """What this rank must send / receive before each A X, and the operator remapped to [own | halo] columns."""
 
-    def __init__(self, rows_block, bounds, rank, device, group=None):
-        """rows_block: scipy CSR, this rank's rows x ALL global columns."""
+    def __init__(self, rows_block, bounds, rank, device, group=None, self_halo=0):
+        """rows_block: scipy CSR, this rank's rows x ALL global columns.
+        self_halo (test hook, NDCN_SELF_HALO): the first `self_halo` OWN columns are additionally routed through the
+        exchange as if a peer owned them (this rank sends them to itself), so that a single rank drives a non-empty
+        all-to-all-v over the real backend - on a 1-GPU box that is the only way RCCL's collective ever executes."""
         self.group = group
         self.rank, self.world = rank, len(bounds) - 1
         self.bounds = list(bounds)
@@ -39,7 +42,7 @@ class HaloPlan:
         blk.sort_indices()
         assert blk.shape[0] == self.n_own
         cols = blk.indices.astype(np.int64)
-        remote = (cols < lo) | (cols >= hi)
+        remote = (cols < lo) | (cols >= hi) | (cols < lo + int(self_halo))
         need = np.unique(cols[remote])                                   # sorted global ids = halo order
         owner = np.searchsorted(np.asarray(bounds[1:]), need, side='right')
         self.recv_counts = [int((owner == p).sum()) for p in range(self.world)]
@@ -51,11 +54,43 @@ class HaloPlan:
         local.sort_indices()
         self.local_op = CsrOperator.from_scipy(local, device)
         self.local_nnz = int(local.nnz)
+        # Row ranges for overlapping the exchange with compute: rows that reference no halo column ("interior") can be
+        # evaluated while the halo is in flight.  With node-range sharding of a graph in a locality-preserving order they
+        # form one long run between two thin boundary bands (grid: all but the first and last lattice row of the shard).
+        self.ranges = self._row_ranges(local, device)
         # tell every owner which of its rows we need (plan-time exchange of index lists)
         want = [need[owner == p] - bounds[p] for p in range(self.world)]     # owner-local row ids
         self.send_counts, send_idx = self._exchange_requests(want, device)
         self.send_idx = send_idx.to(torch.int32)                             # rows of OUR panel to pack, grouped by peer
         self.device = device
+
+    def _row_ranges(self, local, device):
+        """[(a, b, operator of rows [a, b), needs_halo)] covering the shard, or None when no long interior run exists."""
+        n = self.n_own
+        if n == 0 or self.n_halo == 0:
+            return None
+        has_halo = np.zeros(n, dtype=bool)
+        rows = np.repeat(np.arange(n), np.diff(local.indptr))
+        has_halo[rows[local.indices >= n]] = True
+        idx = np.flatnonzero(has_halo)
+        if idx.size == 0:
+            return None
+        # longest run of interior rows
+        edges = np.concatenate([[-1], idx, [n]])
+        gaps = np.diff(edges) - 1
+        g = int(np.argmax(gaps))
+        a, b = int(edges[g] + 1), int(edges[g + 1])
+        if b - a < 0.5 * n:
+            return None
+        out = []
+        for lo_, hi_, halo in ((0, a, True), (a, b, False), (b, n, True)):
+            if hi_ <= lo_:
+                continue
+            sub = local[lo_:hi_]
+            if not halo:
+                sub = sub[:, :n]                                    # interior rows reference own columns only
+            out.append((lo_, hi_, CsrOperator.from_scipy(sub, device), halo))
+        return out
 
     def _exchange_requests(self, want, device):
         world = self.world
@@ -76,7 +111,7 @@ class HaloPlan:
         """Returns the halo panel (n_halo x H) for the local panel X."""
         H = X.shape[1]
         halo = torch.empty((self.n_halo, H), dtype=X.dtype, device=X.device)
-        if self.world == 1:
+        if self.n_halo == 0 and sum(self.send_counts) == 0:
             return halo
         packed = ops.gather_rows(X, self.send_idx) if self.send_idx.numel() else X[:0]
         if X.is_cuda and dist.get_backend(self.group) != 'nccl':
@@ -92,25 +127,103 @@ class HaloPlan:
 
 class ShardedODEFunc(nn.Module):
     """ODEFunc on one shard: halo exchange, then the local fused RHS over [own | halo]
-    (neural_dynamics.py:20-39 semantics on the global graph)."""
+    (neural_dynamics.py:20-39 semantics on the global graph).
+
+    Overlap: when the shard has a long run of interior rows (HaloPlan.ranges) the exchange runs on a side stream while
+    the interior rows - a launch that needs no halo panel - are evaluated on the caller's stream; the two thin boundary
+    bands follow once the halo has landed.  Results are identical to the un-split evaluation (rows are independent).
+    The error-record launch of a dopri5 step stays un-split (its epilogue re-reads y1 by row index)."""
 
     ndcn_autonomous = True
 
-    def __init__(self, odefunc, plan, ops):
+    def __init__(self, odefunc, plan, ops, overlap=True):
         super().__init__()
         self.f = odefunc
         self.plan = plan
         self.ops = ops
         self.nfe = 0
         self.halo_bytes = 0
+        self.overlap = overlap and plan.ranges is not None
+        self.comm = None                  # side stream of the exchange (created on first use, CUDA only)
+        self.timing = None                # when a dict: accumulates {exchange_us, interior_us, exposed_us, n}
+
+    # -- exchange on the side stream; returns (halo, event-or-None)
+    def _start_exchange(self, x):
+        self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
+        if not (self.overlap and x.is_cuda):
+            return self.plan.exchange(self.ops, x), None
+        import torch.cuda as tc
+        if self.comm is None:
+            self.comm = tc.Stream(device=x.device)
+        cur = tc.current_stream(x.device)
+        self.comm.wait_stream(cur)                                   # x is complete
+        ev = None
+        with tc.stream(self.comm):
+            if self.timing is not None:
+                e0 = tc.Event(enable_timing=True)
+                e0.record()
+            halo = self.plan.exchange(self.ops, x)
+            halo.record_stream(cur)
+            x.record_stream(self.comm)
+            if self.timing is not None:
+                e1 = tc.Event(enable_timing=True)
+                e1.record()
+                ev = (e0, e1)
+        return halo, ev
+
+    def _finish_exchange(self, x, ev, t_int):
+        if self.comm is None or not x.is_cuda:
+            return
+        import torch.cuda as tc
+        cur = tc.current_stream(x.device)
+        if self.timing is not None and ev is not None:
+            i0, i1 = t_int
+            i1.record()
+        cur.wait_stream(self.comm)
+        if self.timing is not None and ev is not None:
+            w = tc.Event(enable_timing=True)
+            w.record()
+            self.timing.setdefault('pending', []).append((ev[0], ev[1], i0, i1, w))
+
+    def drain_timing(self):
+        """Fold the recorded events into microsecond sums (call after a device synchronise)."""
+        t = self.timing
+        if not t:
+            return t
+        for e0, e1, i0, i1, w in t.pop('pending', []):
+            t['exchange_us'] = t.get('exchange_us', 0.0) + 1e3 * e0.elapsed_time(e1)
+            t['interior_us'] = t.get('interior_us', 0.0) + 1e3 * i0.elapsed_time(i1)
+            t['exposed_us'] = t.get('exposed_us', 0.0) + 1e3 * max(0.0, i1.elapsed_time(w))
+            t['n'] = t.get('n', 0) + 1
+        return t
+
+    def _split_eval(self, x, call):
+        """call(op, X_halo, a, b) evaluates rows [a, b) of the shard; interior first, boundary after the exchange."""
+        halo, ev = self._start_exchange(x)
+        t_int = None
+        if self.timing is not None and ev is not None:
+            import torch.cuda as tc
+            t_int = (tc.Event(enable_timing=True), tc.Event(enable_timing=True))
+            t_int[0].record()
+        for a, b, op, needs in self.plan.ranges:
+            if not needs:
+                call(op, None, a, b)
+        self._finish_exchange(x, ev, t_int)
+        for a, b, op, needs in self.plan.ranges:
+            if needs:
+                call(op, halo, a, b)
 
     def forward(self, t, x):
         self.nfe += 1
         f = self.f
         if f.no_graph:
             return self.ops.rhs(None, x, f.wt.weight, f.wt.bias, no_graph=True, no_control=f.no_control)
-        halo = self.plan.exchange(self.ops, x)
-        self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
+        if self.overlap:
+            out = torch.empty_like(x)
+            self._split_eval(x, lambda op, halo, a, b: self.ops.rhs(op, x, f.wt.weight, f.wt.bias, no_control=f.no_control,
+                                                                    X_halo=halo, out=out[a:b]))
+            return out
+        halo, _ = self._start_exchange(x)
         return self.ops.rhs(self.plan.local_op, x, f.wt.weight, f.wt.bias, no_control=f.no_control, X_halo=halo)
 
     def rhs_rk(self, x, mode, y0, kprev, cs, rtol, atol):
@@ -118,10 +231,17 @@ class ShardedODEFunc(nn.Module):
         over ranks here so every rank sees the same controller input."""
         self.nfe += 1
         f = self.f
+        if self.overlap and not f.no_graph and mode in ('combine', 'rk4'):
+            k, y_next = torch.empty_like(x), torch.empty_like(x)
+            self._split_eval(x, lambda op, halo, a, b: self.ops.rhs_rk(
+                op, x, f.wt.weight, f.wt.bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
+                no_control=f.no_control, X_halo=halo, out_K=k[a:b], out_y=y_next[a:b]))
+            return k, y_next
         halo = None
         if not f.no_graph:
-            halo = self.plan.exchange(self.ops, x)
-            self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
+            halo, _ = self._start_exchange(x)
+            if self.comm is not None and x.is_cuda:
+                torch.cuda.current_stream(x.device).wait_stream(self.comm)
         k, out = self.ops.rhs_rk(None if f.no_graph else self.plan.local_op, x, f.wt.weight, f.wt.bias, mode, y0, kprev, cs,
                                  rtol, atol, no_graph=f.no_graph, no_control=f.no_control, X_halo=halo)
         if mode == 'error' and self.plan.world > 1:
@@ -193,7 +313,8 @@ class ShardedGridBench:
         R = S * world
         block = graphs.grid_operator_row_block(R, S, rank * S, (rank + 1) * S, 'norm_lap')
         bounds = [r * S * S for r in range(world + 1)]
-        self.plan = HaloPlan(block, bounds, rank, device, group)
+        import os
+        self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=int(os.environ.get('NDCN_SELF_HALO', '0')))
         self.local_nnz = self.plan.local_nnz
         self.func = ShardedODEFunc(odefunc, self.plan, ops)
         self.dops = DistOps(ops, R * S, S * S, group)

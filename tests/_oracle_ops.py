@@ -56,14 +56,24 @@ class OracleOps:
             x = cls.spmm(A, X, X_halo)
         if not no_control:
             x = torch.nn.functional.linear(x, W, b)
-        return torch.relu(x)
+        x = torch.relu(x)
+        if out is not None:
+            out.copy_(x)
+            return out
+        return x
 
     @classmethod
-    def rhs_rk(cls, A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None):
+    def rhs_rk(cls, A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
+               out_K=None, out_y=None):
         k = cls.rhs(A, X, W, b, no_graph=no_graph, no_control=no_control, X_halo=X_halo)
         ks = list(kprev) + [k]
+        if out_K is not None:
+            out_K.copy_(k)
         if mode == 'combine':
-            return k, cls.combine(y0, ks, cs)
+            y = cls.combine(y0, ks, cs)
+            if out_y is not None:
+                out_y.copy_(y)
+            return k, y
         return k, cls.error(y0, X, ks, cs, rtol, atol)
 
     @staticmethod

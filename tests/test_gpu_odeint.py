@@ -349,9 +349,31 @@ def test_sharded_path_single_rank_equals_device_solver(dev):
             yb = sharding.sharded_odeint(hip, f, plan, side * side, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
         assert [r[2] for r in la[:-1]] == [r[2] for r in lb if r[0] != 'nfe']
         assert float((ya - yb).abs().max()) <= 1e-5 * float(ya.abs().max())
-        # bench runner of the sharded path
+        # RCCL's all-to-all-v actually executes: the self-halo hook routes the first 2 lattice rows through the exchange
+        # (non-empty self split), on the side stream, overlapped with the interior launch
+        plan2 = sharding.HaloPlan(L, [0, side * side], 0, dev, self_halo=2 * side)
+        assert plan2.n_halo == 2 * side and plan2.send_counts == [2 * side] and plan2.ranges is not None
+        with torch.no_grad():
+            lc = []
+            yc = sharding.sharded_odeint(hip, f, plan2, side * side, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lc)
+            yr = sharding.sharded_odeint(hip, f, plan2, side * side, x0, torch.linspace(0., 1., 4).to(dev), method='rk4')
+            y4 = ode.odeint(f, x0, torch.linspace(0., 1., 4).to(dev), method='rk4')
+        assert [r[2] for r in lc if r[0] != 'nfe'] == [r[2] for r in lb if r[0] != 'nfe']
+        assert float((yc - yb).abs().max()) <= 1e-5 * float(ya.abs().max())
+        assert float((yr - y4).abs().max()) <= 1e-5 * float(y4.abs().max())
+        # bench runner of the sharded path (with the hook: exchange timing is recorded)
         runner = sharding.ShardedGridBench(f, 48, 1, 0, dev, 5.0, .01, .001)
         assert runner.run_steps(3) == 3 and runner.nfe() >= 2 + 18
+        os.environ['NDCN_SELF_HALO'] = str(2 * side)
+        try:
+            runner = sharding.ShardedGridBench(f, 48, 1, 0, dev, 5.0, .01, .001)
+            runner.func.timing = {}
+            assert runner.run_steps(3) == 3
+            torch.cuda.synchronize()
+            tm = runner.func.drain_timing()
+            assert tm['n'] >= 10 and tm['exchange_us'] > 0 and tm['interior_us'] > 0
+        finally:
+            del os.environ['NDCN_SELF_HALO']
     finally:
         dist.destroy_process_group()
 

@@ -40,6 +40,10 @@ def _worker(rank, world, port, case, ret):
             block = full[bounds[rank]:bounds[rank + 1]]
         n = full.shape[0]
         plan = sharding.HaloPlan(block, bounds, rank, cpu)
+        # the grid shard has one long interior run (exchange / compute overlap path), the small-world shard has none
+        assert (plan.ranges is not None) == (case == 'grid')
+        if case == 'grid':
+            assert [r[3] for r in plan.ranges].count(False) == 1 and sum(r[1] - r[0] for r in plan.ranges) == plan.n_own
         x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
         xl = x[bounds[rank]:bounds[rank + 1]].contiguous()
         t = torch.linspace(0., 1.5, 4)
@@ -95,3 +99,48 @@ def test_two_rank_sharded_solve_equals_single_process_oracle(case):
     ref = orc.odeint(f, x, torch.flip(t, [0]), rtol=1e-3, atol=1e-4, method='dopri5').numpy()
     got = np.concatenate([ret[r]['dopri5_rev'] for r in range(world)], axis=1)
     assert np.abs(got - ref).max() < 5e-6
+
+
+def _self_halo_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ndcn_amd import graphs, sharding
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from _oracle_ops import OracleOps
+        H = 8
+        torch.manual_seed(0)
+        f = ODEFunc(H, None)
+        full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(12, 7))
+        n = full.shape[0]
+        plan = sharding.HaloPlan(full, [0, n], 0, torch.device('cpu'), self_halo=14)
+        assert plan.n_halo == 14 and plan.send_counts == [14] and plan.recv_counts == [14] and plan.ranges is not None
+        x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
+        t = torch.linspace(0., 1., 3)
+        y = sharding.sharded_odeint(OracleOps, f, plan, n, x, t, rtol=1e-3, atol=1e-4, method='dopri5')
+        ret['y'] = y.detach().numpy()
+        ret['W'], ret['b'] = f.wt.weight.detach().numpy(), f.wt.bias.detach().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_self_halo_drives_a_real_all_to_all():
+    """The NDCN_SELF_HALO test hook: one rank routes some of its OWN columns through the exchange (all-to-all-v with a
+    non-empty self split) and still reproduces the un-sharded oracle - the configuration that lets a 1-GPU box execute
+    RCCL's collective (tests/test_gpu_odeint.py runs the same over nccl)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_self_halo_worker, args=(1, 29950 + (os.getpid() % 40), ret), nprocs=1, join=True)
+    sys.path.insert(0, ROOT)
+    from ndcn_amd import graphs
+    from oracle import ndcn_oracle as orc
+    full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(12, 7))
+    A = orc.coo_from_csr(full.indptr, full.indices, full.data, full.shape)
+    f = orc.OracleODEFunc(A, torch.from_numpy(ret['W']), torch.from_numpy(ret['b']))
+    x = torch.rand(full.shape[0], 8, generator=torch.Generator().manual_seed(1))
+    ref = orc.odeint(f, x, torch.linspace(0., 1., 3), rtol=1e-3, atol=1e-4, method='dopri5').numpy()
+    assert np.abs(ret['y'] - ref).max() < 5e-6
