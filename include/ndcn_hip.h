@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 5
+#define NDCN_ABI_VERSION 6
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -122,6 +122,22 @@ NDCN_API int ndcn_spmm_f32(const ndcn_csr *A, const float *X, const float *X_hal
  * Y must not alias S. */
 NDCN_API int ndcn_linear_f32(const float *S, const float *W, const float *b, float *Y,
                     int64_t n, int H_in, int H_out, uint32_t flags, void *stream);
+
+/* Backward of Y = act(S W^T + b) - the reference trains by plain autograd through every solver op
+ * (heat_dynamics.py:333, dgnn.py:204; neural_dynamics.py:33,36,143-148).  gZ = g (.) [Y > 0] when the ReLU output Y is
+ * given (nullable: no activation), then
+ *   gS [n, H_in]      = gZ W               (nullable)
+ *   gW [H_out, H_in]  = gZ^T S             (nullable; reduction over rows split into chunks, partials summed in a fixed
+ *                                           order: deterministic, no atomics)
+ *   gb [H_out]        = column sums of gZ  (nullable)
+ * S: the forward input (needed for gW).  work: ndcn_linear_bwd_work_bytes() bytes of device scratch (gW / gb).       */
+NDCN_API int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW,
+                                 float *gb, void *work, int64_t n, int H_in, int H_out, void *stream);
+NDCN_API int64_t ndcn_linear_bwd_work_bytes(int64_t n, int H_in, int H_out);
+/* out = w * x: the VJP of one term of the Runge-Kutta linear combinations (rk_common.py:51,75-78; interp.py:21-35). */
+NDCN_API int ndcn_scale_f32(float *out, const float *x, float w, int64_t n_elem, void *stream);
+/* out = g where y > 0, else 0: the VJP of relu given its OUTPUT y (neural_dynamics.py:36; the no_control RHS). */
+NDCN_API int ndcn_relu_bwd_f32(float *out, const float *g, const float *y, int64_t n_elem, void *stream);
 
 /* The whole ODEFunc.forward in one call: Y = relu(W (A X) + b) honouring NO_GRAPH / NO_CONTROL
  * (neural_dynamics.py:20-39, dropout p = 0).  `work`: device scratch of ndcn_rhs_work_bytes() bytes, 16-byte

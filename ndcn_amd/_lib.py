@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
@@ -70,6 +70,10 @@ SIGNATURES = {
     'ndcn_device_info': (_I, [ctypes.POINTER(_L)]),
     'ndcn_spmm_f32': (_I, [_CSR, _P, _P, _L, _P, _I, _F, _U, _P]),
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
+    'ndcn_linear_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'ndcn_linear_bwd_work_bytes': (_L, [_L, _I, _I]),
+    'ndcn_scale_f32': (_I, [_P, _P, _F, _L, _P]),
+    'ndcn_relu_bwd_f32': (_I, [_P, _P, _P, _L, _P]),
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,

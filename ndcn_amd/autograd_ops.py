@@ -3,8 +3,8 @@
 The reference trains by plain autograd THROUGH every solver op (heat_dynamics.py:333; no adjoint).  Here
 each forward is the same HIP kernel the inference path uses; the backward of the two heavy ops runs on
 HIP kernels too (g_X = A^T g through the SpMM on the transposed CSR, g_S = g W through the MFMA Linear);
-the weight gradient g^T S is a plain library GEMM (torch.mm -> rocBLAS) and the per-term scalings of the
-Runge-Kutta algebra are elementwise torch ops on the gradient.
+the weight gradient g^T S as a split-row fp32-MFMA kernel with the ReLU mask and the bias gradient fused in
+(csrc/linear_bwd.hip)), and the per-term scalings of the Runge-Kutta algebra are one streaming HIP kernel each.
 
 dopri5: the reference differentiates through its step-size controller too; that chain lives in
 ndcn_amd/torchdiffeq/_impl/autograd_path.py.  The wrappers below serve the right-hand side and the fixed-grid
@@ -15,10 +15,6 @@ import torch
 
 from .csr import as_csr
 from .ops import hip
-
-
-def _wt(W):
-    return W.detach().t().contiguous()
 
 
 class _Spmm(torch.autograd.Function):
@@ -42,12 +38,8 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         S, W = ctx.saved_tensors
-        g = g.contiguous()
-        gS = hip.linear(g, _wt(W)) if ctx.needs_input_grad[0] else None
-        g2, S2 = g.reshape(-1, g.shape[-1]), S.detach().reshape(-1, S.shape[-1])
-        gW = torch.mm(g2.t(), S2) if ctx.needs_input_grad[1] else None
-        gb = g2.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
-        return gS, gW, gb
+        return hip.linear_bwd(g.contiguous(), W.detach(), S=S.detach(), need_gS=ctx.needs_input_grad[0],
+                              need_gW=ctx.needs_input_grad[1], need_gb=ctx.has_b and ctx.needs_input_grad[2])
 
 
 class _Rhs(torch.autograd.Function):
@@ -63,17 +55,18 @@ class _Rhs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, W, Y = ctx.saved_tensors
-        gZ = g * (Y > 0).to(g.dtype)
+        g = g.contiguous()
         gW = gb = None
-        gS = gZ
         if not ctx.no_control:
-            if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            # ReLU mask fused into the operand loads of the two GEMMs; g_W = gZ^T S split over row chunks, g_b with it
+            need_w = ctx.needs_input_grad[1]
+            need_b = ctx.has_b and ctx.needs_input_grad[2]
+            S = None
+            if need_w:
                 S = X.detach() if ctx.no_graph else hip.spmm(ctx.A, X.detach())
-                if ctx.needs_input_grad[1]:
-                    gW = torch.mm(gZ.t(), S)
-                if ctx.has_b and ctx.needs_input_grad[2]:
-                    gb = gZ.sum(0)
-            gS = hip.linear(gZ, _wt(W)) if ctx.needs_input_grad[0] else None
+            gS, gW, gb = hip.linear_bwd(g, W.detach(), S=S, Y=Y, need_gS=ctx.needs_input_grad[0], need_gW=need_w, need_gb=need_b)
+        else:
+            gS = hip.relu_bwd(g, Y) if ctx.needs_input_grad[0] else None
         gX = None
         if ctx.needs_input_grad[0]:
             gX = gS if ctx.no_graph else hip.spmm(ctx.A.transpose(), gS.contiguous())
@@ -108,7 +101,7 @@ class _LinMap(torch.autograd.Function):
     def backward(ctx, g):
         grads = []
         for need, w in zip(ctx.needs_input_grad[2:], ctx.weights):
-            grads.append(g * float(w) if (need and w != 0) else (torch.zeros_like(g) if need else None))
+            grads.append(hip.scale(g, w) if (need and w != 0) else (torch.zeros_like(g) if need else None))
         return (None, None) + tuple(grads)
 
 

@@ -71,6 +71,27 @@ int ndcn_linear_f32(const float *S, const float *W, const float *b, float *Y, in
 
 int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) { return rhs_work_bytes(n_rows, H, flags); }
 
+int64_t ndcn_linear_bwd_work_bytes(int64_t n, int H_in, int H_out) { return linear_bwd_work_bytes(n, H_in, H_out); }
+
+int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb,
+                        void *work, int64_t n, int H_in, int H_out, void *stream) {
+    NDCN_CHECK_ARG(n >= 0 && H_in > 0 && H_out > 0, "bad shape");
+    NDCN_CHECK_ARG(n == 0 || g, "null gradient");
+    NDCN_CHECK_ARG(!gS || W, "gS needs the weight");
+    NDCN_CHECK_ARG(gS != g, "gS must not alias g");
+    return linear_bwd_f32(g, Y, S, W, gS, gW, gb, work, n, H_in, H_out, ST(stream));
+}
+
+int ndcn_relu_bwd_f32(float *out, const float *g, const float *y, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && (n_elem == 0 || (out && g && y)), "bad argument");
+    return relu_bwd_f32(out, g, y, n_elem, ST(stream));
+}
+
+int ndcn_scale_f32(float *out, const float *x, float w, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && (n_elem == 0 || (out && x)), "bad argument");
+    return scale_f32(out, x, w, n_elem, ST(stream));
+}
+
 int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
                  float *Y, float *work, int H, uint32_t flags, void *stream) {
     NDCN_CHECK_ARG(A, "null operator descriptor (n_rows is read from it even under NO_GRAPH)");

@@ -351,6 +351,38 @@ __global__ void scale_coef_kernel(float *__restrict__ out, const float *__restri
     if (i < n) out[i] = dt[0] * beta[i];
 }
 
+// out = w * x  (the VJP of one term of a Runge-Kutta linear combination)
+__global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ out, const float *__restrict__ x, float w, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ld4(x, i);
+        st4(out, i, make_float4(w * v.x, w * v.y, w * v.z, w * v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[4 * n4 + threadIdx.x] = w * x[4 * n4 + threadIdx.x];
+}
+
+// out = g where y > 0, else 0  (VJP of relu given its output; neural_dynamics.py:36)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float *__restrict__ out, const float *__restrict__ g, const float *__restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y[i] > 0.f ? g[i] : 0.f;
+}
+
+int relu_bwd_f32(float *out, const float *g, const float *y, int64_t n, hipStream_t st) {
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_STAGE, st, 12.0 * n, 0.0);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, out, g, y, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int scale_f32(float *out, const float *x, float w, int64_t n, hipStream_t st) {
+    if (n == 0) return NDCN_OK;
+    if (!(aligned16(out) && aligned16(x))) { set_error("scale: panels must be 16-byte aligned"); return NDCN_EINVAL; }
+    ProfScope prof(PROF_STAGE, st, 8.0 * n, 1.0 * n);
+    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, st, out, x, w, n / 4, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 // -------------------------------------------------------------------------------- host wrappers
 int scale_coef_f32(float *out, const float *beta, const float *dt, int n, hipStream_t st) {
     if (n <= 0) return NDCN_OK;

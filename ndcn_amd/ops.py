@@ -102,6 +102,49 @@ class HipOps:
         return Y.view(*lead, Ho)
 
     @staticmethod
+    def linear_bwd(g, W, S=None, Y=None, need_gS=True, need_gW=True, need_gb=True):
+        """Backward of act(S W^T + b): returns (gS, gW, gb) (None where not requested).  Y: the ReLU output (mask
+        gZ = g where Y > 0) or None.  One GEMM launch for gS, one split-row launch + fixed-order sum for gW / gb."""
+        g = _panel(g)
+        W = _panel(W, 'weight')
+        Ho, Hi = W.shape
+        lead = g.shape[:-1]
+        g2 = g.reshape(-1, Ho)
+        n = g2.shape[0]
+        S2 = _panel(S).reshape(-1, Hi) if S is not None else None
+        Y2 = _panel(Y).reshape(-1, Ho) if Y is not None else None
+        need_gW = need_gW and S2 is not None
+        lib = _lib.load()
+        gS = torch.empty((n, Hi), dtype=torch.float32, device=g.device) if need_gS else None
+        gW = torch.empty((Ho, Hi), dtype=torch.float32, device=g.device) if need_gW else None
+        gb = torch.empty((Ho,), dtype=torch.float32, device=g.device) if need_gb else None
+        work = None
+        if need_gW or need_gb:
+            work = torch.empty(int(lib.ndcn_linear_bwd_work_bytes(n, Hi, Ho)), dtype=torch.uint8, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib.ndcn_linear_bwd_f32(ptr(g2), ptr(Y2), ptr(S2 if S2 is not None else g2), ptr(W), ptr(gS), ptr(gW), ptr(gb),
+                                          ptr(work), n, Hi, Ho, stream_ptr()))
+        return (gS.view(*lead, Hi) if gS is not None else None), gW, gb
+
+    @staticmethod
+    def relu_bwd(g, y):
+        """g where y > 0 else 0 (VJP of relu from its output)."""
+        g, y = _panel(g), _panel(y)
+        out = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            check(_lib.load().ndcn_relu_bwd_f32(ptr(out), ptr(g), ptr(y), g.numel(), stream_ptr()))
+        return out
+
+    @staticmethod
+    def scale(x, w):
+        """w * x as one streaming kernel."""
+        x = _panel(x)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(_lib.load().ndcn_scale_f32(ptr(out), ptr(x), float(w), x.numel(), stream_ptr()))
+        return out
+
+    @staticmethod
     def rhs(A, X, W, b, no_graph=False, no_control=False, X_halo=None, out=None):
         """The whole ODEFunc.forward: relu(W (A X) + b)   (neural_dynamics.py:20-39, dropout 0)."""
         X = _panel(X)

@@ -156,3 +156,30 @@ def test_odeint_adjoint_against_reference_gradients(dev, method):
     blk = ODEBlock(f, rtol=1e-3, atol=1e-4, method='dopri5', adjoint=True, terminal=True)
     out = blk(T(d['t']).to(dev), T(d['x0']).to(dev))
     assert out.requires_grad and out.shape == (144, 8)
+
+
+@pytest.mark.parametrize('n,Hi,Ho', [(400, 20, 20), (1000, 256, 256), (777, 1, 20), (777, 20, 1), (3001, 64, 16), (130, 300, 40),
+                                     (9, 256, 256), (70000, 256, 256)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_linear_backward_kernels(dev, n, Hi, Ho, masked):
+    """ndcn_linear_bwd_f32 (gS = gZ W as an MFMA GEMM with W read transposed, gW = gZ^T S split over row chunks with a
+    fixed-order sum, gb with it, ReLU mask fused into the operand loads) against fp64; deterministic run to run."""
+    from ndcn_amd import hip
+    gen = torch.Generator().manual_seed(n + Hi)
+    S = torch.randn(n, Hi, generator=gen).to(dev)
+    W = (torch.randn(Ho, Hi, generator=gen) / 4).to(dev)
+    g = torch.randn(n, Ho, generator=gen).to(dev)
+    Y = torch.relu(torch.randn(n, Ho, generator=gen)).to(dev) if masked else None
+    gS, gW, gb = hip.linear_bwd(g, W, S=S, Y=Y)
+    gZ = (g * (Y > 0)).double() if masked else g.double()
+    scale = float(np.sqrt(n))
+    assert float((gS.double() - gZ @ W.double()).abs().max()) < 2e-5 * max(1.0, Ho ** 0.5)
+    assert float((gW.double() - gZ.t() @ S.double()).abs().max()) < 3e-5 * scale * 4
+    assert float((gb.double() - gZ.sum(0)).abs().max()) < 3e-5 * scale * 4
+    gS2, gW2, gb2 = hip.linear_bwd(g, W, S=S, Y=Y)
+    assert torch.equal(gW, gW2) and torch.equal(gb, gb2) and torch.equal(gS, gS2)
+    only = hip.linear_bwd(g, W, S=S, Y=Y, need_gS=False, need_gb=False)
+    assert only[0] is None and only[2] is None and torch.equal(only[1], gW)
+    if masked:
+        assert torch.equal(hip.relu_bwd(g, Y), g * (Y > 0))
+    assert torch.equal(hip.scale(g, -0.37), g * np.float32(-0.37))

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Training-step timing (measurement aid, not the judged bench line): what every reference driver does per iteration
+(heat_dynamics.py:326-335): NDCN forward through the solver, L1 loss, backward through every solver op, Adam step.
+Two cases: C1 (400-node grid, H = 20, Euler on linspace(0,5,80) - the README command) and a 100k-node grid with H = 256
+(Euler, 10 ticks).  The CPU oracle (torch autograd through the restated solver) runs the same step where it fits."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def one_case(name, side, H, ticks, method, dev, cpu_reps):
+    from ndcn_amd import graphs
+    from ndcn_amd.neural_dynamics import NDCN
+    from oracle import ndcn_oracle as orc
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    n = side * side
+    A = graphs.to_device(L, dev)
+    torch.manual_seed(0)
+    model = NDCN(input_size=1, hidden_size=H, A=A, num_classes=1, rtol=.01, atol=.001, method=method).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=1e-3)
+    x0 = torch.from_numpy(graphs.x0_blocks(side)[:n]).to(dev)
+    t = torch.linspace(0., 5., ticks).to(dev)
+    target = torch.rand(n, ticks, device=dev)
+
+    def step():
+        opt.zero_grad()
+        pred = model(t, x0).squeeze().t()
+        loss = F.l1_loss(pred, target)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    res = {'case': name, 'n': n, 'H': H, 'method': method, 'ticks': ticks, 'gpu_ms_per_adam_step': round(1e3 * float(np.median(times)), 3)}
+    if cpu_reps:
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        Ac = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        optc = torch.optim.Adam(list(sd.values()), lr=0.01, weight_decay=1e-3)
+        xc, tc, tg = x0.cpu(), t.cpu(), target.cpu()
+        ct = []
+        for r in range(1 + cpu_reps):
+            t0 = time.perf_counter()
+            optc.zero_grad()
+            pred = orc.ndcn_forward(sd, Ac, tc, xc, method).squeeze().t()
+            F.l1_loss(pred, tg).backward()
+            optc.step()
+            if r:
+                ct.append(time.perf_counter() - t0)
+        res['cpu_oracle_ms_per_adam_step'] = round(1e3 * float(np.median(ct)), 2)
+        res['cpu_threads'] = torch.get_num_threads()
+    return res
+
+
+def main():
+    dev = torch.device('cuda:0')
+    out = [one_case('C1 heat_dynamics --network grid --baseline ndcn (README)', 20, 20, 80, 'euler', dev, 3),
+           one_case('C1 with dopri5', 20, 20, 80, 'dopri5', dev, 3),
+           one_case('100k-node grid, H=256', 316, 256, 10, 'euler', dev, 1)]
+    for r in out:
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == '__main__':
+    main()
