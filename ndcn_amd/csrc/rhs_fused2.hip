@@ -48,7 +48,18 @@ constexpr int kH2 = 256;
 constexpr int kTile2 = 64;
 constexpr int kLd2 = kH2 + 4;              // +4 floats: row m starts on 16-byte slot (4 m) mod 64 -> conflict-free b128
 constexpr int kTileFloats2 = kTile2 * kLd2;
-constexpr int kProd = 12;                                   // gather waves (3 per SIMD, next to one MFMA wave)
+// NDCN_SPLIT = 1 (default): the dense 256 x 256 product runs on the bf16 matrix cores with fp32 operands split
+// error-free into three bf16 pieces each (x = x1 + x2 + x3, 8 + 8 + 8 significand bits) and the six partial products
+// with i + j <= 4 accumulated in fp32 - measured (tools/micro/gemm_split_lab.hip, profiles/r02c_gemm_split_lab.txt): max
+// error against fp64 2.0e-6 vs 2.3e-6 for the fp32-MFMA chain on the same data (the dropped products are ~2^-24 of a
+// product, below the rounding of the fp32 accumulation both variants share; 8 or all 9 products give the identical
+// error) at 6/16 of the fp32 MFMA's matrix-pipe time.  NDCN_SPLIT = 0 builds the fp32-MFMA consumer (A/B reference).
+#ifndef NDCN_SPLIT
+#define NDCN_SPLIT 1
+#endif
+// gather waves: 12 beside the fp32 MFMA waves (16 waves per CU, 128 registers each); 8 beside the split consumer, whose
+// three-k-step weight ring needs ~160 registers (12 waves per CU, 168 each)
+constexpr int kProd = NDCN_SPLIT ? 8 : 12;
 constexpr int kWaves = 4 + kProd;
 constexpr int kRowsPerProd = (kTile2 + kProd - 1) / kProd;  // rows p, p+12, ... < 64 of every tile: 6 (p < 4) or 5
 constexpr int kMaxPrev = 5;              // dopri5 needs at most 5 earlier stages with a non-zero coefficient
@@ -74,6 +85,7 @@ struct Fused2Args {
     unsigned x_bytes, xh_bytes;             // sizes of the gathered panels (buffer descriptors: < 2^32)
     int n_own;
     const float *Wp, *bias;
+    const void *Wq;                         // split weights (pack_weight_256: three bf16 planes in MFMA B-operand order)
     float *K;                               // relu(...) output panel
     int n_rows, n_tiles, relu;
     unsigned long long *dbg_cycles;         // NDCN_FUSED_TIMING: per (block, wave) {work cycles, barrier-wait cycles}
@@ -341,6 +353,87 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             }
         }
     };
+#if NDCN_SPLIT
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    // split weights: block (n-tile j, k-step s of 16, plane p) = 64 lanes x 16 bytes (8 bf16: W[32 j + (lane & 31)][16 s +
+    // 8 (lane >> 5) + 0..7]); ring of kRingQ k-steps x {2 n-tiles of this wave} x 3 planes, refilled right after use
+    constexpr int kRingQ = 3;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, 8 * 16 * 3 * 1024, 0x00020000);
+    const int q_slab = (2 * (wave & 3)) * 16 * 3 * 1024;
+    auto ldq = [&](int jj, int ks, int pl) {
+        int ws = q_slab;
+        asm volatile("" : "+s"(ws));
+        return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, ws + ((jj * 16 + ks) * 3 + pl) * 1024, 0);
+    };
+    u32x4 Bq[kRingQ][2][3];
+    auto ring_fill_q = [&]() {
+#pragma unroll
+        for (int u = 0; u < kRingQ; ++u)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, u, pl);
+    };
+    auto cvt_pk = [](float lo, float hi) {
+        unsigned r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    };
+    // 8 consecutive fp32 -> three bf16x8 pieces whose sum is the input, exactly (round to nearest even each time)
+    auto split8 = [&](f32x4 r0, f32x4 r1, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+        const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float va = x[2 * q], vb = x[2 * q + 1];
+            const unsigned h = cvt_pk(va, vb);
+            const float ra = va - __builtin_bit_cast(float, h << 16), rb = vb - __builtin_bit_cast(float, h & 0xffff0000u);
+            const unsigned m = cvt_pk(ra, rb);
+            const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+            p1[q] = h; p2[q] = m; p3[q] = cvt_pk(sa, sb);
+        }
+    };
+    auto mfma_tile_split = [&](const float *src) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
+        const float *ap = src + (lane & 31) * kLd2 + 8 * (lane >> 5);
+        f32x4 n0 = *reinterpret_cast<const f32x4 *>(ap), n1 = *reinterpret_cast<const f32x4 *>(ap + 4);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int u = ks % kRingQ;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 r0 = n0, r1 = n1;
+                {   // the NEXT block's A values leave LDS while this block's products run
+                    const int nk = mt == 0 ? ks : ks + 1, nm = mt ^ 1;
+                    if (nk < 16) {
+                        n0 = *reinterpret_cast<const f32x4 *>(ap + nm * 32 * kLd2 + 16 * nk);
+                        n1 = *reinterpret_cast<const f32x4 *>(ap + nm * 32 * kLd2 + 16 * nk + 4);
+                    }
+                }
+                u32x4 A0, A1, A2;
+                split8(r0, r1, A0, A1, A2);
+                auto mm = [&](f32x16 &acc, u32x4 av, u32x4 bv) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                };
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    f32x16 &acc = mt == 0 ? (jj == 0 ? acc00 : acc01) : (jj == 0 ? acc10 : acc11);
+                    // small products first
+                    mm(acc, A0, Bq[u][jj][2]); mm(acc, A2, Bq[u][jj][0]); mm(acc, A1, Bq[u][jj][1]);
+                    mm(acc, A0, Bq[u][jj][1]); mm(acc, A1, Bq[u][jj][0]);
+                    mm(acc, A0, Bq[u][jj][0]);
+                }
+            }
+            if (!(a.dbg & 64)) {
+                const int kn = ks + kRingQ < 16 ? ks + kRingQ : u;     // the last kRingQ k-steps refill their slot with k-step (slot index) of the NEXT tile
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kn, pl);
+            }
+        }
+    };
+#endif
     auto dump_tile = [&](float *dst) {
         // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]
 #pragma unroll
@@ -397,12 +490,20 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             }
         }
     } else {
+#if NDCN_SPLIT
+        ring_fill_q();                                         // weight fetches fly while the first tile is gathered
+#else
         ring_fill();                                           // weight fetches fly while the first tile is gathered
+#endif
         __syncthreads();                                       // S[0] ready
         for (int it = 0; it < my_tiles; ++it) {
             float *cur = s_tile + (it & 1) * kTileFloats2;
             const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
+#if NDCN_SPLIT
+            if (!(a.dbg & 1)) mfma_tile_split(cur);
+#else
             if (!(a.dbg & 1)) mfma_tile(cur);
+#endif
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();                                   // every consumer is done reading `cur`
             const unsigned long long c2 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
@@ -505,7 +606,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         set_error("rhs_fused2: panel of %lld bytes exceeds the 4 GiB buffer-descriptor range", (long long)(xb > xhb ? xb : xhb));
         return NDCN_EINVAL;
     }
-    a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (unsigned)xb; a.xh_bytes = (unsigned)xhb; a.Wp = Wp; a.bias = b; a.K = K;
+    a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (unsigned)xb; a.xh_bytes = (unsigned)xhb; a.Wp = Wp; a.Wq = Wp + kH2 * kH2; a.bias = b; a.K = K;
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     EpiArgs ea;
     ea.y0 = y0; ea.n_prev = n_prev; ea.y_next = y_next; ea.rtol = rtol; ea.atol = atol;
