@@ -61,8 +61,18 @@ __device__ __forceinline__ void g_issue(const int *__restrict__ colidx, const fl
     // all scalar loads first: a volatile asm is a scheduling barrier, and U separate s_load_dword + waits (instead of
     // one s_load_dwordx8) would serialise a scalar-cache round trip per neighbour
     int cc[U];
+#ifdef NDCN_DBG_NOIDX      // timing experiment: lattice-like indices formed arithmetically, no index loads (results are wrong)
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+        const int e = O + q, rr = j / 9;
+        int c = rr + (e % 3 - 1) + (e / 3 % 3 - 1) * 1000;
+        cc[q] = __builtin_amdgcn_readfirstlane(c < 0 ? 0 : (c > 999999 ? 999999 : c));
+        vv[O + q] = 0.1f;
+    }
+#else
 #pragma unroll
     for (int q = 0; q < U; ++q) { cc[q] = colidx[j + q]; vv[O + q] = val[j + q]; }
+#endif
 #pragma unroll
     for (int q = 0; q < U; ++q) {
         u32x4 rs = rsX;

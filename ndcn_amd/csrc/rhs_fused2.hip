@@ -234,6 +234,13 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
         if (MODE != MODE_PLAIN) ea = epi_args();               // one (laundered) read of the epilogue arguments per tile
         const int r0 = t_epi * kTile2 + p, g0 = t_next * kTile2 + p;
         RowExt ext = do_gather ? row_ext(g0) : RowExt{0, 0};
+        // The row-local panels of row k + 1 are requested while row k is being finished (two register sets, ping-pong):
+        // they are YOUNGER than row k's neighbour fetches, so the wait for those leaves them in flight, and OLDER than
+        // row k + 1's - complete, by in-order return, when that row's neighbours are.  A row then costs
+        // max(gather latency, panel latency) instead of their sum.
+        constexpr int kEpiFetches = MODE == MODE_PLAIN ? 0 : NP + 1 + (MODE == MODE_ERROR ? 1 : 0);
+        EpiRow e[2];
+        if (MODE != MODE_PLAIN && do_epi && r0 < a.n_rows) epi_load(ea, r0, e[0]);
 #pragma unroll
         for (int k = 0; k < kRowsPerProd; ++k) {
             const int lr = p + kProd * k;
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             const RowExt cur = ext;
             if (do_gather && lr + kProd < kTile2) ext = row_ext(g0 + kProd * (k + 1));
             const bool ep = do_epi && r < a.n_rows;
+            const bool ep_next = do_epi && lr + kProd < kTile2 && r + kProd < a.n_rows;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 x[16];
             float w[16];
@@ -259,22 +267,19 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
                 m = j1 - j;
                 g_row_issue<HALO>(colidx, val, j, m, rsX, rsH, a.n_own, lane_off, x, w);
             }
-            EpiRow e;
-            // the row-local panels are the kEpiFetches youngest fetches: the neighbour rows are complete when at most
-            // that many are outstanding
-            constexpr int kEpiFetches = MODE == MODE_PLAIN ? 0 : NP + 1 + (MODE == MODE_ERROR ? 1 : 0);
-            if (MODE != MODE_PLAIN && ep) { epi_load(ea, r, e); wait_vmcnt<kEpiFetches>(); }
+            // the next row's panels are the kEpiFetches youngest fetches: this row's neighbours (and panels) are
+            // complete when at most that many are outstanding
+            if (MODE != MODE_PLAIN && ep_next) { epi_load(ea, r + kProd, e[(k + 1) & 1]); wait_vmcnt<kEpiFetches>(); }
             else wait_vmcnt<0>();
             if (do_gather) g_row_accum(m, x, w, acc);
             if (ep) {
                 if (MODE != MODE_PLAIN) {
-                    wait_vmcnt<0>();
 #pragma unroll
-                    for (int i = 0; i < NP; ++i) tie(e.km[i]);
-                    tie(e.y0v);
-                    if (MODE == MODE_ERROR) tie(e.y1v);
+                    for (int i = 0; i < NP; ++i) tie(e[k & 1].km[i]);
+                    tie(e[k & 1].y0v);
+                    if (MODE == MODE_ERROR) tie(e[k & 1].y1v);
                 }
-                epi_finish(ea, r, buf + lr * kLd2, e);
+                epi_finish(ea, r, buf + lr * kLd2, e[k & 1]);
             }
             if (do_gather) *reinterpret_cast<f32x4 *>(buf + lr * kLd2 + 4 * lane) = acc;
         }
@@ -392,6 +397,9 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             p1[q] = h; p2[q] = m; p3[q] = cvt_pk(sa, sb);
         }
     };
+    // (A hand-built software pipeline of the split - stages of block b + 1 placed between the product groups of block b -
+    // and a two-k-step ring were measured too: same launch times; the loop runs at ~70 % of the matrix-pipe rate alone
+    // (17.7 k cycles per tile) and at 24-34 k next to the gather waves, whose fetches its weight fetches queue behind.)
     auto mfma_tile_split = [&](const float *src) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
