@@ -9,7 +9,7 @@ _lib = ctypes.CDLL(os.environ.get('NDCN_HIP_LIB', 'libndcn_hip.so'))   # import 
 _i32, _i64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 class Csr(ctypes.Structure):                    # struct ndcn_csr (ABI 6): the optional plans stay zero = absent
     _fields_ = [('n_rows', _i64), ('n_cols', _i64), ('nnz', _i64), ('rowptr', _p), ('colidx', _p), ('val', _p),
-                ('row_order', _p),
+                ('row_order', _p), ('tile_order', _p),
                 ('rec_rows', _i32), ('rec_cap', _i32), ('rec_kib', _i32), ('rec_groups', _i32), ('rec', _p),
                 ('hub_n', _i32), ('hub_nseg', _i32), ('hub_H', _i32), ('hub_nnz', _i64), ('lt_nnz', _i64),
                 ('hub_seg_rowptr', _p), ('hub_colidx', _p), ('hub_val', _p),

@@ -60,6 +60,8 @@ typedef struct ndcn_csr {
     const int32_t *row_order; /* [n_rows] or NULL: a permutation of the rows giving the order in which the
                                  kernels WALK them (a cache-locality hint, e.g. lattice tiles); results are
                                  identical for any permutation                                              */
+    const int32_t *tile_order; /* [ceil(n_rows / 64)] or NULL: the order in which the fused RHS kernel walks its 64-row
+                                 tiles (a permutation; locality hint like row_order - results are identical)      */
     /* Optional "group record" plan (rec = NULL when absent), built once per operator by the host
      * (ndcn_amd/csr.py:build_rec_plan) for H = 256 panels.  The rows are cut into groups of rec_rows rows that are
      * consecutive in the operator's walk order (row_order, or 0..n-1); group g owns the fixed-size record

@@ -34,7 +34,7 @@ class CsrView(ctypes.Structure):
     """struct ndcn_csr"""
     _fields_ = [('n_rows', ctypes.c_int64), ('n_cols', ctypes.c_int64), ('nnz', ctypes.c_int64),
                 ('rowptr', ctypes.c_void_p), ('colidx', ctypes.c_void_p), ('val', ctypes.c_void_p),
-                ('row_order', ctypes.c_void_p),
+                ('row_order', ctypes.c_void_p), ('tile_order', ctypes.c_void_p),
                 ('rec_rows', ctypes.c_int32), ('rec_cap', ctypes.c_int32), ('rec_kib', ctypes.c_int32),
                 ('rec_groups', ctypes.c_int32), ('rec', ctypes.c_void_p),
                 ('hub_n', ctypes.c_int32), ('hub_nseg', ctypes.c_int32), ('hub_H', ctypes.c_int32),

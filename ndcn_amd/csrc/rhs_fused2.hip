@@ -88,6 +88,7 @@ struct Fused2Args {
     const void *Wq;                         // split weights (pack_weight_256: three bf16 planes in MFMA B-operand order)
     float *K;                               // relu(...) output panel
     int n_rows, n_tiles, relu;
+    const int *tile_order;                  // nullable: walk position -> 64-row tile (ndcn_csr::tile_order)
     unsigned long long *dbg_cycles;         // NDCN_FUSED_TIMING: per (block, wave) {work cycles, barrier-wait cycles}
     int dbg;                                // cycle-accounting experiments only (NDCN_FUSED_DBG): 1 skip MFMA, 2 skip gather,
                                             // 4 skip epilogue, 64 no weight refills, 8192 report MFMA loop | dump separately
@@ -232,6 +233,11 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     auto producer_phase = [&](float *buf, int t_epi, int t_next, bool do_epi, bool do_gather) {
         EpiPtr ea = nullptr;
         if (MODE != MODE_PLAIN) ea = epi_args();               // one (laundered) read of the epilogue arguments per tile
+        // walk positions -> tiles (a locality hint: an XCD's concurrent tiles then cover a compact lattice block)
+        if (a.tile_order) {
+            if (do_epi) t_epi = a.tile_order[t_epi];
+            if (do_gather) t_next = a.tile_order[t_next];
+        }
         const int r0 = t_epi * kTile2 + p, g0 = t_next * kTile2 + p;
         RowExt ext = do_gather ? row_ext(g0) : RowExt{0, 0};
         // The row-local panels of row k + 1 are requested while row k is being finished (two register sets, ping-pong):
@@ -615,6 +621,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         return NDCN_EINVAL;
     }
     a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.x_bytes = (unsigned)xb; a.xh_bytes = (unsigned)xhb; a.Wp = Wp; a.Wq = Wp + kH2 * kH2; a.bias = b; a.K = K;
+    a.tile_order = A->tile_order;
     a.n_rows = n_rows; a.n_tiles = (n_rows + kTile2 - 1) / kTile2; a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     EpiArgs ea;
     ea.y0 = y0; ea.n_prev = n_prev; ea.y_next = y_next; ea.rtol = rtol; ea.atol = atol;
