@@ -141,6 +141,31 @@ NDCN_API int ndcn_scale_f32(float *out, const float *x, float w, int64_t n_elem,
 /* out = g where y > 0, else 0: the VJP of relu given its OUTPUT y (neural_dynamics.py:36; the no_control RHS). */
 NDCN_API int ndcn_relu_bwd_f32(float *out, const float *g, const float *y, int64_t n_elem, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Vector-Jacobian products of the dopri5 panel operations.  The reference's vendored torchdiffeq differentiates through
+ * its step-size controller - dt, dt * beta, the error ratio, the initial-step norms and the interpolation abscissa are
+ * tensors with autograd history (rk_common.py:41-61, misc.py:84-170, interp.py:38-65) - and the drivers train by plain
+ * backprop through the solver.  Each call is ONE pass: every panel gradient of the operation (h_gk / g* entries may be
+ * NULL) plus, in d_dots[0..7] (fp64, fixed-order sums), the inner products that become the gradients of the scalar
+ * inputs.  d_ws: ndcn_rk_bwd_ws_bytes() bytes of device scratch.
+ *   combine   (misc.py:22-25)     y = y0 + sum_j c_j k_j :  gk_j = c_j g ;  d_dots[j] = <g, k_j> (= g_cj) ;  g_y0 = g
+ *   error     (misc.py:146-157)   r = mean((sum_j c_j k_j / tol)^2), tol = atol + rtol max(|y0|, |y1|), upstream g_r,
+ *                                 inv_n = 1 / numel :  gk_j, gy0, gy1 ;  d_dots[j] = d r / d c_j (multiply by g_r)
+ *   rms       (misc.py:71-76)     o = ||(a - b) / (atol + |y| rtol)||_2 / sqrt(N), coef = g_o / (||.|| sqrt(N)) :  ga, gb, gy
+ *   interp    (dopri5.py:39-45, interp.py:21-65)  o = dense output at abscissa x for step size dt :  gy0, gy1, gk_0..6 ;
+ *                                 d_dots[0] = <g, d o / d x>, d_dots[1] = <g, d o / d dt>                              */
+NDCN_API int64_t ndcn_rk_bwd_ws_bytes(void);
+NDCN_API int ndcn_rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk,
+                                     double *d_dots, void *d_ws, int64_t n_elem, void *stream);
+NDCN_API int ndcn_rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k,
+                                   float rtol, float atol, float g_r, double inv_n, float *gy0, float *gy1,
+                                   float *const *h_gk, double *d_dots, void *d_ws, int64_t n_elem, void *stream);
+NDCN_API int ndcn_rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, float atol, float coef, float *ga,
+                                 float *gb, float *gy, int64_t n_elem, void *stream);
+NDCN_API int ndcn_dopri5_interp_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k /*7*/,
+                                        float dt, float x, float *gy0, float *gy1, float *const *h_gk /*7*/, double *d_dots,
+                                        void *d_ws, int64_t n_elem, void *stream);
+
 /* The whole ODEFunc.forward in one call: Y = relu(W (A X) + b) honouring NO_GRAPH / NO_CONTROL
  * (neural_dynamics.py:20-39, dropout p = 0).  `work`: device scratch of ndcn_rhs_work_bytes() bytes, 16-byte
  * aligned (H = 256: the fused SpMM->LDS->MFMA kernel keeps its packed weights there; other widths: the

@@ -55,6 +55,17 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
                    hipStream_t st, const float *dt_dev = nullptr);
 int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
                  float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev = nullptr);
+// VJPs of the dopri5 panel operations (rk_bwd.hip); d_dots receives 8 doubles, d_ws: rk_bwd_ws_bytes() bytes
+int64_t rk_bwd_ws_bytes();
+int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, double *d_dots,
+                       void *d_ws, int64_t n, hipStream_t st);
+int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol, float atol,
+                     float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n,
+                     hipStream_t st);
+int rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, float atol, float coef, float *ga, float *gb,
+                   float *gy, int64_t n, hipStream_t st);
+int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k, float dt, float x, float *gy0,
+                     float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n, hipStream_t st);
 void prof_pause(bool on);     // no launch timing while a stream is being captured
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st);

@@ -1,0 +1,260 @@
+// Vector-Jacobian products of the dopri5 panel operations.  The reference's (old) torchdiffeq differentiates THROUGH its
+// step-size controller: dt, the stage coefficients dt * beta, the error ratio, the initial-step norms and the
+// interpolation abscissa are tensors with autograd history (rk_common.py:41-61, misc.py:84-170, interp.py:38-65), and
+// the drivers train by plain backprop through the solver (heat_dynamics.py:333, dgnn.py:204).  Each kernel below is ONE
+// pass that produces every panel gradient of its operation plus the inner products that become the gradients of the
+// scalar inputs (fp64 partials per workgroup, summed in a fixed order: deterministic):
+//
+//   combine     y = y0 + sum_j c_j k_j                                   g_kj = c_j g ;  g_cj = <g, k_j> ;  (g_y0 = g)
+//   error ratio r = mean(((sum_j c_j k_j) / tol)^2), tol = atol + rtol max(|y0|, |y1|)      (misc.py:146-157)
+//   rms         o = ||(a - b) / (atol + |y| rtol)||_2 / sqrt(N)                               (misc.py:71-76,121-138)
+//   dense out   o = a x^4 + b x^3 + c x^2 + d x + y0 with the dopri5 fit                      (dopri5.py:39-45, interp.py:21-65)
+#include "common.h"
+#include "kernels.h"
+
+namespace ndcn {
+
+constexpr int kBwdMaxK = 8;
+constexpr int kBwdBlocks = 1024;
+constexpr int kBwdDots = 8;
+
+struct BwdTerms {
+    const float *k[kBwdMaxK];
+    float *gk[kBwdMaxK];           // nullable each
+    float c[kBwdMaxK];
+    int n;
+};
+
+// per-block sums of kBwdDots doubles -> partial[block][kBwdDots]
+__device__ __forceinline__ void block_store_dots(double (&d)[kBwdDots], double *__restrict__ partial) {
+    __shared__ double sh[4][kBwdDots];
+#pragma unroll
+    for (int q = 0; q < kBwdDots; ++q) {
+        double v = d[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        d[q] = v;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < kBwdDots; ++q) sh[w][q] = d[q];
+    __syncthreads();
+    if (threadIdx.x < kBwdDots)
+        partial[(size_t)blockIdx.x * kBwdDots + threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void dots_finish_kernel(const double *__restrict__ partial, int n_blocks, double *__restrict__ out) {
+    __shared__ double sh[256];
+    for (int q = 0; q < kBwdDots; ++q) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_blocks; i += 256) s += partial[(size_t)i * kBwdDots + q];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[q] = sh[0];
+        __syncthreads();
+    }
+}
+
+static int bwd_grid(int64_t n) {
+    int g = stream_grid(n, 256);
+    return g > kBwdBlocks ? kBwdBlocks : g;
+}
+
+// ------------------------------------------------------------------------------------------------ combine
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const float *__restrict__ g, BwdTerms t, int64_t n, double *__restrict__ partial) {
+    double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gv = g[i];
+#pragma unroll
+        for (int j = 0; j < kBwdMaxK; ++j)
+            if (j < t.n) {
+                d[j] += (double)(gv * t.k[j][i]);
+                if (t.gk[j]) t.gk[j][i] = t.c[j] * gv;
+            }
+    }
+    block_store_dots(d, partial);
+}
+
+// ------------------------------------------------------------------------------------------------ error ratio
+struct ErrBwdArgs {
+    const float *y0, *y1;
+    float *gy0, *gy1;              // nullable
+    BwdTerms t;
+    float rtol, atol, g_r, inv_n;  // inv_n = 1 / numel (global count when the mean spans ranks)
+};
+
+__global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n, double *__restrict__ partial) {
+    double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float e = p.t.c[0] * p.t.k[0][i];
+#pragma unroll
+        for (int j = 1; j < kBwdMaxK; ++j)
+            if (j < p.t.n) e = e + p.t.c[j] * p.t.k[j][i];
+        const float a0 = p.y0[i], a1 = p.y1[i];
+        const float m0 = fabsf(a0), m1 = fabsf(a1);
+        const float tol = p.atol + p.rtol * fmaxf(m0, m1);
+        const float q = e / tol;
+        const float s = 2.f * q * p.inv_n / tol;             // d r / d e
+#pragma unroll
+        for (int j = 0; j < kBwdMaxK; ++j)
+            if (j < p.t.n) {
+                d[j] += (double)(s * p.t.k[j][i]);            // d r / d c_j (times g_r on the host)
+                if (p.t.gk[j]) p.t.gk[j][i] = p.g_r * (p.t.c[j] * s);
+            }
+        // d r / d tol = -q s ; tol = atol + rtol max(|y0|, |y1|) ; torch.max splits the gradient evenly on ties
+        const float gm = p.g_r * (-q * s) * p.rtol;
+        const float w0 = m0 > m1 ? 1.f : (m0 == m1 ? 0.5f : 0.f);
+        if (p.gy0) p.gy0[i] = gm * w0 * (a0 > 0.f ? 1.f : (a0 < 0.f ? -1.f : 0.f));
+        if (p.gy1) p.gy1[i] = gm * (1.f - w0) * (a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f));
+    }
+    block_store_dots(d, partial);
+}
+
+// ------------------------------------------------------------------------------------------------ rms
+// o = ||v|| / sqrt(N), v = (a - b) / scale, scale = atol + |y| rtol ; coef = g_o / (||v|| sqrt(N))
+__global__ __launch_bounds__(256) void rms_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ y,
+                                                      float rtol, float atol, float coef, float *__restrict__ ga, float *__restrict__ gb,
+                                                      float *__restrict__ gy, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float yv = y[i];
+        const float scale = atol + fabsf(yv) * rtol;
+        const float v = (b ? a[i] - b[i] : a[i]) / scale;
+        const float gv = coef * v;
+        const float g_a = gv / scale;
+        const float g_y = -(gv * v / scale) * rtol * (yv > 0.f ? 1.f : (yv < 0.f ? -1.f : 0.f));
+        if (ga) ga[i] = g_a;
+        if (gy) gy[i] = g_y;                                 // (a may BE y, misc.py:123: the caller's autograd adds the two)
+        if (gb) gb[i] = -g_a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dense output
+struct DenseBwdArgs {
+    const float *g, *y0, *y1;
+    const float *k[7];
+    float *gy0, *gy1, *gk[7];      // nullable each
+    float cm[7];                   // dt * DPS_C_MID (fp32, as the forward)
+    float cmid[7];                 // DPS_C_MID
+    float dt, x;
+};
+
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p, int64_t n, double *__restrict__ partial) {
+    double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float x = p.x, x2 = x * x, x3 = x2 * x, x4 = x3 * x, dt = p.dt;
+    const float w_ym = 16.f * x4 - 32.f * x3 + 16.f * x2;
+    const float w_y0 = (-8.f * x4 + 18.f * x3 - 11.f * x2 + 1.f) + w_ym;
+    const float w_y1 = -8.f * x4 + 14.f * x3 - 5.f * x2;
+    const float w_f0 = dt * (-2.f * x4 + 5.f * x3 - 4.f * x2 + x);
+    const float w_f1 = dt * (2.f * x4 - 3.f * x3 + x2);
+    float wk[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) wk[j] = w_ym * p.cm[j];
+    wk[0] += w_f0;
+    wk[6] += w_f1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gv = p.g[i];
+        const float y0 = p.y0[i], y1 = p.y1[i];
+        float kv[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) kv[j] = p.k[j][i];
+        float sm = 0.f, sc = 0.f;                            // sum cm_j k_j (= ymid - y0) and sum cmid_j k_j (= d ymid / d dt)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { sm += p.cm[j] * kv[j]; sc += p.cmid[j] * kv[j]; }
+        const float ym = y0 + sm, f0 = kv[0], f1 = kv[6];
+        const float ca = 2.f * dt * (f1 - f0) - 8.f * y0 - 8.f * y1 + 16.f * ym;
+        const float cb = dt * (5.f * f0 - 3.f * f1) + 18.f * y0 + 14.f * y1 - 32.f * ym;
+        const float cc = dt * (f1 - 4.f * f0) - 11.f * y0 - 5.f * y1 + 16.f * ym;
+        const float cd = dt * f0;
+        d[0] += (double)(gv * (4.f * ca * x3 + 3.f * cb * x2 + 2.f * cc * x + cd));                      // d o / d x
+        d[1] += (double)(gv * (x4 * (2.f * (f1 - f0) + 16.f * sc) + x3 * (5.f * f0 - 3.f * f1 - 32.f * sc) +
+                               x2 * (f1 - 4.f * f0 + 16.f * sc) + x * f0));                              // d o / d dt
+        if (p.gy0) p.gy0[i] = w_y0 * gv;
+        if (p.gy1) p.gy1[i] = w_y1 * gv;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (p.gk[j]) p.gk[j][i] = wk[j] * gv;
+    }
+    block_store_dots(d, partial);
+}
+
+// ------------------------------------------------------------------------------------------------ host wrappers
+int64_t rk_bwd_ws_bytes() { return (int64_t)kBwdBlocks * kBwdDots * sizeof(double); }
+
+static int fill_bwd(BwdTerms &t, const float *const *h_k, float *const *h_gk, const float *h_c, int n_k) {
+    if (n_k < 1 || n_k > kBwdMaxK) { set_error("rk backward: 1..%d terms", kBwdMaxK); return NDCN_EINVAL; }
+    t.n = n_k;
+    for (int j = 0; j < kBwdMaxK; ++j) {
+        t.k[j] = j < n_k ? h_k[j] : h_k[0];
+        t.gk[j] = (j < n_k && h_gk) ? h_gk[j] : nullptr;
+        t.c[j] = j < n_k ? h_c[j] : 0.f;
+        if (j < n_k && !h_k[j]) { set_error("rk backward: null stage pointer"); return NDCN_EINVAL; }
+    }
+    return NDCN_OK;
+}
+
+int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, double *d_dots,
+                       void *d_ws, int64_t n, hipStream_t st) {
+    BwdTerms t;
+    int rc = fill_bwd(t, h_k, h_gk, h_c, n_k);
+    if (rc) return rc;
+    const int grid = bwd_grid(n);
+    ProfScope prof(PROF_COMBINE, st, 4.0 * n * (2 * n_k + 1), 2.0 * n * n_k);
+    hipLaunchKernelGGL(combine_bwd_kernel, dim3(grid), dim3(256), 0, st, g, t, n, static_cast<double *>(d_ws));
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol, float atol,
+                     float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n,
+                     hipStream_t st) {
+    ErrBwdArgs p;
+    int rc = fill_bwd(p.t, h_k, h_gk, h_c, n_k);
+    if (rc) return rc;
+    p.y0 = y0; p.y1 = y1; p.gy0 = gy0; p.gy1 = gy1; p.rtol = rtol; p.atol = atol; p.g_r = g_r; p.inv_n = (float)inv_n;
+    const int grid = bwd_grid(n);
+    ProfScope prof(PROF_ERROR, st, 4.0 * n * (2 * n_k + 4), 2.0 * n * (3 * n_k + 12));
+    hipLaunchKernelGGL(error_bwd_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, float atol, float coef, float *ga, float *gb,
+                   float *gy, int64_t n, hipStream_t st) {
+    ProfScope prof(PROF_SUMSQ, st, 4.0 * n * 5, 10.0 * n);
+    hipLaunchKernelGGL(rms_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, a, b, y, rtol, atol, coef, ga, gb, gy, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+static const double kCMidBwd[7] = {
+    6025192743. / 30085553152. / 2, 0, 51252292925. / 65400821598. / 2, -2691868925. / 45128329728. / 2,
+    187940372067. / 1594534317056. / 2, -1776094331. / 19743644256. / 2, 11237099. / 235043384. / 2,
+};
+
+int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k, float dt, float x, float *gy0,
+                     float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
+    DenseBwdArgs p;
+    p.g = g; p.y0 = y0; p.y1 = y1; p.gy0 = gy0; p.gy1 = gy1; p.dt = dt; p.x = x;
+    for (int j = 0; j < 7; ++j) {
+        if (!h_k[j]) { set_error("dense backward: null stage pointer"); return NDCN_EINVAL; }
+        p.k[j] = h_k[j];
+        p.gk[j] = h_gk ? h_gk[j] : nullptr;
+        p.cmid[j] = (float)kCMidBwd[j];
+        p.cm[j] = dt * (float)kCMidBwd[j];
+    }
+    const int grid = bwd_grid(n);
+    ProfScope prof(PROF_EVAL, st, 4.0 * n * 19, 2.0 * n * 60);
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+}  // namespace ndcn
