@@ -54,6 +54,32 @@ class _Reducer:
         return float(self.host[0]), float(self.host[1])
 
 
+class _BwdDots:
+    """Per-device scratch of the solver VJP kernels: partial sums + the 8-double result + its pinned host mirror."""
+    _by_device = {}
+
+    @classmethod
+    def get(cls, device):
+        r = cls._by_device.get(device)
+        if r is None:
+            r = cls()
+            r.ws = torch.empty(int(_lib.load().ndcn_rk_bwd_ws_bytes()), dtype=torch.uint8, device=device)
+            r.out = torch.zeros(8, dtype=torch.float64, device=device)
+            r.host = torch.zeros(8, dtype=torch.float64).pin_memory()
+            cls._by_device[device] = r
+        return r
+
+    def fetch(self):
+        self.host.copy_(self.out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.host.tolist()
+
+
+def _grad_ptrs(like, needs):
+    outs = [torch.empty_like(like) if n else None for n in needs]
+    return outs, (_P * len(needs))(*[None if o is None else o.data_ptr() for o in outs])
+
+
 class HipOps:
     """Panel operations on fp32 CUDA tensors, each ONE kernel launch through the C-ABI."""
 
@@ -266,6 +292,67 @@ class HipOps:
             check(_lib.load().ndcn_scaled_sumsq_f32(ptr(a), ptr(b), ptr(y), float(rtol), float(atol), a.numel(),
                                                     ptr(red.out), ptr(red.ws), stream_ptr()))
             return red.fetch()
+
+    # ---------------------------------------------------------------- VJPs of the dopri5 panel operations
+    @staticmethod
+    def combine_bwd(g, ks, cs, need_k, need_dots=True):
+        """VJP of combine: ([c_j g or None], [<g, k_j>] as host floats or None)."""
+        g = _panel(g)
+        ks = [_panel(k) for k in ks]
+        arr_k, arr_c, n = _terms(ks, cs)
+        gk, arr_g = _grad_ptrs(g, need_k)
+        d = _BwdDots.get(g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.load().ndcn_rk_combine_bwd_f32(ptr(g), arr_k, arr_c, n, arr_g, ptr(d.out), ptr(d.ws), g.numel(),
+                                                      stream_ptr()))
+            return gk, (d.fetch()[:n] if need_dots else None)
+
+    @staticmethod
+    def error_bwd(y0, y1, ks, cs, rtol, atol, g_r, need_y0, need_y1, need_k, need_dots=True):
+        """VJP of the error ratio mean(((sum c_j k_j) / tol)^2) for upstream gradient g_r:
+        (gy0, gy1, [gk_j], [d ratio / d c_j] (NOT yet multiplied by g_r) as host floats)."""
+        y0, y1 = _panel(y0), _panel(y1)
+        ks = [_panel(k) for k in ks]
+        arr_k, arr_c, n = _terms(ks, cs)
+        gk, arr_g = _grad_ptrs(y0, need_k)
+        gy0 = torch.empty_like(y0) if need_y0 else None
+        gy1 = torch.empty_like(y0) if need_y1 else None
+        d = _BwdDots.get(y0.device)
+        with torch.cuda.device(y0.device):
+            check(_lib.load().ndcn_rk_error_bwd_f32(ptr(y0), ptr(y1), arr_k, arr_c, n, float(rtol), float(atol), float(g_r),
+                                                    1.0 / y0.numel(), ptr(gy0), ptr(gy1), arr_g, ptr(d.out), ptr(d.ws),
+                                                    y0.numel(), stream_ptr()))
+            return gy0, gy1, gk, (d.fetch()[:n] if need_dots else None)
+
+    @staticmethod
+    def rms_bwd(a, b, y, rtol, atol, coef, need_a, need_b, need_y):
+        """VJP of ||(a - b) / (atol + |y| rtol)|| / sqrt(N); coef = g / (||.|| sqrt(N))."""
+        a, y = _panel(a), _panel(y)
+        b = _panel(b) if b is not None else None
+        ga = torch.empty_like(a) if need_a else None
+        gb = torch.empty_like(a) if (need_b and b is not None) else None
+        gy = torch.empty_like(a) if need_y else None
+        with torch.cuda.device(a.device):
+            check(_lib.load().ndcn_rk_rms_bwd_f32(ptr(a), ptr(b), ptr(y), float(rtol), float(atol), float(coef), ptr(ga),
+                                                  ptr(gb), ptr(gy), a.numel(), stream_ptr()))
+        return ga, gb, gy
+
+    @staticmethod
+    def interp_bwd(g, y0, y1, ks, dt, x, need_y0, need_y1, need_k, need_dots=True):
+        """VJP of the dopri5 dense output at abscissa x: (gy0, gy1, [gk_j], <g, do/dx>, <g, do/ddt>)."""
+        g, y0, y1 = _panel(g), _panel(y0), _panel(y1)
+        ks = [_panel(k) for k in ks]
+        assert len(ks) == 7
+        arr_k = (_P * 7)(*[k.data_ptr() for k in ks])
+        gk, arr_g = _grad_ptrs(g, need_k)
+        gy0 = torch.empty_like(g) if need_y0 else None
+        gy1 = torch.empty_like(g) if need_y1 else None
+        d = _BwdDots.get(g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.load().ndcn_dopri5_interp_bwd_f32(ptr(g), ptr(y0), ptr(y1), arr_k, float(dt), float(x), ptr(gy0),
+                                                         ptr(gy1), arr_g, ptr(d.out), ptr(d.ws), g.numel(), stream_ptr()))
+            dots = d.fetch() if need_dots else (0.0, 0.0)
+        return gy0, gy1, gk, dots[0], dots[1]
 
     @staticmethod
     def interp_fit(y0, y1, ks, cmid, dt):

@@ -9,10 +9,11 @@ TENSORS with autograd history - the step-size controller is part of the differen
 (misc.py:84-170, dopri5.py:94-122).  Dropping those paths changes what the model learns (measured on Cora with
 the README command: 81.6 % with them, 78.6 % without), so they are kept: the scalar chain below is torch 0-d
 tensors exactly as in the reference, every panel VALUE comes from the HIP kernel the inference path uses, and
-every panel op's backward is autograd through the equivalent torch expression, recomputed on the device
-(`_HipValue`).  The RHS itself (`func`) is differentiated by its own autograd Function (HIP SpMM / Linear).
+every panel op's backward is ONE analytic VJP kernel (csrc/rk_bwd.hip: panel gradients + the inner products that are
+the gradients of the scalar coefficients).  The RHS itself (`func`) is differentiated by its own autograd Function (HIP SpMM / Linear).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -67,18 +68,58 @@ def _on(dev, s):
     return s.to(dev) if s.device != dev else s
 
 
-# ---- the panel ops: (HIP forward, torch expression) pairs -------------------------------------------------------
+# ---- the panel ops: HIP forward, HIP vector-Jacobian product (csrc/rk_bwd.hip) --------------------------------------
+# NDCN_VJP=torch switches every op below back to `_HipValue` (autograd through the torch expression): the A/B the GPU
+# tests use to check the analytic kernels.
+
+def _analytic():
+    return os.environ.get('NDCN_VJP', 'hip') != 'torch'
+
+
+def _scalar_like(ref, v):
+    return torch.tensor(v, dtype=ref.dtype, device=ref.device)
+
+
+def _active(ks, cs):
+    """the terms the forward kernels are handed: zero coefficients are dropped (misc.py:22-25 adds exact zeros)"""
+    idx = [j for j, c in enumerate(cs) if float(c) != 0.0]
+    return idx, [ks[j] for j in idx], [f32(float(cs[j])) for j in idx]
+
+
+class _CombineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, y0, *rest):
+        ks, cs = rest[:n], rest[n:]
+        idx, kk, cc = _active(ks, cs)
+        ctx.n, ctx.idx, ctx.cc = n, idx, cc
+        ctx.save_for_backward(*kk, *cs)
+        return hip.combine(y0, kk, cc) if kk else y0.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        n, idx, cc = ctx.n, ctx.idx, ctx.cc
+        saved = ctx.saved_tensors
+        kk, cs = saved[:len(idx)], saved[len(idx):]
+        needs = ctx.needs_input_grad
+        need_k, need_c = needs[2:2 + n], needs[2 + n:]
+        gk_all, gc_all = [None] * n, [None] * n
+        if idx and (any(need_k[j] for j in idx) or any(need_c[j] for j in idx)):
+            gk, dots = hip.combine_bwd(g, kk, cc, [need_k[j] for j in idx], need_dots=any(need_c[j] for j in idx))
+            for q, j in enumerate(idx):
+                gk_all[j] = gk[q]
+                if need_c[j]:
+                    gc_all[j] = _scalar_like(cs[j], dots[q])
+        return (None, g if needs[1] else None) + tuple(gk_all) + tuple(gc_all)
+
 
 def _combine(y0, ks, cs):
     """y0 + sum_j c_j k_j with c_j 0-d tensors (dt * beta in the state dtype, misc.py:22-25)."""
     n = len(ks)
+    if _analytic():
+        return _CombineFn.apply(n, y0, *ks, *cs)
 
     def hip_fn(y, *rest):
-        kk, cc = [], []
-        for k, c in zip(rest[:n], rest[n:]):
-            if float(c) != 0.0:
-                kk.append(k)
-                cc.append(f32(float(c)))
+        _, kk, cc = _active(rest[:n], rest[n:])
         return hip.combine(y, kk, cc) if kk else y.clone()
 
     def torch_fn(y, *rest):
@@ -90,16 +131,44 @@ def _combine(y0, ks, cs):
     return _HipValue.apply(hip_fn, torch_fn, y0, *ks, *cs)
 
 
+class _ErrorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, rtol, atol, bad_out, y0, y1, *rest):
+        ks, cs = rest[:n], rest[n:]
+        idx, kk, cc = _active(ks, cs)
+        s, bad = hip.error(y0, y1, kk, cc, rtol, atol)
+        bad_out.append(bad)
+        ctx.n, ctx.idx, ctx.cc, ctx.tol = n, idx, cc, (rtol, atol)
+        ctx.save_for_backward(y0, y1, *kk, *cs)
+        return torch.tensor(f32(s / y0.numel()), dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, idx, cc = ctx.n, ctx.idx, ctx.cc
+        saved = ctx.saved_tensors
+        y0, y1 = saved[:2]
+        kk, cs = saved[2:2 + len(idx)], saved[2 + len(idx):]
+        needs = ctx.needs_input_grad
+        need_k, need_c = needs[6:6 + n], needs[6 + n:]
+        g_r = float(g)
+        gy0, gy1, gk, dots = hip.error_bwd(y0, y1, kk, cc, ctx.tol[0], ctx.tol[1], g_r, needs[4], needs[5],
+                                           [need_k[j] for j in idx], need_dots=any(need_c[j] for j in idx))
+        gk_all, gc_all = [None] * n, [None] * n
+        for q, j in enumerate(idx):
+            gk_all[j] = gk[q]
+            if need_c[j]:
+                gc_all[j] = _scalar_like(cs[j], g_r * dots[q])
+        return (None, None, None, None, gy0, gy1) + tuple(gk_all) + tuple(gc_all)
+
+
 def _error_ratio(y0, y1, ks, cs, rtol, atol, bad_out):
     """mean(((sum_j c_j k_j) / (atol + rtol max(|y0|, |y1|)))^2) as a float32 0-d CPU tensor (misc.py:146-157)."""
     n = len(ks)
+    if _analytic():
+        return _ErrorFn.apply(n, rtol, atol, bad_out, y0, y1, *ks, *cs)
 
     def hip_fn(a, b, *rest):
-        kk, cc = [], []
-        for k, c in zip(rest[:n], rest[n:]):
-            if float(c) != 0.0:
-                kk.append(k)
-                cc.append(f32(float(c)))
+        _, kk, cc = _active(rest[:n], rest[n:])
         s, bad = hip.error(a, b, kk, cc, rtol, atol)
         bad_out.append(bad)
         return torch.tensor(f32(s / a.numel()), dtype=torch.float32)
@@ -115,9 +184,41 @@ def _error_ratio(y0, y1, ks, cs, rtol, atol, bad_out):
     return _HipValue.apply(hip_fn, torch_fn, y0, y1, *ks, *cs)
 
 
+def _rms_value(s, numel):
+    nrm = f32(math.sqrt(s)) if s == s and s >= 0 else f32('nan')
+    return torch.tensor(f32(nrm / f32(math.sqrt(numel))), dtype=torch.float32)
+
+
+class _RmsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rtol, atol, bad_out, has_b, *xs):
+        a, y = xs[0], xs[-1]
+        b = xs[1] if has_b else None
+        s, bad = hip.scaled_sumsq(a, b, y, rtol, atol)
+        if bad_out is not None:
+            bad_out.append(bad)
+        ctx.has_b, ctx.tol, ctx.s = has_b, (rtol, atol), s
+        ctx.save_for_backward(*xs)
+        return _rms_value(s, a.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        xs = ctx.saved_tensors
+        a, y = xs[0], xs[-1]
+        b = xs[1] if ctx.has_b else None
+        needs = ctx.needs_input_grad[4:]
+        # d (||v|| / sqrt(N)) / d v = v / (||v|| sqrt(N)); torch's norm backward is 0 at v = 0
+        coef = float(g) / (math.sqrt(ctx.s) * math.sqrt(a.numel())) if ctx.s > 0 else 0.0
+        ga, gb, gy = hip.rms_bwd(a, b, y, ctx.tol[0], ctx.tol[1], coef, needs[0], ctx.has_b and needs[1], needs[-1])
+        return (None, None, None, None) + ((ga, gb, gy) if ctx.has_b else (ga, gy))
+
+
 def _rms(a, b, y, rtol, atol, bad_out=None):
     """misc.py:71-76 of (a [- b]) / (atol + |y| rtol): float32 0-d CPU tensor."""
     has_b = b is not None
+    args = (a, b, y) if has_b else (a, y)
+    if _analytic():
+        return _RmsFn.apply(rtol, atol, bad_out, has_b, *args)
 
     def hip_fn(*xs):
         aa, yy = xs[0], xs[-1]
@@ -125,8 +226,7 @@ def _rms(a, b, y, rtol, atol, bad_out=None):
         s, bad = hip.scaled_sumsq(aa, bb, yy, rtol, atol)
         if bad_out is not None:
             bad_out.append(bad)
-        nrm = f32(math.sqrt(s)) if s == s and s >= 0 else f32('nan')
-        return torch.tensor(f32(nrm / f32(math.sqrt(aa.numel()))), dtype=torch.float32)
+        return _rms_value(s, aa.numel())
 
     def torch_fn(*xs):
         aa, yy = xs[0], xs[-1]
@@ -134,24 +234,46 @@ def _rms(a, b, y, rtol, atol, bad_out=None):
         v = ((aa - xs[1]) if has_b else aa) / scale
         return v.norm() / (v.numel() ** 0.5)
 
-    args = (a, b, y) if has_b else (a, y)
     return _HipValue.apply(hip_fn, torch_fn, *args)
+
+
+def _dense_value(cache, a0, a1, kk, dt_, x_):
+    dt32 = f32(float(dt_))
+    if 'fit' not in cache:
+        cmid = [f32(dt32 * f32(c)) for c in core.DP_C_MID]
+        cache['fit'] = hip.interp_fit(a0, a1, list(kk), cmid, dt32)
+    xv = f32(float(x_))
+    x2 = f32(xv * xv)
+    x3 = f32(x2 * xv)
+    x4 = f32(x3 * xv)
+    return hip.interp_eval(cache['fit'], a0, (x4, x3, x2, xv, f32(1)))
+
+
+class _DenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cache, a0, a1, *rest):
+        kk, dt_, x_ = rest[:7], rest[7], rest[8]
+        ctx.save_for_backward(a0, a1, *rest)
+        return _dense_value(cache, a0, a1, kk, dt_, x_)
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        a0, a1, kk, dt_, x_ = saved[0], saved[1], saved[2:9], saved[9], saved[10]
+        needs = ctx.needs_input_grad
+        gy0, gy1, gk, d_x, d_dt = hip.interp_bwd(g, a0, a1, list(kk), f32(float(dt_)), f32(float(x_)), needs[1], needs[2],
+                                                 list(needs[3:10]), need_dots=needs[10] or needs[11])
+        return (None, gy0, gy1) + tuple(gk) + (_scalar_like(dt_, d_dt) if needs[10] else None,
+                                               _scalar_like(x_, d_x) if needs[11] else None)
 
 
 def _dense_output(y0, y1, ks, dts, x, cache):
     """dopri5.py:39-45 + interp.py:21-35,58-65 at abscissa x (0-d, state dtype) for step size dts (0-d)."""
+    if _analytic():
+        return _DenseFn.apply(cache, y0, y1, *ks, dts, x)
 
     def hip_fn(a0, a1, *rest):
-        kk, dt_, x_ = rest[:7], rest[7], rest[8]
-        dt32 = f32(float(dt_))
-        if 'fit' not in cache:
-            cmid = [f32(dt32 * f32(c)) for c in core.DP_C_MID]
-            cache['fit'] = hip.interp_fit(a0, a1, list(kk), cmid, dt32)
-        xv = f32(float(x_))
-        x2 = f32(xv * xv)
-        x3 = f32(x2 * xv)
-        x4 = f32(x3 * xv)
-        return hip.interp_eval(cache['fit'], a0, (x4, x3, x2, xv, f32(1)))
+        return _dense_value(cache, a0, a1, rest[:7], rest[7], rest[8])
 
     def torch_fn(a0, a1, *rest):
         kk = rest[:7]

@@ -183,3 +183,91 @@ def test_linear_backward_kernels(dev, n, Hi, Ho, masked):
     if masked:
         assert torch.equal(hip.relu_bwd(g, Y), g * (Y > 0))
     assert torch.equal(hip.scale(g, -0.37), g * np.float32(-0.37))
+
+
+@pytest.mark.parametrize('n,H', [(400, 20), (100003, 7)])
+def test_solver_vjp_kernels_against_torch_autograd(dev, n, H):
+    """csrc/rk_bwd.hip: each VJP kernel vs fp64 autograd through the reference's expression of the same op
+    (misc.py:22-25, 71-76, 146-157; dopri5.py:39-45 + interp.py:21-65)."""
+    from ndcn_amd.ops import hip
+    from ndcn_amd.torchdiffeq._impl import core
+    gen = torch.Generator().manual_seed(5)
+    R = lambda *s: torch.randn(*s, generator=gen)
+    y0, y1, g = R(n, H), R(n, H), R(n, H)
+    ks = [R(n, H) for _ in range(7)]
+    cs = [0.3, -0.2, 0.11, 0.05, -0.4, 0.07, 0.25]
+    D = lambda x: x.double().requires_grad_(True)
+    G = lambda x: x.to(dev)
+    close = lambda a, b, tol=2e-5: float((a.cpu().double() - b).abs().max()) <= tol * (float(b.abs().max()) + 1e-30)
+
+    # combine
+    kd, cd = [D(k) for k in ks], [torch.tensor(c, dtype=torch.float64, requires_grad=True) for c in cs]
+    out = y0.double() + sum(c * k for c, k in zip(cd, kd))
+    out.backward(g.double())
+    gk, dots = hip.combine_bwd(G(g), [G(k) for k in ks], cs, [True, False] * 3 + [True])
+    assert gk[1] is None and all(close(gk[j], kd[j].grad) for j in (0, 2, 4, 6))
+    assert all(abs(dots[j] - float(cd[j].grad)) <= 1e-5 * (abs(float(cd[j].grad)) + n ** 0.5) for j in range(7))
+
+    # error ratio
+    rtol, atol, g_r = 1e-2, 1e-3, 0.7
+    kd, cd = [D(k) for k in ks], [torch.tensor(c, dtype=torch.float64, requires_grad=True) for c in cs]
+    a0, a1 = D(y0), D(y1)
+    e = sum(c * k for c, k in zip(cd, kd))
+    r = (e / (atol + rtol * torch.max(a0.abs(), a1.abs())))
+    (r * r).mean().backward(torch.tensor(g_r, dtype=torch.float64))
+    gy0, gy1, gk, dots = hip.error_bwd(G(y0), G(y1), [G(k) for k in ks], cs, rtol, atol, g_r, True, True, [True] * 7)
+    assert close(gy0, a0.grad, 1e-4) and close(gy1, a1.grad, 1e-4)
+    assert all(close(gk[j], kd[j].grad, 1e-4) for j in range(7))
+    assert all(abs(g_r * dots[j] - float(cd[j].grad)) <= 1e-4 * abs(float(cd[j].grad)) + 1e-3 for j in range(7))
+
+    # rms (with and without b)
+    for has_b in (True, False):
+        a, b, y = D(ks[0]), D(ks[1]), D(y0)
+        v = ((a - b) if has_b else a) / (atol + y.abs() * rtol)
+        o = v.norm() / v.numel() ** 0.5
+        o.backward(torch.tensor(1.3, dtype=torch.float64))
+        s, _ = hip.scaled_sumsq(G(ks[0]), G(ks[1]) if has_b else None, G(y0), rtol, atol)
+        coef = 1.3 / (s ** 0.5 * (n * H) ** 0.5)
+        ga, gb, gy = hip.rms_bwd(G(ks[0]), G(ks[1]) if has_b else None, G(y0), rtol, atol, coef, True, True, True)
+        assert close(ga, a.grad, 1e-4) and close(gy, y.grad, 1e-4)
+        assert (gb is None) if not has_b else close(gb, b.grad, 1e-4)
+
+    # dense output
+    dt, x = 0.37, 0.61
+    kd, a0, a1 = [D(k) for k in ks], D(y0), D(y1)
+    dtd, xd = torch.tensor(dt, dtype=torch.float64, requires_grad=True), torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ym = a0 + sum((dtd * c) * k for k, c in zip(kd, core.DP_C_MID))
+    f0, f1 = kd[0], kd[6]
+    ca = (-2 * dtd) * f0 + (2 * dtd) * f1 + -8 * a0 + -8 * a1 + 16 * ym
+    cb = (5 * dtd) * f0 + (-3 * dtd) * f1 + 18 * a0 + 14 * a1 + -32 * ym
+    cc = (-4 * dtd) * f0 + dtd * f1 + -11 * a0 + -5 * a1 + 16 * ym
+    o = ca * xd ** 4 + cb * xd ** 3 + cc * xd ** 2 + (dtd * f0) * xd + a0
+    o.backward(g.double())
+    gy0, gy1, gk, d_x, d_dt = hip.interp_bwd(G(g), G(y0), G(y1), [G(k) for k in ks], dt, x, True, True, [True] * 7)
+    assert close(gy0, a0.grad) and close(gy1, a1.grad)
+    assert all(close(gk[j], kd[j].grad, 1e-4) for j in (0, 2, 3, 4, 5, 6)) and float(gk[1].abs().max()) == 0.0
+    assert abs(d_x - float(xd.grad)) <= 1e-4 * abs(float(xd.grad)) + 1e-3 * n ** 0.5
+    assert abs(d_dt - float(dtd.grad)) <= 1e-4 * abs(float(dtd.grad)) + 1e-3 * n ** 0.5
+
+
+def test_dopri5_backprop_analytic_vjps_equal_torch_expression_vjps(dev, monkeypatch):
+    """A/B of autograd_path.py: NDCN_VJP=torch (autograd through the torch expression of every panel op) vs the
+    analytic kernels, same forward."""
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('fixed_rk4_equal')
+    t = torch.linspace(0., 1., 5).to(dev)
+    target = torch.rand(5, 400, 20, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    for mode in ('hip', 'torch'):
+        monkeypatch.setenv('NDCN_VJP', mode)
+        f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
+        f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+        x = T(d['x0']).to(dev).requires_grad_(True)
+        y = ode.odeint(f, x, t, rtol=1e-3, atol=1e-4, method='dopri5')
+        torch.nn.functional.l1_loss(y, target).backward()
+        res[mode] = (y.detach().clone(), x.grad.clone(), f.wt.weight.grad.clone(), f.wt.bias.grad.clone())
+    assert torch.equal(res['hip'][0], res['torch'][0])
+    for a, b in zip(res['hip'][1:], res['torch'][1:]):
+        assert rel(a, b) < 1e-3                 # fp32 rounding of differently-ordered sums; the oracle test above bounds both

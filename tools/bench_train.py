@@ -71,7 +71,14 @@ def main():
     dev = torch.device('cuda:0')
     out = [one_case('C1 heat_dynamics --network grid --baseline ndcn (README)', 20, 20, 80, 'euler', dev, 3),
            one_case('C1 with dopri5', 20, 20, 80, 'dopri5', dev, 3),
-           one_case('100k-node grid, H=256', 316, 256, 10, 'euler', dev, 1)]
+           one_case('100k-node grid, H=256', 316, 256, 10, 'euler', dev, 1),
+           one_case('100k-node grid, H=256, dopri5', 316, 256, 10, 'dopri5', dev, 1)]
+    # A/B: the solver's panel-op VJPs as autograd through torch expressions instead of the csrc/rk_bwd.hip kernels
+    os.environ['NDCN_VJP'] = 'torch'
+    for r in (one_case('C1 with dopri5 [NDCN_VJP=torch]', 20, 20, 80, 'dopri5', dev, 0),
+              one_case('100k-node grid, H=256, dopri5 [NDCN_VJP=torch]', 316, 256, 10, 'dopri5', dev, 0)):
+        out.append(r)
+    os.environ.pop('NDCN_VJP')
     for r in out:
         print(json.dumps(r), flush=True)
 
