@@ -291,6 +291,15 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
         }
     };
 
+    // (Measured and dropped, profiles/r02g_fused_timing.txt: TWO rows in flight per gather wave - the next row's <= 12
+    // neighbour fetches, branch-free through null descriptors, issued before the wait for the current row's.  Bit-equal,
+    // but slower: plain launch 1.05 -> 1.21 ms, one / two earlier stages 1.38 -> 1.52 / 1.48 -> 1.59 ms.  The gather
+    // phase takes the same 1.7 M cycles per launch with the MFMA waves switched off and with twice the fetches in
+    // flight: it is bound by the vector-memory path's rate for 1 KiB row fetches (9 per output row = 9 GB per launch
+    // L2 -> CU at ~20 B/clk/CU), not by a wave's latency chain.  The lever is FEWER fetches per row - the record plan
+    // of spmm_rec.hip stages each distinct neighbour row once per 16-row group - which needs the LDS this kernel spends
+    // on its two 64-row S tiles.)
+
     // ---- consumer -----------------------------------------------------------------------------------
     // wave w owns output columns [64 w, 64 w + 64) (n-tiles 2w, 2w+1) for both 32-row m-tiles
     f32x16 acc00, acc01, acc10, acc11;
