@@ -33,6 +33,13 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
                    int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
 // fixed-order sum of n {sum, bad} fp64 pairs into d_out[0..1] (one workgroup: deterministic accept / reject)
 int partials_finish(const double *partials, int n, double *d_out, hipStream_t st);
+// rhs_fused3.hip: the same contract as rhs_fused2_f32 for operators that carry the 16-row group-record plan (Wq: the
+// split weights of pack_weight_256, i.e. Wp + 256 * 256 floats)
+int rhs_fused3_supported(const ndcn_csr *A);
+int rhs_fused3_variant(int mode, int n_prev);
+int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
+                   uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
+                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
 int spmm_rec_supported(const ndcn_csr *A, int H);
 int spmm_rec_variant(int mode, int n_prev);
 int64_t spmm_rec_partials_bytes();

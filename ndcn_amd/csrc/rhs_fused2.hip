@@ -622,6 +622,10 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         Xh = A->hub_S;
         A = &light;
     }
+    // operators with the 16-row group-record plan (lattices): neighbour rows staged once per 4 x 4 patch (rhs_fused3.hip)
+    if (NDCN_SPLIT && rhs_fused3_supported(A) && rhs_fused3_variant(mode, n_prev))
+        return rhs_fused3_f32(A, X, Xh, n_own, Wp + kH2 * kH2, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out,
+                              d_ws, st);
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;
     const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;

@@ -1,0 +1,624 @@
+// The whole ODEFunc  K = relu(W (A X) + b)  (neural_dynamics.py:27-36) plus the Runge-Kutta algebra that consumes K
+// (rk_common.py:45-60,72-78; misc.py:22-25,146-157), H = 256, for operators that carry the 16-row group-record plan
+// (ndcn_csr::rec, csr.py:build_rec_plan): the gather side of spmm_rec.hip feeding the split-bf16 MFMA product of
+// rhs_fused2.hip, one persistent workgroup per CU.
+//
+// Why (profiles/r02g_fused_timing.txt): rhs_fused2's gather waves fetch every neighbour row through the vector-memory
+// path into registers - 9 fetches of 1 KiB per output row on the 8-neighbour lattice, 9 GB per launch L2 -> CU - and
+// that path, not HBM and not the matrix pipe, bounds its low-stage launches (1.7 M cycles per launch with the MFMA
+// waves idle; twice the fetches in flight change nothing).  The group-record plan stages each DISTINCT neighbour row of
+// a 4 x 4 lattice patch once (36 rows for 16 outputs: 2.25 fetches per row) by LDS-DMA, no register round trip; the
+// LDS that costs is found by shrinking the S tile from 64 to 32 rows (the weights are then streamed twice as often:
+// 12 KiB per row from L2, still less than the 9 KiB per row of fetches it replaces plus the 6 KiB it had).
+//
+//   12 waves: 8 producer | 4 MFMA, in lock-step over "steps" (one 16-row group each), ONE workgroup barrier per step
+//     producer step s: own LDS-DMA requests of group s landed (counted vmcnt); barrier; request record s + 2 and its
+//              share (5 of 40) of the union rows of group s + 1 (column ids out of the record that landed a step
+//              earlier); then two rows: fold the row's (slot, value) entries over the staged union rows (stored order:
+//              bit-identical to a sequential loop) -> row 16 (s & 1) + i of S tile (s / 2) & 1.  The slot it overwrites
+//              holds K of the tile staged 4 steps earlier: that row's RK epilogue (K out, y_next / error sums) comes
+//              first; its row-local panels were requested half a step ahead.
+//     MFMA     step s: half (s & 1) of the 16 k-steps of tile s / 2 - 1 (the other S buffer): wave w owns output
+//              columns [64 w, 64 w + 64); fp32 operands split error-free into 3 bf16 pieces, 6 partial products
+//              (rhs_fused2.hip).  After the second half the four waves meet on an LDS counter (everyone has read S) and
+//              drop K = relu(. + b) into the tile they consumed.
+//   (Measured on the way: 4 DMA + 8 compute + 4 MFMA waves (16 waves: 128 registers, a two-k-step weight ring) ran the
+//   MFMA side at 22 k cycles per 32-row tile, 3.6 x its matrix-pipe time - every k-step waited an L2 round trip for its
+//   weights - while the producer side alone was at the HBM floor of every launch; 8 producer + 8 MFMA waves (one n-tile
+//   each, two per SIMD) took 13 k cycles per tile even with the weight fetches switched off: eight waves each splitting
+//   the whole A tile into bf16 pieces make the loop VALU-bound.)
+//   LDS: 2 union buffers (40 KiB) + 3 records (2 KiB) + 2 S tiles (32 x 260 floats) + row ids = 151 KiB.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+#include "gather.h"
+#include "rec_common.h"
+
+#pragma clang fp contract(off)   // the RK algebra must round like the reference's separate mul / add ops
+
+namespace ndcn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this kernel is written for
+// MFMA waves: 4 (two n-tiles each, 12 waves per CU: 168 registers) or 8 (one n-tile each, two per SIMD, 128 registers)
+#ifndef NDCN_F3_MFMA_WAVES
+#define NDCN_F3_MFMA_WAVES 8
+#endif
+#ifndef NDCN_F3_RING
+#define NDCN_F3_RING 2
+#endif
+// The weight stream (12 KiB per row from L2), not HBM, bounds this kernel: with the refills switched off the dopri5 step
+// of the metric case takes 6.2 ms instead of 11.9.  Whatever registers the MFMA waves have left hold the first k-steps of
+// their weights for good.
+#ifndef NDCN_F3_RESIDENT
+#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 5 : 1)
+#endif
+constexpr int kF3WP = 8, kF3WM = NDCN_F3_MFMA_WAVES, kF3Waves = kF3WP + kF3WM;    // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
+constexpr int kF3NBuf = 2, kF3NRec = 3;                  // one group in flight ahead of the one being folded
+constexpr int kF3Tile = 32, kF3Ld = 260;                 // S tile: 2 groups; +4 floats per row: conflict-free b128
+constexpr int kF3MaxPrev = 5;
+constexpr int kF3CapD = kF3Cap / kF3WP, kF3E0 = kF3Cap + 2 * kF3R;
+constexpr unsigned kF3OffRec = kF3NBuf * kF3Cap * 1024;
+constexpr unsigned kF3OffS = kF3OffRec + kF3NRec * kF3RecW * 1024;
+constexpr unsigned kF3OffRow = kF3OffS + 2 * kF3Tile * kF3Ld * 4;
+constexpr unsigned kF3OffSync = kF3OffRow + 2 * kF3Tile * 4;
+constexpr unsigned kF3OffBias = kF3OffSync + 16;
+constexpr unsigned kF3Lds = kF3OffBias + 256 * 4;
+
+// workgroup barrier: this wave's LDS traffic has been performed first, and hipcc moves no memory access across it
+__device__ __forceinline__ void f3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// cycle accounting is compiled in only on request (its counters cost the MFMA waves registers they do not have)
+#ifdef NDCN_F3_TIMING
+constexpr bool kF3Timing = true;
+#else
+constexpr bool kF3Timing = false;
+#endif
+
+enum { F3_PLAIN = 0, F3_COMBINE = 1, F3_ERROR = 2, F3_RK4 = 3 };
+
+struct F3Args {
+    const int *rec;
+    int n_groups;
+    const float *X, *Xh;
+    int n_own;
+    const void *Wq;                  // split weights (pack_weight_256: three bf16 planes in MFMA B-operand order)
+    const float *bias;
+    float *K;
+    int relu;
+    const int *rowptr, *colidx;      // direct gather of groups the plan could not stage
+    const float *val;
+    unsigned long long *dbg_cycles;  // NDCN_FUSED3_TIMING: per (block, wave) {cycles between barriers, cycles inside barriers}
+    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 64 no weight refills
+};
+struct F3Epi {
+    const float *y0;
+    const float *kprev[kF3MaxPrev];
+    float *y_next;
+    double *partials;                // ERROR: [gridDim.x * kF3WP][2]
+    float c[kF3MaxPrev + 1];         // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K ; RK4: c[0] = dt
+    float rtol, atol;
+};
+
+template <bool HALO, int MODE, int NP>
+__global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3Epi e) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane_off = lane * 16;
+    const unsigned lds_x = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float *)lds;
+    const unsigned lds_r = lds_x + kF3OffRec;
+    const int *rbuf = reinterpret_cast<const int *>(lds) + kF3OffRec / 4;
+    float *s_tiles = lds + kF3OffS / 4;
+    int *s_rowid = reinterpret_cast<int *>(lds) + kF3OffRow / 4;
+    unsigned *s_sync = reinterpret_cast<unsigned *>(lds) + kF3OffSync / 4;
+    float *s_bias = lds + kF3OffBias / 4;          // a fetch issued from inside the MFMA loop queues behind the producers' requests
+
+    // groups of this workgroup: XCD x owns a contiguous chunk, its workgroups take the chunk's groups round-robin
+    const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wpx = gridDim.x / kXcds;
+    const int chunk = (a.n_groups + kXcds - 1) / kXcds;
+    const int g_lo = xcd * chunk, g_hi = min(a.n_groups, g_lo + chunk);
+    const int g0 = g_lo + wg;
+    const int my = g0 < g_hi ? (g_hi - g0 + wpx - 1) / wpx : 0;
+    const int n_tiles = (my + 1) >> 1;
+    const int n_steps = 2 * n_tiles + 4;                       // + 2 for the MFMA lag, + 2 for the epilogue lag
+    if (my == 0) {
+        if (MODE == F3_ERROR && wave < kF3WP && lane == 0) {  // the finish kernel sums EVERY slot
+            e.partials[2 * (blockIdx.x * kF3WP + wave)] = 0.0;
+            e.partials[2 * (blockIdx.x * kF3WP + wave) + 1] = 0.0;
+        }
+        return;
+    }
+
+    if (wave >= kF3WP) {
+        // ------------------------------------------------------------------------------------------ MFMA waves
+        // wave w owns kNT n-tiles of 32 output columns: [32 kNT w, 32 kNT (w + 1)).  Split weights: block (n-tile j, k-step
+        // ks, plane pl) = 64 lanes x 16 bytes; a ring of kRing k-steps x kNT n-tiles x 3 planes in registers, every slot
+        // refilled right after use.  The ring runs on across halves and tiles: the weights are the same for every tile.
+        const int mw = wave - kF3WP;
+        constexpr int kNT = 8 / kF3WM;
+        constexpr int kRing = NDCN_F3_RING;
+        constexpr int kRes = NDCN_F3_RESIDENT;              // k-steps [0, kRes) of the wave's weights never leave its registers
+        constexpr int kNS = 16 - kRes;                       // streamed k-steps per tile
+        static_assert(kRing <= kNS, "ring");
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, 8 * 16 * 3 * 1024, 0x00020000);
+        const int q_slab = (kNT * mw) * 16 * 3 * 1024;
+        auto ldq = [&](int jj, int ks, int pl) {
+            int ws = q_slab;
+            asm volatile("" : "+s"(ws));
+            return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, ws + ((jj * 16 + ks) * 3 + pl) * 1024, 0);
+        };
+        u32x4 Bq[kRing][kNT][3];
+        u32x4 Br[kRes > 0 ? kRes : 1][kNT][3];
+#pragma unroll
+        for (int k = 0; k < kRes; ++k)
+#pragma unroll
+            for (int jj = 0; jj < kNT; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Br[k][jj][pl] = ldq(jj, k, pl);
+#pragma unroll
+        for (int u = 0; u < kRing; ++u)
+#pragma unroll
+            for (int jj = 0; jj < kNT; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kRes + u, pl);
+        auto cvt_pk = [](float lo, float hi) {
+            unsigned r;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+            return r;
+        };
+        // 8 consecutive fp32 -> three bf16x8 pieces whose sum is the input, exactly
+        auto split8 = [&](f32x4 r0, f32x4 r1, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+            const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float va = x[2 * q], vb = x[2 * q + 1];
+                const unsigned h = cvt_pk(va, vb);
+                const float ra = va - __builtin_bit_cast(float, h << 16), rb = vb - __builtin_bit_cast(float, h & 0xffff0000u);
+                const unsigned m = cvt_pk(ra, rb);
+                const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+                p1[q] = h; p2[q] = m; p3[q] = cvt_pk(sa, sb);
+            }
+        };
+        f32x16 acc[kNT];
+        // k-steps [8 HALF, 8 HALF + 8) of the tile at `src`
+        auto mfma_half = [&](const float *src, auto half_tag) {
+            constexpr int HALF = decltype(half_tag)::value;
+            // per-lane addresses are re-derived from a laundered lane id at every use: hoisted out of the step loop they
+            // occupy registers the ring needs, and hipcc then parks them in scratch - whose reloads queue behind the
+            // producers' requests like every other vector-memory operation of this CU
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const float *ap = src + (ln & 31) * kF3Ld + 8 * (ln >> 5) + 128 * HALF;
+            // with one MFMA wave per SIMD the next block's A values leave LDS while this block's products run (8 registers);
+            // with two per SIMD the other wave covers the LDS latency and the registers go to the weight ring instead
+            constexpr bool kAhead = kNT > 1;
+            f32x4 n0, n1;
+            if (kAhead) { n0 = *reinterpret_cast<const f32x4 *>(ap); n1 = *reinterpret_cast<const f32x4 *>(ap + 4); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int ks = 8 * HALF + i;
+                const bool res = ks < kRes;
+                const int u = res ? 0 : (ks - kRes) % kRing;
+                f32x4 r0, r1;
+                if (kAhead) {
+                    r0 = n0; r1 = n1;
+                    if (i + 1 < 8) {
+                        n0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
+                        n1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
+                    }
+                } else {
+                    r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * i);
+                    r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * i + 4);
+                }
+                u32x4 A0, A1, A2;
+                split8(r0, r1, A0, A1, A2);
+                auto mm = [&](f32x16 &c, u32x4 av, u32x4 bv) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+                };
+                // small products first (the order of rhs_fused2.hip: identical rounding); the n-tiles alternate
+                auto bq = [&](int jj, int pl) -> const u32x4 & { return res ? Br[res ? ks : 0][jj][pl] : Bq[u][jj][pl]; };
+#pragma unroll
+                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 2));
+#pragma unroll
+                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A2, bq(jj, 0));
+#pragma unroll
+                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A1, bq(jj, 1));
+#pragma unroll
+                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 1));
+#pragma unroll
+                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A1, bq(jj, 0));
+#pragma unroll
+                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 0));
+                __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot (hoisted, they need 12 more registers)
+                if (!res && !(a.dbg & 64)) {
+                    // streamed k-step j = ks - kRes: its slot is refilled with j + kRing or, for the last kRing of a tile,
+                    // with streamed k-step (slot index) of the NEXT tile
+                    const int j = ks - kRes;
+                    const int kn = kRes + (j + kRing < kNS ? j + kRing : u);
+#pragma unroll
+                    for (int jj = 0; jj < kNT; ++jj)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kn, pl);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto dump_tile = [&](float *dst) {
+            // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int jj = 0; jj < kNT; ++jj) {
+                const int col = 32 * (kNT * mw + jj) + (ln & 31);
+                const float bv = s_bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                    float o = acc[jj][r] + bv;
+                    if (a.relu) o = fmaxf(o, 0.f);
+                    dst[m * kF3Ld + col] = o;
+                }
+            }
+        };
+        // One loop iteration = one tile = two steps, straight-line: the ring's registers then flow from half to half and
+        // around ONE back edge.  (With a per-step loop and the halves on two branches hipcc reconciled the two register
+        // assignments of the ring with v_mov copies behind s_waitcnt vmcnt at every join - i.e. each half ended by
+        // waiting for the refills it had just requested.)
+        unsigned long long cyc_work = 0, cyc_wait = 0, c_prev = 0;
+        auto barrier_t = [&]() {
+            const unsigned long long cb = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
+            f3_barrier();
+            if (kF3Timing && a.dbg_cycles) { const unsigned long long ce = __builtin_readcyclecounter(); cyc_work += cb - c_prev; cyc_wait += ce - cb; c_prev = ce; }
+        };
+        f3_barrier();                                               // [P]
+        if (kF3Timing && a.dbg_cycles) c_prev = __builtin_readcyclecounter();
+        barrier_t();                                                // [A_0]
+        barrier_t();                                                // [A_1]
+        for (int t = 0; t < n_tiles; ++t) {                         // the tile whose S rows were folded in steps 2 t, 2 t + 1
+            float *tile = s_tiles + (t & 1) * kF3Tile * kF3Ld;
+            barrier_t();                                            // [A_(2t+2)]
+#pragma unroll
+            for (int jj = 0; jj < kNT; ++jj)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[jj][i] = 0.f;
+            if (!(a.dbg & 1)) mfma_half(tile, std::integral_constant<int, 0>{});
+            barrier_t();                                            // [A_(2t+3)]
+            if (!(a.dbg & 1)) mfma_half(tile, std::integral_constant<int, 1>{});
+            // every MFMA wave has read its last S value before anyone overwrites the tile with K
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(s_sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(kF3WM * (t + 1)))
+                __builtin_amdgcn_s_sleep(1);
+            dump_tile(tile);
+        }
+        barrier_t();                                                // the two steps in which the producers finish the last tile's K rows
+        barrier_t();
+        // the last refills of the weight ring wrap into a tile that does not exist
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+        if (kF3Timing && a.dbg_cycles && lane == 0) {
+            a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave)] = cyc_work;
+            a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave) + 1] = cyc_wait;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------- producer waves
+    // (LDS-DMA requests, fold, RK epilogue).  One vector-memory counter serves three kinds of requests that complete in
+    // issue order: the DMA of the NEXT group (must have landed at the top of the next step), the row-local panels of slot
+    // 0 / slot 1 (consumed half a step after their request) and the epilogue's stores.  since_dma / since_p0 / since_p1
+    // count what was issued AFTER the respective request: exactly that many operations may still be outstanding when
+    // its data is used.
+    const int pw = wave;
+    constexpr int kLoads = MODE == F3_PLAIN ? 0 : NP + 1 + (MODE == F3_ERROR ? 1 : 0);
+    struct Panels { f32x4 km[NP > 0 ? NP : 1]; f32x4 y0v, y1v; };
+    double err_sum = 0.0, err_bad = 0.0;
+    int since_dma = 0, since_p0 = 0, since_p1 = 0;
+    auto issued = [&](int n) { since_dma += n; since_p0 += n; since_p1 += n; };
+    if (lane < 2 * kF3Tile / kF3WP) s_rowid[pw * (2 * kF3Tile / kF3WP) + lane] = -1;     // 64 slots, 8 per wave
+    if (pw == 0 && lane == 0) *s_sync = 0u;
+    if (pw < 4) s_bias[64 * pw + lane] = a.bias ? a.bias[64 * pw + lane] : 0.f;
+
+    auto dma_rec = [&](int it) {
+        if (pw < kF3RecW && it < my) {
+            dma_row(reinterpret_cast<const float *>(a.rec + ((size_t)(g0 + it * wpx) * kF3RecW + pw) * 256),
+                    lds_r + (unsigned)(((it % kF3NRec) * kF3RecW + pw) * 1024), lane_off);
+            issued(1);
+        }
+    };
+    auto dma_x = [&](int it) {
+        const int *r = rbuf + (it % kF3NRec) * kF3RecW * 256 + pw * kF3CapD;
+        int cc[kF3CapD];
+#pragma unroll
+        for (int k = 0; k < kF3CapD; ++k) cc[k] = __builtin_amdgcn_readfirstlane(r[k]);
+#pragma unroll
+        for (int k = 0; k < kF3CapD; ++k) {
+            const float *base = a.X;
+            int c = cc[k];
+            if (HALO && c >= a.n_own) { base = a.Xh; c -= a.n_own; }
+            dma_row(base + (size_t)c * 256, lds_x + (unsigned)(((it % kF3NBuf) * kF3Cap + pw * kF3CapD + k) * 1024), lane_off);
+        }
+        issued(kF3CapD);
+    };
+    auto ldp = [&](const float *base /*uniform*/, int voff) {
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v) : "v"(voff), "s"(base) : "memory");
+        return v;
+    };
+    // row-local panels of one K row; branch-free (a slot without a row requests row 0 and ignores it): a register that
+    // is the target of an in-flight fetch must be assigned on ONE path only, or hipcc copies it around
+    auto request = [&](int row, Panels &p) {
+        const int voff = (max(row, 0) << 10) + lane_off;           // panels < 4 GiB (launcher check)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) p.km[m] = ldp(e.kprev[m], voff);
+        p.y0v = ldp(e.y0, voff);
+        if (MODE == F3_ERROR) p.y1v = ldp(a.X, voff);               // the input of this evaluation is y1 (own rows)
+        issued(kLoads);
+    };
+    auto arrived = [&](Panels &p) {
+#pragma unroll
+        for (int m = 0; m < NP; ++m) asm volatile("" : "+v"(p.km[m]));
+        asm volatile("" : "+v"(p.y0v));
+        if (MODE == F3_ERROR) asm volatile("" : "+v"(p.y1v));
+    };
+    auto stp = [&](float *base /*uniform*/, int voff, f32x4 v) {
+        // (s_nop: the data registers of a 16-byte store must not be written in the next wait state)
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+    };
+    // RK epilogue of one K row (as rhs_fused2.hip: epi_finish)
+    auto epilogue = [&](int row, f32x4 kn, const Panels &p) {
+        const int voff = (row << 10) + lane_off;
+        stp(a.K, voff, kn);
+        issued(1);
+        if (MODE == F3_PLAIN) return;
+        if (MODE == F3_RK4) {
+            // rk4_alt_step_func (rk_common.py:72-78), same operator order as fixed_stage_kernel ops 2-5
+            const float dt = e.c[0];
+            f32x4 s;
+            if (NP == 0) s = (kn * dt) / 3.f;
+            else if (NP == 1) s = (p.km[0] / -3.f + kn) * dt;
+            else if (NP == 2) s = ((p.km[0] - p.km[NP > 1 ? 1 : 0]) + kn) * dt;
+            else s = (((p.km[0] + p.km[NP > 1 ? 1 : 0] * 3.f) + p.km[NP > 2 ? 2 : 0] * 3.f) + kn) * (dt / 8.f);
+            stp(e.y_next, voff, p.y0v + s);
+            issued(1);
+            return;
+        }
+        // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
+        f32x4 s = kn * e.c[NP];
+        if (NP > 0) {
+            f32x4 u = p.km[0] * e.c[0];
+#pragma unroll
+            for (int m = 1; m < NP; ++m) u = u + p.km[m] * e.c[m];
+            s = u + s;
+        }
+        if (MODE == F3_COMBINE) {
+            stp(e.y_next, voff, p.y0v + s);
+            issued(1);
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float tol = e.atol + e.rtol * fmaxf(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
+            const float z = s[q] / tol;
+            err_sum += (double)(z * z);
+            err_bad += (double)(int)(!(fabsf(p.y1v[q]) <= 3.402823466e38f));
+        }
+    };
+    // fold of row i of the group staged for step s -> acc; returns the row id (-1: padding)
+    auto fold = [&](int s, int i, f32x4 &acc) -> int {
+        const int *r = rbuf + (s % kF3NRec) * kF3RecW * 256;
+        const f32x4 *xb = reinterpret_cast<const f32x4 *>(lds) + (s % kF3NBuf) * kF3Cap * 64;
+        const int row = __builtin_amdgcn_readfirstlane(r[kF3Cap + 2 * i]);
+        const int meta = __builtin_amdgcn_readfirstlane(r[kF3Cap + 2 * i + 1]);
+        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (row < 0 || (a.dbg & 2)) return row;
+        const int cnt = meta & 0xffff, ofs = meta >> 16;
+        if (cnt != 0xffff) {
+            int es = 0;
+            float ev = 0.f;
+            if (lane < cnt) { es = r[kF3E0 + 2 * (ofs + lane)]; ev = __builtin_bit_cast(float, r[kF3E0 + 2 * (ofs + lane) + 1]); }
+            rec_row<true>(es, ev, cnt, [&](int slot) { return xb[slot * 64 + lane]; }, acc);
+        } else {
+            // group not staged: gather this row from the CSR arrays, 64 entries at a time (rare; full waits: every
+            // request of this wave, the panels in flight included, has landed afterwards)
+            const int j0 = a.rowptr[row], j1 = a.rowptr[row + 1];
+            for (int jb = j0; jb < j1; jb += 64) {
+                const int n = min(64, j1 - jb);
+                int es = 0;
+                float ev = 0.f;
+                if (lane < n) {
+                    const int eo = (jb + lane) * 4;
+                    asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(es), "=&v"(ev) : "v"(eo), "s"(a.colidx), "s"(a.val) : "memory");
+                }
+                rec_row<false>(es, ev, n, [&](int c) {
+                    const float *p = a.X;
+                    if (HALO && c >= a.n_own) { p = a.Xh; c -= a.n_own; }
+                    f32x4 v;
+                    asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(lane_off), "s"(p + (size_t)c * 256) : "memory");
+                    return v;
+                }, acc);
+            }
+        }
+        return row;
+    };
+    // slot q (0, 1) of step s: S-tile row and its row-id cell
+    auto slot_of = [&](int s, int q) { return ((s >> 1) & 1) * kF3Tile + 16 * (s & 1) + pw + kF3WP * q; };
+    auto rowid_at = [&](int sl) { return __builtin_amdgcn_readfirstlane(s_rowid[sl]); };
+
+    dma_rec(0);
+    dma_rec(1);
+    rec_wait_vmcnt<0>();
+    f3_barrier();                                                   // [P] the first records are readable
+    dma_x(0);
+    since_dma = 0;
+    Panels p0, p1;
+    if (MODE != F3_PLAIN) { request(-1, p0); since_p0 = 0; }       // (uniform bookkeeping: slot 0 of step 0 has no K row yet)
+    unsigned long long cyc_work = 0, cyc_wait = 0, cyc_dma = 0, c_prev = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
+    for (int s = 0; s < n_steps; ++s) {
+        const unsigned long long ca = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
+        rec_wait_vmcnt_rt(since_dma);                               // this wave's share of group s (and of record s + 1) has landed
+        const unsigned long long cb = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
+        f3_barrier();                                               // [A_s]
+        if (kF3Timing && a.dbg_cycles) { const unsigned long long ce = __builtin_readcyclecounter(); cyc_work += ca - c_prev; cyc_dma += cb - ca; cyc_wait += ce - cb; c_prev = ce; }
+        dma_rec(s + 2);
+        if (s + 1 < my) dma_x(s + 1);
+        since_dma = 0;
+        const int sl0 = slot_of(s, 0), sl1 = slot_of(s, 1);
+        const int er0 = rowid_at(sl0), er1 = rowid_at(sl1);         // K rows waiting in the two slots (-1: none)
+        if (MODE != F3_PLAIN) { request(er1, p1); since_p1 = 0; }
+        // ---- slot 0
+        {
+            f32x4 acc;
+            int row = -1;
+            if (s < my) row = fold(s, pw, acc);
+            float *srow = s_tiles + sl0 * kF3Ld + 4 * lane;
+            if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p0); arrived(p0); }
+            if (er0 >= 0 && !(a.dbg & 4)) epilogue(er0, *reinterpret_cast<const f32x4 *>(srow), p0);
+            if (row >= 0) *reinterpret_cast<f32x4 *>(srow) = acc;
+            s_rowid[sl0] = row;
+        }
+        // the panels of slot 0 of the NEXT step (its K rows were staged 3 steps ago)
+        if (MODE != F3_PLAIN) { request(s + 1 < n_steps ? rowid_at(slot_of(s + 1, 0)) : -1, p0); since_p0 = 0; }
+        // ---- slot 1
+        {
+            f32x4 acc;
+            int row = -1;
+            if (s < my) row = fold(s, pw + kF3WP, acc);
+            float *srow = s_tiles + sl1 * kF3Ld + 4 * lane;
+            if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p1); arrived(p1); }
+            if (er1 >= 0 && !(a.dbg & 4)) epilogue(er1, *reinterpret_cast<const f32x4 *>(srow), p1);
+            if (row >= 0) *reinterpret_cast<f32x4 *>(srow) = acc;
+            s_rowid[sl1] = row;
+        }
+    }
+    rec_wait_vmcnt<0>();
+    if (MODE != F3_PLAIN) { arrived(p0); arrived(p1); }
+    if (kF3Timing && a.dbg_cycles && lane == 0) {
+        a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave)] = cyc_work;
+        a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave) + 1] = cyc_wait + (cyc_dma << 32);
+    }
+    if (MODE == F3_ERROR) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            err_sum += __shfl_down(err_sum, off, 64);
+            err_bad += __shfl_down(err_bad, off, 64);
+        }
+        if (lane == 0) {
+            e.partials[2 * (blockIdx.x * kF3WP + pw)] = err_sum;
+            e.partials[2 * (blockIdx.x * kF3WP + pw) + 1] = err_bad;
+        }
+    }
+}
+
+static int env_int_f3(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// the operator carries the 16-row plan; no halo panel in the hub sense (Xh is served), H = 256 is the caller's check
+int rhs_fused3_supported(const ndcn_csr *A) {
+    static const int enabled = env_int_f3("NDCN_RHS_FUSED3", 1);
+    if (!enabled || !A || !A->rec || A->rec_groups <= 0) return 0;
+    if (!(A->rec_rows == kF3R && A->rec_cap == kF3Cap && A->rec_kib == kF3RecW)) return 0;
+    return (A->n_cols * (int64_t)1024 < (1ll << 32) && A->n_rows * (int64_t)1024 < (1ll << 32)) ? 1 : 0;
+}
+
+int rhs_fused3_variant(int mode, int n_prev) {
+    if (mode == F3_PLAIN) return 1;
+    if (mode == F3_COMBINE) return n_prev >= 0 && n_prev <= kF3MaxPrev;
+    if (mode == F3_RK4) return n_prev >= 0 && n_prev <= 3;
+    return mode == F3_ERROR && n_prev == kF3MaxPrev;
+}
+
+template <bool HALO, int MODE, int NP>
+static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st) {
+    auto kern = rhs_fused3_kernel<HALO, MODE, NP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kF3Waves), kF3Lds, st, a, e);
+    return NDCN_OK;
+}
+
+// Wq: the split weights of pack_weight_256 (Wp + 256 * 256 floats); arguments as rhs_fused2_f32
+int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
+                   uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
+                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
+    if (A->n_rows == 0) return NDCN_OK;
+    if (!rhs_fused3_variant(mode, n_prev)) { set_error("rhs_fused3: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
+    F3Args a;
+    a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
+    a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
+    a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val;
+    static const int dbg = env_int_f3("NDCN_FUSED3_DBG", 0);
+    a.dbg = dbg;
+    static const int timing = kF3Timing ? env_int_f3("NDCN_FUSED3_TIMING", 0) : 0;
+    static unsigned long long *d_cyc = nullptr;
+    static int timing_prints = 0;
+    if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * kF3Waves * 2 * sizeof(unsigned long long));
+    a.dbg_cycles = timing ? d_cyc : nullptr;
+    F3Epi e = {};
+    e.y0 = y0; e.y_next = y_next; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
+    for (int m = 0; m < kF3MaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
+    for (int m = 0; m <= kF3MaxPrev; ++m) e.c[m] = (mode != F3_PLAIN && mode != F3_RK4 && m <= n_prev) ? h_c[m] : 0.f;
+    if (mode == F3_RK4) e.c[0] = h_c[0];
+    int per_xcd = kCus / kXcds;
+    const int need = (a.n_groups + kXcds - 1) / kXcds;
+    if (per_xcd > need) per_xcd = need;
+    const dim3 grid(per_xcd * kXcds);
+    const double P = 4.0 * 256 * (double)A->n_rows;
+    double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * 256 * (double)(A->n_rows + A->n_cols) + 4.0 * 256 * 256;
+    if (mode != F3_PLAIN) bytes += P * (n_prev + 2);
+    ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
+    int rc = NDCN_OK;
+#define NDCN_F3(HALO_, MODE_, NP_) rc = launch_f3<HALO_, MODE_, NP_>(a, e, grid, st)
+#define NDCN_F3_DISPATCH(HALO_)                                       \
+    do {                                                              \
+        if (mode == F3_PLAIN) NDCN_F3(HALO_, F3_PLAIN, 0);            \
+        else if (mode == F3_ERROR) NDCN_F3(HALO_, F3_ERROR, 5);       \
+        else if (mode == F3_RK4) switch (n_prev) {                    \
+            case 0: NDCN_F3(HALO_, F3_RK4, 0); break;                 \
+            case 1: NDCN_F3(HALO_, F3_RK4, 1); break;                 \
+            case 2: NDCN_F3(HALO_, F3_RK4, 2); break;                 \
+            default: NDCN_F3(HALO_, F3_RK4, 3); break;                \
+        }                                                             \
+        else switch (n_prev) {                                        \
+            case 0: NDCN_F3(HALO_, F3_COMBINE, 0); break;             \
+            case 1: NDCN_F3(HALO_, F3_COMBINE, 1); break;             \
+            case 2: NDCN_F3(HALO_, F3_COMBINE, 2); break;             \
+            case 3: NDCN_F3(HALO_, F3_COMBINE, 3); break;             \
+            case 4: NDCN_F3(HALO_, F3_COMBINE, 4); break;             \
+            default: NDCN_F3(HALO_, F3_COMBINE, 5); break;            \
+        }                                                             \
+    } while (0)
+    if (Xh) NDCN_F3_DISPATCH(true);
+    else NDCN_F3_DISPATCH(false);
+#undef NDCN_F3_DISPATCH
+#undef NDCN_F3
+    if (rc) return rc;
+    NDCN_LAUNCH_CHECK();
+    if (timing && timing_prints < timing) {                          // debugging aid: cycle accounting of workgroup 100
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[2 * kF3Waves];
+        (void)hipMemcpy(h, d_cyc + (size_t)100 * 2 * kF3Waves, sizeof(h), hipMemcpyDeviceToHost);
+        double pw = 0, pq = 0, pd = 0, mw = 0, mq = 0;
+        for (int w = 0; w < kF3WP; ++w) { pw += h[2 * w] / (double)kF3WP; pq += (h[2 * w + 1] & 0xffffffffull) / (double)kF3WP; pd += (h[2 * w + 1] >> 32) / (double)kF3WP; }
+        for (int w = kF3WP; w < kF3Waves; ++w) { mw += h[2 * w] / (double)kF3WM; mq += h[2 * w + 1] / (double)kF3WM; }
+        fprintf(stderr, "[fused3 timing] mode %d n_prev %d block 100: producer waves work %.0f dma-wait %.0f barrier %.0f | mfma waves work %.0f barrier %.0f\n",
+                mode, n_prev, pw, pd, pq, mw, mq);
+        ++timing_prints;
+    }
+    if (mode == F3_ERROR) return partials_finish(e.partials, (int)grid.x * kF3WP, d_out, st);
+    return NDCN_OK;
+}
+
+}  // namespace ndcn
