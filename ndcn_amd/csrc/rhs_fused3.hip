@@ -55,10 +55,17 @@ constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this 
 // The weight stream (12 KiB per row from L2), not HBM, bounds this kernel: with the refills switched off the dopri5 step
 // of the metric case takes 6.2 ms instead of 11.9.  Whatever registers the MFMA waves have left hold the first k-steps of
 // their weights for good.
+// A operands fetched from LDS one k-step ahead (8 registers)
+#ifndef NDCN_F3_AHEAD
+#define NDCN_F3_AHEAD 1
+#endif
 #ifndef NDCN_F3_RESIDENT
 #define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 5 : 1)
 #endif
-constexpr int kF3WP = 8, kF3WM = NDCN_F3_MFMA_WAVES, kF3Waves = kF3WP + kF3WM;    // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
+#ifndef NDCN_F3_PRODUCERS
+#define NDCN_F3_PRODUCERS 8
+#endif
+constexpr int kF3WP = NDCN_F3_PRODUCERS, kF3WM = NDCN_F3_MFMA_WAVES, kF3Waves = kF3WP + kF3WM;    // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
 constexpr int kF3NBuf = 2, kF3NRec = 3;                  // one group in flight ahead of the one being folded
 constexpr int kF3Tile = 32, kF3Ld = 260;                 // S tile: 2 groups; +4 floats per row: conflict-free b128
 constexpr int kF3MaxPrev = 5;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             const float *ap = src + (ln & 31) * kF3Ld + 8 * (ln >> 5) + 128 * HALF;
             // with one MFMA wave per SIMD the next block's A values leave LDS while this block's products run (8 registers);
             // with two per SIMD the other wave covers the LDS latency and the registers go to the weight ring instead
-            constexpr bool kAhead = kNT > 1;
+            constexpr bool kAhead = NDCN_F3_AHEAD;
             f32x4 n0, n1;
             if (kAhead) { n0 = *reinterpret_cast<const f32x4 *>(ap); n1 = *reinterpret_cast<const f32x4 *>(ap + 4); }
 #pragma unroll
@@ -312,16 +319,21 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     // ---------------------------------------------------------------------------------------------- producer waves
     // (LDS-DMA requests, fold, RK epilogue).  One vector-memory counter serves three kinds of requests that complete in
     // issue order: the DMA of the NEXT group (must have landed at the top of the next step), the row-local panels of slot
-    // 0 / slot 1 (consumed half a step after their request) and the epilogue's stores.  since_dma / since_p0 / since_p1
+    // of each slot (consumed a step after their request) and the epilogue's stores.  since_dma / since_p[q]
     // count what was issued AFTER the respective request: exactly that many operations may still be outstanding when
     // its data is used.
     const int pw = wave;
     constexpr int kLoads = MODE == F3_PLAIN ? 0 : NP + 1 + (MODE == F3_ERROR ? 1 : 0);
     struct Panels { f32x4 km[NP > 0 ? NP : 1]; f32x4 y0v, y1v; };
     double err_sum = 0.0, err_bad = 0.0;
-    int since_dma = 0, since_p0 = 0, since_p1 = 0;
-    auto issued = [&](int n) { since_dma += n; since_p0 += n; since_p1 += n; };
-    if (lane < 2 * kF3Tile / kF3WP) s_rowid[pw * (2 * kF3Tile / kF3WP) + lane] = -1;     // 64 slots, 8 per wave
+    constexpr int kRPW = kF3R / kF3WP;                            // rows (slots) per producer wave and step
+    int since_dma = 0, since_p[kRPW] = {};
+    auto issued = [&](int n) {
+        since_dma += n;
+#pragma unroll
+        for (int q = 0; q < kRPW; ++q) since_p[q] += n;
+    };
+    if (lane < 2 * kF3Tile / kF3WP) s_rowid[pw * (2 * kF3Tile / kF3WP) + lane] = -1;     // 64 slots
     if (pw == 0 && lane == 0) *s_sync = 0u;
     if (pw < 4) s_bias[64 * pw + lane] = a.bias ? a.bias[64 * pw + lane] : 0.f;
 
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             int es = 0;
             float ev = 0.f;
             if (lane < cnt) { es = r[kF3E0 + 2 * (ofs + lane)]; ev = __builtin_bit_cast(float, r[kF3E0 + 2 * (ofs + lane) + 1]); }
-            rec_row<true>(es, ev, cnt, [&](int slot) { return xb[slot * 64 + lane]; }, acc);
+            rec_row<(kF3WP == 8 || kLoads < 5)>(es, ev, cnt, [&](int slot) { return xb[slot * 64 + lane]; }, acc);
         } else {
             // group not staged: gather this row from the CSR arrays, 64 entries at a time (rare; full waits: every
             // request of this wave, the panels in flight included, has landed afterwards)
@@ -458,8 +470,13 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     f3_barrier();                                                   // [P] the first records are readable
     dma_x(0);
     since_dma = 0;
-    Panels p0, p1;
-    if (MODE != F3_PLAIN) { request(-1, p0); since_p0 = 0; }       // (uniform bookkeeping: slot 0 of step 0 has no K row yet)
+    // One panel set per slot; the panels of slot q of step s + 1 are requested right after slot q of step s is done with
+    // them - a whole step ahead.
+    Panels pan[kRPW];
+    if (MODE != F3_PLAIN) {
+#pragma unroll
+        for (int q = 0; q < kRPW; ++q) { request(-1, pan[q]); since_p[q] = 0; }     // (uniform bookkeeping: no K rows yet)
+    }
     unsigned long long cyc_work = 0, cyc_wait = 0, cyc_dma = 0, c_prev = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
     for (int s = 0; s < n_steps; ++s) {
         const unsigned long long ca = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
@@ -470,36 +487,27 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         dma_rec(s + 2);
         if (s + 1 < my) dma_x(s + 1);
         since_dma = 0;
-        const int sl0 = slot_of(s, 0), sl1 = slot_of(s, 1);
-        const int er0 = rowid_at(sl0), er1 = rowid_at(sl1);         // K rows waiting in the two slots (-1: none)
-        if (MODE != F3_PLAIN) { request(er1, p1); since_p1 = 0; }
-        // ---- slot 0
-        {
+#pragma unroll
+        for (int q = 0; q < kRPW; ++q) {
+            const int sl = slot_of(s, q);
+            const int er = rowid_at(sl);                            // the K row waiting in the slot (-1: none)
             f32x4 acc;
             int row = -1;
-            if (s < my) row = fold(s, pw, acc);
-            float *srow = s_tiles + sl0 * kF3Ld + 4 * lane;
-            if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p0); arrived(p0); }
-            if (er0 >= 0 && !(a.dbg & 4)) epilogue(er0, *reinterpret_cast<const f32x4 *>(srow), p0);
+            if (s < my) row = fold(s, pw + kF3WP * q, acc);
+            float *srow = s_tiles + sl * kF3Ld + 4 * lane;
+            if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p[q]); arrived(pan[q]); }
+            if (er >= 0 && !(a.dbg & 4)) epilogue(er, *reinterpret_cast<const f32x4 *>(srow), pan[q]);
             if (row >= 0) *reinterpret_cast<f32x4 *>(srow) = acc;
-            s_rowid[sl0] = row;
-        }
-        // the panels of slot 0 of the NEXT step (its K rows were staged 3 steps ago)
-        if (MODE != F3_PLAIN) { request(s + 1 < n_steps ? rowid_at(slot_of(s + 1, 0)) : -1, p0); since_p0 = 0; }
-        // ---- slot 1
-        {
-            f32x4 acc;
-            int row = -1;
-            if (s < my) row = fold(s, pw + kF3WP, acc);
-            float *srow = s_tiles + sl1 * kF3Ld + 4 * lane;
-            if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p1); arrived(p1); }
-            if (er1 >= 0 && !(a.dbg & 4)) epilogue(er1, *reinterpret_cast<const f32x4 *>(srow), p1);
-            if (row >= 0) *reinterpret_cast<f32x4 *>(srow) = acc;
-            s_rowid[sl1] = row;
+            s_rowid[sl] = row;
+            // the panels of this slot in the NEXT step (its K rows were staged 3 steps ago)
+            if (MODE != F3_PLAIN) { request(s + 1 < n_steps ? rowid_at(slot_of(s + 1, q)) : -1, pan[q]); since_p[q] = 0; }
         }
     }
     rec_wait_vmcnt<0>();
-    if (MODE != F3_PLAIN) { arrived(p0); arrived(p1); }
+    if (MODE != F3_PLAIN) {
+#pragma unroll
+        for (int q = 0; q < kRPW; ++q) arrived(pan[q]);
+    }
     if (kF3Timing && a.dbg_cycles && lane == 0) {
         a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave)] = cyc_work;
         a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave) + 1] = cyc_wait + (cyc_dma << 32);
