@@ -8,6 +8,7 @@ logic is written against (ndcn_amd/torchdiffeq/_impl/core.py).  Tests drive that
 an oracle-backed double to check the control flow without a GPU; product code never does.
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -30,6 +31,13 @@ def _terms(ks, cs):
     arr_k = (_P * n)(*[k.data_ptr() for k in ks])
     arr_c = (_F * n)(*[float(c) for c in cs])
     return arr_k, arr_c, n
+
+
+# The reductions below share per-device scratch (partials, the result record, its pinned host mirror).  Under autograd
+# they are reached from TWO threads at once - the engine runs the backward of nodes whose gradient lives on the GPU on its
+# device thread and the nodes of the solver's CPU scalar chain (error ratio, norms) on the calling thread - so launch +
+# read-back of one reduction is one critical section.
+_REDUCE_LOCK = threading.RLock()
 
 
 class _Reducer:
@@ -240,7 +248,7 @@ class HipOps:
         rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR, 'rk4': _lib.RK_RK4}[mode]
         y_next = (out_y if out_y is not None else torch.empty_like(K)) if mode in ('combine', 'rk4') else None
         red = _Reducer.get(X.device)
-        with torch.cuda.device(X.device):
+        with _REDUCE_LOCK, torch.cuda.device(X.device):
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                       ptr(None if no_control else b), ptr(K), ptr(work), H, flags, rk, ptr(y0), arr_k,
                                       arr_c, len(kprev), ptr(y_next), float(rtol), float(atol), ptr(red.out), ptr(red.ws),
@@ -277,7 +285,7 @@ class HipOps:
         ks = [_panel(k) for k in ks]
         red = _Reducer.get(y0.device)
         arr_k, arr_c, n = _terms(ks, cs)
-        with torch.cuda.device(y0.device):
+        with _REDUCE_LOCK, torch.cuda.device(y0.device):
             check(_lib.load().ndcn_rk_error_f32(ptr(y0), ptr(y1), arr_k, arr_c, n, float(rtol), float(atol), y0.numel(),
                                                 ptr(red.out), ptr(red.ws), stream_ptr()))
             return red.fetch()
@@ -288,7 +296,7 @@ class HipOps:
         a, y = _panel(a), _panel(y)
         b = _panel(b) if b is not None else None
         red = _Reducer.get(a.device)
-        with torch.cuda.device(a.device):
+        with _REDUCE_LOCK, torch.cuda.device(a.device):
             check(_lib.load().ndcn_scaled_sumsq_f32(ptr(a), ptr(b), ptr(y), float(rtol), float(atol), a.numel(),
                                                     ptr(red.out), ptr(red.ws), stream_ptr()))
             return red.fetch()
@@ -302,7 +310,7 @@ class HipOps:
         arr_k, arr_c, n = _terms(ks, cs)
         gk, arr_g = _grad_ptrs(g, need_k)
         d = _BwdDots.get(g.device)
-        with torch.cuda.device(g.device):
+        with _REDUCE_LOCK, torch.cuda.device(g.device):
             check(_lib.load().ndcn_rk_combine_bwd_f32(ptr(g), arr_k, arr_c, n, arr_g, ptr(d.out), ptr(d.ws), g.numel(),
                                                       stream_ptr()))
             return gk, (d.fetch()[:n] if need_dots else None)
@@ -318,7 +326,7 @@ class HipOps:
         gy0 = torch.empty_like(y0) if need_y0 else None
         gy1 = torch.empty_like(y0) if need_y1 else None
         d = _BwdDots.get(y0.device)
-        with torch.cuda.device(y0.device):
+        with _REDUCE_LOCK, torch.cuda.device(y0.device):
             check(_lib.load().ndcn_rk_error_bwd_f32(ptr(y0), ptr(y1), arr_k, arr_c, n, float(rtol), float(atol), float(g_r),
                                                     1.0 / y0.numel(), ptr(gy0), ptr(gy1), arr_g, ptr(d.out), ptr(d.ws),
                                                     y0.numel(), stream_ptr()))
@@ -348,7 +356,7 @@ class HipOps:
         gy0 = torch.empty_like(g) if need_y0 else None
         gy1 = torch.empty_like(g) if need_y1 else None
         d = _BwdDots.get(g.device)
-        with torch.cuda.device(g.device):
+        with _REDUCE_LOCK, torch.cuda.device(g.device):
             check(_lib.load().ndcn_dopri5_interp_bwd_f32(ptr(g), ptr(y0), ptr(y1), arr_k, float(dt), float(x), ptr(gy0),
                                                          ptr(gy1), arr_g, ptr(d.out), ptr(d.ws), g.numel(), stream_ptr()))
             dots = d.fetch() if need_dots else (0.0, 0.0)

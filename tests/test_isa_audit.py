@@ -24,3 +24,19 @@ def test_group_record_kernels_never_touch_panels_in_flight(tmp_path):
     text = open(asm).read()
     assert '.vgpr_spill_count: 0' in text and 'vgpr_spill_count:' in text
     assert all(l.strip().endswith(' 0') for l in text.split('\n') if '.vgpr_spill_count:' in l)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_fused3_producers_never_touch_panels_in_flight(tmp_path):
+    """rhs_fused3.hip: the producer waves' row-local panels are requested a step ahead from inline asm and awaited by a
+    run-time vmcnt count; no spill anywhere (a reload would queue behind the producers' requests)."""
+    asm = str(tmp_path / 'rhs_fused3.s')
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-o', asm,
+                    os.path.join(ROOT, 'ndcn_amd', 'csrc', 'rhs_fused3.hip')], check=True, stderr=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'audit_async_regs.py'), asm, 'rhs_fused3_kernel'],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and 'TOTAL problems 0' in out.stdout, out.stdout[-2000:]
+    assert out.stdout.count('asm loads') == 24            # halo x {plain, combine 0-5, error, rk4 0-3}
+    text = open(asm).read()
+    spills = [l for l in text.split('\n') if '.vgpr_spill_count:' in l]
+    assert spills and all(l.strip().endswith(' 0') for l in spills)
