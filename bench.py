@@ -74,7 +74,7 @@ def parse():
     p.add_argument('--cpu-side', type=int, default=256, help='grid side of the bounded CPU-baseline sample')
     p.add_argument('--no-profile-pass', action='store_true')
     p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (needs torchrun, works with 1 rank)')
-    p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C5'], help='workload (default M = the metric\'s own case)')
+    p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')
     p.add_argument('--cpu-runs', type=int, default=3, help='timed solves of the CPU-baseline leg (after one warm-up)')
     return p.parse_args()
@@ -168,6 +168,9 @@ def cpu_baseline(side, H, T, rtol, atol, threads, runs=3):
                                                 ', '.join('%.2f' % v for v in times))}
 
 
+C4_NODES_PER_GPU = int(os.environ.get('NDCN_C4_NODES', '500000'))    # BASELINE config 4: a 4M-node small world over 8 GPUs (override: tests)
+
+
 def build_workload(args, dev):
     """(ODEFunc, x0, runner kwargs, description) of a single-GPU configuration (BASELINE.json configs; SURVEY 8d inputs)."""
     from ndcn_amd import graphs, CsrOperator
@@ -201,6 +204,17 @@ def build_workload(args, dev):
         what = ('C3: NDCN ODEFunc relu(W(AX)+b), Barabasi-Albert n=1000000 m=5 (max degree %d), layout %s, normalised-Laplacian '
                 'CSR nnz=%d, H=%d, dopri5 rtol=%g atol=%g t in [0,%g]'
                 % (int(np.diff(L.indptr).max()), args.layout, L.nnz, H, args.rtol, args.atol, args.T))
+        step = 'one attempted dopri5 step (6 RHS evals + stage algebra + error norm + controller)'
+    elif args.config == 'C4':
+        n = C4_NODES_PER_GPU
+        G = graphs.make_graph('small_world', n, seed=0, layout=args.layout)
+        L = graphs.normalized_laplacian(G)
+        A = graphs.to_device(L, dev)
+        f = ODEFunc(H, A).to(dev).eval()
+        kw = dict(T=args.T, rtol=args.rtol, atol=args.atol, method='dopri5')
+        what = ('C4 (one GPU\'s share of the 8-GPU configuration): NDCN ODEFunc relu(W(AX)+b), Newman-Watts-Strogatz small world '
+                'n=%d k=5 p=0.5 (gene_dynamics.py:103), layout %s, normalised-Laplacian CSR nnz=%d, H=%d, dopri5 rtol=%g atol=%g '
+                't in [0,%g]' % (n, args.layout, L.nnz, H, args.rtol, args.atol, args.T))
         step = 'one attempted dopri5 step (6 RHS evals + stage algebra + error norm + controller)'
     else:
         g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'operators_pubmed.npz')))
@@ -272,16 +286,32 @@ def main():
                          'plan': None if A_op.rec is None else 'group-record %d rows / %d columns' % (A_op.rec['rows'], A_op.rec['cap'])}
             del Y
     else:
-        assert args.config == 'M', 'the sharded path runs the metric\'s grid'
+        assert args.config in ('M', 'C4'), 'the sharded path runs the metric\'s grid or config 4\'s small world'
         torch.manual_seed(0)
         f = ODEFunc(H, None).to(dev).eval()                      # nn.Linear default init, seed 0
-        n_local = S * S
-        from ndcn_amd.sharding import ShardedGridBench
-        runner = ShardedGridBench(f, S, world, rank, dev, args.T, args.rtol, args.atol)
-        nnz = runner.local_nnz
-        what = ('NDCN ODEFunc relu(W(AX)+b), %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR nnz=%d '
-                'per GPU, H=%d, dopri5 rtol=%g atol=%g t in [0,%g], state X~U(0,1) seed = rank, nn.Linear default init seed 0'
-                % (S, S, n_local * world, nnz, H, args.rtol, args.atol, args.T))
+        if args.config == 'M':
+            n_local = S * S
+            from ndcn_amd.sharding import ShardedGridBench
+            runner = ShardedGridBench(f, S, world, rank, dev, args.T, args.rtol, args.atol)
+            nnz = runner.local_nnz
+            what = ('NDCN ODEFunc relu(W(AX)+b), %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR nnz=%d '
+                    'per GPU, H=%d, dopri5 rtol=%g atol=%g t in [0,%g], state X~U(0,1) seed = rank, nn.Linear default init seed 0'
+                    % (S, S, n_local * world, nnz, H, args.rtol, args.atol, args.T))
+        else:
+            # weak scaling of config 4: a (500k x world)-node small world, node-range sharded; every rank generates the
+            # same graph (O(n) generator, seed 0) and keeps its own rows of the normalised Laplacian
+            from ndcn_amd.sharding import ShardedBench, even_bounds
+            n_glob = C4_NODES_PER_GPU * world
+            L = graphs.normalized_laplacian(graphs.make_graph('small_world', n_glob, seed=0)).tocsr()
+            bounds = even_bounds(n_glob, world)
+            n_local = int(bounds[rank + 1] - bounds[rank])
+            runner = ShardedBench(f, L[bounds[rank]:bounds[rank + 1]], bounds, rank, dev, args.T, args.rtol, args.atol)
+            del L
+            nnz = runner.local_nnz
+            what = ('C4: NDCN ODEFunc relu(W(AX)+b), Newman-Watts-Strogatz small world k=5 p=0.5, %d nodes per GPU (N=%d nodes '
+                    'total), node-range sharded, halo rows by all-to-all-v per RHS (%d halo rows on this rank), normalised-Laplacian '
+                    'CSR nnz=%d on rank 0, H=%d, dopri5 rtol=%g atol=%g t in [0,%g], state X~U(0,1) seed = rank, nn.Linear default '
+                    'init seed 0' % (n_local, n_glob, runner.plan.n_halo, nnz, H, args.rtol, args.atol, args.T))
         step_desc = 'one attempted dopri5 step (6 RHS evals + stage algebra + error norm + controller)'
 
     def barrier():

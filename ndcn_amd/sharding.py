@@ -302,23 +302,21 @@ def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, ato
     return torch.stack([s[0] for s in sol])
 
 
-class ShardedGridBench:
-    """bench.py's N > 1 workload: the (S*world) x S grid, rank r owns lattice rows [r*S, (r+1)*S)."""
+class ShardedBench:
+    """bench.py's N > 1 workload on ANY row-sharded operator: rank r owns rows [bounds[r], bounds[r+1]) of the global
+    operator and is handed only that row block (global column indices)."""
 
-    def __init__(self, odefunc, S, world, rank, device, T, rtol, atol, ops=None, group=None):
-        from . import graphs
+    def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, ops=None, group=None):
         from .torchdiffeq._impl import core
         if ops is None:
             from .ops import hip as ops
-        R = S * world
-        block = graphs.grid_operator_row_block(R, S, rank * S, (rank + 1) * S, 'norm_lap')
-        bounds = [r * S * S for r in range(world + 1)]
         import os
+        n_local = int(bounds[rank + 1] - bounds[rank])
         self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=int(os.environ.get('NDCN_SELF_HALO', '0')))
         self.local_nnz = self.plan.local_nnz
         self.func = ShardedODEFunc(odefunc, self.plan, ops)
-        self.dops = DistOps(ops, R * S, S * S, group)
-        self.x0 = torch.rand(S * S, odefunc.hidden_size, generator=torch.Generator().manual_seed(rank)).to(device)
+        self.dops = DistOps(ops, int(bounds[-1]), n_local, group)
+        self.x0 = torch.rand(n_local, odefunc.hidden_size, generator=torch.Generator().manual_seed(rank)).to(device)
         self.T, self.rtol, self.atol = T, rtol, atol
         self.core = core
         self._begin()
@@ -342,3 +340,14 @@ class ShardedGridBench:
 
     def nfe(self):
         return getattr(self, '_nfe_base', 0) + self.solver.nfe
+
+
+class ShardedGridBench(ShardedBench):
+    """the metric's grid, weak scaling: the (S*world) x S grid, rank r owns lattice rows [r*S, (r+1)*S) and builds only
+    its own rows (graphs.grid_operator_row_block)."""
+
+    def __init__(self, odefunc, S, world, rank, device, T, rtol, atol, ops=None, group=None):
+        from . import graphs
+        block = graphs.grid_operator_row_block(S * world, S, rank * S, (rank + 1) * S, 'norm_lap')
+        bounds = [r * S * S for r in range(world + 1)]
+        super().__init__(odefunc, block, bounds, rank, device, T, rtol, atol, ops, group)

@@ -449,16 +449,18 @@ def test_two_rank_sharded_hip_path_equals_device_solver(dev, case):
             assert np.abs(got - ref).max() < 2e-5, method
 
 
-def test_bench_two_ranks_on_one_device(dev):
+@pytest.mark.parametrize('config', ['M', 'C4'])
+def test_bench_two_ranks_on_one_device(dev, config):
     """bench.py's N > 1 flow end to end (torchrun, sharded runner, barriers, max over ranks, one JSON line from rank 0)
-    with two ranks on the one device of the test box (gloo hook); the driver runs it with nccl on 2/4/8 GPUs."""
+    with two ranks on the one device of the test box (gloo hook); the driver runs it with nccl on 2/4/8 GPUs.  M: the
+    metric's grid (each rank builds its own lattice rows); C4: the small world of BASELINE config 4 (scattered halo)."""
     import json
     import subprocess
     import sys
-    env = dict(os.environ, NDCN_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, NDCN_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', NDCN_C4_NODES='6000')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(29700 + os.getpid() % 200), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--side', '96',
-           '--steps', '6', '--warmup', '2']
+           '--steps', '6', '--warmup', '2', '--config', config]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
@@ -620,6 +622,42 @@ def test_config_c3_full_size_properties(dev):
     out = hip.mutual_rhs(Aadj, x)
     want = 0.1 + 2.0 * (1 - 2.0 / 5) * (2.0 / 1 - 1) + (deg - 1) * (2.0 * 2.0 / (5 + 0.9 * 2.0 + 0.1 * 2.0))
     assert np.abs(out.cpu().numpy().reshape(-1) - want.astype(np.float32)).max() < 1e-3 * want.max()
+
+
+def test_config_c4_share_full_size_properties(dev):
+    """One GPU's share of BASELINE config 4 (500k-node Newman-Watts-Strogatz small world k = 5 p = 0.5, H = 256, dopri5;
+    the 8-GPU run shards a 4M-node graph of the same generator): sampled RHS rows against fp64, SpMM linearity, the
+    device-resident solver agrees with the generic path (same accept / reject decisions), and the truth dynamics of the
+    config (gene regulation, edge-wise kernel) run at this size."""
+    from ndcn_amd import graphs, hip
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    n, H = 500000, 256
+    G = graphs.make_graph('small_world', n, seed=0)
+    L = graphs.normalized_laplacian(G)
+    deg = np.diff(L.indptr)
+    assert 5.5 < L.nnz / n - 1 < 6.1 and deg.max() < 64
+    A = graphs.to_device(L, dev)
+    torch.manual_seed(0)
+    f = ODEFunc(H, A).to(dev).eval()
+    X = torch.rand(n, H, device=dev)
+    Z = torch.rand(n, H, device=dev)
+    assert float((hip.spmm(A, X + 2 * Z) - (hip.spmm(A, X) + 2 * hip.spmm(A, Z))).abs().max()) < 1e-4
+    del Z
+    _sampled_rhs_check(L, A, f, X, dev, np.r_[0:48, 250000:250048, n - 48:n])
+    t = torch.tensor([0., 0.5], device=dev)
+    with torch.no_grad():
+        la, lb = [], []
+        ya = ode.odeint(f, X, t, rtol=.01, atol=.001, method='dopri5', step_log=la)
+        yb = ode.odeint(lambda tt, y: f(tt, y), X, t, rtol=.01, atol=.001, method='dopri5', step_log=lb)
+    assert la[-1] == lb[-1] and [r[2] for r in la[:-1]] == [r[2] for r in lb[:-1]]
+    assert float((ya[-1] - yb[-1]).abs().max()) < 1e-4 * max(1.0, float(yb[-1].abs().max()))
+    del ya, yb, X
+    # truth RHS of the config on a constant state x = 2: -b x^f + sum_j A_ij x^h / (x^h + 1) with b = f = 1, h = 2
+    x = torch.full((n, 1), 2.0, device=dev)
+    out = hip.gene_rhs(graphs.to_device(G, dev), x)
+    want = -2.0 + (deg - 1) * (4.0 / 5.0)
+    assert np.abs(out.cpu().numpy().reshape(-1) - want.astype(np.float32)).max() < 1e-4 * np.abs(want).max()
 
 
 @pytest.mark.parametrize('kind', ['heat', 'gene', 'mutualistic'])
