@@ -196,6 +196,60 @@ def test_no_control_rhs_rk_epilogue_in_group_record_kernel(dev, shape):
             assert torch.equal(K, K_ref) and torch.equal(yn, want)
 
 
+@pytest.mark.parametrize('side', [41, 64])
+def test_fused3_equals_fused2(dev, side):
+    """The whole ODEFunc + RK epilogue on an operator with the 16-row group-record plan (rhs_fused3.hip: LDS-DMA staging,
+    32-row S tiles) against the same operator without a plan (rhs_fused2.hip: register gather, 64-row tiles): staged
+    groups in lattice-patch order and in row order, groups the record cannot hold (gathered directly inside the kernel),
+    a ragged last group, an odd number of groups per workgroup, a halo panel - same fold order, same k order, same
+    products: bit-equal K, y_next; error sums to fp64 rounding."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H = 256
+    n = side * side
+    grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    rnd = rand_csr(n, n, 9, seed=5, hubs=2)
+    mixed = sp.vstack([grid[:1000], rnd[1000:]]).tocsr()
+    g = torch.Generator().manual_seed(4)
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    for m, hinted in ((grid, True), (grid, False), (mixed, False)):
+        m.sort_indices()
+        P = _no_plan(CsrOperator.from_scipy(m, dev))
+        A = _no_plan(CsrOperator.from_scipy(m, dev))
+        if hinted:
+            A.group_order = torch.as_tensor(A.detect_stencil_order(), dtype=torch.int32).to(dev)
+        staged, _ = A.build_rec_plan(16, 40, 2)
+        assert A.view().rec_groups > 0 and (staged == 1.0 if hinted else staged < 1.0 or m is grid)
+        K_ref = hip.rhs(P, X, W, b)
+        assert torch.equal(hip.rhs(A, X, W, b), K_ref)
+        got = hip.rhs(A, X[:1200].contiguous(), W, b, X_halo=X[1200:].contiguous())
+        assert torch.equal(got, K_ref)
+        for npv in range(6):
+            K, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], cs[:npv] + [cs[5]])
+            K2, yn2 = hip.rhs_rk(P, X, W, b, 'combine', y0, ks[:npv], cs[:npv] + [cs[5]])
+            assert torch.equal(K, K_ref) and torch.equal(K2, K_ref) and torch.equal(yn, yn2)
+        for _ in range(3):                                          # repeated: a premature read of a panel is a race
+            K, (s1, b1) = hip.rhs_rk(A, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
+            _, (s2, b2) = hip.rhs_rk(P, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
+            assert torch.equal(K, K_ref) and abs(s1 - s2) <= 1e-9 * abs(s2) and b1 == b2 == 0.0
+        Xbad = X.clone()
+        Xbad[5, 7] = float('inf')
+        _, (_, bad) = hip.rhs_rk(A, Xbad, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
+        assert bad == 1.0
+        dt = np.float32(0.37)
+        for st in range(4):
+            K, yn = hip.rhs_rk(A, X, W, b, 'rk4', y0, ks[:st], [dt])
+            assert torch.equal(K, K_ref) and torch.equal(yn, hip.fixed_stage(2 + st, y0, *(ks[:st] + [K_ref]), dt=dt))
+    ref64 = np.maximum(orc.spmm_f64(grid.indptr, grid.indices, grid.data, X.cpu().numpy()) @ W.cpu().double().numpy().T
+                       + b.cpu().double().numpy(), 0)
+    A = CsrOperator.from_scipy(grid, dev)
+    A.ensure_plans(H)
+    assert A.rec is not None and np.abs(hip.rhs(A, X, W, b).cpu().numpy() - ref64).max() < 2e-5
+
+
 def test_gather_rows(dev):
     from ndcn_amd import hip
     X = torch.randn(1000, 20).to(dev)
