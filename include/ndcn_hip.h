@@ -87,7 +87,9 @@ typedef struct ndcn_csr {
      *   lt_*      : the operator with every hub row replaced by ONE entry (column n_cols + h, value 1): the
      *               fused kernel reads S_hub as its second ("halo") panel.
      * hub_S / hub_Sseg are scratch owned by the operator (one launch stream at a time).  Used by ndcn_rhs_f32 /
-     * ndcn_rhs_rk_f32 / the solver when H == hub_H and no halo panel is passed.                              */
+     * ndcn_rhs_rk_f32 / the solver when H == hub_H and either no halo panel is passed or hub_S lies directly behind
+     * the halo panel in ONE allocation (hub_S == X_halo + n_halo * H: the kernel's second panel is then
+     * [halo | hubs]; node-range shards of power-law graphs, ndcn_amd/sharding.py).                              */
     int32_t        hub_n, hub_nseg, hub_H;
     int64_t        hub_nnz, lt_nnz;
     const int32_t *hub_seg_rowptr;  /* [hub_nseg + 1] */
@@ -325,6 +327,14 @@ NDCN_API int64_t ndcn_solver_steplog(const ndcn_solver *s, double *h_rows, int64
 NDCN_API int ndcn_prof_enable(int on);
 NDCN_API int ndcn_prof_read(double *h_out, int n_kinds);
 NDCN_API int ndcn_prof_kinds(void);
+/* Which kernel family the LAST fused right-hand side of this thread was dispatched to (tests: the intended native path
+ * ran, not merely a correct one): bit 0 rhs_fused2, bit 1 rhs_fused3 (group-record plan), bit 2 long-row plan active,
+ * bit 3 a halo panel was passed; 0 before the first call.                                                          */
+#define NDCN_PATH_FUSED2 1
+#define NDCN_PATH_FUSED3 2
+#define NDCN_PATH_HUB    4
+#define NDCN_PATH_HALO   8
+NDCN_API int ndcn_debug_last_rhs_path(void);
 
 #ifdef __cplusplus
 }

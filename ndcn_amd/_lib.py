@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
 ABI_VERSION = 6
+PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
@@ -107,6 +108,7 @@ SIGNATURES = {
     'ndcn_prof_enable': (_I, [_I]),
     'ndcn_prof_read': (_I, [ctypes.POINTER(_D), _I]),
     'ndcn_prof_kinds': (_I, []),
+    'ndcn_debug_last_rhs_path': (_I, []),
 }
 
 _lib = None

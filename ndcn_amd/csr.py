@@ -298,8 +298,13 @@ class CsrOperator:
             'cmb_val': torch.ones(seg_len.size, dtype=torch.float32, device=dev),
             'lt_rowptr': t32(lt_rowptr), 'lt_colidx': torch.from_numpy(lt_ci).to(dev), 'lt_val': torch.from_numpy(lt_va).to(dev),
             'Sseg': torch.empty(seg_len.size, H, dtype=torch.float32, device=dev),
-            'S': torch.empty(hubs.size, H, dtype=torch.float32, device=dev),
         }
+        # The hubs' rows: scratch the fused kernel reads as (part of) its second panel.  For a shard with a halo panel
+        # (n_halo > 0: HaloPlan sets it before the plan is built) ONE buffer holds [halo rows | hub rows]: the exchange
+        # receives into its head, 'S' is its tail - the layout the C side accepts next to a halo panel (ndcn_hip.h).
+        n_halo = int(getattr(self, 'n_halo', 0))
+        self.hub['halo_S'] = torch.empty(n_halo + hubs.size, H, dtype=torch.float32, device=dev)
+        self.hub['S'] = self.hub['halo_S'][n_halo:]
         return int(hubs.size)
 
     def ensure_plans(self, H):

@@ -33,6 +33,7 @@ using namespace ndcn;
 extern "C" {
 
 int ndcn_abi_version(void) { return NDCN_ABI_VERSION; }
+int ndcn_debug_last_rhs_path(void) { return g_last_rhs_path; }
 const char *ndcn_last_error(void) { return g_err; }
 
 int ndcn_device_info(int64_t h_out[6]) {

@@ -73,7 +73,8 @@ int rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, f
                    float *gy, int64_t n, hipStream_t st);
 int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k, float dt, float x, float *gy0,
                      float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n, hipStream_t st);
-void prof_pause(bool on);     // no launch timing while a stream is being captured
+void prof_pause(bool on);
+extern thread_local int g_last_rhs_path;     // ndcn_debug_last_rhs_path     // no launch timing while a stream is being captured
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st);
 int64_t reduce_ws_bytes();

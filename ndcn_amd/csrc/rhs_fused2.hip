@@ -570,6 +570,8 @@ int partials_finish(const double *partials, int n, double *d_out, hipStream_t st
     return NDCN_OK;
 }
 
+thread_local int g_last_rhs_path = 0;
+
 static int env_int3(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
@@ -604,11 +606,16 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     // kernel runs on the "light" operator that reads them as its second panel (include/ndcn_hip.h, struct ndcn_csr).
     ndcn_csr light;
     const ndcn_csr *A_full = A;
-    if (A->hub_n > 0 && !Xh && A->hub_H == kH2 && A->hub_S && A->hub_Sseg) {
+    // With a halo panel the plan still applies when the caller laid the hubs' rows out right BEHIND the halo rows (one
+    // allocation: [halo | hub_S], what ndcn_amd/csr.py + sharding.py do for node-range shards of power-law graphs): the
+    // kernel's second panel is then [halo | hubs], and the light operator's hub columns n_cols + h index into it as they are.
+    const int64_t n_halo = Xh ? A->n_cols - n_own : 0;
+    const bool hub_behind_halo = Xh && A->hub_S == Xh + n_halo * (int64_t)kH2;
+    if (A->hub_n > 0 && (!Xh || hub_behind_halo) && A->hub_H == kH2 && A->hub_S && A->hub_Sseg) {
         ndcn_csr seg = {};
         seg.n_rows = A->hub_nseg; seg.n_cols = A->n_cols; seg.nnz = A->hub_nnz;
         seg.rowptr = A->hub_seg_rowptr; seg.colidx = A->hub_colidx; seg.val = A->hub_val;
-        int rc = spmm_f32(&seg, X, nullptr, A->n_cols, A->hub_Sseg, kH2, 1.f, 0, st);
+        int rc = spmm_f32(&seg, X, Xh, Xh ? n_own : A->n_cols, A->hub_Sseg, kH2, 1.f, 0, st);
         if (rc) return rc;
         ndcn_csr cmb = {};
         cmb.n_rows = A->hub_n; cmb.n_cols = A->hub_nseg; cmb.nnz = A->hub_nseg;
@@ -618,14 +625,20 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         light = ndcn_csr{};
         light.n_rows = A->n_rows; light.n_cols = A->n_cols + A->hub_n; light.nnz = A->lt_nnz;
         light.rowptr = A->lt_rowptr; light.colidx = A->lt_colidx; light.val = A->lt_val;
-        n_own = A->n_cols;
-        Xh = A->hub_S;
+        if (!Xh) {
+            n_own = A->n_cols;
+            Xh = A->hub_S;
+        }
         A = &light;
     }
+    const int path_bits = (A == &light ? NDCN_PATH_HUB : 0) | (Xh && A_full->n_cols > n_own ? NDCN_PATH_HALO : 0);
     // operators with the 16-row group-record plan (lattices): neighbour rows staged once per 4 x 4 patch (rhs_fused3.hip)
-    if (NDCN_SPLIT && rhs_fused3_supported(A) && rhs_fused3_variant(mode, n_prev))
+    if (NDCN_SPLIT && rhs_fused3_supported(A) && rhs_fused3_variant(mode, n_prev)) {
+        g_last_rhs_path = NDCN_PATH_FUSED3 | path_bits;
         return rhs_fused3_f32(A, X, Xh, n_own, Wp + kH2 * kH2, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out,
                               d_ws, st);
+    }
+    g_last_rhs_path = NDCN_PATH_FUSED2 | path_bits;
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;
     const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;

@@ -53,6 +53,7 @@ class HaloPlan:
                               shape=(self.n_own, self.n_own + self.n_halo))
         local.sort_indices()
         self.local_op = CsrOperator.from_scipy(local, device)
+        self.local_op.n_halo = self.n_halo                               # the long-row plan lays its scratch out behind the halo rows
         self.local_nnz = int(local.nnz)
         # Row ranges for overlapping the exchange with compute: rows that reference no halo column ("interior") can be
         # evaluated while the halo is in flight.  With node-range sharding of a graph in a locality-preserving order they
@@ -110,7 +111,13 @@ class HaloPlan:
     def exchange(self, ops, X):
         """Returns the halo panel (n_halo x H) for the local panel X."""
         H = X.shape[1]
-        halo = torch.empty((self.n_halo, H), dtype=X.dtype, device=X.device)
+        hub = getattr(self.local_op, 'hub', None)
+        if hub is not None and hub['H'] == H and hub['halo_S'].shape[0] == self.n_halo + hub['n'] and X.is_cuda:
+            # long-row plan on this shard: the halo rows land in the head of the plan's [halo | hub rows] buffer (the
+            # next exchange cannot start before every launch that reads it has produced its part of the next panel)
+            halo = hub['halo_S'][:self.n_halo]
+        else:
+            halo = torch.empty((self.n_halo, H), dtype=X.dtype, device=X.device)
         if self.n_halo == 0 and sum(self.send_counts) == 0:
             return halo
         packed = ops.gather_rows(X, self.send_idx) if self.send_idx.numel() else X[:0]

@@ -223,9 +223,13 @@ def test_fused3_equals_fused2(dev, side):
             A.group_order = torch.as_tensor(A.detect_stencil_order(), dtype=torch.int32).to(dev)
         staged, _ = A.build_rec_plan(16, 40, 2)
         assert A.view().rec_groups > 0 and (staged == 1.0 if hinted else staged < 1.0 or m is grid)
+        from ndcn_amd import _lib
         K_ref = hip.rhs(P, X, W, b)
+        assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED2
         assert torch.equal(hip.rhs(A, X, W, b), K_ref)
+        assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3
         got = hip.rhs(A, X[:1200].contiguous(), W, b, X_halo=X[1200:].contiguous())
+        assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3 | _lib.PATH_HALO
         assert torch.equal(got, K_ref)
         for npv in range(6):
             K, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], cs[:npv] + [cs[5]])

@@ -383,6 +383,9 @@ def _two_rank_graph(case):
     if case == 'grid':
         R, C = 60, 40                                          # 2400 nodes, 30 lattice rows per rank
         return graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(R, C)), [0, 30 * C, R * C]
+    if case == 'power_law':                                    # hubs: the long-row plan next to the halo panel
+        full = graphs.normalized_laplacian(graphs.make_graph('power_law', 4000, seed=2))
+        return full, [0, 2000, 4000]
     full = graphs.normalized_laplacian(graphs.make_graph('small_world', 3000, seed=3))    # random shortcuts: wide halo
     return full, [0, 1500, 3000]
 
@@ -408,19 +411,27 @@ def _two_rank_worker(rank, world, port, case, ret):
         xl = x[bounds[rank]:bounds[rank + 1]].contiguous().to(dev)
         t = torch.linspace(0., 1.5, 4).to(dev)
         out = {'halo': plan.n_halo}
+        if case == 'power_law':
+            plan.local_op.ensure_plans(H)
+            hub = plan.local_op.hub
+            out['hubs'] = 0 if hub is None else hub['n']
+            # (Barabasi-Albert: the early nodes are the hubs - rank 0 owns them; rank 1's rows may have none)
+            assert hub is None or hub['halo_S'].shape[0] == plan.n_halo + hub['n']
         with torch.no_grad():
             for method in ('rk4', 'dopri5'):
                 log = []
                 y = sharding.sharded_odeint(hip, f, plan, n, xl, t, rtol=1e-3, atol=1e-4, method=method, step_log=log)
                 out[method] = y.cpu().numpy()
                 out[method + '_log'] = [r for r in log if r[0] != 'nfe']
+        from ndcn_amd import _lib
+        out['path'] = int(_lib.load().ndcn_debug_last_rhs_path())
         out['W'], out['b'] = f.wt.weight.detach().cpu().numpy(), f.wt.bias.detach().cpu().numpy()
         ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['grid', 'small_world'])
+@pytest.mark.parametrize('case', ['grid', 'small_world', 'power_law'])
 def test_two_rank_sharded_hip_path_equals_device_solver(dev, case):
     """The N > 1 product path with world size 2 ON THE GPU: two processes (both on cuda:0, gloo with host staging
     because RCCL refuses two ranks on one device) run HaloPlan + halo exchange + the HALO variants of the fused
@@ -430,10 +441,14 @@ def test_two_rank_sharded_hip_path_equals_device_solver(dev, case):
     from ndcn_amd import graphs, CsrOperator
     from ndcn_amd.neural_dynamics import ODEFunc
     from ndcn_amd.torchdiffeq import odeint
-    world, port = 2, 29900 + os.getpid() % 90 + (0 if case == 'grid' else 1)
+    world, port = 2, 29900 + os.getpid() % 90 + {'grid': 0, 'small_world': 1, 'power_law': 2}[case]
     ret = mp.Manager().dict()
     mp.spawn(_two_rank_worker, args=(world, port, case, ret), nprocs=world, join=True)
     assert len(ret) == world and ret[0]['halo'] > 0 and ret[1]['halo'] > 0
+    if case == 'power_law':                                    # the long-row plan was active on the shards, beside their halo panels
+        from ndcn_amd import _lib
+        assert ret[0]['hubs'] > 0
+        assert ret[0]['path'] == _lib.PATH_FUSED2 | _lib.PATH_HUB | _lib.PATH_HALO, ret[0]['path']
     H = 256
     full, _ = _two_rank_graph(case)
     f = ODEFunc(H, CsrOperator.from_scipy(full, dev)).to(dev)
