@@ -254,6 +254,41 @@ def test_fused3_equals_fused2(dev, side):
     assert A.rec is not None and np.abs(hip.rhs(A, X, W, b).cpu().numpy() - ref64).max() < 2e-5
 
 
+def test_group_record_kernels_beyond_two_million_rows(dev):
+    """Row offsets row << 10 pass 2^31 bytes at 2^21 rows: the group-record kernels address row-local panels as a 64-bit
+    base + a 32-bit per-lane byte offset that must be read as UNSIGNED.  1500 x 1500 lattice (2.25 M rows, 2.3 GB panels):
+    rhs_fused3 / spmm_rec against the plan-free kernels (buffer descriptors) on the whole panel, last rows against fp64."""
+    from ndcn_amd import hip, CsrOperator, graphs, _lib
+    side, H = 1500, 256
+    n = side * side
+    assert n > (1 << 21)
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    A = CsrOperator.from_scipy(L, dev)
+    A.ensure_plans(H)
+    assert A.rec is not None and A.rec['rows'] == 16
+    P = _no_plan(CsrOperator.from_scipy(L, dev))
+    g = torch.Generator().manual_seed(6)
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    X = torch.rand(n, H, device=dev)
+    y0 = torch.rand(n, H, device=dev)
+    k1 = torch.randn(n, H, device=dev)
+    cs = [np.float32(0.11), np.float32(0.19)]
+    assert torch.equal(hip.spmm(A, X), hip.spmm(P, X))
+    K, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, [k1], cs)
+    assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3
+    K2, yn2 = hip.rhs_rk(P, X, W, b, 'combine', y0, [k1], cs)
+    assert torch.equal(K, K2) and torch.equal(yn, yn2)
+    Kn, ynn = hip.rhs_rk(A, X, None, None, 'combine', y0, [k1], cs, no_control=True)          # spmm_rec epilogue
+    Kn2, ynn2 = hip.rhs_rk(P, X, None, None, 'combine', y0, [k1], cs, no_control=True)
+    assert torch.equal(Kn, Kn2) and torch.equal(ynn, ynn2)
+    rows = np.r_[n - 64:n]
+    sub = L[rows]
+    S = orc.spmm_f64(sub.indptr, sub.indices, sub.data, X.cpu().numpy())
+    ref = np.maximum(S @ W.cpu().double().numpy().T + b.cpu().double().numpy(), 0)
+    assert np.abs(K[n - 64:].cpu().double().numpy() - ref).max() < 2e-5
+
+
 def test_gather_rows(dev):
     from ndcn_amd import hip
     X = torch.randn(1000, 20).to(dev)
