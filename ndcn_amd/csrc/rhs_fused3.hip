@@ -55,12 +55,12 @@ constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this 
 // The weight stream (12 KiB per row from L2), not HBM, bounds this kernel: with the refills switched off the dopri5 step
 // of the metric case takes 6.2 ms instead of 11.9.  Whatever registers the MFMA waves have left hold the first k-steps of
 // their weights for good.
-// A operands fetched from LDS one k-step ahead (8 registers)
-#ifndef NDCN_F3_AHEAD
-#define NDCN_F3_AHEAD 1
+// the bf16 split of the next k-step interleaved with this k-step's products (experiment, see mfma_half)
+#ifndef NDCN_F3_PIPE
+#define NDCN_F3_PIPE 0
 #endif
 #ifndef NDCN_F3_RESIDENT
-#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 5 : 1)
+#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? (NDCN_F3_PIPE ? 4 : 5) : 1)
 #endif
 #ifndef NDCN_F3_PRODUCERS
 #define NDCN_F3_PRODUCERS 8
@@ -174,22 +174,21 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kRes + u, pl);
-        auto cvt_pk = [](float lo, float hi) {
-            unsigned r;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-            return r;
-        };
-        // 8 consecutive fp32 -> three bf16x8 pieces whose sum is the input, exactly
+        // 8 consecutive fp32 -> three bf16x8 pieces whose sum is the input, exactly (round to nearest even each time).
+        // Two elements per instruction: v_cvt_pk_bf16_f32, the two halves widened back (shift / mask), v_pk_add_f32.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         auto split8 = [&](f32x4 r0, f32x4 r1, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
-            const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const f32x2 x[4] = {{r0.x, r0.y}, {r0.z, r0.w}, {r1.x, r1.y}, {r1.z, r1.w}};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float va = x[2 * q], vb = x[2 * q + 1];
-                const unsigned h = cvt_pk(va, vb);
-                const float ra = va - __builtin_bit_cast(float, h << 16), rb = vb - __builtin_bit_cast(float, h & 0xffff0000u);
-                const unsigned m = cvt_pk(ra, rb);
-                const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
-                p1[q] = h; p2[q] = m; p3[q] = cvt_pk(sa, sb);
+                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x[q], bf16x2));
+                const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+                const f32x2 ra = x[q] - hf;
+                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2));
+                const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+                const f32x2 sa = ra - mf;
+                p1[q] = h; p2[q] = m; p3[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(sa, bf16x2));
             }
         };
         f32x16 acc[kNT];
@@ -202,35 +201,37 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const float *ap = src + (ln & 31) * kF3Ld + 8 * (ln >> 5) + 128 * HALF;
-            // with one MFMA wave per SIMD the next block's A values leave LDS while this block's products run (8 registers);
-            // with two per SIMD the other wave covers the LDS latency and the registers go to the weight ring instead
-            constexpr bool kAhead = NDCN_F3_AHEAD;
-            f32x4 n0, n1;
-            if (kAhead) { n0 = *reinterpret_cast<const f32x4 *>(ap); n1 = *reinterpret_cast<const f32x4 *>(ap + 4); }
+            auto mm = [&](f32x16 &c, u32x4 av, u32x4 bv) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+            };
+            // NDCN_F3_PIPE = 1 (measured, not the default): the split of k-step i + 1 interleaved with the products of
+            // k-step i (sched_group_barrier: one MFMA, then a slice of the split's 38 VALU instructions, six times) - the
+            // ISA comes out as intended, but with two MFMA waves per SIMD the other wave already fills those gaps:
+            // 11.36 -> 11.55 ms/step, and 0.66 -> 0.76 ms for the plain launch with the weight stream switched off.
+            constexpr bool kPipe = NDCN_F3_PIPE;
+            f32x4 r0 = *reinterpret_cast<const f32x4 *>(ap), r1 = *reinterpret_cast<const f32x4 *>(ap + 4);
+            u32x4 A0, A1, A2;
+            if (kPipe) split8(r0, r1, A0, A1, A2);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 constexpr int dummy = 0; (void)dummy;
                 const int ks = 8 * HALF + i;
                 const bool res = ks < kRes;
                 const int u = res ? 0 : (ks - kRes) % kRing;
-                f32x4 r0, r1;
-                if (kAhead) {
-                    r0 = n0; r1 = n1;
-                    if (i + 1 < 8) {
-                        n0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
-                        n1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
-                    }
-                } else {
-                    r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * i);
-                    r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * i + 4);
-                }
-                u32x4 A0, A1, A2;
-                split8(r0, r1, A0, A1, A2);
-                auto mm = [&](f32x16 &c, u32x4 av, u32x4 bv) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-                };
-                // small products first (the order of rhs_fused2.hip: identical rounding); the n-tiles alternate
                 auto bq = [&](int jj, int pl) -> const u32x4 & { return res ? Br[res ? ks : 0][jj][pl] : Bq[u][jj][pl]; };
+                u32x4 N0 = A0, N1 = A1, N2 = A2;
+                if (!kPipe) {
+                    split8(r0, r1, A0, A1, A2);
+                    if (i + 1 < 8) {                                // the next block's A values leave LDS while these products run
+                        r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
+                        r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
+                    }
+                } else if (i + 1 < 8) {
+                    r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
+                    r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
+                    split8(r0, r1, N0, N1, N2);
+                }
+                // small products first (the order of rhs_fused2.hip: identical rounding); the n-tiles alternate
 #pragma unroll
                 for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 2));
 #pragma unroll
@@ -243,6 +244,15 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
                 for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A1, bq(jj, 0));
 #pragma unroll
                 for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 0));
+                if (kPipe) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the two LDS reads of the next block first
+#pragma unroll
+                    for (int g = 0; g < 6 * kNT; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, (38 + 6 * kNT - 1) / (6 * kNT), 0);   // a slice of the split
+                    }
+                    A0 = N0; A1 = N1; A2 = N2;
+                }
                 __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot (hoisted, they need 12 more registers)
                 if (!res && !(a.dbg & 64)) {
                     // streamed k-step j = ks - kRes: its slot is refilled with j + kRing or, for the last kRing of a tile,
