@@ -43,6 +43,8 @@ extern "C" {
 #define NDCN_F_RELU        1u   /* apply relu to the result            (neural_dynamics.py:36)   */
 #define NDCN_F_NO_GRAPH    2u   /* skip A*x                            (neural_dynamics.py:27)   */
 #define NDCN_F_NO_CONTROL  4u   /* skip the Linear                     (neural_dynamics.py:32)   */
+#define NDCN_F_PACKED      8u   /* ndcn_rhs_f32 / ndcn_rhs_rk_f32, H = 256: `work` still holds the packed image of W that an
+                                 * earlier call on this stream (flag clear, same W contents) left there - skip the re-pack   */
 
 /* integrator methods (torchdiffeq/_impl/odeint.py:8-17, the in-scope subset) */
 #define NDCN_M_EULER    0

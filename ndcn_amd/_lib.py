@@ -17,7 +17,7 @@ PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
 
-F_RELU, F_NO_GRAPH, F_NO_CONTROL = 1, 2, 4
+F_RELU, F_NO_GRAPH, F_NO_CONTROL, F_PACKED = 1, 2, 4, 8
 RK_NONE, RK_COMBINE, RK_ERROR, RK_RK4 = 0, 1, 2, 3
 M_EULER, M_MIDPOINT, M_RK4, M_DOPRI5 = 0, 1, 2, 3
 METHODS = {'euler': M_EULER, 'midpoint': M_MIDPOINT, 'rk4': M_RK4, 'dopri5': M_DOPRI5}

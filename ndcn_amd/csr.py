@@ -202,12 +202,18 @@ class CsrOperator:
         patch share most of their neighbours: 36 distinct columns for 16 rows of the 8-neighbour grid instead of 54):
         an int32 array of px * py slots per patch, -1 where a patch sticks out of the lattice.  None otherwise.  O(nnz)."""
         n = self.shape[0]
-        if self.nnz == 0 or self.shape[0] != self.shape[1] or n < 64:
+        # A row block of a sharded lattice (ndcn_amd/sharding.py) says where it sits: lattice_hint = (row_base, n_own) -
+        # row r is node row_base + r of the shard, columns < n_own are the shard's own nodes (checked against the
+        # stencil), columns >= n_own are halo rows (any: they only join the groups' column lists).
+        row_base, n_own = getattr(self, 'lattice_hint', None) or (0, self.shape[1])
+        if self.nnz == 0 or n < 64 or (getattr(self, 'lattice_hint', None) is None and self.shape[0] != self.shape[1]):
             return None
         counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
-        rows = torch.repeat_interleave(torch.arange(n, device=self.device), counts)
-        off = torch.unique(self.colidx.to(torch.int64) - rows)
-        if off.numel() > 25:
+        rows = torch.repeat_interleave(torch.arange(n, device=self.device), counts) + row_base
+        cols = self.colidx.to(torch.int64)
+        own = cols < n_own
+        off = torch.unique((cols - rows)[own])
+        if off.numel() > 25 or off.numel() == 0:
             return None
         off = off.cpu().numpy()
         big = off[off > 2]
@@ -224,13 +230,14 @@ class CsrOperator:
         if S == 0:
             return None
         self.stencil_stride = S
-        # patches in row-major patch order, each padded to px * py slots (-1) so that groups never straddle patches
-        Rl = (n + S - 1) // S
-        PX, PY = (Rl + px - 1) // px, (S + py - 1) // py
-        x = (np.arange(PX)[:, None, None, None] * px + np.arange(px)[None, None, :, None])
+        # patches in row-major patch order, each padded to px * py slots (-1) so that groups never straddle patches;
+        # lattice coordinates are those of the shard (node = row_base + r), slots hold this operator's row indices
+        x_lo, x_hi = row_base // S, (row_base + n - 1) // S + 1
+        PX, PY = (x_hi - x_lo + px - 1) // px, (S + py - 1) // py
+        x = x_lo + (np.arange(PX)[:, None, None, None] * px + np.arange(px)[None, None, :, None])
         y = (np.arange(PY)[None, :, None, None] * py + np.arange(py)[None, None, None, :])
         node = x * S + y
-        node = np.where((x < Rl) & (y < S) & (node < n), node, -1)
+        node = np.where((x < x_hi) & (y < S) & (node >= row_base) & (node < row_base + n), node - row_base, -1)
         return node.reshape(-1).astype(np.int32)
 
     def lattice_tile_order(self, S, block_rows=32, n_chunks=8):
@@ -337,7 +344,7 @@ class CsrOperator:
             order = self.detect_stencil_order()
             if order is not None:
                 self.group_order = torch.as_tensor(order, dtype=torch.int32).to(self.device)
-                if os.environ.get('NDCN_TILE_ORDER', '1') != '0':
+                if os.environ.get('NDCN_TILE_ORDER', '1') != '0' and getattr(self, 'lattice_hint', None) is None:
                     self.tile_order = torch.as_tensor(self.lattice_tile_order(self.stencil_stride), dtype=torch.int32).to(self.device)
         avg = self.nnz / max(self.shape[0], 1)
         best = None

@@ -38,7 +38,7 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
                     set_error("rhs: panels must be 16-byte aligned");
                     return NDCN_EINVAL;
                 }
-                int rc = pack_weight_256(W, work, st);
+                int rc = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256(W, work, st);
                 if (rc) return rc;
                 return rhs_fused2_f32(A, X, Xh, n_own, work, b, Y, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f,
                                       0.f, nullptr, nullptr, st);
@@ -67,7 +67,7 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
     const bool both = !(flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
     if (both && rhs_fused2_supported(A, H, flags) && rhs_fused2_variant(rk_mode, n_prev)) {
         if (!work) { set_error("rhs_rk: scratch of ndcn_rhs_work_bytes() bytes required"); return NDCN_EINVAL; }
-        int rc = pack_weight_256(W, work, st);
+        int rc = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256(W, work, st);
         if (rc) return rc;
         return rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                               d_out, d_ws, st);

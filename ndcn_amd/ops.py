@@ -62,6 +62,25 @@ class _Reducer:
         return float(self.host[0]), float(self.host[1])
 
 
+class _PackedWeights:
+    """The fused H = 256 kernels read W in a packed, split form that ndcn_rhs_f32 / ndcn_rhs_rk_f32 build in their
+    scratch at every call (two small launches in front of the big one).  A solver calls them thousands of times with
+    the same weights: the scratch is kept per (weight storage, version, stream) and later calls pass NDCN_F_PACKED."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, W, nbytes):
+        key = (W.data_ptr(), W._version, W.device, torch.cuda.current_stream(W.device).cuda_stream, nbytes)
+        hit = cls._cache.get(key)
+        if hit is not None:
+            return hit, _lib.F_PACKED
+        if len(cls._cache) >= 8:
+            cls._cache.pop(next(iter(cls._cache)))
+        work = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+        cls._cache[key] = work
+        return work, 0
+
+
 class _BwdDots:
     """Per-device scratch of the solver VJP kernels: partial sums + the 8-double result + its pinned host mirror."""
     _by_device = {}
@@ -206,7 +225,11 @@ class HipOps:
         work = None
         wbytes = int(lib.ndcn_rhs_work_bytes(n_rows, H, flags))
         if wbytes:
-            work = torch.empty(wbytes, dtype=torch.uint8, device=X.device)
+            if H == 256 and not no_control and not no_graph and not torch.is_grad_enabled():
+                work, packed = _PackedWeights.get(W, wbytes)
+                flags |= packed
+            else:
+                work = torch.empty(wbytes, dtype=torch.uint8, device=X.device)
         with torch.cuda.device(X.device):
             check(lib.ndcn_rhs_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                    ptr(None if no_control else b), ptr(Y), ptr(work), H, flags, stream_ptr()))
@@ -242,7 +265,13 @@ class HipOps:
         K = out_K if out_K is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
         assert K.is_contiguous() and tuple(K.shape) == (n_rows, H)
         wbytes = int(lib.ndcn_rhs_work_bytes(n_rows, H, flags))
-        work = torch.empty(wbytes, dtype=torch.uint8, device=X.device) if wbytes else None
+        work = None
+        if wbytes:
+            if H == 256 and not no_control and not no_graph and not torch.is_grad_enabled():
+                work, packed = _PackedWeights.get(W, wbytes)
+                flags |= packed
+            else:
+                work = torch.empty(wbytes, dtype=torch.uint8, device=X.device)
         arr_k = (_P * max(len(kprev), 1))(*[k.data_ptr() for k in kprev])
         arr_c = (_F * len(cs))(*[float(c) for c in cs])
         rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR, 'rk4': _lib.RK_RK4}[mode]

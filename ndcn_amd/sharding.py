@@ -54,6 +54,7 @@ class HaloPlan:
         local.sort_indices()
         self.local_op = CsrOperator.from_scipy(local, device)
         self.local_op.n_halo = self.n_halo                               # the long-row plan lays its scratch out behind the halo rows
+        self.local_op.lattice_hint = (0, self.n_own)                     # columns >= n_own are halo rows
         self.local_nnz = int(local.nnz)
         # Row ranges for overlapping the exchange with compute: rows that reference no halo column ("interior") can be
         # evaluated while the halo is in flight.  With node-range sharding of a graph in a locality-preserving order they
@@ -90,7 +91,9 @@ class HaloPlan:
             sub = local[lo_:hi_]
             if not halo:
                 sub = sub[:, :n]                                    # interior rows reference own columns only
-            out.append((lo_, hi_, CsrOperator.from_scipy(sub, device), halo))
+            op = CsrOperator.from_scipy(sub, device)
+            op.lattice_hint = (lo_, n)                              # where the row block sits in the shard (csr.py: detect_stencil_order)
+            out.append((lo_, hi_, op, halo))
         return out
 
     def _exchange_requests(self, want, device):

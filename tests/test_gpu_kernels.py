@@ -663,3 +663,25 @@ def test_truth_rhs_kernels(dev):
         got = hip.gene_rhs(A, x.to(dev)).cpu()
         ref = orc.gene_rhs(Ac, x)
         assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_packed_weight_cache_follows_weight_updates(dev):
+    """ops keeps the packed (split-bf16) image of W between no-grad calls (NDCN_F_PACKED); an in-place update of W must
+    be seen by the next call."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H = 256
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(40))
+    A = CsrOperator.from_scipy(L, dev)
+    g = torch.Generator().manual_seed(8)
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = torch.zeros(H, device=dev)
+    X = torch.rand(1600, H, generator=g).to(dev)
+    with torch.no_grad():
+        k1 = hip.rhs(A, X, W, b)
+        assert torch.equal(hip.rhs(A, X, W, b), k1)                 # second call: cached image
+        W.mul_(-1.5)                                                 # in-place: version counter moves
+        k2 = hip.rhs(A, X, W, b)
+        ref = torch.relu(hip.spmm(A, X) @ W.t())
+        assert float((k2 - ref).abs().max()) < 1e-4 and not torch.equal(k1, k2)
+        K, _ = hip.rhs_rk(A, X, W, b, 'combine', X, [], [np.float32(0.5)])
+        assert torch.equal(K, k2)
