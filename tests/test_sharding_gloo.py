@@ -144,3 +144,67 @@ def test_single_rank_self_halo_drives_a_real_all_to_all():
     x = torch.rand(full.shape[0], 8, generator=torch.Generator().manual_seed(1))
     ref = orc.odeint(f, x, torch.linspace(0., 1., 3), rtol=1e-3, atol=1e-4, method='dopri5').numpy()
     assert np.abs(ret['y'] - ref).max() < 5e-6
+
+
+def _bench_runner_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ndcn_amd import graphs, sharding
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from _oracle_ops import OracleOps
+        H = 8
+        torch.manual_seed(0)
+        f = ODEFunc(H, None)
+        full = graphs.normalized_laplacian(graphs.make_graph('small_world', 120, seed=5)).tocsr()
+        bounds = sharding.even_bounds(120, world)
+        b = sharding.ShardedBench(f, full[bounds[rank]:bounds[rank + 1]], bounds, rank, torch.device('cpu'), 5.0, 1e-2, 1e-3,
+                                  ops=OracleOps)
+        with torch.no_grad():
+            done = b.run_steps(7)                                  # crosses a solve restart (t reaches T after a few steps)
+        ret[rank] = {'done': done, 'nfe': b.nfe(), 'log': list(b.solver.log), 'y': b.solver.y[0].detach().numpy(),
+                     'x0': b.x0.numpy(), 'W': f.wt.weight.detach().numpy(), 'b': f.wt.bias.detach().numpy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_runner_two_ranks_equals_single_process():
+    """bench.py's N > 1 runner on a general graph (sharding.ShardedBench: config C4's small world): two gloo ranks
+    attempt exactly K steps, restart the solve when it reaches T, and agree with each other and with the same stepping in
+    one process on the whole graph (state x0 = per-rank seeds, stitched)."""
+    from ndcn_amd import graphs
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq._impl import core
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from _oracle_ops import OracleOps
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_runner_worker, args=(world, 29620 + os.getpid() % 40, ret), nprocs=world, join=True)
+    assert ret[0]['done'] == ret[1]['done'] == 7 and ret[0]['nfe'] == ret[1]['nfe']
+    assert ret[0]['log'] == ret[1]['log']                          # identical controller decisions on both ranks
+    H = 8
+    from oracle import ndcn_oracle as orc
+    full = graphs.normalized_laplacian(graphs.make_graph('small_world', 120, seed=5)).tocsr()
+    A = orc.coo_from_csr(full.indptr, full.indices, full.data, full.shape)
+    W, bias = torch.from_numpy(ret[0]['W']), torch.from_numpy(ret[0]['b'])
+    f = lambda t, x: orc.odefunc_rhs(A, x, W, bias)
+    x0 = torch.from_numpy(np.concatenate([ret[0]['x0'], ret[1]['x0']], axis=0))
+    done, logs = 0, []
+    with torch.no_grad():
+        while done < 7:
+            s = core.Dopri5(OracleOps, lambda t, y: (f(t, y[0]),), (x0,), 1e-2, 1e-3, autonomous=True)
+            s.begin(0.0)
+            out = s.advance(5.0, step_budget=7 - done)
+            done += len(s.log)
+            logs = list(s.log)
+            if out is None:
+                break
+    assert len(logs) == len(ret[0]['log'])
+    assert np.allclose(np.array(logs)[:, :3], np.array(ret[0]['log'])[:, :3], rtol=1e-5)
+    got = np.concatenate([ret[0]['y'], ret[1]['y']], axis=0)
+    assert np.abs(got - s.y[0].numpy()).max() < 1e-5
