@@ -9,6 +9,7 @@ an oracle-backed double to check the control flow without a GPU; product code ne
 """
 import ctypes
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -65,19 +66,23 @@ class _Reducer:
 class _PackedWeights:
     """The fused H = 256 kernels read W in a packed, split form that ndcn_rhs_f32 / ndcn_rhs_rk_f32 build in their
     scratch at every call (two small launches in front of the big one).  A solver calls them thousands of times with
-    the same weights: the scratch is kept per (weight storage, version, stream) and later calls pass NDCN_F_PACKED."""
+    the same weights: the scratch is kept per weight TENSOR OBJECT (weak reference: a new tensor that happens to reuse the
+    address or the id of a dead one never hits), version counter (in-place updates - optimizers, load_state_dict - move
+    it) and stream; later calls pass NDCN_F_PACKED."""
     _cache = {}
 
     @classmethod
     def get(cls, W, nbytes):
-        key = (W.data_ptr(), W._version, W.device, torch.cuda.current_stream(W.device).cuda_stream, nbytes)
+        key = (id(W), torch.cuda.current_stream(W.device).cuda_stream, nbytes)
         hit = cls._cache.get(key)
-        if hit is not None:
-            return hit, _lib.F_PACKED
+        if hit is not None and hit[0]() is W and hit[1] == W._version and hit[2] == W.data_ptr():
+            return hit[3], _lib.F_PACKED
         if len(cls._cache) >= 8:
-            cls._cache.pop(next(iter(cls._cache)))
+            dead = [k for k, v in cls._cache.items() if v[0]() is None]
+            for k in dead or [next(iter(cls._cache))]:
+                cls._cache.pop(k)
         work = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
-        cls._cache[key] = work
+        cls._cache[key] = (weakref.ref(W), W._version, W.data_ptr(), work)
         return work, 0
 
 

@@ -685,3 +685,22 @@ def test_packed_weight_cache_follows_weight_updates(dev):
         assert float((k2 - ref).abs().max()) < 1e-4 and not torch.equal(k1, k2)
         K, _ = hip.rhs_rk(A, X, W, b, 'combine', X, [], [np.float32(0.5)])
         assert torch.equal(K, k2)
+
+
+def test_packed_weight_cache_is_not_fooled_by_address_reuse(dev):
+    """A NEW weight tensor that lands on the address of a freed one (same shape: the caching allocator hands the block
+    out again) must not hit the packed image of the old one."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H = 256
+    A = CsrOperator.from_scipy(graphs.normalized_laplacian(graphs.grid_8_neighbor(40)), dev)
+    X = torch.rand(1600, H, device=dev)
+    b = torch.zeros(H, device=dev)
+    seen = set()
+    with torch.no_grad():
+        for i in range(4):
+            W = ((torch.rand(H, H, generator=torch.Generator().manual_seed(i)) - 0.5) / 8).to(dev)
+            seen.add(W.data_ptr())
+            k = hip.rhs(A, X, W, b)
+            assert float((k - torch.relu(hip.spmm(A, X) @ W.t())).abs().max()) < 1e-4, i
+            del W
+    assert len(seen) < 4                                            # the allocator did reuse an address
