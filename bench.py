@@ -75,6 +75,7 @@ def parse():
     p.add_argument('--no-profile-pass', action='store_true')
     p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (needs torchrun, works with 1 rank)')
     p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
+    p.add_argument('--no-control', action='store_true', help='config M with ODEFunc(no_control=True): relu(A X), the pure HBM right-hand side (neural_dynamics.py:32)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')
     p.add_argument('--cpu-runs', type=int, default=3, help='timed solves of the CPU-baseline leg (after one warm-up)')
     return p.parse_args()
@@ -181,9 +182,9 @@ def build_workload(args, dev):
         S = args.side
         L = graphs.normalized_laplacian(graphs.grid_8_neighbor(S))
         A = graphs.to_device(L, dev)
-        f = ODEFunc(H, A).to(dev).eval()
+        f = ODEFunc(H, A, no_control=args.no_control).to(dev).eval()
         kw = dict(T=args.T, rtol=args.rtol, atol=args.atol, method='dopri5')
-        what = ('NDCN ODEFunc relu(W(AX)+b), %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR '
+        what = (('NDCN ODEFunc(no_control) relu(AX)' if args.no_control else 'NDCN ODEFunc relu(W(AX)+b)') + ', %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR '
                 'nnz=%d per GPU, H=%d, dopri5 rtol=%g atol=%g t in [0,%g]' % (S, S, S * S, L.nnz, H, args.rtol, args.atol, args.T))
         step = 'one attempted dopri5 step (6 RHS evals + stage algebra + error norm + controller)'
     elif args.config == 'C2':
