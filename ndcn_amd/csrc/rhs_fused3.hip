@@ -101,7 +101,7 @@ struct F3Args {
     const int *rowptr, *colidx;      // direct gather of groups the plan could not stage
     const float *val;
     unsigned long long *dbg_cycles;  // NDCN_FUSED3_TIMING: per (block, wave) {cycles between barriers, cycles inside barriers}
-    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 64 no weight refills
+    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 64 no weight refills, 128 no bf16 split
 };
 struct F3Epi {
     const float *y0;
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
                 auto bq = [&](int jj, int pl) -> const u32x4 & { return res ? Br[res ? ks : 0][jj][pl] : Bq[u][jj][pl]; };
                 u32x4 N0 = A0, N1 = A1, N2 = A2;
                 if (!kPipe) {
-                    split8(r0, r1, A0, A1, A2);
+                    if (a.dbg & 128) { A0 = __builtin_bit_cast(u32x4, r0); A1 = __builtin_bit_cast(u32x4, r1); A2 = A0; }   // timing: no split
+                    else split8(r0, r1, A0, A1, A2);
                     if (i + 1 < 8) {                                // the next block's A values leave LDS while these products run
                         r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
                         r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
