@@ -89,6 +89,36 @@ def test_dopri5_golden(dev, name, as_module):
     assert np.allclose(log[:, 3], ref[:, 3], rtol=5e-3, atol=1e-12)
 
 
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4', 'dopri5'])
+def test_lattice_h256_solvers_against_oracle(dev, method):
+    """H = 256 on a lattice: the device-resident solver runs rhs_fused3 (group-record plan) with the stage algebra of every
+    method in its epilogues (RK4 stages, dopri5 COMBINE / ERROR) - trajectory and, for dopri5, the accept / reject log
+    against the CPU oracle on the same inputs."""
+    from ndcn_amd import torchdiffeq as ode, graphs, CsrOperator, _lib
+    from ndcn_amd.neural_dynamics import ODEFunc
+    side, H = 30, 256
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    A = CsrOperator.from_scipy(L, dev)
+    torch.manual_seed(3)
+    f = ODEFunc(H, A).to(dev).eval()
+    x0 = torch.rand(side * side, H, generator=torch.Generator().manual_seed(4))
+    t = torch.linspace(0., 1.2, 7)
+    log = []
+    with torch.no_grad():
+        y = ode.odeint(f, x0.to(dev), t.to(dev), rtol=1e-3, atol=1e-4, method=method, step_log=log if method == 'dopri5' else None)
+    assert A.rec is not None and _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3
+    Ao = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
+    W, b = f.wt.weight.detach().cpu(), f.wt.bias.detach().cpu()
+    ref_log = []
+    ref = orc.odeint(lambda tt, xx: orc.odefunc_rhs(Ao, xx, W, b), x0, t, rtol=1e-3, atol=1e-4, method=method,
+                     **({'step_log': ref_log} if method == 'dopri5' else {}))
+    check_traj(y.cpu().numpy(), ref.numpy(), l1=1e-5, mx=2e-4)
+    if method == 'dopri5':
+        got = [r for r in log if r[0] != 'nfe']
+        want = [r for r in ref_log if r[0] != 'nfe']
+        assert len(got) == len(want) and [r[2] for r in got] == [r[2] for r in want]
+
+
 @pytest.mark.parametrize('name', names('ndcn_*.npz'))
 def test_ndcn_end_to_end_golden(dev, name):
     from ndcn_amd.neural_dynamics import NDCN
