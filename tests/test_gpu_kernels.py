@@ -231,6 +231,22 @@ def test_fused3_equals_fused2(dev, side):
         got = hip.rhs(A, X[:1200].contiguous(), W, b, X_halo=X[1200:].contiguous())
         assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3 | _lib.PATH_HALO
         assert torch.equal(got, K_ref)
+        # the HALO variants of the epilogue modes: own rows [0, 1200), the rest of X as the halo panel
+        sub = m[:1200]
+        Ah = _no_plan(CsrOperator.from_scipy(sub, dev))
+        Ah.lattice_hint = (0, 1200)
+        if hinted:
+            Ah.group_order = torch.as_tensor(Ah.detect_stencil_order(), dtype=torch.int32).to(dev)
+        Ah.build_rec_plan(16, 40, 2)
+        Xo, Xh = X[:1200].contiguous(), X[1200:].contiguous()
+        Kh, ynh = hip.rhs_rk(Ah, Xo, W, b, 'combine', y0[:1200], [k[:1200] for k in ks[:3]], cs[:3] + [cs[5]], X_halo=Xh)
+        assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3 | _lib.PATH_HALO
+        Kf, ynf = hip.rhs_rk(P, X, W, b, 'combine', y0, ks[:3], cs[:3] + [cs[5]])
+        assert torch.equal(Kh, Kf[:1200]) and torch.equal(ynh, ynf[:1200])
+        _, (se, be) = hip.rhs_rk(Ah, Xo, W, b, 'error', y0[:1200], [k[:1200] for k in ks], cs, rtol=1e-2, atol=1e-3, X_halo=Xh)
+        Ph = _no_plan(CsrOperator.from_scipy(sub, dev))
+        _, (se2, be2) = hip.rhs_rk(Ph, Xo, W, b, 'error', y0[:1200], [k[:1200] for k in ks], cs, rtol=1e-2, atol=1e-3, X_halo=Xh)
+        assert abs(se - se2) <= 1e-9 * abs(se2) and be == be2 == 0.0
         for npv in range(6):
             K, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], cs[:npv] + [cs[5]])
             K2, yn2 = hip.rhs_rk(P, X, W, b, 'combine', y0, ks[:npv], cs[:npv] + [cs[5]])
