@@ -40,6 +40,12 @@ constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
 constexpr int kCus = 256;
 
+// torch's relu / max propagate NaN (F.relu, neural_dynamics.py:36; torch.max, misc.py:149): v_max_f32 (fmaxf) does not - it
+// returns the other operand, which would turn a NaN born inside the right-hand side into K = 0 and hide it from the
+// solver's finiteness assertion (dopri5.py:101-102).
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Contiguous-chunk-per-XCD remap of a 1-D grid (bijective for any grid size): blocks that the

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float *__restric
             const int64_t gr = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (gr < n) {
                 float v = acc[t][r] + bv;
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu) v = relu_nan(v);
                 Y[gr * Ho + go] = v;
             }
         }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float *__restri
         float acc = 0.f;
         for (int k = 0; k < Hi; ++k) acc = fmaf(s[k], w[k], acc);
         if (bias) acc += bias[o];
-        if (relu) acc = fmaxf(acc, 0.f);
+        if (relu) acc = relu_nan(acc);
         Y[i] = acc;
     }
 }

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict_
                                                         int relu) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = x[i];
-        y[i] = relu ? fmaxf(v, 0.f) : v;
+        y[i] = relu ? relu_nan(v) : v;
     }
 }
 

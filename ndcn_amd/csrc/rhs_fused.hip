@@ -167,7 +167,7 @@ __device__ __forceinline__ void consume_tile(const float *src, const f32x4 *__re
                 const int row = row0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < n_rows) {
                     float o = acc[m][n][r] + bv;
-                    if (relu) o = fmaxf(o, 0.f);
+                    if (relu) o = relu_nan(o);
                     __builtin_nontemporal_store(o, &Y[(size_t)row * kH + col]);
                 }
             }

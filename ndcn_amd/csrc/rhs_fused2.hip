@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             const float rtol = ea->rtol, atol = ea->atol;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float tol = atol + rtol * fmaxf(fabsf(e.y0v[q]), fabsf(e.y1v[q]));
+                const float tol = atol + rtol * max_nan(fabsf(e.y0v[q]), fabsf(e.y1v[q]));
                 const float z = s[q] / tol;
                 err_sum += (double)(z * z);
                 err_bad += (double)(int)(!(fabsf(e.y1v[q]) <= 3.402823466e38f));
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
                 for (int r = 0; r < 16; ++r) {
                     const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     float o = (mt == 0 ? (n == 0 ? acc00[r] : acc01[r]) : (n == 0 ? acc10[r] : acc11[r])) + bv;
-                    if (a.relu) o = fmaxf(o, 0.f);
+                    if (a.relu) o = relu_nan(o);
                     dst[m * kLd2 + col] = o;
                 }
         }

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
                     float o = acc[jj][r] + bv;
-                    if (a.relu) o = fmaxf(o, 0.f);
+                    if (a.relu) o = relu_nan(o);
                     dst[m * kF3Ld + col] = o;
                 }
             }
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float tol = e.atol + e.rtol * fmaxf(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
+            const float tol = e.atol + e.rtol * max_nan(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
             const float z = s[q] / tol;
             err_sum += (double)(z * z);
             err_bad += (double)(int)(!(fabsf(p.y1v[q]) <= 3.402823466e38f));

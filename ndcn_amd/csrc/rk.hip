@@ -97,7 +97,7 @@ __device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.4028
 
 __device__ __forceinline__ float err_ratio_sq(float e, float a, float b, float rtol, float atol) {
     // misc.py:151-156: tol = atol + rtol * max(|y0|, |y1|); r = err / tol; r * r
-    const float tol = atol + rtol * fmaxf(fabsf(a), fabsf(b));
+    const float tol = atol + rtol * max_nan(fabsf(a), fabsf(b));
     const float r = e / tol;
     return r * r;
 }
@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ out, con
         const float4 v = ld4(x, i);
         st4(out, i, make_float4(w * v.x, w * v.y, w * v.z, w * v.w));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[4 * n4 + threadIdx.x] = w * x[4 * n4 + threadIdx.x];
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = w * x[i];
 }
 
 // out = g where y > 0, else 0  (VJP of relu given its output; neural_dynamics.py:36)
@@ -376,9 +377,11 @@ int relu_bwd_f32(float *out, const float *g, const float *y, int64_t n, hipStrea
 
 int scale_f32(float *out, const float *x, float w, int64_t n, hipStream_t st) {
     if (n == 0) return NDCN_OK;
-    if (!(aligned16(out) && aligned16(x))) { set_error("scale: panels must be 16-byte aligned"); return NDCN_EINVAL; }
     ProfScope prof(PROF_STAGE, st, 8.0 * n, 1.0 * n);
-    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, st, out, x, w, n / 4, n);
+    // views at odd element offsets (torch.stack's backward hands out slices of one buffer): scalar path, like the
+    // other panel kernels of this file
+    const int64_t n4 = (aligned16(out) && aligned16(x)) ? n / 4 : 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid((n4 ? n4 : n) + 1, 256)), dim3(256), 0, st, out, x, w, n4, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n,
             if (j < p.t.n) e = e + p.t.c[j] * p.t.k[j][i];
         const float a0 = p.y0[i], a1 = p.y1[i];
         const float m0 = fabsf(a0), m1 = fabsf(a1);
-        const float tol = p.atol + p.rtol * fmaxf(m0, m1);
+        const float tol = p.atol + p.rtol * max_nan(m0, m1);
         const float q = e / tol;
         const float s = 2.f * q * p.inv_n / tol;             // d r / d e
 #pragma unroll

@@ -37,12 +37,12 @@ template <> __device__ __forceinline__ float4 vzero<4>() { return vzero4(); }
 template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
 __device__ __forceinline__ float4 vfinish(float4 a, float alpha, bool relu) {
     a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;
-    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    if (relu) { a.x = relu_nan(a.x); a.y = relu_nan(a.y); a.z = relu_nan(a.z); a.w = relu_nan(a.w); }
     return a;
 }
 __device__ __forceinline__ float vfinish(float a, float alpha, bool relu) {
     a *= alpha;
-    return relu ? fmaxf(a, 0.f) : a;
+    return relu ? relu_nan(a) : a;
 }
 
 // One row: acc = sum_j val[j] * X[col[j], slot]; `cols`/`vals` index from `j0` (LDS or global view).
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             f32x4 o = acc[u] * alpha;
-            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (relu) { o.x = relu_nan(o.x); o.y = relu_nan(o.y); o.z = relu_nan(o.z); o.w = relu_nan(o.w); }
             __builtin_nontemporal_store(o, &Y[(size_t)r * stride + lane + 64 * u]);
             if (MODE != WIDE_PLAIN && u == 0) {
 #pragma clang fp contract(off)       // the RK algebra rounds like the reference's separate mul / add ops
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float tol = e.atol + e.rtol * fmaxf(fabsf(py0[q]), fabsf(py1[q]));
+                            const float tol = e.atol + e.rtol * max_nan(fabsf(py0[q]), fabsf(py1[q]));
                             const float z = sm[q] / tol;
                             err_sum += (double)(z * z);
                             err_bad += (double)(int)(!(fabsf(py1[q]) <= 3.402823466e38f));

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float tol = e.atol + e.rtol * fmaxf(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
+                const float tol = e.atol + e.rtol * max_nan(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
                 const float z = s[q] / tol;
                 err_sum += (double)(z * z);
                 err_bad += (double)(int)(!(fabsf(p.y1v[q]) <= 3.402823466e38f));
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
                 }
             }
             f32x4 o = acc * a.alpha;
-            if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (a.relu) { o.x = relu_nan(o.x); o.y = relu_nan(o.y); o.z = relu_nan(o.z); o.w = relu_nan(o.w); }
             __builtin_nontemporal_store(o, &Y[(size_t)row * 64 + lane]);
             ++s_cur; ++s_nxt;
             kn[q] = o;

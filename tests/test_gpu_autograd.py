@@ -271,3 +271,40 @@ def test_dopri5_backprop_analytic_vjps_equal_torch_expression_vjps(dev, monkeypa
     assert torch.equal(res['hip'][0], res['torch'][0])
     for a, b in zip(res['hip'][1:], res['torch'][1:]):
         assert rel(a, b) < 1e-3                 # fp32 rounding of differently-ordered sums; the oracle test above bounds both
+
+
+def test_scale_accepts_views_at_odd_element_offsets(dev):
+    """ndcn_scale_f32 is the VJP of one RK term; autograd hands it slices of torch.stack's gradient buffer, which start at
+    multiples of n * H elements - not of 16 bytes when n * H % 4 != 0."""
+    from ndcn_amd import hip
+    base = torch.randn(4 * 111 + 3, device=dev)
+    for off in (0, 1, 2, 3, 111, 222):
+        for n in (1, 3, 111, 256):
+            x = base[off:off + n]
+            assert torch.equal(hip.scale(x, 0.37), x * np.float32(0.37))
+
+
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])
+def test_fixed_grid_training_with_odd_panel_sizes(dev, method):
+    """n * H = 37 * 3 = 111 elements per tick and a loss on sol[-1] only (the dgnn drivers' terminal=True): the gradient
+    reaching the solver ops is an unbind slice at element offset 4 * 111 of the stacked solution's gradient."""
+    import scipy.sparse as sp
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    n, H = 37, 3
+    rng = np.random.RandomState(0)
+    m = sp.random(n, n, density=0.2, random_state=rng, format='csr', dtype=np.float32)
+    m.sort_indices()
+    torch.manual_seed(0)
+    f = ODEFunc(H, CsrOperator.from_scipy(m, dev)).to(dev)
+    x = torch.rand(n, H).to(dev).requires_grad_(True)
+    t = torch.linspace(0., 1., 5)
+    y = ode.odeint(f, x, t.to(dev), method=method)
+    y[-1].square().sum().backward()
+    A = orc.coo_from_csr(m.indptr, m.indices, m.data, m.shape)
+    W, b = f.wt.weight.detach().cpu().requires_grad_(True), f.wt.bias.detach().cpu().requires_grad_(True)
+    xc = x.detach().cpu().requires_grad_(True)
+    yo = orc.odeint(lambda tt, xx: orc.odefunc_rhs(A, xx, W, b), xc, t, method=method)
+    yo[-1].square().sum().backward()
+    assert rel(x.grad.cpu(), xc.grad) < 2e-4 and rel(f.wt.weight.grad.cpu(), W.grad) < 2e-4
