@@ -33,18 +33,21 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
+SPLIT_PRODUCTS = 6             # the fused H = 256 kernels form W S from 3-way bf16 splits: 6 bf16 MFMA products per fp32 product
 
 
 KERNEL_FAMILY = {'rhs_fused': 'rhs_fused', 'spmm': 'spmm_', 'combine': 'combine_kernel', 'linear': 'linear_',
                  'error': 'rk_error_kernel'}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (profiles/*traffic_pmc.json,
-    produced by tools/gpu_final.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted mean over the family's kernels; None if absent."""
+def pmc_traffic(family, cfg):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary OF THIS CONFIGURATION
+    (profiles/*_traffic_pmc_<cfg>.json, produced by tools/gpu.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted mean over the family's kernels; (None, None)
+    when no summary of this configuration is committed - a number measured on another workload is not this line's traffic."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*traffic_pmc.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic_pmc_%s.json' % cfg)))
     if not files:
         return None, None
     try:
@@ -71,13 +74,13 @@ def parse():
     p.add_argument('--atol', type=float, default=0.001)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-threads', type=int, default=32, help='host threads of the CPU-baseline leg')
-    p.add_argument('--cpu-side', type=int, default=256, help='grid side of the bounded CPU-baseline sample')
+    p.add_argument('--cpu-nodes', type=int, default=0, help='nodes of the bounded CPU-baseline sample (0: per-configuration default)')
     p.add_argument('--no-profile-pass', action='store_true')
     p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (needs torchrun, works with 1 rank)')
     p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
     p.add_argument('--no-control', action='store_true', help='config M with ODEFunc(no_control=True): relu(A X), the pure HBM right-hand side (neural_dynamics.py:32)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')
-    p.add_argument('--cpu-runs', type=int, default=3, help='timed solves of the CPU-baseline leg (after one warm-up)')
+    p.add_argument('--cpu-runs', type=int, default=5, help='timed solves of the CPU-baseline leg (after two warm-ups; BASELINE.md section 3)')
     return p.parse_args()
 
 
@@ -128,45 +131,71 @@ class SingleGpuRunner:
         return self.nfe_done + int(self.solver.stats()['nfe'])
 
 
-def cpu_baseline(side, H, T, rtol, atol, threads, runs=3):
-    """The CPU oracle (torch-CPU restatement of the reference path: torch.sparse.mm on COO + F.linear + the restated
-    dopri5 loop, checked against fixtures of the reference itself) on a BOUNDED sample of the metric's workload: the same
-    generators, seeds, H, tolerances and time span on a side x side grid that one solve finishes in seconds.  Protocol
-    (bounded): one warm-up solve, `runs` timed solves, median.  node-states/s is a per-node rate:
-    the CPU figure at N = side^2 stands in for N = 10^6 (the reference-style solver needs ~40 panels of temporaries per
-    step - ~40 GB at 10^6 x 256 - and minutes per solve there; BASELINE.md measured 4.8 k node-states/s at N = 10^5 on 8
-    cores)."""
+# bounded CPU samples per configuration: {nodes, ticks} such that 2 warm-ups + 5 timed solves stay within ~10-30 s of CPU work
+CPU_SAMPLE = {'M': 128 * 128, 'NC': 128 * 128, 'C2': 8000, 'C3': 16000, 'C4': 16000, 'C5': 0}
+
+
+def cpu_workload(cfg, H, n, T):
+    """(operator as scipy CSR, no_control, method, ticks, description) of configuration cfg at n nodes - the same
+    generators, seeds and solver settings as build_workload."""
     from ndcn_amd import graphs
+    if cfg in ('M', 'NC'):
+        side = int(round(n ** 0.5))
+        return (graphs.normalized_laplacian(graphs.grid_8_neighbor(side)), cfg == 'NC', 'dopri5', [0., T],
+                '%dx%d grid' % (side, side))
+    if cfg == 'C2':
+        return (graphs.normalized_laplacian(graphs.make_graph('random', n, seed=0)), False, 'rk4',
+                torch.linspace(0., 5., 100)[:21].tolist(), 'G(n,p) n=%d mean degree 39.9, the first 20 of the 99 RK4 steps' % n)
+    if cfg == 'C3':
+        return graphs.normalized_laplacian(graphs.make_graph('power_law', n, seed=0)), False, 'dopri5', [0., T], 'Barabasi-Albert n=%d m=5' % n
+    if cfg == 'C4':
+        return graphs.normalized_laplacian(graphs.make_graph('small_world', n, seed=0)), False, 'dopri5', [0., T], 'small world n=%d k=5 p=0.5' % n
+    import scipy.sparse as sp
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'operators_pubmed.npz')))
+    m = sp.csr_matrix((g['alpha00_data'], g['alpha00_indices'], g['alpha00_indptr']), shape=(int(g['n']), int(g['n'])))
+    return m, True, 'dopri5', torch.linspace(0., 1.2, 16).tolist(), 'Pubmed topology, FULL size (%d nodes), 16 ticks' % int(g['n'])
+
+
+def cpu_baseline(cfg, H, T, rtol, atol, threads, runs=5, nodes=0):
+    """The CPU oracle (torch-CPU restatement of the reference path: torch.sparse.mm on COO + F.linear + the restated
+    solver loops, checked against fixtures of the reference itself) on a BOUNDED sample of this configuration's workload:
+    the same generators, seeds, H, tolerances and time grid at a node count that one solve finishes in seconds (C5: the
+    full workload).  Protocol: two warm-up solves, `runs` >= 5 timed solves, median.
+    node-states/s is a per-node rate: the figure at the sample's N stands in for the full N (the reference-style solver
+    needs ~40 panels of temporaries per step - ~40 GB at 10^6 x 256 - and minutes per solve there; BASELINE.md measured
+    4.8 k node-states/s at N = 10^5 on 8 cores)."""
     from oracle import ndcn_oracle as orc
     # the reference's op-per-term solver issues ~300 small tensor ops per step: beyond a few dozen threads the
     # fork/join cost of each op outweighs the work, so the leg uses a bounded thread count and says which
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
-    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    n = nodes or CPU_SAMPLE[cfg]
+    L, no_control, method, ticks, what = cpu_workload(cfg, H, n, T)
+    n = L.shape[0]
+    if cfg == 'C5':
+        rtol, atol = .1, .1
     A = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
     torch.manual_seed(0)
     lin = torch.nn.Linear(H, H)
-    f = orc.OracleODEFunc(A, lin.weight.detach(), lin.bias.detach())
-    x0 = torch.rand(side * side, H, generator=torch.Generator().manual_seed(0))
-    n = side * side
-    times, log = [], []
-    t_leg = time.perf_counter()
-    for r in range(1 + runs):
+    f = orc.OracleODEFunc(A, lin.weight.detach(), lin.bias.detach(), no_control=no_control)
+    x0 = torch.rand(n, H, generator=torch.Generator().manual_seed(0))
+    tt = torch.tensor(ticks)
+    times, steps = [], 0
+    for r in range(2 + max(runs, 5)):
         log = []
         nfe0 = f.nfe
         t0 = time.perf_counter()
-        orc.odeint(f, x0, torch.tensor([0., T]), rtol=rtol, atol=atol, method='dopri5', step_log=log)
+        orc.odeint(f, x0, tt, rtol=rtol, atol=atol, method=method, step_log=log if method == 'dopri5' else None)
         dt = time.perf_counter() - t0
-        if r > 0:
+        if r >= 2:
             times.append(dt)
         nfe = f.nfe - nfe0
-        if time.perf_counter() - t_leg > 45 and times:      # keep the leg bounded on a slow host
-            break
+        steps = len([row for row in log if row[0] != 'nfe']) if method == 'dopri5' else len(ticks) - 1
     med = float(np.median(times))
-    return {'value': n * len(log) / med, 'unit': 'node-states/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '1 warm-up + %d timed dopri5 solves t in [0,%g] on a %dx%d grid (N=%d, H=%d, same generators / seeds / '
-                      'tolerances as the GPU run): %d steps, %d RHS evals per solve, median %.2f s (all: %s); per-node rate, '
-                      'stands in for N=10^6' % (len(times), T, side, side, n, H, len(log), nfe, med,
-                                                ', '.join('%.2f' % v for v in times))}
+    return {'value': n * steps / med, 'unit': 'node-states/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '2 warm-ups + %d timed %s solves on %s (N=%d, H=%d, same generators / seeds / tolerances / time grid as '
+                      'the GPU run): %d steps, %d RHS evals per solve, median %.2f s (all: %s); per-node rate, stands in for '
+                      'the full node count' % (len(times), method, what, n, H, steps, nfe, med,
+                                               ', '.join('%.2f' % v for v in times))}
 
 
 C4_NODES_PER_GPU = int(os.environ.get('NDCN_C4_NODES', '500000'))    # BASELINE config 4: a 4M-node small world over 8 GPUs (override: tests)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 6
+#define NDCN_ABI_VERSION 7
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -45,6 +45,8 @@ extern "C" {
 #define NDCN_F_NO_CONTROL  4u   /* skip the Linear                     (neural_dynamics.py:32)   */
 #define NDCN_F_PACKED      8u   /* ndcn_rhs_f32 / ndcn_rhs_rk_f32, H = 256: `work` still holds the packed image of W that an
                                  * earlier call on this stream (flag clear, same W contents) left there - skip the re-pack   */
+#define NDCN_F_ACCUM      16u   /* ndcn_rhs_rk_f32, NDCN_RK_ERROR: ADD this launch's {sum, bad} to d_out instead of overwriting
+                                 * it - an evaluation split into several launches on one stream (row blocks of a shard)      */
 
 /* integrator methods (torchdiffeq/_impl/odeint.py:8-17, the in-scope subset) */
 #define NDCN_M_EULER    0
@@ -144,6 +146,9 @@ NDCN_API int64_t ndcn_linear_bwd_work_bytes(int64_t n, int H_in, int H_out);
 NDCN_API int ndcn_scale_f32(float *out, const float *x, float w, int64_t n_elem, void *stream);
 /* out = g where y > 0, else 0: the VJP of relu given its OUTPUT y (neural_dynamics.py:36; the no_control RHS). */
 NDCN_API int ndcn_relu_bwd_f32(float *out, const float *g, const float *y, int64_t n_elem, void *stream);
+/* dst = src, the library's plain streaming pass (16 bytes per lane, non-temporal): what `x.clone()` / the solver's state
+ * hand-overs cost, and the measured HBM ceiling bench.py quotes next to the 8 TB/s spec peak.                            */
+NDCN_API int ndcn_copy_f32(float *dst, const float *src, int64_t n_elem, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Vector-Jacobian products of the dopri5 panel operations.  The reference's vendored torchdiffeq differentiates through
@@ -192,6 +197,11 @@ NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
  *                                0: y0 + dt K / 3            1: y0 + dt (K - k1 / 3)
  *                                2: y0 + dt (k1 - k2 + K)    3: y0 + (k1 + 3 k2 + 3 k3 + K) dt / 8
  *                              (y_next may alias y0 here: both are row-local to the epilogue)
+ * y1 (nullable, NDCN_RK_ERROR only): the state whose error record is formed, indexed by ROW OF THIS LAUNCH; NULL = X, the
+ *   evaluation's own input (the single-launch case).  Two callers pass it: a launch over a row block [a, b) of a shard
+ *   (X stays the whole own panel because columns index it; y1 = X + a * H), and the second phase of a two-phase
+ *   evaluation, whose X is the partial sum A_own X rather than the state (ndcn_amd/sharding.py).  With NDCN_F_ACCUM the
+ *   record is added to d_out.
  * h_kprev / h_c are HOST arrays (n_prev <= 5 device pointers; n_prev + 1 coefficients, already dt * beta in
  * fp32).  X, K, y_next, y0 and the kprev panels must not alias each other.                              */
 #define NDCN_RK_COMBINE 1
@@ -200,7 +210,7 @@ NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 NDCN_API int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
                              const float *W, const float *b, float *K, float *work, int H, uint32_t flags,
                              int rk_mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
-                             float *y_next, float rtol, float atol, double *d_out, void *d_ws, void *stream);
+                             float *y_next, const float *y1, float rtol, float atol, double *d_out, void *d_ws, void *stream);
 
 /* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
 NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);
@@ -270,6 +280,9 @@ NDCN_API int ndcn_mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, 
  * `row_normalization` / `RowNorm.forward` (ode_gcn.py:9-26; used by ResBlock(normalize=True) ode_gcn.py:50-57 and the
  * odeGCN input stack dgnn.py:152).  Y may alias X.                                                                   */
 NDCN_API int ndcn_row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows, int H, void *stream);
+/* Its vector-Jacobian product (training through ResBlock(normalize=True), ode_gcn.py:50-57): GX = dL/dX given G = dL/dY
+ * and the forward input X.  GX may alias G.                                                                            */
+NDCN_API int ndcn_row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int64_t n_rows, int H, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Device-resident integrator for the ODEFunc RHS (state, stage derivatives and dense-output coefficients

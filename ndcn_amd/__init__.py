@@ -8,6 +8,6 @@ kernels behind the reference's own Python API.
 """
 from . import _lib
 from .csr import CsrOperator, as_csr
-from .ops import HipOps, hip, device_info
+from .ops import HipOps, hip, device_info, invalidate_packed_weights
 
-__all__ = ['CsrOperator', 'as_csr', 'HipOps', 'hip', 'device_info', '_lib']
+__all__ = ['CsrOperator', 'as_csr', 'HipOps', 'hip', 'device_info', 'invalidate_packed_weights', '_lib']

@@ -11,13 +11,13 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
 
-F_RELU, F_NO_GRAPH, F_NO_CONTROL, F_PACKED = 1, 2, 4, 8
+F_RELU, F_NO_GRAPH, F_NO_CONTROL, F_PACKED, F_ACCUM = 1, 2, 4, 8, 16
 RK_NONE, RK_COMBINE, RK_ERROR, RK_RK4 = 0, 1, 2, 3
 M_EULER, M_MIDPOINT, M_RK4, M_DOPRI5 = 0, 1, 2, 3
 METHODS = {'euler': M_EULER, 'midpoint': M_MIDPOINT, 'rk4': M_RK4, 'dopri5': M_DOPRI5}
@@ -75,6 +75,7 @@ SIGNATURES = {
     'ndcn_linear_bwd_work_bytes': (_L, [_L, _I, _I]),
     'ndcn_scale_f32': (_I, [_P, _P, _F, _L, _P]),
     'ndcn_relu_bwd_f32': (_I, [_P, _P, _P, _L, _P]),
+    'ndcn_copy_f32': (_I, [_P, _P, _L, _P]),
     'ndcn_rk_bwd_ws_bytes': (_L, []),
     'ndcn_rk_combine_bwd_f32': (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, ctypes.POINTER(_P), _P, _P, _L, _P]),
     'ndcn_rk_error_bwd_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _F, _D, _P, _P,
@@ -84,7 +85,7 @@ SIGNATURES = {
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
-                        _P, _F, _F, _P, _P, _P]),
+                        _P, _P, _F, _F, _P, _P, _P]),
     'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
     'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     'ndcn_interp_eval_f32': (_I, [_P, _P, _P, _P, _P, ctypes.POINTER(_F), _P, _L, _P]),
     'ndcn_fixed_stage_f32': (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _L, _P]),
     'ndcn_row_l1_normalize_f32': (_I, [_P, _P, _L, _I, _P]),
+    'ndcn_row_l1_normalize_bwd_f32': (_I, [_P, _P, _P, _L, _I, _P]),
     'ndcn_gene_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _P]),
     'ndcn_mutual_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     'ndcn_solver_workspace_bytes': (_L, [ctypes.POINTER(SolverDesc)]),

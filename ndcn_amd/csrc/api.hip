@@ -136,10 +136,21 @@ int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t
     return rhs_f32(A, X, X_halo, n_own, W, b, Y, work, H, flags, ST(stream));
 }
 
+int ndcn_copy_f32(float *dst, const float *src, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && (n_elem == 0 || (dst && src)), "bad argument");
+    return copy_f32(dst, src, n_elem, ST(stream));
+}
+
+int ndcn_row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int64_t n_rows, int H, void *stream) {
+    NDCN_CHECK_ARG(n_rows >= 0 && H >= 0, "negative size");
+    NDCN_CHECK_ARG(n_rows == 0 || H == 0 || (G && X && GX), "null panel");
+    return row_l1_normalize_bwd_f32(G, X, GX, n_rows, H, ST(stream));
+}
+
 int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
                     float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
-                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, float rtol, float atol,
-                    double *d_out, void *d_ws, void *stream) {
+                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float rtol,
+                    float atol, double *d_out, void *d_ws, void *stream) {
     NDCN_CHECK_ARG(A, "null operator descriptor");
     NDCN_CHECK_ARG(H > 0, "H must be positive");
     NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 3, "rk_mode must be 0, NDCN_RK_COMBINE, NDCN_RK_ERROR or NDCN_RK_RK4");
@@ -158,8 +169,9 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
         NDCN_CHECK_ARG(rk_mode != NDCN_RK_RK4 || (y_next && y_next != X && y_next != K && n_prev >= 0 && n_prev <= 3),
                        "rk4 stage: y_next missing / aliased or stage index outside 0..3");
     }
+    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0};
     return rhs_rk_f32(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
-                      d_out, d_ws, ST(stream));
+                      d_out, d_ws, ST(stream), &opt);
 }
 
 int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream) {

@@ -5,6 +5,14 @@
 
 namespace ndcn {
 
+// Options of an RK-epilogue launch that only the sharded callers use (ndcn_rhs_rk_f32: y1 / NDCN_F_ACCUM):
+//   y1     ERROR mode - the state whose error record is formed, by ROW of this launch (NULL: X, the evaluation's input).
+//          A launch over a row block of a shard, or the second phase of a two-phase evaluation (whose X is the partial sum
+//          A_own X, not y1), passes it explicitly.
+//   accum  ERROR mode - add this launch's {sum, bad} to d_out instead of overwriting it (an evaluation split into
+//          several launches on one stream; the order of the launches fixes the order of the sum)
+struct RkOpt { const float *y1; int accum; };
+
 int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
              uint32_t flags, hipStream_t st);
 int gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, hipStream_t st);
@@ -18,10 +26,11 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
 int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho);
 int scale_f32(float *out, const float *x, float w, int64_t n, hipStream_t st);
 int relu_bwd_f32(float *out, const float *g, const float *y, int64_t n, hipStream_t st);
+int copy_f32(float *dst, const float *src, int64_t n, hipStream_t st);
 int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *K,
                float *work, int H, uint32_t flags, int rk_mode, const float *y0, const float *const *h_kprev,
                const float *h_c, int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws,
-               hipStream_t st);
+               hipStream_t st, const RkOpt *opt = nullptr);
 int rhs_fused_supported(int H, uint32_t flags);
 int pack_weight_256(const float *W, float *Wp, hipStream_t st);
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);
@@ -30,29 +39,32 @@ int64_t rhs_fused2_partials_bytes();
 // mode 0: K only; 1: also y_next = y0 + sum c_m kprev_m + c_new K; 2: also the dopri5 error record into d_out
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
                    float *K, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c,
-                   int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
+                   int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st,
+                   const RkOpt *opt = nullptr);
 // fixed-order sum of n {sum, bad} fp64 pairs into d_out[0..1] (one workgroup: deterministic accept / reject)
-int partials_finish(const double *partials, int n, double *d_out, hipStream_t st);
+int partials_finish(const double *partials, int n, double *d_out, hipStream_t st, int accum = 0);
 // rhs_fused3.hip: the same contract as rhs_fused2_f32 for operators that carry the 16-row group-record plan (Wq: the
 // split weights of pack_weight_256, i.e. Wp + 256 * 256 floats)
 int rhs_fused3_supported(const ndcn_csr *A);
 int rhs_fused3_variant(int mode, int n_prev);
 int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
                    uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
-                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st);
+                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const RkOpt *opt = nullptr);
 int spmm_rec_supported(const ndcn_csr *A, int H);
 int spmm_rec_variant(int mode, int n_prev);
 int64_t spmm_rec_partials_bytes();
 // mode 0: Y = alpha (A X) [relu]; modes 1-3 (NDCN_RK_*): K = relu(A X) plus the RK algebra, as rhs_fused2_f32
 int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha, uint32_t flags,
                  int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next,
-                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr);
+                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr,
+                 const RkOpt *opt = nullptr);
 // out[i] = fl(dt[0] * beta[i]), i < n: the effective coefficients of a replayed adaptive step (device-resident step size)
 int scale_coef_f32(float *out, const float *beta, const float *dt, int n, hipStream_t st);
 int spmm_wide_rk_supported(const ndcn_csr *A, int H);
 int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *K, uint32_t flags, int mode,
                      const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, float rtol,
-                     float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr);
+                     float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr,
+                     const RkOpt *opt = nullptr);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 
@@ -61,7 +73,7 @@ int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int
 int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n,
                    hipStream_t st, const float *dt_dev = nullptr);
 int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
-                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev = nullptr);
+                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev = nullptr, int accum = 0);
 // VJPs of the dopri5 panel operations (rk_bwd.hip); d_dots receives 8 doubles, d_ws: rk_bwd_ws_bytes() bytes
 int64_t rk_bwd_ws_bytes();
 int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, double *d_dots,
@@ -91,6 +103,7 @@ int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const f
                     const float *k4, float dt, int64_t n, hipStream_t st, const float *dt_dev = nullptr);
 
 int row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows, int H, hipStream_t st);
+int row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int64_t n_rows, int H, hipStream_t st);
 int gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f, float h, hipStream_t st);
 int mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d, float e, float h,
                    hipStream_t st);

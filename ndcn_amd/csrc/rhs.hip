@@ -61,7 +61,7 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
 int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *K,
                float *work, int H, uint32_t flags, int rk_mode, const float *y0, const float *const *h_kprev,
                const float *h_c, int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws,
-               hipStream_t st) {
+               hipStream_t st, const RkOpt *opt) {
     if (rk_mode == 0) return rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
     if (n_prev < 0 || n_prev > 5) { set_error("rhs_rk: n_prev must be 0..5"); return NDCN_EINVAL; }
     const bool both = !(flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
@@ -70,15 +70,17 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
         int rc = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256(W, work, st);
         if (rc) return rc;
         return rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
-                              d_out, d_ws, st);
+                              d_out, d_ws, st, opt);
     }
     // no_control: relu(A X) with the stage algebra in the epilogue of the group-record SpMM (spmm_rec.hip)
     const bool graph_only = !(flags & NDCN_F_NO_GRAPH) && (flags & NDCN_F_NO_CONTROL);
     if (graph_only && spmm_rec_supported(A, H) && spmm_rec_variant(rk_mode, n_prev) && A->n_rows * (int64_t)1024 < (1ll << 32) &&
         aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))
-        return spmm_rec_f32(A, X, Xh, n_own, K, 1.f, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st);
+        return spmm_rec_f32(A, X, Xh, n_own, K, 1.f, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st,
+                            nullptr, opt);
     if (graph_only && spmm_wide_rk_supported(A, H) && aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))     // any other graph
-        return spmm_wide_rk_f32(A, X, Xh, n_own, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st);
+        return spmm_wide_rk_f32(A, X, Xh, n_own, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st,
+                                nullptr, opt);
     // composition with the same term order: K first, then the algebra over {kprev..., K}
     int rc = rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
     if (rc) return rc;
@@ -90,7 +92,8 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
         return fixed_stage_f32(2 + n_prev, y_next, y0, kk[0], n_prev > 0 ? kk[1] : nullptr, n_prev > 1 ? kk[2] : nullptr,
                                n_prev > 2 ? kk[3] : nullptr, h_c[0], n, st, nullptr);
     if (rk_mode == 1) return rk_combine_f32(y_next, y0, kk, h_c, n_prev + 1, n, st);
-    return rk_error_f32(y0, X, kk, h_c, n_prev + 1, rtol, atol, n, d_out, d_ws, st);
+    return rk_error_f32(y0, (opt && opt->y1) ? opt->y1 : X, kk, h_c, n_prev + 1, rtol, atol, n, d_out, d_ws, st, nullptr,
+                        (opt && opt->accum) ? 1 : 0);
 }
 
 }  // namespace ndcn

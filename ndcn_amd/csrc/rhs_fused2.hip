@@ -78,6 +78,7 @@ struct EpiArgs {
     float c[kMaxPrev + 1];                  // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K
     int n_prev;
     float rtol, atol;
+    const float *y1;                        // ERROR: the state of the error record, by row of this launch
 };
 
 struct Fused2Args {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
 #pragma unroll
         for (int m = 0; m < NP; ++m) e.km[m] = ldp(ea->kprev[m], off);
         e.y0v = ldp(ea->y0, off);
-        if (MODE == MODE_ERROR) e.y1v = ldp(a.X, off);         // the input of this evaluation is y1 (own rows); measured:
+        if (MODE == MODE_ERROR) e.y1v = ldp(ea->y1, off);      // the input of this evaluation is y1 (own rows); measured:
                                                                // non-temporal here too reads less (8.69 vs 9.01 GB)
     };
     auto epi_finish = [&](EpiPtr ea, int r, const float *src_row, const EpiRow &e) {
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
 }
 
 // fixed-order sum of the per-producer partials (deterministic accept / reject)
-__global__ __launch_bounds__(256) void fused2_finish_kernel(const double *__restrict__ partial, int n, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void fused2_finish_kernel(const double *__restrict__ partial, int n, double *__restrict__ out, int accum) {
     __shared__ double sa[256], sb[256];
     double s = 0.0, bad = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) { s += partial[2 * i]; bad += partial[2 * i + 1]; }
@@ -561,11 +562,11 @@ __global__ __launch_bounds__(256) void fused2_finish_kernel(const double *__rest
         if (threadIdx.x < w) { sa[threadIdx.x] += sa[threadIdx.x + w]; sb[threadIdx.x] += sb[threadIdx.x + w]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
+    if (threadIdx.x == 0) { out[0] = accum ? out[0] + sa[0] : sa[0]; out[1] = accum ? out[1] + sb[0] : sb[0]; }
 }
 
-int partials_finish(const double *partials, int n, double *d_out, hipStream_t st) {
-    hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, partials, n, d_out);
+int partials_finish(const double *partials, int n, double *d_out, hipStream_t st, int accum) {
+    hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, partials, n, d_out, accum);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -599,7 +600,8 @@ int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kProd * 2 * sizeof(
 // mode: 0 plain; 1 combine (y_next = y0 + sum c_m k_m, new K last); 2 error (d_out[0..1], d_ws scratch)
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
                    float *K, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c,
-                   int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
+                   int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st,
+                   const RkOpt *opt) {
     const int n_rows = (int)A->n_rows;
     if (n_rows == 0) return NDCN_OK;
     // Long-row plan: the hub rows' (A X) rows are formed ahead by two small SpMMs (segments, then their sums) and the
@@ -636,7 +638,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (NDCN_SPLIT && rhs_fused3_supported(A) && rhs_fused3_variant(mode, n_prev)) {
         g_last_rhs_path = NDCN_PATH_FUSED3 | path_bits;
         return rhs_fused3_f32(A, X, Xh, n_own, Wp + kH2 * kH2, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out,
-                              d_ws, st);
+                              d_ws, st, opt);
     }
     g_last_rhs_path = NDCN_PATH_FUSED2 | path_bits;
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
@@ -652,6 +654,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     EpiArgs ea;
     ea.y0 = y0; ea.n_prev = n_prev; ea.y_next = y_next; ea.rtol = rtol; ea.atol = atol;
     ea.partials = static_cast<double *>(d_ws);
+    ea.y1 = (opt && opt->y1) ? opt->y1 : X;
     static const int dbg = env_int3("NDCN_FUSED_DBG", 0);
     a.dbg = dbg;
     static const int timing = env_int3("NDCN_FUSED_TIMING", 0);
@@ -698,7 +701,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
 #undef NDCN_F2_DISPATCH
 #undef NDCN_F2
     if (mode == MODE_ERROR)
-        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, ea.partials, (int)grid.x * kProd, d_out);
+        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, ea.partials, (int)grid.x * kProd, d_out, (opt && opt->accum) ? 1 : 0);
     NDCN_LAUNCH_CHECK();
     if (timing && timing_prints < timing) {                          // debugging aid: s_memtime accounting of block 0 and 100
         (void)hipStreamSynchronize(st);

@@ -110,6 +110,7 @@ struct F3Epi {
     double *partials;                // ERROR: [gridDim.x * kF3WP][2]
     float c[kF3MaxPrev + 1];         // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K ; RK4: c[0] = dt
     float rtol, atol;
+    const float *y1;                 // ERROR: the state of the error record, by row of this launch
 };
 
 template <bool HALO, int MODE, int NP>
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
 #pragma unroll
         for (int m = 0; m < NP; ++m) p.km[m] = ldp(e.kprev[m], voff);
         p.y0v = ldp(e.y0, voff);
-        if (MODE == F3_ERROR) p.y1v = ldp(a.X, voff);               // the input of this evaluation is y1 (own rows)
+        if (MODE == F3_ERROR) p.y1v = ldp(e.y1, voff);              // the input of this evaluation is y1 (own rows)
         issued(kLoads);
     };
     auto arrived = [&](Panels &p) {
@@ -571,7 +572,7 @@ static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st)
 // Wq: the split weights of pack_weight_256 (Wp + 256 * 256 floats); arguments as rhs_fused2_f32
 int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
                    uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
-                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st) {
+                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const RkOpt *opt) {
     if (A->n_rows == 0) return NDCN_OK;
     if (!rhs_fused3_variant(mode, n_prev)) { set_error("rhs_fused3: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     F3Args a;
@@ -587,6 +588,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     a.dbg_cycles = timing ? d_cyc : nullptr;
     F3Epi e = {};
     e.y0 = y0; e.y_next = y_next; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
+    e.y1 = (opt && opt->y1) ? opt->y1 : X;
     for (int m = 0; m < kF3MaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kF3MaxPrev; ++m) e.c[m] = (mode != F3_PLAIN && mode != F3_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == F3_RK4) e.c[0] = h_c[0];
@@ -636,7 +638,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
                 mode, n_prev, pw, pd, pq, mw, mq);
         ++timing_prints;
     }
-    if (mode == F3_ERROR) return partials_finish(e.partials, (int)grid.x * kF3WP, d_out, st);
+    if (mode == F3_ERROR) return partials_finish(e.partials, (int)grid.x * kF3WP, d_out, st, (opt && opt->accum) ? 1 : 0);
     return NDCN_OK;
 }
 

@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void scaled_sumsq_kernel(const float *__restri
 
 // fixed-order final sum of the per-block partials
 __global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__restrict__ partial, int n_partial,
-                                                            double *__restrict__ out) {
+                                                            double *__restrict__ out, int accum) {
     double s = 0.0, bad = 0.0;
     for (int i = threadIdx.x; i < n_partial; i += 256) { s += partial[2 * i]; bad += partial[2 * i + 1]; }
     block_sum2(s, bad);
-    if (threadIdx.x == 0) { out[0] = s; out[1] = bad; }
+    if (threadIdx.x == 0) { out[0] = accum ? out[0] + s : s; out[1] = accum ? out[1] + bad : bad; }
 }
 
 // -------------------------------------------------------------------------------- dense output
@@ -361,6 +361,35 @@ __global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ out, con
         out[i] = w * x[i];
 }
 
+// dst = src, 16 bytes per lane and 4 independent accesses in flight per lane: the streaming rate the box sustains for a
+// plain panel pass (bench.py reports every kernel's HBM traffic against it next to the 8 TB/s spec peak)
+typedef float cp_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n4, int64_t n) {
+    const cp_f32x4 *s = reinterpret_cast<const cp_f32x4 *>(src);
+    cp_f32x4 *d = reinterpret_cast<cp_f32x4 *>(dst);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const cp_f32x4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride);
+        const cp_f32x4 c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
+        __builtin_nontemporal_store(a, d + i);
+        __builtin_nontemporal_store(b, d + i + stride);
+        __builtin_nontemporal_store(c, d + i + 2 * stride);
+        __builtin_nontemporal_store(e, d + i + 3 * stride);
+    }
+    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) dst[j] = src[j];
+}
+
+int copy_f32(float *dst, const float *src, int64_t n, hipStream_t st) {
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_STAGE, st, 8.0 * n, 0.0);
+    const int64_t n4 = (aligned16(dst) && aligned16(src)) ? n / 4 : 0;
+    hipLaunchKernelGGL(copy_kernel, dim3(kCus * 8), dim3(256), 0, st, dst, src, n4, n);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 // out = g where y > 0, else 0  (VJP of relu given its output; neural_dynamics.py:36)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(float *__restrict__ out, const float *__restrict__ g, const float *__restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -436,7 +465,7 @@ static int red_grid(int64_t items) {
 }
 
 int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
-                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev) {
+                 float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev, int accum) {
     Terms t;
     t.dt_dev = dt_dev;
     bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1);
@@ -447,7 +476,7 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
     ProfScope prof(PROF_ERROR, st, 4.0 * n * (n_k + 2), 2.0 * n * (n_k + 4));
     if (vec) hipLaunchKernelGGL((rk_error_kernel<true>), dim3(g), dim3(256), 0, st, y0, y1, t, rtol, atol, items, partial);
     else hipLaunchKernelGGL((rk_error_kernel<false>), dim3(g), dim3(256), 0, st, y0, y1, t, rtol, atol, items, partial);
-    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out);
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out, accum);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -463,7 +492,7 @@ int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol,
     if (vec) { if (b) NDCN_SS(true, true); else NDCN_SS(true, false); }
     else { if (b) NDCN_SS(false, true); else NDCN_SS(false, false); }
 #undef NDCN_SS
-    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out);
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out, 0);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

@@ -59,6 +59,44 @@ __global__ __launch_bounds__(256) void rownorm_any_kernel(const float *__restric
     }
 }
 
+// VJP of the above (training through ResBlock(normalize=True) / RowNorm, ode_gcn.py:50-57): with s = sum_j |x_j|,
+// den = max(s, 1e-12), gm = g where the output is finite (the masked_fill entries pass no gradient):
+//   gx_j = gm_j / den - sign(x_j) (sum_i gm_i x_i) / den^2      (second term only where the clamp is inactive, s >= 1e-12)
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float *__restrict__ G, const float *__restrict__ X,
+                                                          float *__restrict__ GX, int64_t n_rows, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < n_rows; r += n_waves) {
+        const float *xr = X + r * H, *gr = G + r * H;
+        float s = 0.f;
+        for (int c = lane; c < H; c += 64) s += fabsf(xr[c]);
+        s = wave_sum(s);
+        const float den = fmaxf(s, 1e-12f);
+        float t = 0.f;
+        for (int c = lane; c < H; c += 64) {
+            const float x = xr[c];
+            if (fabsf(x / den) != INFINITY) t += gr[c] * x;
+        }
+        t = (s >= 1e-12f) ? wave_sum(t) / (den * den) : 0.f;
+        float *o = GX + r * H;
+        for (int c = lane; c < H; c += 64) {
+            const float x = xr[c];
+            const float gm = (fabsf(x / den) != INFINITY) ? gr[c] : 0.f;
+            const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+            o[c] = gm / den - sg * t;
+        }
+    }
+}
+
+int row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int64_t n_rows, int H, hipStream_t st) {
+    if (n_rows == 0 || H == 0) return NDCN_OK;
+    int64_t g = (n_rows + 3) / 4;
+    if (g > (int64_t)kCus * 16) g = (int64_t)kCus * 16;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)g), dim3(256), 0, st, G, X, GX, n_rows, H);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 int row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows, int H, hipStream_t st) {
     if (n_rows == 0 || H == 0) return NDCN_OK;
     int64_t g = (n_rows + 3) / 4;

@@ -195,6 +195,7 @@ struct WideEpi {
     int n_prev;
     float rtol, atol;
     const float *c_dev;               // nullable: coefficients in device memory (hipGraph replay)
+    const float *y1;                  // ERROR: the state of the error record, by row of this launch
 };
 enum { WIDE_PLAIN = 0, WIDE_COMBINE = 1, WIDE_ERROR = 2, WIDE_RK4 = 3 };
 
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
             for (int m = 0; m < kWideMaxPrev; ++m)
                 if (m < np) pk[m] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(e.kprev[m]) + o);
             py0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(e.y0) + o);
-            if (MODE == WIDE_ERROR) py1 = __builtin_nontemporal_load(X + o);
+            if (MODE == WIDE_ERROR) py1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(e.y1) + o);
         }
         int nc = 0;
         float nv = 0.f;
@@ -364,11 +365,12 @@ int spmm_wide_rk_supported(const ndcn_csr *A, int H) {
 // K = relu(A X) plus the RK algebra in the row SpMM's epilogue (modes and arguments as spmm_rec_f32 / rhs_fused2_f32)
 int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *K, uint32_t flags, int mode,
                      const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, float rtol,
-                     float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev) {
+                     float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev, const RkOpt *opt) {
     if (n_prev < 0 || n_prev > kWideMaxPrev || (mode == WIDE_RK4 && n_prev > 3)) { set_error("spmm_wide_rk: bad stage count"); return NDCN_EINVAL; }
     WideEpi e = {};
     e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
     e.c_dev = c_dev;
+    e.y1 = (opt && opt->y1) ? opt->y1 : X;
     for (int m = 0; m < kWideMaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kWideMaxPrev; ++m) e.c[m] = (mode != WIDE_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == WIDE_RK4) e.c[0] = h_c[0];
@@ -380,7 +382,7 @@ int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t
     else if (mode == WIDE_ERROR) rc = launch_wide<1, WIDE_ERROR>(A, X, Xh, n_own, K, 1.f, flags, st, &e, &np);
     else rc = launch_wide<1, WIDE_RK4>(A, X, Xh, n_own, K, 1.f, flags, st, &e, &np);
     if (rc) return rc;
-    if (mode == WIDE_ERROR) return partials_finish(e.partials, np, d_out, st);
+    if (mode == WIDE_ERROR) return partials_finish(e.partials, np, d_out, st, (opt && opt->accum) ? 1 : 0);
     return NDCN_OK;
 }
 

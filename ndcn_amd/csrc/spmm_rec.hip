@@ -72,6 +72,7 @@ struct RecEpi {
     float c[kRecMaxPrev + 1];        // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K ; RK4: c[0] = dt
     int n_prev;
     float rtol, atol;
+    const float *y1;                 // ERROR: the state of the error record, by row of this launch
     const float *c_dev;              // nullable: the coefficients live in device memory instead of c[] (hipGraph replay: one
                                      // captured launch serves every step size; filled by scale_coef_kernel as fl(dt * c))
 };
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
         for (int m = 0; m < MAXP; ++m)
             if (m < np) p.km[m] = ldp(e.kprev[m], voff);
         p.y0v = ldp(e.y0, voff);
-        if (MODE == REC_ERROR) p.y1v = ldp(a.X, voff);               // the input of this evaluation is y1 (own rows)
+        if (MODE == REC_ERROR) p.y1v = ldp(e.y1, voff);              // the input of this evaluation is y1 (own rows)
         s_cur += np + 1 + (MODE == REC_ERROR ? 1 : 0);
     };
     auto arrived = [&](Panels &p) {
@@ -393,7 +394,7 @@ static int launch_rec(const RecArgs &a, const RecEpi &e, int mode, bool halo, hi
 // mode 0: Y = alpha (A X) [relu];  modes 1-3: K = relu(A X) plus the RK algebra (see rhs_fused2_f32)
 int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, float alpha, uint32_t flags,
                  int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev, float *y_next,
-                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev) {
+                 float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev, const RkOpt *opt) {
     if (A->n_rows == 0) return NDCN_OK;
     if (!spmm_rec_variant(mode, n_prev)) { set_error("spmm_rec: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     RecArgs a;
@@ -404,6 +405,7 @@ int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_o
     RecEpi e = {};
     e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
     e.c_dev = c_dev;
+    e.y1 = (opt && opt->y1) ? opt->y1 : X;
     for (int m = 0; m < kRecMaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kRecMaxPrev; ++m) e.c[m] = (mode != REC_PLAIN && mode != REC_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == REC_RK4) e.c[0] = h_c[0];
@@ -416,7 +418,7 @@ int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_o
     if (A->rec_rows == 8) rc = launch_rec<8, 32, 1>(a, e, mode, Xh != nullptr, st, grid);
     else rc = launch_rec<16, 40, 2>(a, e, mode, Xh != nullptr, st, grid);
     if (rc) return rc;
-    if (mode == REC_ERROR) return partials_finish(e.partials, (int)grid.x * kRecWC, d_out, st);
+    if (mode == REC_ERROR) return partials_finish(e.partials, (int)grid.x * kRecWC, d_out, st, (opt && opt->accum) ? 1 : 0);
     return NDCN_OK;
 }
 

@@ -14,18 +14,33 @@ autograd_ops (HIP forward, VJP = SpMM with A^T / GEMM) and the pointwise parts t
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .neural_dynamics import _needs_grad
 from .ops import hip
 
 
+class _RowNorm(torch.autograd.Function):
+    """ndcn_row_l1_normalize_f32 forward, ndcn_row_l1_normalize_bwd_f32 backward."""
+
+    @staticmethod
+    def forward(ctx, X):
+        ctx.save_for_backward(X)
+        return hip.row_l1_normalize(X)
+
+    @staticmethod
+    def backward(ctx, g):
+        (X,) = ctx.saved_tensors
+        return hip.row_l1_normalize_bwd(g.contiguous(), X)
+
+
 def row_normalization(X):
-    """Row-normalize: each row / max(L1 norm, 1e-12), infinities zeroed  (ode_gcn.py:9-16)."""
+    """Row-normalize: each row / max(L1 norm, 1e-12), infinities zeroed  (ode_gcn.py:9-16).  Device tensors only (host
+    tensors are refused like everywhere in this package: there is no CPU path); with gradients enabled the backward is
+    the library's VJP kernel."""
     X = X.float()
-    if _needs_grad(X) or not X.is_cuda:
-        X = F.normalize(X, 1, 1)
-        return X.masked_fill(torch.isinf(X), 0)
+    if _needs_grad(X):
+        from ._lib import require_device
+        return _RowNorm.apply(require_device(X, 'row_normalization input').contiguous())
     return hip.row_l1_normalize(X)
 
 

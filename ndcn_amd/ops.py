@@ -8,6 +8,7 @@ logic is written against (ndcn_amd/torchdiffeq/_impl/core.py).  Tests drive that
 an oracle-backed double to check the control flow without a GPU; product code never does.
 """
 import ctypes
+import os
 import threading
 import weakref
 
@@ -68,11 +69,22 @@ class _PackedWeights:
     scratch at every call (two small launches in front of the big one).  A solver calls them thousands of times with
     the same weights: the scratch is kept per weight TENSOR OBJECT (weak reference: a new tensor that happens to reuse the
     address or the id of a dead one never hits), version counter (in-place updates - optimizers, load_state_dict - move
-    it) and stream; later calls pass NDCN_F_PACKED."""
+    it) and stream; later calls pass NDCN_F_PACKED.
+
+    What the key cannot see: writes that bypass the tensor's version counter - `W.data.copy_()`, `dist.broadcast(W.data)`,
+    raw-pointer writes through the C ABI.  After such a write call `ndcn_amd.ops.invalidate_packed_weights()` (or run with
+    NDCN_PACK_CACHE=0, which re-packs at every call: two small launches, ~10 us)."""
     _cache = {}
+    enabled = os.environ.get('NDCN_PACK_CACHE', '1') != '0'
+
+    @classmethod
+    def invalidate(cls):
+        cls._cache.clear()
 
     @classmethod
     def get(cls, W, nbytes):
+        if not cls.enabled:
+            return torch.empty(nbytes, dtype=torch.uint8, device=W.device), 0
         key = (id(W), torch.cuda.current_stream(W.device).cuda_stream, nbytes)
         hit = cls._cache.get(key)
         if hit is not None and hit[0]() is W and hit[1] == W._version and hit[2] == W.data_ptr():
@@ -194,6 +206,17 @@ class HipOps:
         return out
 
     @staticmethod
+    def copy(x, out=None):
+        """out = x as the library's streaming pass (ndcn_copy_f32)."""
+        x = _panel(x)
+        if out is None:
+            out = torch.empty_like(x)
+        assert out.is_contiguous() and out.numel() == x.numel()
+        with torch.cuda.device(x.device):
+            check(_lib.load().ndcn_copy_f32(ptr(out), ptr(x), x.numel(), stream_ptr()))
+        return out
+
+    @staticmethod
     def scale(x, w):
         """w * x as one streaming kernel."""
         x = _panel(x)
@@ -242,11 +265,14 @@ class HipOps:
 
     @staticmethod
     def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
         mode 'combine': returns (K, y0 + sum cs[m] kprev[m] + cs[-1] K); mode 'error': returns
         (K, (sum of squared error ratios, non-finite count of X)) - the dopri5 error record with X = y1;
-        mode 'rk4': stage len(kprev) of the 3/8-rule step, cs = [dt]: returns (K, next stage input / step result)."""
+        mode 'rk4': stage len(kprev) of the 3/8-rule step, cs = [dt]: returns (K, next stage input / step result).
+        mode 'error' only - y1: the rows of the state whose error record is formed (default X: the single-launch case);
+        accum: add the record to the one already in the device buffer (an evaluation split into several launches);
+        fetch=False: leave the record on the device (returns (K, None); the last launch of the split fetches)."""
         X = _panel(X)
         H = X.shape[1]
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
@@ -267,6 +293,11 @@ class HipOps:
         assert len(cs) == (1 if mode == 'rk4' else len(kprev) + 1)
         if X_halo is not None:
             X_halo = _panel(X_halo, 'halo panel')
+        if y1 is not None:
+            y1 = _panel(y1, 'y1')
+            assert mode == 'error' and tuple(y1.shape) == (n_rows, H)
+        if accum:
+            flags |= _lib.F_ACCUM
         K = out_K if out_K is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
         assert K.is_contiguous() and tuple(K.shape) == (n_rows, H)
         wbytes = int(lib.ndcn_rhs_work_bytes(n_rows, H, flags))
@@ -285,11 +316,11 @@ class HipOps:
         with _REDUCE_LOCK, torch.cuda.device(X.device):
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                       ptr(None if no_control else b), ptr(K), ptr(work), H, flags, rk, ptr(y0), arr_k,
-                                      arr_c, len(kprev), ptr(y_next), float(rtol), float(atol), ptr(red.out), ptr(red.ws),
-                                      stream_ptr()))
+                                      arr_c, len(kprev), ptr(y_next), ptr(y1), float(rtol), float(atol), ptr(red.out),
+                                      ptr(red.ws), stream_ptr()))
             if mode in ('combine', 'rk4'):
                 return K, y_next
-            return K, red.fetch()
+            return K, (red.fetch() if fetch else None)
 
     @staticmethod
     def gather_rows(X, idx):
@@ -459,6 +490,15 @@ class HipOps:
         return out
 
     @staticmethod
+    def row_l1_normalize_bwd(g, X):
+        """VJP of row_l1_normalize at X for the upstream gradient g."""
+        g, X = _panel(g), _panel(X)
+        out = torch.empty_like(X)
+        with torch.cuda.device(X.device):
+            check(_lib.load().ndcn_row_l1_normalize_bwd_f32(ptr(g), ptr(X), ptr(out), X.shape[0], X.shape[1], stream_ptr()))
+        return out
+
+    @staticmethod
     def gene_rhs(A, x, b=1.0, f=1.0, h=2.0):
         A = as_csr(A)
         x = _panel(x)
@@ -481,6 +521,12 @@ class HipOps:
 hip = HipOps()
 
 
+def invalidate_packed_weights():
+    """Drop the cached packed images of ODEFunc weights (see _PackedWeights): call after writing weights in a way that
+    does not move the tensor's version counter (`.data` writes, collectives on `.data`, raw-pointer writes)."""
+    _PackedWeights.invalidate()
+
+
 def device_info():
     out = (ctypes.c_int64 * 6)()
     check(_lib.load().ndcn_device_info(out))
@@ -488,4 +534,4 @@ def device_info():
     return dict(zip(keys, [int(v) for v in out]))
 
 
-__all__ = ['HipOps', 'hip', 'device_info', 'CsrOperator', 'as_csr']
+__all__ = ['HipOps', 'hip', 'device_info', 'CsrOperator', 'as_csr', 'invalidate_packed_weights']

@@ -11,6 +11,8 @@ one 16-byte all-reduce.  All ranks see identical scalars, hence take identical a
 torch.distributed is the transport ("nccl" = RCCL on ROCm; "gloo" in the CPU tests, which drive this same
 code with the oracle-backed ops double).
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -28,13 +30,15 @@ def even_bounds(n, world):
 class HaloPlan:
     """What this rank must send / receive before each A X, and the operator remapped to [own | halo] columns."""
 
-    def __init__(self, rows_block, bounds, rank, device, group=None, self_halo=0):
+    def __init__(self, rows_block, bounds, rank, device, group=None, self_halo=0, two_phase=None):
         """rows_block: scipy CSR, this rank's rows x ALL global columns.
         self_halo (test hook, NDCN_SELF_HALO): the first `self_halo` OWN columns are additionally routed through the
         exchange as if a peer owned them (this rank sends them to itself), so that a single rank drives a non-empty
         all-to-all-v over the real backend - on a 1-GPU box that is the only way RCCL's collective ever executes."""
         self.group = group
         self.rank, self.world = rank, len(bounds) - 1
+        if two_phase is None:
+            two_phase = os.environ.get('NDCN_TWO_PHASE', '1') != '0'
         self.bounds = list(bounds)
         lo, hi = bounds[rank], bounds[rank + 1]
         self.n_own = hi - lo
@@ -42,7 +46,7 @@ class HaloPlan:
         blk.sort_indices()
         assert blk.shape[0] == self.n_own
         cols = blk.indices.astype(np.int64)
-        remote = (cols < lo) | (cols >= hi) | (cols < lo + int(self_halo))
+        remote = (cols < lo) | (cols >= hi) | self._self_halo_mask(cols - lo, self_halo)
         need = np.unique(cols[remote])                                   # sorted global ids = halo order
         owner = np.searchsorted(np.asarray(bounds[1:]), need, side='right')
         self.recv_counts = [int((owner == p).sum()) for p in range(self.world)]
@@ -60,11 +64,51 @@ class HaloPlan:
         # evaluated while the halo is in flight.  With node-range sharding of a graph in a locality-preserving order they
         # form one long run between two thin boundary bands (grid: all but the first and last lattice row of the shard).
         self.ranges = self._row_ranges(local, device)
+        # Shards whose halo columns are scattered over all rows (small-world shortcuts, power-law graphs) have no interior
+        # run to hide the exchange behind.  They evaluate A X in two phases instead, A = [A_own | A_halo]:
+        #   phase 1 (while the all-to-all-v is in flight)  S = A_own X                          own columns only
+        #   phase 2 (halo landed)                          the fused RHS on [I | A_halo] over the panels [S | X_halo]
+        # Row i of the phase-2 operator is {(i, 1.0)} followed by the row's halo entries: the fold starts from S_i and adds
+        # the halo products in the stored order - the very sequence of fma's the one-launch form performs (halo columns
+        # sort behind the own ones), so the two forms agree bit for bit (up to the sign of a zero).
+        self.two_phase = self._two_phase_ops(local, device) if two_phase and self.ranges is None and self.n_halo > 0 else None
         # tell every owner which of its rows we need (plan-time exchange of index lists)
         want = [need[owner == p] - bounds[p] for p in range(self.world)]     # owner-local row ids
         self.send_counts, send_idx = self._exchange_requests(want, device)
         self.send_idx = send_idx.to(torch.int32)                             # rows of OUR panel to pack, grouped by peer
         self.device = device
+        # Whether ANY rank moves a row: a collective may only be skipped on a fact every rank agrees on (a rank whose
+        # shard happens to have no cross-shard edge - a disconnected component, a block-diagonal graph - must still
+        # enter the all-to-all its peers enter, with zero counts).
+        tot = torch.tensor([self.n_halo + sum(self.send_counts)], dtype=torch.int64,
+                           device=device if dist.get_backend(group) == 'nccl' else torch.device('cpu'))
+        if self.world > 1:
+            dist.all_reduce(tot, group=group)
+        self.global_rows_moved = int(tot.item())
+
+    def _self_halo_mask(self, own_cols, spec):
+        """Own columns routed through the exchange by the self-halo hook: an int k = the first k own columns (a lattice
+        shard's boundary band), 'scatter:k' = k own columns drawn uniformly (seed 0) - a halo as scattered as a
+        small-world shard's, so that a single GPU exercises the two-phase evaluation against a real RCCL exchange."""
+        if isinstance(spec, str) and spec.startswith('scatter:'):
+            k = min(int(spec.split(':')[1]), self.n_own)
+            pick = np.zeros(self.n_own + 1, dtype=bool)
+            pick[np.random.RandomState(0).choice(self.n_own, size=k, replace=False)] = True
+            inside = (own_cols >= 0) & (own_cols < self.n_own)
+            return inside & pick[np.clip(own_cols, 0, self.n_own)]
+        return (own_cols >= 0) & (own_cols < int(spec or 0))
+
+    def _two_phase_ops(self, local, device):
+        n = self.n_own
+        own = local[:, :n].tocsr()
+        own_op = CsrOperator.from_scipy(own, device)
+        halo_part = local[:, n:].tocsr()
+        eye = sp.identity(n, dtype=np.float32, format='csr')
+        second = sp.hstack([eye, halo_part], format='csr')
+        second.sort_indices()
+        halo_op = CsrOperator.from_scipy(second, device)
+        halo_op.n_halo = self.n_halo                        # long-row plan: scratch behind the halo rows (as local_op)
+        return own_op, halo_op
 
     def _row_ranges(self, local, device):
         """[(a, b, operator of rows [a, b), needs_halo)] covering the shard, or None when no long interior run exists."""
@@ -114,14 +158,14 @@ class HaloPlan:
     def exchange(self, ops, X):
         """Returns the halo panel (n_halo x H) for the local panel X."""
         H = X.shape[1]
-        hub = getattr(self.local_op, 'hub', None)
+        hub = getattr(self.two_phase[1] if self.two_phase is not None else self.local_op, 'hub', None)
         if hub is not None and hub['H'] == H and hub['halo_S'].shape[0] == self.n_halo + hub['n'] and X.is_cuda:
             # long-row plan on this shard: the halo rows land in the head of the plan's [halo | hub rows] buffer (the
             # next exchange cannot start before every launch that reads it has produced its part of the next panel)
             halo = hub['halo_S'][:self.n_halo]
         else:
             halo = torch.empty((self.n_halo, H), dtype=X.dtype, device=X.device)
-        if self.n_halo == 0 and sum(self.send_counts) == 0:
+        if self.global_rows_moved == 0:                                   # nobody sends or receives: no collective on ANY rank
             return halo
         packed = ops.gather_rows(X, self.send_idx) if self.send_idx.numel() else X[:0]
         if X.is_cuda and dist.get_backend(self.group) != 'nccl':
@@ -139,10 +183,16 @@ class ShardedODEFunc(nn.Module):
     """ODEFunc on one shard: halo exchange, then the local fused RHS over [own | halo]
     (neural_dynamics.py:20-39 semantics on the global graph).
 
-    Overlap: when the shard has a long run of interior rows (HaloPlan.ranges) the exchange runs on a side stream while
-    the interior rows - a launch that needs no halo panel - are evaluated on the caller's stream; the two thin boundary
-    bands follow once the halo has landed.  Results are identical to the un-split evaluation (rows are independent).
-    The error-record launch of a dopri5 step stays un-split (its epilogue re-reads y1 by row index)."""
+    Overlap of the exchange (side stream) with compute (caller's stream), two forms:
+      * row split - the shard has a long run of interior rows (HaloPlan.ranges; lattices): the interior rows - a launch
+        that needs no halo panel - run during the exchange, the two thin boundary bands follow once the halo has landed.
+        Every launch mode is split, the dopri5 error record too: its launches take the rows of y1 they own explicitly
+        (`y1=`) and add their {sum, bad} into one device record (`accum=`), read back once.
+      * two-phase - the halo columns are scattered over all rows (HaloPlan.two_phase; small-world, power-law shards):
+        S = A_own X runs during the exchange, then ONE fused launch on [I | A_halo] over [S | X_halo] finishes A X and
+        carries the Linear and the RK epilogue.
+    Results are identical to the un-split evaluation of the shard (rows are independent; the two-phase fold performs the
+    same fma sequence)."""
 
     ndcn_autonomous = True
 
@@ -154,13 +204,14 @@ class ShardedODEFunc(nn.Module):
         self.nfe = 0
         self.halo_bytes = 0
         self.overlap = overlap and plan.ranges is not None
+        self.two_phase = overlap and plan.two_phase is not None
         self.comm = None                  # side stream of the exchange (created on first use, CUDA only)
         self.timing = None                # when a dict: accumulates {exchange_us, interior_us, exposed_us, n}
 
     # -- exchange on the side stream; returns (halo, event-or-None)
     def _start_exchange(self, x):
         self.halo_bytes += self.plan.bytes_per_exchange(x.shape[1])
-        if not (self.overlap and x.is_cuda):
+        if not ((self.overlap or self.two_phase) and x.is_cuda):
             return self.plan.exchange(self.ops, x), None
         import torch.cuda as tc
         if self.comm is None:
@@ -207,53 +258,88 @@ class ShardedODEFunc(nn.Module):
             t['n'] = t.get('n', 0) + 1
         return t
 
-    def _split_eval(self, x, call):
-        """call(op, X_halo, a, b) evaluates rows [a, b) of the shard; interior first, boundary after the exchange."""
+    def _overlapped(self, x, during, after):
+        """during() runs on the caller's stream while the exchange of x is in flight; after(halo) once it has landed."""
         halo, ev = self._start_exchange(x)
         t_int = None
         if self.timing is not None and ev is not None:
             import torch.cuda as tc
             t_int = (tc.Event(enable_timing=True), tc.Event(enable_timing=True))
             t_int[0].record()
-        for a, b, op, needs in self.plan.ranges:
-            if not needs:
-                call(op, None, a, b)
+        mid = during()
         self._finish_exchange(x, ev, t_int)
-        for a, b, op, needs in self.plan.ranges:
-            if needs:
-                call(op, halo, a, b)
+        return after(halo, mid)
+
+    def _split_eval(self, x, call):
+        """call(op, X_halo, a, b, first, last) evaluates rows [a, b) of the shard; interior first, boundary after the
+        exchange."""
+        rr = self.plan.ranges
+        inner = [r for r in rr if not r[3]]
+        outer = [r for r in rr if r[3]]
+
+        def during():
+            for i, (a, b, op, _) in enumerate(inner):
+                call(op, None, a, b, i == 0, False)
+
+        def after(halo, _):
+            out = None
+            for i, (a, b, op, _) in enumerate(outer):
+                out = call(op, halo, a, b, not inner and i == 0, i == len(outer) - 1)
+            return out
+        return self._overlapped(x, during, after)
 
     def forward(self, t, x):
         self.nfe += 1
         f = self.f
+        W, bias = f.wt.weight, f.wt.bias
         if f.no_graph:
-            return self.ops.rhs(None, x, f.wt.weight, f.wt.bias, no_graph=True, no_control=f.no_control)
+            return self.ops.rhs(None, x, W, bias, no_graph=True, no_control=f.no_control)
         if self.overlap:
             out = torch.empty_like(x)
-            self._split_eval(x, lambda op, halo, a, b: self.ops.rhs(op, x, f.wt.weight, f.wt.bias, no_control=f.no_control,
-                                                                    X_halo=halo, out=out[a:b]))
+            self._split_eval(x, lambda op, halo, a, b, first, last: self.ops.rhs(op, x, W, bias, no_control=f.no_control,
+                                                                                  X_halo=halo, out=out[a:b]))
             return out
+        if self.two_phase:
+            own_op, halo_op = self.plan.two_phase
+            return self._overlapped(x, lambda: self.ops.spmm(own_op, x),
+                                    lambda halo, S: self.ops.rhs(halo_op, S, W, bias, no_control=f.no_control, X_halo=halo))
         halo, _ = self._start_exchange(x)
-        return self.ops.rhs(self.plan.local_op, x, f.wt.weight, f.wt.bias, no_control=f.no_control, X_halo=halo)
+        return self.ops.rhs(self.plan.local_op, x, W, bias, no_control=f.no_control, X_halo=halo)
 
     def rhs_rk(self, x, mode, y0, kprev, cs, rtol, atol):
         """RHS + the stage algebra consuming it (core.Dopri5's `fused` protocol); the error record is summed
         over ranks here so every rank sees the same controller input."""
         self.nfe += 1
         f = self.f
-        if self.overlap and not f.no_graph and mode in ('combine', 'rk4'):
-            k, y_next = torch.empty_like(x), torch.empty_like(x)
-            self._split_eval(x, lambda op, halo, a, b: self.ops.rhs_rk(
-                op, x, f.wt.weight, f.wt.bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
-                no_control=f.no_control, X_halo=halo, out_K=k[a:b], out_y=y_next[a:b]))
-            return k, y_next
-        halo = None
-        if not f.no_graph:
-            halo, _ = self._start_exchange(x)
-            if self.comm is not None and x.is_cuda:
-                torch.cuda.current_stream(x.device).wait_stream(self.comm)
-        k, out = self.ops.rhs_rk(None if f.no_graph else self.plan.local_op, x, f.wt.weight, f.wt.bias, mode, y0, kprev, cs,
-                                 rtol, atol, no_graph=f.no_graph, no_control=f.no_control, X_halo=halo)
+        W, bias = f.wt.weight, f.wt.bias
+        if self.overlap and not f.no_graph:
+            k = torch.empty_like(x)
+            y_next = torch.empty_like(x) if mode in ('combine', 'rk4') else None
+
+            def call(op, halo, a, b, first, last):
+                if mode == 'error':
+                    return self.ops.rhs_rk(op, x, W, bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
+                                           no_control=f.no_control, X_halo=halo, out_K=k[a:b], y1=x[a:b], accum=not first,
+                                           fetch=last)[1]
+                self.ops.rhs_rk(op, x, W, bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
+                                no_control=f.no_control, X_halo=halo, out_K=k[a:b], out_y=y_next[a:b])
+            out = self._split_eval(x, call)
+            if mode != 'error':
+                return k, y_next
+        elif self.two_phase and not f.no_graph:
+            own_op, halo_op = self.plan.two_phase
+            k, out = self._overlapped(x, lambda: self.ops.spmm(own_op, x),
+                                      lambda halo, S: self.ops.rhs_rk(halo_op, S, W, bias, mode, y0, kprev, cs, rtol, atol,
+                                                                      no_control=f.no_control, X_halo=halo,
+                                                                      y1=x if mode == 'error' else None))
+            if mode != 'error':
+                return k, out
+        else:
+            halo = None
+            if not f.no_graph:
+                halo, _ = self._start_exchange(x)
+            k, out = self.ops.rhs_rk(None if f.no_graph else self.plan.local_op, x, W, bias, mode, y0, kprev, cs,
+                                     rtol, atol, no_graph=f.no_graph, no_control=f.no_control, X_halo=halo)
         if mode == 'error' and self.plan.world > 1:
             dev = x.device if dist.get_backend(self.plan.group) == 'nccl' else torch.device('cpu')
             v = torch.tensor([out[0], out[1]], dtype=torch.float64, device=dev)
@@ -320,9 +406,9 @@ class ShardedBench:
         from .torchdiffeq._impl import core
         if ops is None:
             from .ops import hip as ops
-        import os
         n_local = int(bounds[rank + 1] - bounds[rank])
-        self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=int(os.environ.get('NDCN_SELF_HALO', '0')))
+        sh = os.environ.get('NDCN_SELF_HALO', '0')
+        self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=sh if sh.startswith('scatter:') else int(sh))
         self.local_nnz = self.plan.local_nnz
         self.func = ShardedODEFunc(odefunc, self.plan, ops)
         self.dops = DistOps(ops, int(bounds[-1]), n_local, group)

@@ -27,19 +27,37 @@ def _autonomous(func):
 
 
 def _needs_grad(func, y0, probe=None):
-    """True when the solve must be differentiable: the state or the parameters of an nn.Module `func` require grad - or
-    `func` is a plain callable (lambda, bound method, closure over parameters) whose output carries autograd history:
-    the reference differentiates through any callable, so that case is detected by evaluating `probe()` = func(t0, y0)."""
+    """(needs_grad, probe output or None).  True when the solve must be differentiable: the state or the parameters of
+    an nn.Module `func` require grad - or `func` is a plain callable (lambda, bound method, closure over parameters)
+    whose output carries autograd history: the reference differentiates through any callable, so that case is detected
+    by evaluating `probe()` = func(t0, y0).  That evaluation is the solver's own first one (f0 of dopri5.py:78, k1 of
+    the first fixed-grid step): its output is handed back so that the solve REUSES it instead of evaluating twice
+    (user-side evaluation counters and RNG-consuming functions see exactly the reference's sequence of calls)."""
     if not torch.is_grad_enabled():
-        return False
+        return False, None
     if any(y.requires_grad for y in y0):
-        return True
+        return True, None
     if isinstance(func, torch.nn.Module):
-        return any(p.requires_grad for p in func.parameters())
+        return any(p.requires_grad for p in func.parameters()), None
     if probe is not None:
         out = probe()
-        return any(torch.is_tensor(o) and o.requires_grad for o in out)
-    return False
+        return any(torch.is_tensor(o) and o.requires_grad for o in out), out
+    return False, None
+
+
+def _reuse_first_evaluation(func, y0, out):
+    """func, except that its FIRST call - which every solver path makes at (t[0], y0) - returns `out`, the value the
+    differentiability probe already computed there."""
+    pending = [out]
+
+    def wrapped(t, y):
+        o = pending[0]
+        if o is not None:
+            pending[0] = None
+            if len(y) == len(y0) and all(a is b for a, b in zip(y, y0)):
+                return o
+        return func(t, y)
+    return wrapped
 
 
 def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_log=None):
@@ -68,7 +86,10 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
 
     for y in y0:
         _lib.require_device(y, 'state y0')
-    if _needs_grad(user_func, y0, probe=lambda: func(t[0].to(y0[0].dtype), y0)):
+    needs_grad, f0 = _needs_grad(user_func, y0, probe=lambda: func(t[0].to(y0[0].dtype), y0))
+    if f0 is not None:
+        func = _reuse_first_evaluation(func, y0, f0)
+    if needs_grad:
         from .autograd_path import odeint_with_grad
         sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func),
                                step_log=step_log)

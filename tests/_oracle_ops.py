@@ -62,9 +62,11 @@ class OracleOps:
             return out
         return x
 
+    _record = [0.0, 0.0]             # the "device" error record of split launches (accum / fetch of HipOps.rhs_rk)
+
     @classmethod
     def rhs_rk(cls, A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True):
         k = cls.rhs(A, X, W, b, no_graph=no_graph, no_control=no_control, X_halo=X_halo)
         ks = list(kprev) + [k]
         if out_K is not None:
@@ -74,7 +76,14 @@ class OracleOps:
             if out_y is not None:
                 out_y.copy_(y)
             return k, y
-        return k, cls.error(y0, X, ks, cs, rtol, atol)
+        if mode == 'rk4':
+            y = cls.fixed_stage(2 + len(kprev), y0, *ks, dt=cs[0])
+            if out_y is not None:
+                out_y.copy_(y)
+            return k, y
+        s, bad = cls.error(y0, X if y1 is None else y1, ks, cs, rtol, atol)
+        cls._record = [cls._record[0] + s, cls._record[1] + bad] if accum else [s, bad]
+        return k, (tuple(cls._record) if fetch else None)
 
     @staticmethod
     def gather_rows(X, idx):

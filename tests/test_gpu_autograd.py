@@ -308,3 +308,35 @@ def test_fixed_grid_training_with_odd_panel_sizes(dev, method):
     yo = orc.odeint(lambda tt, xx: orc.odefunc_rhs(A, xx, W, b), xc, t, method=method)
     yo[-1].square().sum().backward()
     assert rel(x.grad.cpu(), xc.grad) < 2e-4 and rel(f.wt.weight.grad.cpu(), W.grad) < 2e-4
+
+
+@pytest.mark.parametrize('method', ['dopri5', 'euler'])
+@pytest.mark.parametrize('trainable', [True, False])
+def test_plain_callable_is_evaluated_exactly_as_often_as_in_the_reference(dev, method, trainable):
+    """Under grad mode a non-Module callable is evaluated once at (t0, y0) to see whether its output carries autograd
+    history; the solve reuses that value as its own first evaluation, so a user-side counter (or an RNG-consuming
+    function) sees the reference's number of calls - not one more."""
+    from ndcn_amd import hip, CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    d = load_golden('fixed_rk4_equal')
+    A = CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)
+    Ao = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape'])
+    w = torch.tensor(0.7, device=dev, requires_grad=trainable)
+    wo = torch.tensor(0.7, requires_grad=trainable)
+    calls = {'hip': 0, 'ref': 0}
+
+    def f(t, x):
+        calls['hip'] += 1
+        return torch.tanh(hip.spmm(A, x.detach())) * w if not trainable else torch.tanh(x) * w
+
+    def fo(t, x):
+        calls['ref'] += 1
+        return torch.tanh(torch.sparse.mm(Ao, x)) * wo if not trainable else torch.tanh(x) * wo
+
+    t = torch.linspace(0., 1., 4)
+    x0 = T(d['x0'])
+    y = ode.odeint(f, x0.to(dev), t.to(dev), rtol=1e-3, atol=1e-4, method=method)
+    yo = orc.odeint(fo, x0, t, rtol=1e-3, atol=1e-4, method=method)
+    assert calls['hip'] == calls['ref'], calls
+    assert float((y.detach().cpu() - yo.detach()).abs().max()) < 1e-5
+    assert y.requires_grad == trainable

@@ -425,6 +425,97 @@ def test_fused_rhs_rk_with_halo_panel_equals_unsharded(dev, side, cut):
     assert abs(tot - float(ss)) <= 1e-6 * abs(float(ss)) and float(bad) == 0.0
 
 
+@pytest.mark.parametrize('graph', ['small_world', 'power_law', 'grid'])
+@pytest.mark.parametrize('no_control', [False, True])
+def test_two_phase_evaluation_equals_the_one_launch_form(dev, graph, no_control):
+    """Shards whose halo columns are scattered evaluate A X in two phases (sharding.HaloPlan.two_phase): S = A_own X while
+    the exchange is in flight, then the fused launch on [I | A_halo] over [S | X_halo] - with the error record formed
+    from y1 passed explicitly (the launch's X is the partial sum).  Same fma sequence per row as the one-launch form:
+    equal K / y_next, error sums to fp64 rounding, the non-finite count taken from y1."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H = 256
+    if graph == 'grid':
+        m = graphs.normalized_laplacian(graphs.grid_8_neighbor(50))
+        lo, hi = 0, 1250
+    else:
+        m = graphs.normalized_laplacian(graphs.make_graph(graph, 3000, seed=3)).tocsr()
+        lo, hi = (0, 1500) if graph == 'small_world' else (1500, 3000)
+    n = m.shape[0]
+    blk, halo_cols = _shard(m, lo, hi)
+    n_own, n_halo = hi - lo, halo_cols.size
+    own = blk[:, :n_own].tocsr()
+    second = sp.hstack([sp.identity(n_own, dtype=np.float32, format='csr'), blk[:, n_own:]], format='csr')
+    second.sort_indices()
+    A1, A_own, A2 = (CsrOperator.from_scipy(x, dev) for x in (blk, own, second))
+    g = torch.Generator().manual_seed(11)
+    X = torch.rand(n, H, generator=g).to(dev)
+    Xo, Xh = X[lo:hi].contiguous(), X[torch.from_numpy(halo_cols).to(dev)].contiguous()
+    y0 = torch.rand(n_own, H, generator=g).to(dev)
+    ks = [torch.randn(n_own, H, generator=g).to(dev) for _ in range(5)]
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    kw = dict(no_control=no_control)
+    S = hip.spmm(A_own, Xo)
+    assert torch.equal(hip.rhs(A2, S, W, b, X_halo=Xh, **kw), hip.rhs(A1, Xo, W, b, X_halo=Xh, **kw))
+    for npv in (0, 2, 5):
+        c = cs[:npv] + [cs[5]]
+        K1, y1_ = hip.rhs_rk(A1, Xo, W, b, 'combine', y0, ks[:npv], c, X_halo=Xh, **kw)
+        K2, y2_ = hip.rhs_rk(A2, S, W, b, 'combine', y0, ks[:npv], c, X_halo=Xh, **kw)
+        assert torch.equal(K1, K2) and torch.equal(y1_, y2_)
+    Xbad = Xo.clone()
+    Xbad[7, 5] = float('inf')
+    for Xin in (Xo, Xbad):
+        Sin = hip.spmm(A_own, Xin)
+        K1, (s1, b1) = hip.rhs_rk(A1, Xin, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3, X_halo=Xh, **kw)
+        K2, (s2, b2) = hip.rhs_rk(A2, Sin, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3, X_halo=Xh, y1=Xin, **kw)
+        assert b1 == b2 == (0.0 if Xin is Xo else 1.0)
+        if Xin is Xo:
+            assert torch.equal(K1, K2) and abs(s1 - s2) <= 1e-12 * abs(s1)
+    dt = np.float32(0.37)
+    for st in range(4):
+        K1, y1_ = hip.rhs_rk(A1, Xo, W, b, 'rk4', y0, ks[:st], [dt], X_halo=Xh, **kw)
+        K2, y2_ = hip.rhs_rk(A2, S, W, b, 'rk4', y0, ks[:st], [dt], X_halo=Xh, **kw)
+        assert torch.equal(K1, K2) and torch.equal(y1_, y2_)
+
+
+@pytest.mark.parametrize('no_control', [False, True])
+@pytest.mark.parametrize('H', [256, 64])
+def test_error_record_split_over_row_blocks_accumulates(dev, H, no_control):
+    """A shard's error launch split into row blocks (interior during the exchange, boundary bands after it): every launch
+    takes its rows of y1 explicitly and ADDS its record to the device buffer (NDCN_F_ACCUM); one read-back at the end."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    side = 40
+    n = side * side
+    m = graphs.normalized_laplacian(graphs.grid_8_neighbor(side)).tocsr()
+    g = torch.Generator().manual_seed(5)
+    X = torch.rand(n, H, generator=g).to(dev)
+    X[900, 3] = float('nan')
+    X[30, 1] = float('inf')
+    y0 = torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    for Xin, want_bad in ((torch.rand(n, H, generator=g).to(dev), 0.0), (X, 2.0)):
+        K, (s, bad) = hip.rhs_rk(CsrOperator.from_scipy(m, dev), Xin, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3,
+                                 no_control=no_control)
+        Ks = torch.empty_like(K)
+        cuts = [(0, 2 * side), (2 * side, n - 3 * side), (n - 3 * side, n)]
+        rec = None
+        for i, (a, e) in enumerate(cuts):
+            op = CsrOperator.from_scipy(m[a:e], dev)
+            op.lattice_hint = (a, n)
+            _, rec = hip.rhs_rk(op, Xin, W, b, 'error', y0[a:e], [k[a:e] for k in ks], cs, rtol=1e-2, atol=1e-3,
+                                no_control=no_control, out_K=Ks[a:e], y1=Xin[a:e], accum=i > 0, fetch=i == len(cuts) - 1)
+            assert (rec is None) == (i < len(cuts) - 1)
+        assert bad == rec[1] == want_bad
+        if want_bad == 0.0:
+            assert torch.equal(K, Ks) and abs(rec[0] - s) <= 1e-12 * abs(s)
+        else:
+            assert np.isnan(rec[0]) and np.isnan(s)
+
+
 def test_long_row_plan_equals_in_kernel_gather(dev):
     """Power-law graph: rows longer than the plan's threshold are evaluated by the segment SpMMs ahead of the fused
     kernel and enter it as one entry of a second panel - same results as gathering them inside the kernel."""
@@ -701,6 +792,13 @@ def test_packed_weight_cache_follows_weight_updates(dev):
         assert float((k2 - ref).abs().max()) < 1e-4 and not torch.equal(k1, k2)
         K, _ = hip.rhs_rk(A, X, W, b, 'combine', X, [], [np.float32(0.5)])
         assert torch.equal(K, k2)
+        # a write that bypasses the version counter is NOT seen (documented) until the cache is invalidated
+        W.data.mul_(2.0)
+        assert torch.equal(hip.rhs(A, X, W, b), k2)
+        from ndcn_amd.ops import invalidate_packed_weights
+        invalidate_packed_weights()
+        k3 = hip.rhs(A, X, W, b)
+        assert float((k3 - torch.relu(hip.spmm(A, X) @ W.t())).abs().max()) < 2e-4 and not torch.equal(k3, k2)
 
 
 def test_packed_weight_cache_is_not_fooled_by_address_reuse(dev):

@@ -40,8 +40,14 @@ def _worker(rank, world, port, case, ret):
             block = full[bounds[rank]:bounds[rank + 1]]
         n = full.shape[0]
         plan = sharding.HaloPlan(block, bounds, rank, cpu)
-        # the grid shard has one long interior run (exchange / compute overlap path), the small-world shard has none
+        # the grid shard has one long interior run (row-split overlap), the small-world shard has none and evaluates in
+        # two phases: own columns during the exchange, then [I | A_halo] over [S | X_halo]
         assert (plan.ranges is not None) == (case == 'grid')
+        assert (plan.two_phase is not None) == (case != 'grid')
+        if case != 'grid':
+            own_op, halo_op = plan.two_phase
+            assert own_op.shape == (plan.n_own, plan.n_own) and halo_op.shape == (plan.n_own, plan.n_own + plan.n_halo)
+            assert own_op.nnz + halo_op.nnz == plan.local_nnz + plan.n_own          # + the identity
         if case == 'grid':
             assert [r[3] for r in plan.ranges].count(False) == 1 and sum(r[1] - r[0] for r in plan.ranges) == plan.n_own
         x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
@@ -56,6 +62,14 @@ def _worker(rank, world, port, case, ret):
         # decreasing grid: the sign-flipped function must not take the fused (ReLU-epilogue) protocol
         y = sharding.sharded_odeint(OracleOps, f, plan, n, xl, torch.flip(t, [0]), rtol=1e-3, atol=1e-4, method='dopri5')
         out['dopri5_rev'] = y.detach().numpy()
+        if case != 'grid':
+            # the same solve through the one-launch form of the shard (no two-phase split): the same numbers
+            plain = sharding.HaloPlan(block, bounds, rank, cpu, two_phase=False)
+            assert plain.two_phase is None and plain.ranges is None
+            log1 = []
+            y = sharding.sharded_odeint(OracleOps, f, plain, n, xl, t, rtol=1e-3, atol=1e-4, method='dopri5', step_log=log1)
+            assert np.abs(y.detach().numpy() - out['dopri5']).max() < 1e-6
+            assert [r[2] for r in log1 if r[0] != 'nfe'] == [r[2] for r in out['dopri5_log']]
         out['halo'] = plan.n_halo
         out['W'] = f.wt.weight.detach().numpy()
         out['b'] = f.wt.bias.detach().numpy()
@@ -123,6 +137,11 @@ def _self_halo_worker(rank, world, port, ret):
         t = torch.linspace(0., 1., 3)
         y = sharding.sharded_odeint(OracleOps, f, plan, n, x, t, rtol=1e-3, atol=1e-4, method='dopri5')
         ret['y'] = y.detach().numpy()
+        # 'scatter:k': k own columns drawn at random go through the exchange - no interior run, two-phase evaluation
+        plan2 = sharding.HaloPlan(full, [0, n], 0, torch.device('cpu'), self_halo='scatter:30')
+        assert plan2.n_halo == 30 and plan2.ranges is None and plan2.two_phase is not None
+        y2 = sharding.sharded_odeint(OracleOps, f, plan2, n, x, t, rtol=1e-3, atol=1e-4, method='dopri5')
+        ret['y_scatter'] = y2.detach().numpy()
         ret['W'], ret['b'] = f.wt.weight.detach().numpy(), f.wt.bias.detach().numpy()
     finally:
         dist.destroy_process_group()
@@ -144,6 +163,61 @@ def test_single_rank_self_halo_drives_a_real_all_to_all():
     x = torch.rand(full.shape[0], 8, generator=torch.Generator().manual_seed(1))
     ref = orc.odeint(f, x, torch.linspace(0., 1., 3), rtol=1e-3, atol=1e-4, method='dopri5').numpy()
     assert np.abs(ret['y'] - ref).max() < 5e-6
+    assert np.abs(ret['y_scatter'] - ref).max() < 5e-6
+
+
+def _isolated_rank_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+        from ndcn_amd import graphs, sharding
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from _oracle_ops import OracleOps
+        H = 6
+        torch.manual_seed(0)
+        f = ODEFunc(H, None)
+        # block-diagonal graph: component 1 = rank 0's nodes alone, component 2 spans ranks 1 and 2
+        a = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(5, 6))
+        b = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(10, 6))
+        full = sp.block_diag([a, b], format='csr')
+        bounds = [0, 30, 60, 90]
+        plan = sharding.HaloPlan(full[bounds[rank]:bounds[rank + 1]], bounds, rank, torch.device('cpu'))
+        assert (plan.n_halo == 0 and sum(plan.send_counts) == 0) == (rank == 0)
+        assert plan.global_rows_moved > 0                        # rank 0 moves nothing itself but must enter the collective
+        x = torch.rand(90, H, generator=torch.Generator().manual_seed(1))
+        y = sharding.sharded_odeint(OracleOps, f, plan, 90, x[bounds[rank]:bounds[rank + 1]].contiguous(),
+                                    torch.linspace(0., 1., 3), rtol=1e-3, atol=1e-4, method='dopri5')
+        ret[rank] = {'y': y.detach().numpy(), 'W': f.wt.weight.detach().numpy(), 'b': f.wt.bias.detach().numpy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_cross_shard_edges_still_enters_the_collectives():
+    """Three ranks, rank 0's shard is a component of its own (no halo, nothing to send) while ranks 1 and 2 exchange:
+    a rank-local "nothing to move" test would let rank 0 skip the all-to-all its peers enter (hang under gloo, a
+    mis-paired collective under RCCL); the skip is decided on a fact all ranks agree on."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_isolated_rank_worker, args=(world, 29700 + os.getpid() % 40, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    from ndcn_amd import graphs
+    from oracle import ndcn_oracle as orc
+    full = sp.block_diag([graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(5, 6)),
+                          graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(10, 6))], format='csr')
+    A = orc.coo_from_csr(full.indptr, full.indices, full.data, full.shape)
+    f = orc.OracleODEFunc(A, torch.from_numpy(ret[0]['W']), torch.from_numpy(ret[0]['b']))
+    x = torch.rand(90, 6, generator=torch.Generator().manual_seed(1))
+    ref = orc.odeint(f, x, torch.linspace(0., 1., 3), rtol=1e-3, atol=1e-4, method='dopri5').numpy()
+    got = np.concatenate([ret[r]['y'] for r in range(world)], axis=1)
+    assert np.abs(got - ref).max() < 5e-6
 
 
 def _bench_runner_worker(rank, world, port, ret):
