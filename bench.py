@@ -15,8 +15,9 @@ N > 1    : weak scaling - the grid grows to (1000 N) x 1000, node-range sharded,
            Barabasi-Albert m=5, dopri5), C5 (dgnn hot path: Pubmed topology, no_control, dopri5 rtol=atol=.1, 16 ticks).
 
 Prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed on the
-launch stream during a second, instrumented pass over the same K steps) and `cpu_baseline` (the CPU oracle
-timed on a bounded sample, rank 0, N = 1 only).
+launch stream during a second, instrumented pass over the same K steps; `traffic` from the committed PMC summary of THIS
+configuration or null) and `cpu_baseline` (the CPU oracle timed on a bounded sample of this configuration, rank 0, N = 1 only).
+`--gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU).
 """
 import argparse
 import json
@@ -263,8 +264,26 @@ def build_workload(args, dev):
     return f, A, x0, kw, nnz, what + ', state X~U(0,1) seed 0, nn.Linear default init seed 0', step
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with one rank per GPU (what
+    the driver does itself for N > 1); rank 0's JSON line passes through on stdout, the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -391,35 +410,49 @@ def main():
             dom = max(breakdown, key=lambda k: breakdown[k]['ms_total'])
             i = _lib.PROF_KINDS.index(dom)
             cnt, ms, byt, fl = buf[4 * i:4 * i + 4]
-            # which roof is nearer: time the launch would take at the HBM peak vs at the fp32 MFMA peak
+            # which roof is nearer: time the launch would take at the HBM peak vs on the matrix cores.  The fused H = 256
+            # kernels issue bf16 MFMAs - 6 products of 3-way splits per fp32 product - so their matrix work is priced as
+            # 6 x the Linear's flops at the dense bf16 peak; every other kernel with a GEMM runs the fp32 MFMA.
             t_hbm = byt / cnt / (HBM_PEAK_GBS * 1e9)
-            t_mfma = fl / cnt / (MFMA_F32_PEAK_TFLOPS * 1e12)
+            split = dom == 'rhs_fused' and H == 256 and not f.no_control and not f.no_graph
+            lin_flops = 2.0 * n_local * H * H if split else 0.0
+            if split:
+                mfma_peak, mfma_what = MFMA_BF16_PEAK_TFLOPS, 'bf16 32x32x16, %d split products per fp32 product' % SPLIT_PRODUCTS
+                t_mfma = SPLIT_PRODUCTS * lin_flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+            else:
+                mfma_peak, mfma_what = MFMA_F32_PEAK_TFLOPS, 'fp32 32x32x2'
+                t_mfma = fl / cnt / (MFMA_F32_PEAK_TFLOPS * 1e12)
             if t_mfma > t_hbm:
-                ach = fl / ms / 1e9
-                roofline = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4)}
+                ach = (SPLIT_PRODUCTS * lin_flops * cnt if split else fl) / ms / 1e9
+                roofline = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                            'frac': round(ach / mfma_peak, 4)}
             else:
                 ach = byt / ms / 1e6
                 roofline = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': round(ach / HBM_PEAK_GBS, 4)}
-            traffic, src = pmc_traffic(KERNEL_FAMILY.get(dom, dom))
-            roofline.update({'traffic': traffic, 'traffic_source': src, 'kernel': dom, 'launches': int(cnt),
+            cfg_name = 'NC' if (args.config == 'M' and args.no_control) else args.config
+            traffic, src = pmc_traffic(KERNEL_FAMILY.get(dom, dom), cfg_name) if (world == 1 and not args.sharded) else (None, None)
+            roofline.update({'traffic': traffic, 'traffic_source': src, 'mfma_roof': mfma_what,
+                             'traffic_over_algorithmic': round(traffic / (byt / cnt), 3) if traffic else None,
+                             'kernel': dom, 'launches': int(cnt),
                              'avg_ms': round(ms / cnt, 4), 'alg_bytes_per_launch': round(byt / cnt),
                              'alg_flops_per_launch': round(fl / cnt),
                              'ms_at_hbm_peak': round(1e3 * t_hbm, 4), 'ms_at_mfma_peak': round(1e3 * t_mfma, 4),
                              'achieved_GBps': round(byt / ms / 1e6, 1), 'achieved_TFLOPs': round(fl / ms / 1e9, 2),
                              'share_of_kernel_time': round(breakdown[dom]['ms_total'] / tot_ms, 3)})
 
-    # device-to-device copy of one panel: the HBM rate this box actually sustains (report the fraction of
-    # the spec AND of the measured copy)
+    # device-to-device copy of a 1 GiB panel by the library's own streaming kernel (ndcn_copy_f32: 16 bytes per lane,
+    # non-temporal): the HBM rate this box actually sustains (report the fraction of the spec AND of the
+    # measured copy; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)
     if roofline is not None:
+        from ndcn_amd import hip as _hip
         src_p = torch.empty(256 << 20, dtype=torch.float32, device=dev)
         dst_p = torch.empty_like(src_p)
-        dst_p.copy_(src_p)
+        _hip.copy(src_p, out=dst_p)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            dst_p.copy_(src_p)
+            _hip.copy(src_p, out=dst_p)
         e1.record()
         torch.cuda.synchronize()
         copy_gbps = 5 * 2 * src_p.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
@@ -436,7 +469,8 @@ def main():
     if hasattr(runner, 'plan') and (world > 1 or runner.plan.n_halo > 0):
         hb = int(runner.plan.bytes_per_exchange(H))
         halo = {'bytes_received_per_rhs_per_gpu': hb, 'exchanges_per_step': 6,
-                'xgmi_peak_GBps_per_gpu': 7 * 153, 'overlapped_with_interior_rows': bool(runner.func.overlap)}
+                'xgmi_peak_GBps_per_gpu': 7 * 153, 'overlapped_with_interior_rows': bool(runner.func.overlap),
+                'two_phase_own_columns_under_exchange': bool(runner.func.two_phase)}
         # a short instrumented pass: per exchange, its duration on the side stream, the interior launch it hides
         # behind, and what the main stream still waited for (exposed)
         runner.func.timing = {}
@@ -476,8 +510,9 @@ def main():
         'device': device_info(),
         'halo_exchange': halo,
     }
-    if world == 1 and not args.no_cpu_baseline and args.config == 'M':
-        out['cpu_baseline'] = cpu_baseline(args.cpu_side, H, args.T, args.rtol, args.atol, args.cpu_threads, args.cpu_runs)
+    if world == 1 and not args.sharded and not args.no_cpu_baseline:
+        cfg_name = 'NC' if (args.config == 'M' and args.no_control) else args.config
+        out['cpu_baseline'] = cpu_baseline(cfg_name, H, args.T, args.rtol, args.atol, args.cpu_threads, args.cpu_runs, args.cpu_nodes)
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out), flush=True)

@@ -40,6 +40,8 @@ def build_parser():
     p.add_argument('--model', type=str, default='differential_gcn')
     p.add_argument('--iter', type=int, default=1, help='Number of experiments to conduct')
     p.add_argument('--dump', action='store_true', default=False)
+    p.add_argument('--delta', type=float, default=1.0, help='Scale of signals from neighborhoods (parsed and dumped like the reference; its code never reads it)')
+    p.add_argument('--sms', action='store_true', default=False, help='print the summary block once more at the end (the reference texts it; dgnn.py:286-289)')
     p.add_argument('--T', type=float, default=2., help='Terminal Time')
     p.add_argument('--time_tick', type=int, default=5)
     p.add_argument('--no_control', action='store_true', help='No control in DYnamics')

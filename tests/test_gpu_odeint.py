@@ -498,21 +498,25 @@ def test_two_rank_sharded_hip_path_equals_device_solver(dev, case):
 def test_bench_two_ranks_on_one_device(dev, config):
     """bench.py's N > 1 flow end to end (torchrun, sharded runner, barriers, max over ranks, one JSON line from rank 0)
     with two ranks on the one device of the test box (gloo hook); the driver runs it with nccl on 2/4/8 GPUs.  M: the
-    metric's grid (each rank builds its own lattice rows); C4: the small world of BASELINE config 4 (scattered halo)."""
+    metric's grid (each rank builds its own lattice rows), started as plain `python bench.py --gpus 2` - bench.py launches
+    its own ranks; C4: the small world of BASELINE config 4 (scattered halo: two-phase evaluation) under an explicit
+    torch.distributed.run, the form the driver uses."""
     import json
     import subprocess
     import sys
     env = dict(os.environ, NDCN_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', NDCN_C4_NODES='6000')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(29700 + os.getpid() % 200), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--side', '96',
-           '--steps', '6', '--warmup', '2', '--config', config]
+    launcher = [] if config == 'M' else ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                                         '127.0.0.1', '--master-port', str(29700 + os.getpid() % 200)]
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--side', '96', '--steps', '6',
+                                         '--warmup', '2', '--config', config]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 6 and out['value'] > 0 and out['scaling'] == 'weak'
     assert out['halo_exchange']['bytes_received_per_rhs_per_gpu'] > 0 and out['cpu_baseline'] is None
-    assert out['roofline']['kernel'] == 'rhs_fused'
+    assert out['halo_exchange']['two_phase_own_columns_under_exchange'] == (config == 'C4')
+    assert out['roofline']['kernel'] == 'rhs_fused' and out['roofline']['traffic'] is None
 
 
 def test_tuple_state_generic_path(dev):
