@@ -127,6 +127,10 @@ class AutogradOps:
         return _LinMap.apply(lambda y, *k: hip.combine(y, list(k), cs), w, y0, *ks)
 
     @staticmethod
+    def scale(x, w):
+        return _LinMap.apply(lambda xx: hip.scale(xx, w), (float(w),), x)
+
+    @staticmethod
     def fixed_stage(op, y, k1, k2=None, k3=None, k4=None, dt=0.0, out=None):
         w = _STAGE_W[op](float(dt))
         ins = [t for t in (y, k1, k2, k3, k4) if t is not None][:len(w)]

@@ -1,5 +1,6 @@
 // extern "C" boundary of libndcn_hip.so: argument validation + forwarding.  See include/ndcn_hip.h.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -13,6 +14,14 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int stream_grid_full(int64_t n_items, int block) {
+    static const bool full = [] { const char *e = getenv("NDCN_STREAM_FULL"); return !(e && e[0] == '0'); }();
+    if (!full) return stream_grid(n_items, block);
+    int64_t g = (n_items + block - 1) / block;
+    if (g > (1ll << 24)) g = 1ll << 24;             // (grid-stride loops take the rest)
+    return g < 1 ? 1 : (int)g;
 }
 
 static int check_csr(const ndcn_csr *A, const char *who) {

@@ -67,4 +67,11 @@ inline int stream_grid(int64_t n_items, int block) {
     return (int)g;
 }
 
+// Streaming elementwise kernels WITHOUT a reduction: one item per thread, as many workgroups as that takes.  Measured
+// (tools/micro/copy_lab.hip, 1 GiB float4 copy): one float4 per thread with non-temporal accesses 6.49 TB/s; the same
+// loop body on a persistent grid of 2048-16384 workgroups 4.1-5.7 TB/s - a grid-stride loop makes every wave of the chip
+// alternate between a burst of loads and a burst of stores in step, while the dispatcher's stream of short-lived
+// workgroups keeps reads and writes mixed.  NDCN_STREAM_FULL=0 restores the capped grid (A/B).
+int stream_grid_full(int64_t n_items, int block);
+
 }  // namespace ndcn

@@ -368,16 +368,8 @@ __global__ __launch_bounds__(256) void copy_kernel(float *__restrict__ dst, cons
     const cp_f32x4 *s = reinterpret_cast<const cp_f32x4 *>(src);
     cp_f32x4 *d = reinterpret_cast<cp_f32x4 *>(dst);
     const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const cp_f32x4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride);
-        const cp_f32x4 c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
-        __builtin_nontemporal_store(a, d + i);
-        __builtin_nontemporal_store(b, d + i + stride);
-        __builtin_nontemporal_store(c, d + i + 2 * stride);
-        __builtin_nontemporal_store(e, d + i + 3 * stride);
-    }
-    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
     for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) dst[j] = src[j];
 }
 
@@ -385,7 +377,7 @@ int copy_f32(float *dst, const float *src, int64_t n, hipStream_t st) {
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_STAGE, st, 8.0 * n, 0.0);
     const int64_t n4 = (aligned16(dst) && aligned16(src)) ? n / 4 : 0;
-    hipLaunchKernelGGL(copy_kernel, dim3(kCus * 8), dim3(256), 0, st, dst, src, n4, n);
+    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid_full(n4 ? n4 : n, 256)), dim3(256), 0, st, dst, src, n4, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -399,7 +391,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float *__restrict__ out, 
 int relu_bwd_f32(float *out, const float *g, const float *y, int64_t n, hipStream_t st) {
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_STAGE, st, 12.0 * n, 0.0);
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, out, g, y, n);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid_full(n, 256)), dim3(256), 0, st, out, g, y, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -410,7 +402,7 @@ int scale_f32(float *out, const float *x, float w, int64_t n, hipStream_t st) {
     // views at odd element offsets (torch.stack's backward hands out slices of one buffer): scalar path, like the
     // other panel kernels of this file
     const int64_t n4 = (aligned16(out) && aligned16(x)) ? n / 4 : 0;
-    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid((n4 ? n4 : n) + 1, 256)), dim3(256), 0, st, out, x, w, n4, n);
+    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid_full((n4 ? n4 : n) + 1, 256)), dim3(256), 0, st, out, x, w, n4, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -445,8 +437,8 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_combine: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_COMBINE, st, 4.0 * n * (n_k + 2), 2.0 * n * n_k);
-    if (vec) hipLaunchKernelGGL((combine_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, out, y0, t, n / 4);
-    else hipLaunchKernelGGL((combine_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, out, y0, t, n);
+    if (vec) hipLaunchKernelGGL((combine_kernel<true>), dim3(stream_grid_full(n / 4, 256)), dim3(256), 0, st, out, y0, t, n / 4);
+    else hipLaunchKernelGGL((combine_kernel<false>), dim3(stream_grid_full(n, 256)), dim3(256), 0, st, out, y0, t, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -516,8 +508,8 @@ int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, co
     p.y0 = y0; p.y1 = y1; p.f0 = h_k[0]; p.f1 = h_k[6]; p.dt = dt; p.a = a; p.b = b; p.c = c; p.d = d;
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_FIT, st, 4.0 * n * (2 + m + 4), 2.0 * n * (m + 16));
-    if (vec) hipLaunchKernelGGL((interp_fit_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
-    else hipLaunchKernelGGL((interp_fit_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    if (vec) hipLaunchKernelGGL((interp_fit_kernel<true>), dim3(stream_grid_full(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_fit_kernel<false>), dim3(stream_grid_full(n, 256)), dim3(256), 0, st, p, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -543,8 +535,8 @@ int interp_direct_f32(const float *y0, const float *y1, const float *const *h_k,
     p.out = out;
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_EVAL, st, 4.0 * n * (2 + m + 1), 2.0 * n * (m + 24));
-    if (vec) hipLaunchKernelGGL((interp_direct_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
-    else hipLaunchKernelGGL((interp_direct_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    if (vec) hipLaunchKernelGGL((interp_direct_kernel<true>), dim3(stream_grid_full(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_direct_kernel<false>), dim3(stream_grid_full(n, 256)), dim3(256), 0, st, p, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -575,8 +567,8 @@ int interp_direct_multi_f32(const float *y0, const float *y1, const float *const
     }
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_EVAL, st, 4.0 * n * (2 + m + nt), 2.0 * n * (m + 16 + 9 * nt));
-    if (vec) hipLaunchKernelGGL((interp_direct_multi_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
-    else hipLaunchKernelGGL((interp_direct_multi_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    if (vec) hipLaunchKernelGGL((interp_direct_multi_kernel<true>), dim3(stream_grid_full(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_direct_multi_kernel<false>), dim3(stream_grid_full(n, 256)), dim3(256), 0, st, p, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -587,8 +579,8 @@ int interp_eval_f32(const float *a, const float *b, const float *c, const float 
     const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d) && aligned16(e) && aligned16(out);
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_EVAL, st, 4.0 * n * 6, 9.0 * n);
-    if (vec) hipLaunchKernelGGL((interp_eval_kernel<true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, p, n / 4);
-    else hipLaunchKernelGGL((interp_eval_kernel<false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, p, n);
+    if (vec) hipLaunchKernelGGL((interp_eval_kernel<true>), dim3(stream_grid_full(n / 4, 256)), dim3(256), 0, st, p, n / 4);
+    else hipLaunchKernelGGL((interp_eval_kernel<false>), dim3(stream_grid_full(n, 256)), dim3(256), 0, st, p, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
@@ -596,8 +588,8 @@ int interp_eval_f32(const float *a, const float *b, const float *c, const float 
 template <int OP>
 static void launch_stage(bool vec, float *out, const float *y, const float *k1, const float *k2, const float *k3,
                          const float *k4, float dt, const float *dt_dev, int64_t n, hipStream_t st) {
-    if (vec) hipLaunchKernelGGL((fixed_stage_kernel<OP, true>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, dt_dev, n / 4);
-    else hipLaunchKernelGGL((fixed_stage_kernel<OP, false>), dim3(stream_grid(n, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, dt_dev, n);
+    if (vec) hipLaunchKernelGGL((fixed_stage_kernel<OP, true>), dim3(stream_grid_full(n / 4, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, dt_dev, n / 4);
+    else hipLaunchKernelGGL((fixed_stage_kernel<OP, false>), dim3(stream_grid_full(n, 256)), dim3(256), 0, st, out, y, k1, k2, k3, k4, dt, dt_dev, n);
 }
 
 int fixed_stage_f32(int op, float *out, const float *y, const float *k1, const float *k2, const float *k3,

@@ -471,7 +471,7 @@ int gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, fl
     ProfScope prof(PROF_GATHER, st, 8.0 * n_idx * H + 4.0 * n_idx, 0.0);
     if (H % 4 == 0 && aligned16(X) && aligned16(out)) {
         const int64_t total = n_idx * (H / 4);
-        hipLaunchKernelGGL(gather_rows4_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(gather_rows4_kernel, dim3(stream_grid_full(total, 256)), dim3(256), 0, st,
                            reinterpret_cast<const float4 *>(X), idx, n_idx, H / 4, reinterpret_cast<float4 *>(out));
     } else {
         const int64_t total = n_idx * (int64_t)H;

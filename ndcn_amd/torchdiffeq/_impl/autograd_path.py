@@ -28,6 +28,11 @@ f32 = np.float32
 def odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=False, step_log=None):
     if method == 'dopri5':
         return integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=autonomous, step_log=step_log, **options)
+    if method == 'adams':
+        # gradients flow through every panel operation of the accepted steps; the step sizes and orders the controller
+        # chose are constants of the graph (the reference's autograd also follows dt through the error ratios - a
+        # deviation that is stated, not hidden: DESIGN section 2)
+        return core.integrate_adams(autograd_ops, func, y0, t, rtol, atol, autonomous=autonomous, step_log=step_log, **options)
     if options:
         raise NotImplementedError('fixed-grid options %s: only the default grid (grid == t) is provided' % sorted(options))
     return core.integrate_fixed(autograd_ops, func, y0, t, method, autonomous=autonomous)

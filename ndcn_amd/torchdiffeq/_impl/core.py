@@ -4,6 +4,7 @@ Mirrors the control flow and scalar arithmetic of the reference's vendored torch
   input checks      torchdiffeq/_impl/misc.py:173-195, odeint.py:61-76
   fixed grid        torchdiffeq/_impl/solvers.py:79-99 ; fixed_grid.py:7-8,17-19,28-29 ; rk_common.py:72-78
   dopri5            torchdiffeq/_impl/dopri5.py:58-122 ; rk_common.py:22-61 ; misc.py:84-170 ; interp.py:5-65
+  adams             torchdiffeq/_impl/adams.py:11-170 (variable-coefficient Adams-Bashforth-Moulton)
 All per-element work is delegated to `ops` (one fused HIP kernel per reference op chain); what stays
 here is scalar: times and the step-size controller in float64, every quantity the reference forms as a
 0-d tensor of the state dtype (dt*beta, stage times, initial-step heuristic, interpolation abscissa)
@@ -46,9 +47,9 @@ IFACTOR = 10.0
 DFACTOR = float(f32(0.2))
 
 FIXED_METHODS = ('euler', 'midpoint', 'rk4')
-METHODS = FIXED_METHODS + ('dopri5',)
+METHODS = FIXED_METHODS + ('dopri5', 'adams')
 # methods the reference lists (odeint.py:8-17) but this build does not provide
-UNSUPPORTED = ('explicit_adams', 'fixed_adams', 'adams', 'tsit5')
+UNSUPPORTED = ('explicit_adams', 'fixed_adams', 'tsit5')
 
 
 def _nan_max(a, b):
@@ -193,13 +194,14 @@ def select_initial_step(ops, func, targ, t0, y0, order, rtol, atol, f0):
     return float(min(h100, h1)), bad0
 
 
-def optimal_step_size(dt, ratio32, safety=SAFETY, ifactor=IFACTOR, dfactor=DFACTOR):
-    """misc.py:160-170 in float64 with the reference's float32-born constants."""
+def optimal_step_size(dt, ratio32, safety=SAFETY, ifactor=IFACTOR, dfactor=DFACTOR, order=5):
+    """misc.py:160-170 in float64 with the reference's float32-born constants (the exponent 1 / order is born a
+    float32 tensor: `torch.tensor(1 / order).to(last_step)`)."""
     if ratio32 == 0:
         return dt * ifactor
     dfac = 1.0 if ratio32 < 1 else dfactor
     er = float(np.sqrt(f32(ratio32)))
-    expo = float(f32(0.2))
+    expo = float(f32(1.0 / order))
     factor = _nan_max(1.0 / ifactor, _nan_min(math.pow(er, expo) / safety if er == er else float('nan'), 1.0 / dfac))
     return dt / factor
 
@@ -394,6 +396,166 @@ def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=No
     solver = Dopri5(ops, func, y0, rtol, atol, autonomous=autonomous, max_num_steps=opt['max_num_steps'],
                     first_step=opt['first_step'], fused=fused, safety=opt['safety'], ifactor=opt['ifactor'],
                     dfactor=opt['dfactor'])
+    solver.begin(tt[0])
+    sol = [y0]
+    for i in range(1, len(tt)):
+        sol.append(solver.advance(tt[i]))
+    if step_log is not None:
+        step_log.extend(solver.log)
+        step_log.append(('nfe', solver.nfe))
+    return sol
+
+
+# ---------------------------------------------------------------------------------------------------
+# adams: variable-coefficient Adams-Bashforth-Moulton, orders 1..12          torchdiffeq/_impl/adams.py
+# ---------------------------------------------------------------------------------------------------
+
+# adams.py:11-15
+GAMMA_STAR = [
+    1, -1 / 2, -1 / 12, -1 / 24, -19 / 720, -3 / 160, -863 / 60480, -275 / 24192, -33953 / 3628800, -0.00789255,
+    -0.00678585, -0.00592406, -0.00523669, -0.0046775, -0.00421495, -0.0038269
+]
+ADAMS_OPTIONS = ('implicit', 'max_order', 'safety', 'ifactor', 'dfactor')
+
+
+def adams_g_and_beta(prev_t, next_t, k):
+    """The scalar half of adams.py:26-50 in float64 (numpy scalars round like torch's float64 0-d tensors): the g
+    coefficients g[0..k] and the factors beta[1..k-1] that turn implicit phi_j into explicit ones."""
+    curr_t = prev_t[0]
+    dt = next_t - prev_t[0]
+    g = np.empty(k + 1, dtype=np.float64)
+    g[0] = 1.0
+    c = 1.0 / np.arange(1, k + 2, dtype=np.float64)
+    beta = np.float64(1.0)
+    betas = [None]
+    for j in range(1, k):
+        beta = (next_t - prev_t[j - 1]) / (curr_t - prev_t[j]) * beta
+        betas.append(beta)
+        c = c[:-1] - c[1:] if j == 1 else c[:-1] - c[1:] * dt / (next_t - prev_t[j - 1])
+        g[j] = c[0]
+    c = c[:-1] - c[1:] * dt / (next_t - prev_t[k - 1])
+    g[k] = c[0]
+    return g, betas
+
+
+class Adams:
+    """adams.py:62-170 as a resumable object (begin = before_integrate, advance = advance).  All per-element work goes
+    through three panel ops of `ops`: combine (y + sum c_j k_j: predictor, corrector, and - with c = -1 - the phi
+    differences), scale (beta * phi) and error (the mean squared error ratio of ONE scaled phi); the g / beta
+    coefficients, the order selection and the step-size controller are scalar host code in the reference's dtypes.
+    Quirks kept: the state that is carried on (and returned at the ticks) is the PREDICTOR value p_next, not the
+    corrected y_next (:170); every tick is a step end (next_t is clipped to it, :105-106) - no dense output."""
+
+    def __init__(self, ops, func, y0, rtol, atol, autonomous=False, max_order=12, safety=SAFETY, ifactor=IFACTOR,
+                 dfactor=DFACTOR):
+        self.ops, self.func = ops, func
+        self.y = y0
+        self.rtol, self.atol = per_state_tolerance(rtol, len(y0)), per_state_tolerance(atol, len(y0))
+        self.max_order = int(max(1, min(max_order, 12)))
+        self.safety, self.ifactor, self.dfactor = safety, ifactor, dfactor
+        self.targ = TimeArg(y0[0], autonomous)
+        self.n_elem = [_numel(ops, y) for y in y0]
+        self.log = []                 # (t_n, attempted next_t, order, accepted, max error ratio, next next_t)
+        self.nfe = 0
+
+    def _f(self, tval, y):
+        self.nfe += 1
+        return self.func(self.targ(tval), y)
+
+    def begin(self, t0):
+        t0 = np.float64(t0)
+        f0 = self._f(f32(t0), self.y)
+        self.prev_t, self.prev_f, self.phi = [t0], [f0], [f0]       # index 0 = newest (the reference's deque.appendleft)
+        h, _ = select_initial_step(self.ops, lambda tt, yy: self._count(tt, yy), self.targ, t0, self.y, 2,
+                                   self.rtol[0], self.atol[0], f0)
+        self.next_t = t0 + np.float64(h)
+        self.order = 1
+
+    def _count(self, tt, yy):
+        self.nfe += 1
+        return self.func(tt, yy)
+
+    def _ratio(self, coef, phis, y0, y1):
+        """misc.py:146-157 on coef * phi per state tensor: float32 means."""
+        out = []
+        for p, a, b, n, rt, at in zip(phis, y0, y1, self.n_elem, self.rtol, self.atol):
+            s, _ = self.ops.error(a, b, [p], [coef], rt, at)
+            out.append(f32(s / n) if n else f32('nan'))
+        return out
+
+    def step(self, final_t):
+        ops = self.ops
+        y0, prev_t, order = self.y, self.prev_t, self.order
+        next_t = final_t if self.next_t > final_t else self.next_t
+        assert next_t == next_t, 'adams: step size became NaN'       # (the reference would loop forever here)
+        dt = next_t - prev_t[0]
+        dt32 = f32(dt)
+        g64, betas = adams_g_and_beta(prev_t, next_t, order)
+        g = g64.astype(f32)
+        # explicit phi (:37-42): phi_0 as is, phi_j scaled by beta_j cast to the state dtype
+        ephi = [self.phi[0]] + [tuple(ops.scale(p, f32(betas[j])) for p in self.phi[j]) for j in range(1, order)]
+        m = max(1, order - 1)
+        cs = [f32(dt32 * g[j]) for j in range(m)]
+        p_next = tuple(ops.combine(y_, [ephi[j][q] for j in range(m)], cs) for q, y_ in enumerate(y0))
+        nf = self._f(f32(next_t), p_next)
+        # implicit phi of the predictor (:53-59): phi_j = phi_{j-1} - explicit phi_{j-1}
+        k = min(len(ephi) + 1, order + 1)
+        iphi_p = [nf]
+        for j in range(1, k):
+            iphi_p.append(tuple(ops.combine(a, [b], [f32(-1.0)]) for a, b in zip(iphi_p[j - 1], ephi[j - 1])))
+        y_next = tuple(ops.combine(p_, [ip], [f32(dt32 * g[order - 1])]) for p_, ip in zip(p_next, iphi_p[order - 1]))
+        error_k = self._ratio(f32(dt32 * f32(g[order] - g[order - 1])), iphi_p[order], y0, y_next)
+        accept = all(bool(r <= 1) for r in error_k)
+        worst = f32('nan') if any(np.isnan(r) for r in error_k) else max(error_k)
+        if not accept:
+            dt_next = optimal_step_size(dt, worst, self.safety, self.ifactor, self.dfactor, order=order)
+            self.log.append((float(prev_t[0]), float(next_t), order, 0.0, float(worst), float(prev_t[0] + dt_next)))
+            self.next_t = prev_t[0] + np.float64(dt_next)
+            return False
+        nf = self._f(f32(next_t), y_next)
+        k = min(len(ephi) + 1, order + 2)
+        iphi = [nf]
+        for j in range(1, k):
+            iphi.append(tuple(ops.combine(a, [b], [f32(-1.0)]) for a, b in zip(iphi[j - 1], ephi[j - 1])))
+        next_order = order
+        if len(prev_t) <= 4 or order < 3:
+            next_order = min(order + 1, 3, self.max_order)
+        else:
+            e1 = self._ratio(f32(dt32 * f32(g[order - 1] - g[order - 2])), iphi_p[order - 1], y0, y_next)
+            e2 = self._ratio(f32(dt32 * f32(g[order - 2] - g[order - 3])), iphi_p[order - 2], y0, y_next)
+            if min(e1 + e2) < max(error_k):
+                next_order = order - 1
+            elif order < self.max_order:
+                e3 = self._ratio(f32(dt32 * f32(GAMMA_STAR[order])), iphi_p[order], y0, y_next)
+                if max(e3) < max(error_k):
+                    next_order = order + 1
+        dt_next = dt if next_order > order else optimal_step_size(dt, worst, self.safety, self.ifactor, self.dfactor,
+                                                                  order=order + 1)
+        self.log.append((float(prev_t[0]), float(next_t), order, 1.0, float(worst), float(next_t + dt_next)))
+        self.prev_f = ([nf] + self.prev_f)[:self.max_order + 1]
+        self.prev_t = ([next_t] + prev_t)[:self.max_order + 1]
+        self.y, self.next_t, self.phi, self.order = p_next, next_t + np.float64(dt_next), iphi[:self.max_order], next_order
+        return True
+
+    def advance(self, final_t):
+        final_t = np.float64(final_t)
+        while final_t > self.prev_t[0]:
+            self.step(final_t)
+        assert final_t == self.prev_t[0]
+        return self.y
+
+
+def integrate_adams(ops, func, y0, t, rtol, atol, autonomous=False, step_log=None, **options):
+    """solvers.py:25-33 for method 'adams'."""
+    assert_increasing(t)
+    unused = {k: v for k, v in options.items() if k not in ADAMS_OPTIONS}
+    if unused:
+        warnings.warn('VariableCoefficientAdamsBashforth: Unexpected arguments {}'.format(unused))
+    tt = t.detach().to('cpu', torch.float64).numpy()
+    solver = Adams(ops, func, y0, rtol, atol, autonomous=autonomous, max_order=options.get('max_order', 12),
+                   safety=controller_constant(options.get('safety', 0.9)),
+                   ifactor=controller_constant(options.get('ifactor', 10.0)),
+                   dfactor=controller_constant(options.get('dfactor', 0.2)))
     solver.begin(tt[0])
     sol = [y0]
     for i in range(1, len(tt)):

@@ -65,8 +65,8 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
 
     Same signature, defaults, return layout and exceptions as the reference (odeint.py:20-76):
     TypeError for non-float y0 / t, ValueError for `options` without `method`, KeyError for an unknown
-    method, AssertionError for a non-monotone t.  Deviations: only dopri5 / euler / midpoint / rk4 are
-    provided (the others raise NotImplementedError); the state must be float32 on a ROCm device;
+    method, AssertionError for a non-monotone t.  Deviations: dopri5 / adams / euler / midpoint / rk4 are
+    provided (tsit5 / explicit_adams / fixed_adams raise NotImplementedError); the state must be float32 on a ROCm device;
     `step_log` (a list) optionally receives the dopri5 per-attempt log.
     """
     user_func = func
@@ -81,7 +81,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
         method = 'dopri5'
     if method in core.UNSUPPORTED:
         raise NotImplementedError('method %r of the reference is outside the accelerated path '
-                                  '(dopri5, euler, midpoint, rk4 are provided)' % method)
+                                  '(dopri5, adams, euler, midpoint, rk4 are provided)' % method)
     method = SOLVERS[method]                     # KeyError for an unknown name, as the reference's dict lookup
 
     for y in y0:
@@ -98,6 +98,9 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
     elif method == 'dopri5':
         sol = core.integrate_dopri5(hip, func, y0, t, rtol, atol, autonomous=_autonomous(user_func),
                                     step_log=step_log, **options)
+    elif method == 'adams':
+        sol = core.integrate_adams(hip, func, y0, t, rtol, atol, autonomous=_autonomous(user_func),
+                                   step_log=step_log, **options)
     else:
         if options:
             raise NotImplementedError('fixed-grid options %s: only the default grid (grid == t) is provided'
@@ -126,7 +129,7 @@ def _device_resident_ok(user_func, tensor_input, y0, t, method, options):
         return False
     if bool((t[1:] < t[:-1]).any()):            # decreasing grids go through the generic sign flip
         return False
-    return True
+    return method != 'adams'                    # adams steps through the host logic (core.Adams) over the panel kernels
 
 
 class DeviceSolver:

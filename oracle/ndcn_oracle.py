@@ -241,7 +241,7 @@ def _as_state(y0):
 
 
 def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_log=None):
-    """Restatement of odeint.py:20-76 for methods dopri5 / euler / midpoint / rk4.
+    """Restatement of odeint.py:20-76 for methods dopri5 / euler / midpoint / rk4 / adams.
 
     `step_log`, when a list, receives one (t0, dt, accepted, mean_sq_error_ratio, dt_next) row per
     attempted dopri5 step - the same quantities tools/gen_golden.py records from the reference.
@@ -274,6 +274,9 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
                                                              if k in ('safety', 'ifactor', 'dfactor')})
     elif method in ('euler', 'midpoint', 'rk4'):
         sol = _fixed_grid(fn, state, t, method)
+    elif method == 'adams':
+        sol = _adams(fn, state, t, rtol, atol, step_log, **{k: v for k, v in options.items()
+                                                           if k in ('max_order', 'safety', 'ifactor', 'dfactor')})
     else:
         raise KeyError(method)
     out = [torch.stack([s[i] for s in sol]) for i in range(len(state))]
@@ -401,6 +404,129 @@ def _dopri5(fn, y_init, t, rtol, atol, step_log, safety=0.9, ifactor=10.0, dfact
         for _ in range(2, 5):
             xs.append(xs[-1] * x)
         sol.append([_dot(cs, reversed(xs)) for cs in zip(*coeff)])
+    return sol
+
+
+# ------------------------------------------------------------------------------------------------
+# variable-coefficient Adams-Bashforth-Moulton (method 'adams')   torchdiffeq/_impl/adams.py:11-170
+# ------------------------------------------------------------------------------------------------
+
+# adams.py:11-15
+GAMMA_STAR = [
+    1, -1 / 2, -1 / 12, -1 / 24, -19 / 720, -3 / 160, -863 / 60480, -275 / 24192, -33953 / 3628800, -0.00789255,
+    -0.00678585, -0.00592406, -0.00523669, -0.0046775, -0.00421495, -0.0038269
+]
+
+
+def _adams_g_and_explicit_phi(prev_t, next_t, implicit_phi, k):
+    """adams.py:26-50: the g coefficients (float64) and the explicit phi of the divided-difference form."""
+    curr_t = prev_t[0]
+    dt = next_t - prev_t[0]
+    g = torch.empty(k + 1).to(prev_t[0])
+    explicit_phi = [implicit_phi[0]]
+    beta = torch.tensor(1).to(prev_t[0])
+    g[0] = 1
+    c = 1 / torch.arange(1, k + 2).to(prev_t[0])
+    for j in range(1, k):
+        beta = (next_t - prev_t[j - 1]) / (curr_t - prev_t[j]) * beta
+        cast = beta.to(implicit_phi[j][0])
+        explicit_phi.append([p * cast for p in implicit_phi[j]])
+        c = c[:-1] - c[1:] if j == 1 else c[:-1] - c[1:] * dt / (next_t - prev_t[j - 1])
+        g[j] = c[0]
+    c = c[:-1] - c[1:] * dt / (next_t - prev_t[k - 1])
+    g[k] = c[0]
+    return g, explicit_phi
+
+
+def _adams_implicit_phi(explicit_phi, f_n, k):
+    """adams.py:53-59."""
+    k = min(len(explicit_phi) + 1, k)
+    out = [f_n]
+    for j in range(1, k):
+        out.append([a - b for a, b in zip(out[j - 1], explicit_phi[j - 1])])
+    return out
+
+
+def _adams_step_size(last_step, ratios, safety, ifactor, dfactor, order):
+    """misc.py:160-170 with the `order` argument adams passes (the exponent is born a float32 tensor)."""
+    worst = max(ratios)
+    if worst == 0:
+        return last_step * ifactor
+    if worst < 1:
+        dfactor = torch.tensor(1, dtype=torch.float64)
+    er = torch.sqrt(worst).to(last_step)
+    expo = torch.tensor(1 / order).to(last_step)
+    factor = torch.max(1 / ifactor, torch.min(er ** expo / safety, 1 / dfactor))
+    return last_step / factor
+
+
+def _adams(fn, y_init, t, rtol, atol, step_log, max_order=12, safety=0.9, ifactor=10.0, dfactor=0.2):
+    """adams.py:62-170.  `step_log` rows: (t_n, attempted next_t, order, accepted, max error ratio, next next_t)."""
+    n = len(y_init)
+    rtol = list(rtol) if isinstance(rtol, (list, tuple)) else [rtol] * n
+    atol = list(atol) if isinstance(atol, (list, tuple)) else [atol] * n
+    max_order = int(max(1, min(max_order, 12)))
+    safety, ifactor, dfactor = ((v if torch.is_tensor(v) else torch.tensor(v)).type(torch.float64) for v in (safety, ifactor, dfactor))
+    t = t.to(torch.float64)                                                    # solvers.py:28
+    # before_integrate (:82-94)
+    f0 = fn(t[0].type_as(y_init[0]), y_init)
+    prev_t, prev_f, phi = [t[0]], [f0], [f0]                                    # index 0 = newest (deque.appendleft)
+    first_step = _initial_step(fn, t[0], y_init, 2, rtol[0], atol[0], f0).to(t)
+    y_n, next_t, order = y_init, t[0] + first_step, 1
+    sol = [y_init]
+
+    def ratio(coef, phis, tol):                                                 # misc.py:146-157 on dt * coef * phi
+        out = []
+        for p, tl in zip(phis, tol):
+            r = (coef * p) / tl
+            out.append(torch.mean(r * r))
+        return out
+
+    for i in range(1, len(t)):
+        final_t = t[i]
+        while final_t > prev_t[0]:                                              # advance (:96-101)
+            y0 = y_n
+            nt = final_t if next_t > final_t else next_t
+            dt = nt - prev_t[0]
+            dt_cast = dt.to(y0[0])
+            g, ephi = _adams_g_and_explicit_phi(prev_t, nt, phi, order)
+            g = g.to(y0[0])
+            m = max(1, order - 1)
+            p_next = [y_ + _wsum(dt_cast, g[:m], [ephi[j][q] for j in range(m)]) for q, y_ in enumerate(y0)]
+            nf = fn(nt.to(p_next[0]), p_next)
+            iphi_p = _adams_implicit_phi(ephi, nf, order + 1)
+            y_next = [p_ + dt_cast * g[order - 1] * ip for p_, ip in zip(p_next, iphi_p[order - 1])]
+            tol = [a_ + r_ * torch.max(torch.abs(u), torch.abs(v)) for a_, r_, u, v in zip(atol, rtol, y0, y_next)]
+            error_k = ratio(dt_cast * (g[order] - g[order - 1]), iphi_p[order], tol)
+            accept = bool((torch.tensor(error_k) <= 1).all())
+            if not accept:
+                dt_next = _adams_step_size(dt, error_k, safety, ifactor, dfactor, order)
+                if step_log is not None:
+                    step_log.append((float(prev_t[0]), float(nt), order, 0.0, float(max(error_k)), float(prev_t[0] + dt_next)))
+                next_t = prev_t[0] + dt_next
+                continue
+            nf = fn(nt.to(p_next[0]), y_next)
+            iphi = _adams_implicit_phi(ephi, nf, order + 2)
+            next_order = order
+            if len(prev_t) <= 4 or order < 3:
+                next_order = min(order + 1, 3, max_order)
+            else:
+                e1 = ratio(dt_cast * (g[order - 1] - g[order - 2]), iphi_p[order - 1], tol)
+                e2 = ratio(dt_cast * (g[order - 2] - g[order - 3]), iphi_p[order - 2], tol)
+                if min(e1 + e2) < max(error_k):
+                    next_order = order - 1
+                elif order < max_order:
+                    e3 = ratio(dt_cast * GAMMA_STAR[order], iphi_p[order], tol)
+                    if max(e3) < max(error_k):
+                        next_order = order + 1
+            dt_next = dt if next_order > order else _adams_step_size(dt, error_k, safety, ifactor, dfactor, order + 1)
+            if step_log is not None:
+                step_log.append((float(prev_t[0]), float(nt), order, 1.0, float(max(error_k)), float(nt + dt_next)))
+            prev_f = ([nf] + prev_f)[:max_order + 1]
+            prev_t = ([nt] + prev_t)[:max_order + 1]
+            y_n, next_t, phi, order = p_next, nt + dt_next, iphi[:max_order], next_order      # NB the PREDICTOR value is kept (:170)
+        assert final_t == prev_t[0]
+        sol.append(y_n)
     return sol
 
 

@@ -86,6 +86,10 @@ class OracleOps:
         return k, (tuple(cls._record) if fetch else None)
 
     @staticmethod
+    def scale(x, w):
+        return _c(w) * x
+
+    @staticmethod
     def gather_rows(X, idx):
         return X[idx.long()]
 

@@ -89,6 +89,30 @@ def test_dopri5_golden(dev, name, as_module):
     assert np.allclose(log[:, 3], ref[:, 3], rtol=5e-3, atol=1e-12)
 
 
+@pytest.mark.parametrize('as_module', [True, False], ids=['module', 'callable'])
+@pytest.mark.parametrize('name', names('adams_*.npz'))
+def test_adams_golden(dev, name, as_module):
+    """method='adams' (adams.py:62-170) on the HIP panel kernels - combine for predictor / corrector / phi differences,
+    scale for the explicit phi, the error-ratio reduction - against the reference's own run: same orders, same accept /
+    reject sequence, same number of evaluations, trajectory within the path's tolerance."""
+    from ndcn_amd import torchdiffeq as ode
+    d = load_golden(name)
+    f = make_func(d, dev, as_module, no_control=bool(d['no_control']))
+    log = []
+    opts = {k[4:]: (int(v) if k == 'opt_max_order' else float(v)) for k, v in d.items() if k.startswith('opt_')} or None
+    with torch.no_grad():
+        y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), rtol=float(d['rtol']), atol=float(d['atol']), method='adams',
+                       options=opts, step_log=log)
+    nfe = dict([log.pop()])['nfe']
+    ref, got = d['steplog'], np.array(log)
+    check_traj(y.cpu().numpy(), d['traj'], l1=1e-5, mx=2e-4)
+    if name != 'adams_tight':                               # (rtol 1e-5: a 1-ulp difference of an error ratio near 1 may flip a decision)
+        assert got.shape[0] == ref.shape[0] and nfe == int(d['nfe'])
+        assert np.array_equal(got[:, 2:4], ref[:, 2:4])
+    else:
+        assert abs(nfe - int(d['nfe'])) <= 0.15 * int(d['nfe'])
+
+
 @pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4', 'dopri5'])
 def test_lattice_h256_solvers_against_oracle(dev, method):
     """H = 256 on a lattice: the device-resident solver runs rhs_fused3 (group-record plan) with the stage algebra of every

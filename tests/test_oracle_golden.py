@@ -70,6 +70,23 @@ def test_dopri5(name):
     assert np.abs(y.numpy() - d['traj']).max() <= TOL * scale
 
 
+@pytest.mark.parametrize('name', names('adams_*.npz'))
+def test_adams(name):
+    """The oracle's variable-coefficient Adams restatement against the reference's own run (adams.py:62-170): the
+    trajectory bit for bit, and every attempted step's (t_n, next_t, order, accepted, following next_t)."""
+    d = load_golden(name)
+    f = orc.OracleODEFunc(op_from(d), T(d['W']), T(d['b']), no_control=bool(d['no_control']))
+    log = []
+    opts = {k[4:]: (int(v) if k == 'opt_max_order' else float(v)) for k, v in d.items() if k.startswith('opt_')} or None
+    y = orc.odeint(f, T(d['x0']), T(d['t']), rtol=float(d['rtol']), atol=float(d['atol']), method='adams', step_log=log,
+                   options=opts)
+    ref, log = d['steplog'], np.array(log)
+    assert f.nfe == int(d['nfe']) and log.shape[0] == ref.shape[0]
+    assert np.array_equal(log[:, [0, 1, 2, 3, 5]], ref)
+    assert np.array_equal(y.numpy(), d['traj'])
+    assert len(set(ref[:, 2])) >= 2                        # the order really varies
+
+
 @pytest.mark.parametrize('name', names('ndcn_*.npz'))
 def test_ndcn_end_to_end(name):
     d = load_golden(name)

@@ -19,6 +19,7 @@ Fixture families:
   G10 resgcn_*.npz    RowNorm / ResBlock / GCN / resGCN     ode_gcn.py:9-60, models.py:8-47, dgnn.py:129-140
   G11 layout_*.npz    generate_node_mapping degree/community utils_in_learn_dynamics.py:212-230 (+ the P A P^T of :233-247)
   G12 gconv_dense.npz GraphConvolution (dense A, flattened)  neural_dynamics.py:163-176
+  G13 adams_*.npz     odeint adams + per-attempt step log    torchdiffeq/_impl/adams.py:62-170
 """
 import os
 import sys
@@ -494,7 +495,42 @@ def gen_gconv():
         save('gconv_dense', A=A, x=x, W=gc.fc.weight, b=gc.fc.bias, out=gc(x, A), W_nb=gc_nb.fc.weight, out_nb=gc_nb(x, A))
 
 
+def gen_adams():
+    """G13: the variable-coefficient Adams-Bashforth-Moulton solver (adams.py) on the NDCN ODEFunc, with one row per
+    attempted step {t_n, attempted next_t, order, accepted, next next_t} recorded by wrapping (not editing) the
+    reference's step method: loose / tight tolerances (orders 1-5, rejected steps), a dense tick grid (next_t clipped
+    to every tick), max_order 2, the no_control right-hand side."""
+    import torchdiffeq._impl.adams as ref_adams
+    _, OM = grid_operator(20)
+    OMs = ref_u.torch_sensor_to_torch_sparse_tensor(OM)
+    cases = [('loose', .01, .001, torch.linspace(0., 5., 6), {}, {}),
+             ('tight', 1e-5, 1e-7, torch.linspace(0., 2., 5), {}, {}),
+             ('ticks', 1e-3, 1e-4, torch.linspace(0., 5., 30), {}, {}),
+             ('order2', 1e-4, 1e-6, torch.linspace(0., 1., 4), {'max_order': 2, 'safety': 0.8}, {}),
+             ('no_control', .01, .001, torch.linspace(0., 3., 7), {}, {'no_control': True})]
+    orig = ref_adams.VariableCoefficientAdamsBashforth._adaptive_adams_step
+    for name, rtol, atol, t, opts, fkw in cases:
+        f, x = make_func(20, OMs, 41, **fkw)
+        cf = CountingFunc(f)
+        rows = []
+
+        def wrapped(self, st, final_t):
+            t_n, nt, order = float(st.prev_t[0]), min(float(st.next_t), float(final_t)), int(st.order)
+            out = orig(self, st, final_t)
+            rows.append((t_n, nt, order, 1.0 if float(out.prev_t[0]) != t_n else 0.0, float(out.next_t)))
+            return out
+        ref_adams.VariableCoefficientAdamsBashforth._adaptive_adams_step = wrapped
+        try:
+            with torch.no_grad():
+                y = ref_ode.odeint(cf, x, t, rtol=rtol, atol=atol, method='adams', options=dict(opts) if opts else None)
+        finally:
+            ref_adams.VariableCoefficientAdamsBashforth._adaptive_adams_step = orig
+        save('adams_%s' % name, x0=x, t=t, W=f.wt.weight, b=f.wt.bias, traj=y, rtol=rtol, atol=atol,
+             steplog=np.array(rows, dtype=np.float64), nfe=cf.nfe, no_control=int(bool(fkw)),
+             **{'opt_' + k: v for k, v in opts.items()}, **csr_of(OM))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['layout', 'gconv', 'rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint', 'resgcn']
+    which = sys.argv[1:] or ['layout', 'gconv', 'rhs', 'fixed', 'dopri5', 'ndcn', 'truth', 'operators', 'dgnn', 'dataset', 'adjoint', 'resgcn', 'adams']
     for w in which:
         globals()['gen_' + w]()

@@ -73,8 +73,8 @@ kernel_stats() {        # $1 = label, rest = bench flags ; prints per-variant av
   [ -n "$f" ] && cp "$f" "gpurun_out/${lab}_kernel_stats.csv" && python - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if ('rhs_fused' in r['Name'] or 'spmm_' in r['Name']) and '_kernel<' in r['Name']:
-        print('   %-46s n=%4s avg %.3f ms' % (r['Name'].split('(')[0][-46:], r['Calls'], float(r['AverageNs']) / 1e6))
+    if float(r['Percentage']) >= 0.5:
+        print('   %-46s n=%4s avg %.3f ms  %5.1f %%' % (r['Name'].split('(')[0][-46:], r['Calls'], float(r['AverageNs']) / 1e6, float(r['Percentage'])))
 PY
 }
 
