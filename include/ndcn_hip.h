@@ -202,6 +202,12 @@ NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
  *   (X stays the whole own panel because columns index it; y1 = X + a * H), and the second phase of a two-phase
  *   evaluation, whose X is the partial sum A_own X rather than the state (ndcn_amd/sharding.py).  With NDCN_F_ACCUM the
  *   record is added to d_out.
+ * y_aux / h_c_aux (nullable, NDCN_RK_COMBINE only): a SECOND linear combination of the same stages, without y0,
+ *   y_aux = sum_{m<n_prev} h_c_aux[m] kprev[m] + h_c_aux[n_prev] K   (left to right, products rounded on their own),
+ *   written in the same pass.  dopri5 forms E = dt sum_{j<=6} c_err[j] k_j this way in the launch that produces k6, whose
+ *   epilogue holds k1, k3, k4, k5 already; the error launch then runs with n_prev = 1, kprev = {E}, h_c = {1, dt c_err[7]} and
+ *   reads {y0, E, y1} instead of {y0, k1, k3, k4, k5, k6, y1}: 3 P less HBM traffic per step, the same sum in the same order
+ *   (rk_common.py:60; E is the exact partial sum).  NDCN_RK_ERROR therefore accepts n_prev = 1 besides dopri5's 5 in the fused kernels.
  * h_kprev / h_c are HOST arrays (n_prev <= 5 device pointers; n_prev + 1 coefficients, already dt * beta in
  * fp32).  X, K, y_next, y0 and the kprev panels must not alias each other.                              */
 #define NDCN_RK_COMBINE 1
@@ -210,7 +216,8 @@ NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 NDCN_API int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
                              const float *W, const float *b, float *K, float *work, int H, uint32_t flags,
                              int rk_mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
-                             float *y_next, const float *y1, float rtol, float atol, double *d_out, void *d_ws, void *stream);
+                             float *y_next, const float *y1, float *y_aux, const float *h_c_aux, float rtol, float atol,
+                             double *d_out, void *d_ws, void *stream);
 
 /* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
 NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);

@@ -85,7 +85,7 @@ SIGNATURES = {
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
-                        _P, _P, _F, _F, _P, _P, _P]),
+                        _P, _P, _P, ctypes.POINTER(_F), _F, _F, _P, _P, _P]),
     'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
     'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),

@@ -158,8 +158,8 @@ int ndcn_row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int
 
 int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
                     float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
-                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float rtol,
-                    float atol, double *d_out, void *d_ws, void *stream) {
+                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float *y_aux,
+                    const float *h_c_aux, float rtol, float atol, double *d_out, void *d_ws, void *stream) {
     NDCN_CHECK_ARG(A, "null operator descriptor");
     NDCN_CHECK_ARG(H > 0, "H must be positive");
     NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 3, "rk_mode must be 0, NDCN_RK_COMBINE, NDCN_RK_ERROR or NDCN_RK_RK4");
@@ -178,7 +178,9 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
         NDCN_CHECK_ARG(rk_mode != NDCN_RK_RK4 || (y_next && y_next != X && y_next != K && n_prev >= 0 && n_prev <= 3),
                        "rk4 stage: y_next missing / aliased or stage index outside 0..3");
     }
-    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0};
+    NDCN_CHECK_ARG(!y_aux || (rk_mode == NDCN_RK_COMBINE && h_c_aux && y_aux != y_next && y_aux != K && y_aux != X),
+                   "y_aux: NDCN_RK_COMBINE only, with h_c_aux, not aliasing X / K / y_next");
+    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0, y_aux, h_c_aux};
     return rhs_rk_f32(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                       d_out, d_ws, ST(stream), &opt);
 }

@@ -91,7 +91,11 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
     if (rk_mode == 3)
         return fixed_stage_f32(2 + n_prev, y_next, y0, kk[0], n_prev > 0 ? kk[1] : nullptr, n_prev > 1 ? kk[2] : nullptr,
                                n_prev > 2 ? kk[3] : nullptr, h_c[0], n, st, nullptr);
-    if (rk_mode == 1) return rk_combine_f32(y_next, y0, kk, h_c, n_prev + 1, n, st);
+    if (rk_mode == 1) {
+        rc = rk_combine_f32(y_next, y0, kk, h_c, n_prev + 1, n, st);
+        if (!rc && opt && opt->y_aux && opt->c_aux) rc = rk_combine_f32(opt->y_aux, nullptr, kk, opt->c_aux, n_prev + 1, n, st);
+        return rc;
+    }
     return rk_error_f32(y0, (opt && opt->y1) ? opt->y1 : X, kk, h_c, n_prev + 1, rtol, atol, n, d_out, d_ws, st, nullptr,
                         (opt && opt->accum) ? 1 : 0);
 }

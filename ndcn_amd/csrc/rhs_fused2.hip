@@ -79,6 +79,8 @@ struct EpiArgs {
     int n_prev;
     float rtol, atol;
     const float *y1;                        // ERROR: the state of the error record, by row of this launch
+    float *y_aux;                           // COMBINE, nullable: second linear combination (no y0), coefficients c2[]
+    float c2[kMaxPrev + 1];
 };
 
 struct Fused2Args {
@@ -207,6 +209,16 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
         }
         if (MODE == MODE_COMBINE) {
             stp(ea->y_next, off, e.y0v + s);
+            if (ea->y_aux) {                                       // wave-uniform; the store is OLDER than every later fetch
+                f32x4 w2 = kn * ea->c2[NP];
+                if (NP > 0) {
+                    f32x4 u2 = e.km[0] * ea->c2[0];
+#pragma unroll
+                    for (int m = 1; m < NP; ++m) u2 = u2 + e.km[m] * ea->c2[m];
+                    w2 = u2 + w2;
+                }
+                stp(ea->y_aux, off, w2);
+            }
         } else {
             const float rtol = ea->rtol, atol = ea->atol;
 #pragma unroll
@@ -592,7 +604,7 @@ int rhs_fused2_variant(int mode, int n_prev) {
     if (mode == MODE_PLAIN) return 1;
     if (mode == MODE_COMBINE) return n_prev >= 0 && n_prev <= kMaxPrev;
     if (mode == MODE_RK4) return n_prev >= 0 && n_prev <= 3;
-    return mode == MODE_ERROR && n_prev == kMaxPrev;
+    return mode == MODE_ERROR && (n_prev == kMaxPrev || n_prev == 1);
 }
 
 int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kProd * 2 * sizeof(double); }
@@ -655,6 +667,8 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     ea.y0 = y0; ea.n_prev = n_prev; ea.y_next = y_next; ea.rtol = rtol; ea.atol = atol;
     ea.partials = static_cast<double *>(d_ws);
     ea.y1 = (opt && opt->y1) ? opt->y1 : X;
+    ea.y_aux = (mode == MODE_COMBINE && opt && opt->y_aux && opt->c_aux) ? opt->y_aux : nullptr;
+    for (int m = 0; m <= kMaxPrev; ++m) ea.c2[m] = (ea.y_aux && m <= n_prev) ? opt->c_aux[m] : 0.f;
     static const int dbg = env_int3("NDCN_FUSED_DBG", 0);
     a.dbg = dbg;
     static const int timing = env_int3("NDCN_FUSED_TIMING", 0);
@@ -671,7 +685,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     const dim3 grid(per_xcd * kXcds), block(64 * kWaves);
     const double P = 4.0 * kH2 * (double)A->n_rows;
     double bytes = 8.0 * A_full->nnz + 4.0 * (A_full->n_rows + 1) + 4.0 * kH2 * (double)(A_full->n_rows + A_full->n_cols) + 4.0 * kH2 * kH2;
-    if (mode == MODE_COMBINE) bytes += P * (n_prev + 2);        // y0 + earlier stages read, y_next written
+    if (mode == MODE_COMBINE) bytes += P * (n_prev + 2 + (ea.y_aux ? 1 : 0));   // y0 + earlier stages read, y_next (+ y_aux) written
     if (mode == MODE_ERROR) bytes += P * (n_prev + 2);          // y0 + earlier stages + y1 (row-local re-read)
     if (mode == MODE_RK4) bytes += P * (n_prev + 2);            // y + earlier stages read, next input written
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A_full->nnz * kH2 + 2.0 * (double)A_full->n_rows * kH2 * kH2);
@@ -680,7 +694,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
 #define NDCN_F2_DISPATCH(HALO_)                                      \
     do {                                                             \
         if (mode == MODE_PLAIN) NDCN_F2(HALO_, MODE_PLAIN, 0);       \
-        else if (mode == MODE_ERROR) NDCN_F2(HALO_, MODE_ERROR, 5);  \
+        else if (mode == MODE_ERROR) { if (n_prev == 1) NDCN_F2(HALO_, MODE_ERROR, 1); else NDCN_F2(HALO_, MODE_ERROR, 5); } \
         else if (mode == MODE_RK4) switch (n_prev) {                 \
             case 0: NDCN_F2(HALO_, MODE_RK4, 0); break;              \
             case 1: NDCN_F2(HALO_, MODE_RK4, 1); break;              \

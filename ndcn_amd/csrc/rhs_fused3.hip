@@ -111,6 +111,8 @@ struct F3Epi {
     float c[kF3MaxPrev + 1];         // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K ; RK4: c[0] = dt
     float rtol, atol;
     const float *y1;                 // ERROR: the state of the error record, by row of this launch
+    float *y_aux;                    // COMBINE, nullable: second linear combination (no y0), coefficients c2[]
+    float c2[kF3MaxPrev + 1];
 };
 
 template <bool HALO, int MODE, int NP>
@@ -424,6 +426,17 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         if (MODE == F3_COMBINE) {
             stp(e.y_next, voff, p.y0v + s);
             issued(1);
+            if (e.y_aux) {                                          // wave-uniform
+                f32x4 w2 = kn * e.c2[NP];
+                if (NP > 0) {
+                    f32x4 u2 = p.km[0] * e.c2[0];
+#pragma unroll
+                    for (int m = 1; m < NP; ++m) u2 = u2 + p.km[m] * e.c2[m];
+                    w2 = u2 + w2;
+                }
+                stp(e.y_aux, voff, w2);
+                issued(1);
+            }
             return;
         }
 #pragma unroll
@@ -554,7 +567,7 @@ int rhs_fused3_variant(int mode, int n_prev) {
     if (mode == F3_PLAIN) return 1;
     if (mode == F3_COMBINE) return n_prev >= 0 && n_prev <= kF3MaxPrev;
     if (mode == F3_RK4) return n_prev >= 0 && n_prev <= 3;
-    return mode == F3_ERROR && n_prev == kF3MaxPrev;
+    return mode == F3_ERROR && (n_prev == kF3MaxPrev || n_prev == 1);
 }
 
 template <bool HALO, int MODE, int NP>
@@ -589,6 +602,8 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     F3Epi e = {};
     e.y0 = y0; e.y_next = y_next; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
     e.y1 = (opt && opt->y1) ? opt->y1 : X;
+    e.y_aux = (mode == F3_COMBINE && opt && opt->y_aux && opt->c_aux) ? opt->y_aux : nullptr;
+    for (int m = 0; m <= kF3MaxPrev; ++m) e.c2[m] = (e.y_aux && m <= n_prev) ? opt->c_aux[m] : 0.f;
     for (int m = 0; m < kF3MaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kF3MaxPrev; ++m) e.c[m] = (mode != F3_PLAIN && mode != F3_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == F3_RK4) e.c[0] = h_c[0];
@@ -599,13 +614,14 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     const double P = 4.0 * 256 * (double)A->n_rows;
     double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * 256 * (double)(A->n_rows + A->n_cols) + 4.0 * 256 * 256;
     if (mode != F3_PLAIN) bytes += P * (n_prev + 2);
+    if (e.y_aux) bytes += P;
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
     int rc = NDCN_OK;
 #define NDCN_F3(HALO_, MODE_, NP_) rc = launch_f3<HALO_, MODE_, NP_>(a, e, grid, st)
 #define NDCN_F3_DISPATCH(HALO_)                                       \
     do {                                                              \
         if (mode == F3_PLAIN) NDCN_F3(HALO_, F3_PLAIN, 0);            \
-        else if (mode == F3_ERROR) NDCN_F3(HALO_, F3_ERROR, 5);       \
+        else if (mode == F3_ERROR) { if (n_prev == 1) NDCN_F3(HALO_, F3_ERROR, 1); else NDCN_F3(HALO_, F3_ERROR, 5); } \
         else if (mode == F3_RK4) switch (n_prev) {                    \
             case 0: NDCN_F3(HALO_, F3_RK4, 0); break;                 \
             case 1: NDCN_F3(HALO_, F3_RK4, 1); break;                 \

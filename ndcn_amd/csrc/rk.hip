@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void combine_kernel(float *__restrict__ out, c
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         if (VEC) {
             const float4 s = wsum4(t, i);
+            if (!y0) { st4(out, i, s); continue; }              // plain linear combination (no y0 term)
             const float4 y = ld4(y0, i);
             st4(out, i, make_float4(y.x + s.x, y.y + s.y, y.z + s.z, y.w + s.w));
         } else {
-            out[i] = y0[i] + wsum1(t, i);
+            out[i] = y0 ? y0[i] + wsum1(t, i) : wsum1(t, i);
         }
     }
 }
@@ -433,7 +434,7 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
                    hipStream_t st, const float *dt_dev) {
     Terms t;
     t.dt_dev = dt_dev;
-    bool vec = (n % 4 == 0) && aligned16(out) && aligned16(y0);
+    bool vec = (n % 4 == 0) && aligned16(out) && (!y0 || aligned16(y0));
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_combine: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
     if (n == 0) return NDCN_OK;
     ProfScope prof(PROF_COMBINE, st, 4.0 * n * (n_k + 2), 2.0 * n * n_k);

@@ -10,6 +10,7 @@
 // that the reference forms as a 0-d tensor of the state dtype (dt*beta, stage times, the initial-step
 // heuristic, the interpolation abscissa) in float32.
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 
@@ -146,7 +147,7 @@ int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
 // group-record SpMM (no_control RHS)
 int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0, const float *const *kp, const float *cp,
             int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st,
-            const float *dt_dev = nullptr) {
+            const float *dt_dev = nullptr, const RkOpt *opt = nullptr) {
     s->n_rhs++;
     if (s->rec_epi) {
         // replay: cp holds the bare tableau entries; they join the solver's coefficient table, whose scaled image
@@ -160,12 +161,12 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
         }
         if (s->wide_epi)
             return spmm_wide_rk_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next,
-                                    rtol, atol, d_out, d_ws, st, c_dev);
+                                    rtol, atol, d_out, d_ws, st, c_dev, opt);
         return spmm_rec_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, 1.f, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next, rtol,
-                            atol, d_out, d_ws, st, c_dev);
+                            atol, d_out, d_ws, st, c_dev, opt);
     }
     return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev,
-                          y_next, rtol, atol, d_out, d_ws, st);
+                          y_next, rtol, atol, d_out, d_ws, st, opt);
 }
 
 // wait for the reduction record enqueued last on `st`
@@ -254,6 +255,14 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         dt_coeffs(dt32, kBeta[0], 1, s->k, kp, cp, m);
         rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st, dt_dev);
         if (rc) return rc;
+        // The launch that produces k6 (i == 4) holds k1, k3, k4, k5 in its epilogue: it also forms the partial error sum
+        // E = dt (c_err1 k1 + c_err3 k3 + c_err4 k4 + c_err5 k5 + c_err6 k6) - left to right like the reference's sum - into
+        // the stage-input buffer that is free at that point; the error launch reads {y0, E, y1} instead of 7 panels.
+        // (Replayed steps keep the one-launch form: their coefficients are fl(dt * c) of a device-resident dt, and E's
+        // coefficient in the error launch is the constant 1.)
+        static const bool aux_on = [] { const char *e = getenv("NDCN_ERR_PARTIAL"); return !(e && e[0] == '0'); }();
+        const bool use_aux = aux_on && !dt_dev;
+        float *e_panel = nullptr;
         float *in = s->ytmp;
         for (int i = 0; i < 6; ++i) {
             if (i < 5) {
@@ -267,17 +276,38 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
                     ++mp;
                 }
                 cp[mp] = dt32 * (float)kBeta[i + 1][i + 1];   // the K being produced, last term
-                rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st, dt_dev);
+                RkOpt opt = {nullptr, 0, nullptr, nullptr};
+                float c2[8];
+                if (i == 4 && use_aux) {
+                    // the same stages in the same order: beta[5][j] and c_err[j] vanish for the same j (= 1) only
+                    int m2 = 0;
+                    for (int j = 0; j <= i; ++j) {
+                        if ((float)kBeta[i + 1][j] == 0.f) continue;
+                        c2[m2++] = dt32 * (float)kCErr[j];
+                    }
+                    c2[m2] = dt32 * (float)kCErr[i + 1];
+                    e_panel = (in == s->ytmp) ? s->ytmp2 : s->ytmp;
+                    opt.y_aux = e_panel;
+                    opt.c_aux = c2;
+                }
+                rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st, dt_dev,
+                             (i == 4 && use_aux) ? &opt : nullptr);
                 if (rc) return rc;
                 in = out;
             } else {
                 int mp = 0;
-                for (int j = 0; j < 6; ++j) {
-                    const float cj = (float)kCErr[j];
-                    if (cj == 0.f) continue;
-                    kp[mp] = s->k[j];
-                    cp[mp] = dt32 * cj;
-                    ++mp;
+                if (e_panel) {
+                    kp[0] = e_panel;
+                    cp[0] = 1.f;
+                    mp = 1;
+                } else {
+                    for (int j = 0; j < 6; ++j) {
+                        const float cj = (float)kCErr[j];
+                        if (cj == 0.f) continue;
+                        kp[mp] = s->k[j];
+                        cp[mp] = dt32 * cj;
+                        ++mp;
+                    }
                 }
                 cp[mp] = dt32 * (float)kCErr[6];
                 rc = rhs_epi(s, in, s->k[6], 2, s->ycur, kp, cp, mp, nullptr, (float)s->d.rtol, (float)s->d.atol, s->d_red,

@@ -196,6 +196,8 @@ struct WideEpi {
     float rtol, atol;
     const float *c_dev;               // nullable: coefficients in device memory (hipGraph replay)
     const float *y1;                  // ERROR: the state of the error record, by row of this launch
+    float *y_aux;                     // COMBINE, nullable: second linear combination (no y0), coefficients c2[] (by value only)
+    float c2[kWideMaxPrev + 1];
 };
 enum { WIDE_PLAIN = 0, WIDE_COMBINE = 1, WIDE_ERROR = 2, WIDE_RK4 = 3 };
 
@@ -300,6 +302,17 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(const int *__restrict__ 
                     }
                     if (MODE == WIDE_COMBINE) {
                         __builtin_nontemporal_store(py0 + sm, yn + oo);
+                        if (e.y_aux) {
+                            f32x4 w2 = o * e.c2[np];
+                            if (np > 0) {
+                                f32x4 u2 = pk[0] * e.c2[0];
+#pragma unroll
+                                for (int m = 1; m < kWideMaxPrev; ++m)
+                                    if (m < np) u2 = u2 + pk[m] * e.c2[m];
+                                w2 = u2 + w2;
+                            }
+                            __builtin_nontemporal_store(w2, reinterpret_cast<f32x4 *>(e.y_aux) + oo);
+                        }
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -371,6 +384,8 @@ int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t
     e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
     e.c_dev = c_dev;
     e.y1 = (opt && opt->y1) ? opt->y1 : X;
+    e.y_aux = (mode == WIDE_COMBINE && !c_dev && opt && opt->y_aux && opt->c_aux) ? opt->y_aux : nullptr;
+    for (int m = 0; m <= kWideMaxPrev; ++m) e.c2[m] = (e.y_aux && m <= n_prev) ? opt->c_aux[m] : 0.f;
     for (int m = 0; m < kWideMaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kWideMaxPrev; ++m) e.c[m] = (mode != WIDE_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == WIDE_RK4) e.c[0] = h_c[0];

@@ -73,6 +73,8 @@ struct RecEpi {
     int n_prev;
     float rtol, atol;
     const float *y1;                 // ERROR: the state of the error record, by row of this launch
+    float *y_aux;                    // COMBINE, nullable: second linear combination (no y0), coefficients c2[] (by value only)
+    float c2[kRecMaxPrev + 1];
     const float *c_dev;              // nullable: the coefficients live in device memory instead of c[] (hipGraph replay: one
                                      // captured launch serves every step size; filled by scale_coef_kernel as fl(dt * c))
 };
@@ -221,6 +223,18 @@ __global__ __launch_bounds__(64 * (kRecWC + kRecWD)) void spmm_rec_kernel(RecArg
         if (MODE == REC_COMBINE) {
             __builtin_nontemporal_store(p.y0v + s, yn + o);
             ++s_cur; ++s_nxt;
+            if (e.y_aux) {
+                f32x4 w2 = kn * e.c2[np];
+                if (np > 0) {
+                    f32x4 u2 = p.km[0] * e.c2[0];
+#pragma unroll
+                    for (int m = 1; m < MAXP; ++m)
+                        if (m < np) u2 = u2 + p.km[m] * e.c2[m];
+                    w2 = u2 + w2;
+                }
+                __builtin_nontemporal_store(w2, reinterpret_cast<f32x4 *>(e.y_aux) + o);
+                ++s_cur; ++s_nxt;
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -406,12 +420,14 @@ int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_o
     e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
     e.c_dev = c_dev;
     e.y1 = (opt && opt->y1) ? opt->y1 : X;
+    e.y_aux = (mode == REC_COMBINE && !c_dev && opt && opt->y_aux && opt->c_aux) ? opt->y_aux : nullptr;
+    for (int m = 0; m <= kRecMaxPrev; ++m) e.c2[m] = (e.y_aux && m <= n_prev) ? opt->c_aux[m] : 0.f;
     for (int m = 0; m < kRecMaxPrev; ++m) e.kprev[m] = (m < n_prev && h_kprev) ? h_kprev[m] : nullptr;
     for (int m = 0; m <= kRecMaxPrev; ++m) e.c[m] = (mode != REC_PLAIN && mode != REC_RK4 && m <= n_prev) ? h_c[m] : 0.f;
     if (mode == REC_RK4) e.c[0] = h_c[0];
     const double P = 4.0 * 256 * (double)A->n_rows;
     double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * 256 * (double)(A->n_rows + A->n_cols);
-    if (mode != REC_PLAIN) bytes += P * (n_prev + 2);
+    if (mode != REC_PLAIN) bytes += P * (n_prev + 2 + (e.y_aux ? 1 : 0));
     ProfScope prof(mode == REC_PLAIN ? PROF_SPMM : PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256);
     dim3 grid;
     int rc;

@@ -265,14 +265,16 @@ class HipOps:
 
     @staticmethod
     def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None, y1=None, accum=False, fetch=True):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
         mode 'combine': returns (K, y0 + sum cs[m] kprev[m] + cs[-1] K); mode 'error': returns
         (K, (sum of squared error ratios, non-finite count of X)) - the dopri5 error record with X = y1;
         mode 'rk4': stage len(kprev) of the 3/8-rule step, cs = [dt]: returns (K, next stage input / step result).
         mode 'error' only - y1: the rows of the state whose error record is formed (default X: the single-launch case);
         accum: add the record to the one already in the device buffer (an evaluation split into several launches);
-        fetch=False: leave the record on the device (returns (K, None); the last launch of the split fetches)."""
+        fetch=False: leave the record on the device (returns (K, None); the last launch of the split fetches).
+        mode 'combine' only - aux_cs: coefficients of a second linear combination of the same stages (no y0), formed in
+        the same pass: returns (K, y_next, sum aux_cs[m] kprev[m] + aux_cs[-1] K) - dopri5's partial error sum E."""
         X = _panel(X)
         H = X.shape[1]
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
@@ -310,14 +312,21 @@ class HipOps:
                 work = torch.empty(wbytes, dtype=torch.uint8, device=X.device)
         arr_k = (_P * max(len(kprev), 1))(*[k.data_ptr() for k in kprev])
         arr_c = (_F * len(cs))(*[float(c) for c in cs])
+        y_aux = arr_c2 = None
+        if aux_cs is not None:
+            assert mode == 'combine' and len(aux_cs) == len(kprev) + 1
+            arr_c2 = (_F * len(aux_cs))(*[float(c) for c in aux_cs])
+            y_aux = out_aux if out_aux is not None else torch.empty_like(K)
         rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR, 'rk4': _lib.RK_RK4}[mode]
         y_next = (out_y if out_y is not None else torch.empty_like(K)) if mode in ('combine', 'rk4') else None
         red = _Reducer.get(X.device)
         with _REDUCE_LOCK, torch.cuda.device(X.device):
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                       ptr(None if no_control else b), ptr(K), ptr(work), H, flags, rk, ptr(y0), arr_k,
-                                      arr_c, len(kprev), ptr(y_next), ptr(y1), float(rtol), float(atol), ptr(red.out),
-                                      ptr(red.ws), stream_ptr()))
+                                      arr_c, len(kprev), ptr(y_next), ptr(y1), ptr(y_aux), arr_c2, float(rtol), float(atol),
+                                      ptr(red.out), ptr(red.ws), stream_ptr()))
+            if aux_cs is not None:
+                return K, y_next, y_aux
             if mode in ('combine', 'rk4'):
                 return K, y_next
             return K, (red.fetch() if fetch else None)

@@ -195,6 +195,7 @@ class ShardedODEFunc(nn.Module):
     same fma sequence)."""
 
     ndcn_autonomous = True
+    supports_aux = True               # rhs_rk(..., aux_cs=) forms dopri5's partial error sum in the stage-6 launch
 
     def __init__(self, odefunc, plan, ops, overlap=True):
         super().__init__()
@@ -306,12 +307,15 @@ class ShardedODEFunc(nn.Module):
         halo, _ = self._start_exchange(x)
         return self.ops.rhs(self.plan.local_op, x, W, bias, no_control=f.no_control, X_halo=halo)
 
-    def rhs_rk(self, x, mode, y0, kprev, cs, rtol, atol):
+    def rhs_rk(self, x, mode, y0, kprev, cs, rtol, atol, aux_cs=None):
         """RHS + the stage algebra consuming it (core.Dopri5's `fused` protocol); the error record is summed
-        over ranks here so every rank sees the same controller input."""
+        over ranks here so every rank sees the same controller input.  aux_cs (combine): also the second linear
+        combination sum aux_cs[m] kprev[m] + aux_cs[-1] K -> returns (k, y_next, aux)."""
         self.nfe += 1
         f = self.f
         W, bias = f.wt.weight, f.wt.bias
+        akw = lambda a=None, b=None: {} if aux_cs is None else {'aux_cs': aux_cs, 'out_aux': aux if a is None else aux[a:b]}
+        aux = torch.empty_like(x) if aux_cs is not None else None
         if self.overlap and not f.no_graph:
             k = torch.empty_like(x)
             y_next = torch.empty_like(x) if mode in ('combine', 'rk4') else None
@@ -322,24 +326,28 @@ class ShardedODEFunc(nn.Module):
                                            no_control=f.no_control, X_halo=halo, out_K=k[a:b], y1=x[a:b], accum=not first,
                                            fetch=last)[1]
                 self.ops.rhs_rk(op, x, W, bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
-                                no_control=f.no_control, X_halo=halo, out_K=k[a:b], out_y=y_next[a:b])
+                                no_control=f.no_control, X_halo=halo, out_K=k[a:b], out_y=y_next[a:b], **akw(a, b))
             out = self._split_eval(x, call)
             if mode != 'error':
-                return k, y_next
+                return (k, y_next) if aux is None else (k, y_next, aux)
         elif self.two_phase and not f.no_graph:
             own_op, halo_op = self.plan.two_phase
-            k, out = self._overlapped(x, lambda: self.ops.spmm(own_op, x),
-                                      lambda halo, S: self.ops.rhs_rk(halo_op, S, W, bias, mode, y0, kprev, cs, rtol, atol,
-                                                                      no_control=f.no_control, X_halo=halo,
-                                                                      y1=x if mode == 'error' else None))
+            res = self._overlapped(x, lambda: self.ops.spmm(own_op, x),
+                                   lambda halo, S: self.ops.rhs_rk(halo_op, S, W, bias, mode, y0, kprev, cs, rtol, atol,
+                                                                   no_control=f.no_control, X_halo=halo,
+                                                                   y1=x if mode == 'error' else None, **akw()))
             if mode != 'error':
-                return k, out
+                return res
+            k, out = res
         else:
             halo = None
             if not f.no_graph:
                 halo, _ = self._start_exchange(x)
-            k, out = self.ops.rhs_rk(None if f.no_graph else self.plan.local_op, x, W, bias, mode, y0, kprev, cs,
-                                     rtol, atol, no_graph=f.no_graph, no_control=f.no_control, X_halo=halo)
+            res = self.ops.rhs_rk(None if f.no_graph else self.plan.local_op, x, W, bias, mode, y0, kprev, cs,
+                                  rtol, atol, no_graph=f.no_graph, no_control=f.no_control, X_halo=halo, **akw())
+            if mode != 'error':
+                return res
+            k, out = res
         if mode == 'error' and self.plan.world > 1:
             dev = x.device if dist.get_backend(self.plan.group) == 'nccl' else torch.device('cpu')
             v = torch.tensor([out[0], out[1]], dtype=torch.float64, device=dev)

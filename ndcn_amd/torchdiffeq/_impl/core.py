@@ -337,17 +337,31 @@ class Dopri5:
         k = [self.f[0]]
         kk, cs = dt_terms(dt32, DP_BETA[0], k)
         x = self.ops.combine(y0, kk, cs)
+        aux = bool(getattr(self.fused, 'supports_aux', False))
+        E = None
         for i in range(1, 6):
             # the evaluation producing k[i] also forms the input of stage i+1: y0 + dt * sum beta[i][m] k[m]
             prev, cp = dt_terms(dt32, DP_BETA[i][:i], k)
             c_new = f32(dt32 * f32(DP_BETA[i][i]))
             self.nfe += 1
-            k_new, x_next = self.fused.rhs_rk(x, 'combine', y0, prev, cp + [c_new], 0.0, 0.0)
+            if i == 5 and aux:
+                # ... and, holding k1, k3, k4, k5 already, the partial error sum E = dt sum_{j<=6} c_err[j] k_j (the same
+                # stages in the same order: beta[5][j] and c_err[j] vanish for the same j), so that the error evaluation
+                # reads {y0, E, y1} instead of seven panels (include/ndcn_hip.h: y_aux)
+                _, ce = dt_terms(dt32, DP_C_ERR[:5], k)
+                assert len(ce) == len(cp)
+                k_new, x_next, E = self.fused.rhs_rk(x, 'combine', y0, prev, cp + [c_new], 0.0, 0.0,
+                                                     aux_cs=ce + [f32(dt32 * f32(DP_C_ERR[5]))])
+            else:
+                k_new, x_next = self.fused.rhs_rk(x, 'combine', y0, prev, cp + [c_new], 0.0, 0.0)
             k.append(k_new)
             x = x_next
         y1 = x
-        prev, cp = dt_terms(dt32, DP_C_ERR[:6], k)
         c_new = f32(dt32 * f32(DP_C_ERR[6]))
+        if E is not None:
+            prev, cp = [E], [f32(1.0)]
+        else:
+            prev, cp = dt_terms(dt32, DP_C_ERR[:6], k)
         self.nfe += 1
         k_new, (s, bad) = self.fused.rhs_rk(y1, 'error', y0, prev, cp + [c_new], self.rtol[0], self.atol[0])
         k.append(k_new)

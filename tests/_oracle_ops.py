@@ -66,7 +66,7 @@ class OracleOps:
 
     @classmethod
     def rhs_rk(cls, A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None, y1=None, accum=False, fetch=True):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None):
         k = cls.rhs(A, X, W, b, no_graph=no_graph, no_control=no_control, X_halo=X_halo)
         ks = list(kprev) + [k]
         if out_K is not None:
@@ -75,6 +75,11 @@ class OracleOps:
             y = cls.combine(y0, ks, cs)
             if out_y is not None:
                 out_y.copy_(y)
+            if aux_cs is not None:
+                aux = _wsum(ks, aux_cs)
+                if out_aux is not None:
+                    out_aux.copy_(aux)
+                return k, y, aux
             return k, y
         if mode == 'rk4':
             y = cls.fixed_stage(2 + len(kprev), y0, *ks, dt=cs[0])

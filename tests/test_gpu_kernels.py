@@ -516,6 +516,44 @@ def test_error_record_split_over_row_blocks_accumulates(dev, H, no_control):
             assert np.isnan(rec[0]) and np.isnan(s)
 
 
+@pytest.mark.parametrize('kernel', ['fused3', 'fused2', 'rec', 'wide', 'composed'])
+def test_partial_error_sum_in_the_stage6_launch(dev, kernel):
+    """dopri5's error launch used to read {y0, k1, k3, k4, k5, k6, y1}; the launch that produces k6 now also writes
+    E = sum_{j<=6} dt c_err[j] k_j (y_aux of ndcn_rhs_rk_f32) and the error launch runs with ONE earlier 'stage' E with
+    coefficient 1.  Same terms, same order: E equals the separately rounded left-to-right sum bit for bit, and the error
+    record of {E, k7} equals the record of the seven-term launch to the last bit of its fp64 sum."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    H = 64 if kernel == 'composed' else 256
+    side = 40
+    n = side * side
+    m = graphs.normalized_laplacian(graphs.grid_8_neighbor(side)).tocsr()
+    A = _no_plan(CsrOperator.from_scipy(m, dev))
+    if kernel in ('fused3', 'rec'):
+        A.group_order = torch.as_tensor(A.detect_stencil_order(), dtype=torch.int32).to(dev)
+        A.build_rec_plan(16, 40, 2)
+    no_control = kernel in ('rec', 'wide')
+    g = torch.Generator().manual_seed(3)
+    X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    ce = [np.float32(c) for c in (0.013, 0.021, -0.017, 0.009, -0.004, 0.025)]
+    kw = dict(no_control=no_control)
+    for npv in (4, 0, 5):
+        c, c2 = cs[:npv] + [cs[5]], ce[:npv] + [ce[4]]
+        K, yn, E = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], c, aux_cs=c2, **kw)
+        K0, yn0 = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], c, **kw)
+        assert torch.equal(K, K0) and torch.equal(yn, yn0)
+        zero = torch.zeros_like(y0)
+        assert torch.equal(E, hip.combine(zero, ks[:npv] + [K0], c2))              # 0 + s == s exactly
+    # the error launch on {E, K7}: one earlier stage with coefficient 1
+    K6, y1, E = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:4], cs[:4] + [cs[5]], aux_cs=ce[:4] + [ce[4]], **kw)
+    K7a, (sa, ba) = hip.rhs_rk(A, y1, W, b, 'error', y0, [E], [np.float32(1.0), ce[5]], rtol=1e-2, atol=1e-3, **kw)
+    K7b, (sb, bb) = hip.rhs_rk(A, y1, W, b, 'error', y0, ks[:4] + [K6], ce[:4] + [ce[4], ce[5]], rtol=1e-2, atol=1e-3, **kw)
+    assert torch.equal(K7a, K7b) and sa == sb and ba == bb == 0.0
+
+
 def test_long_row_plan_equals_in_kernel_gather(dev):
     """Power-law graph: rows longer than the plan's threshold are evaluated by the segment SpMMs ahead of the fused
     kernel and enter it as one entry of a second panel - same results as gathering them inside the kernel."""
