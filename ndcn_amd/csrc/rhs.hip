@@ -22,6 +22,7 @@ int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) {
     const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
     if (!(graph && ctl)) return 0;
     if (rhs_fused_supported(H, flags)) return rhs_fused_work_bytes(H);       // packed weights
+    if (H <= 128) return 16;                                                   // rhs_small.hip needs none (a token size keeps callers' pointers non-null)
     return n_rows * (int64_t)H * (int64_t)sizeof(float);                        // S = A X between the two kernels
 }
 
@@ -45,6 +46,9 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
             }
             return rhs_fused_f32(A, X, Xh, n_own, W, b, Y, work, H, flags, st);
         }
+        if (rhs_small_supported(A, H, flags))                     // narrow panels: SpMM -> Linear -> ReLU in one launch
+            return rhs_small_f32(A, X, Xh, n_own, W, b, Y, H, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr,
+                                 nullptr, st);
         int rc = spmm_f32(A, X, Xh, n_own, work, H, 1.f, 0, st);
         if (rc) return rc;
         return linear_f32(work, W, b, Y, n, H, H, act, st);
@@ -72,6 +76,9 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
         return rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                               d_out, d_ws, st, opt);
     }
+    if (both && rhs_small_supported(A, H, flags))
+        return rhs_small_f32(A, X, Xh, n_own, W, b, K, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws,
+                             st, nullptr, opt);
     // no_control: relu(A X) with the stage algebra in the epilogue of the group-record SpMM (spmm_rec.hip)
     const bool graph_only = !(flags & NDCN_F_NO_GRAPH) && (flags & NDCN_F_NO_CONTROL);
     if (graph_only && spmm_rec_supported(A, H) && spmm_rec_variant(rk_mode, n_prev) && A->n_rows * (int64_t)1024 < (1ll << 32) &&

@@ -68,6 +68,7 @@ struct ndcn_solver {
     bool fused2 = false;           // the RK algebra rides in the epilogue of the RHS launches (rhs_epi)
     bool rec_epi = false;          // ... of an SpMM kernel (no_control RHS) instead of the fused MFMA kernel:
     bool wide_epi = false;         //     the group-record kernel, or (no plan) the row kernel
+    bool small_epi = false;        // ... of the narrow-panel kernel (H <= 128, rhs_small.hip)
     float *ytmp2 = nullptr;        // second stage-input panel (fused2: a stage's input must outlive its epilogue)
     double t0 = 0, t1 = 0, dt = 0; // dopri5: last interval [t0, t1], next step size
     float tf = 0;                  // fixed grid: current time in the state dtype
@@ -159,6 +160,9 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
             c_dev = s->d_coef + s->n_coef;
             s->n_coef += 8;                                   // slices stay 32-byte aligned
         }
+        if (s->small_epi)
+            return rhs_small_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, K, s->d.H, s->d.rhs_flags, mode, y0, kp, cp,
+                                 n_prev, y_next, rtol, atol, d_out, d_ws, st, c_dev, opt);
         if (s->wide_epi)
             return spmm_wide_rk_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next,
                                     rtol, atol, d_out, d_ws, st, c_dev, opt);
@@ -485,6 +489,10 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
             s->rec_epi = true;
         } else if (!no_graph && no_ctl && spmm_wide_rk_supported(&desc->A, desc->H)) {
             s->fused2 = s->rec_epi = s->wide_epi = true;
+        } else if (both && !s->fused && desc->method == NDCN_M_DOPRI5 && rhs_small_supported(&desc->A, desc->H, desc->rhs_flags)) {
+            // narrow panels: the adaptive step runs 1 combine + 6 launches; fixed-grid methods keep their replayed step,
+            // whose right-hand sides go through the same kernel in plain mode (rhs_f32)
+            s->fused2 = s->rec_epi = s->small_epi = true;
         }
     }
     const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;

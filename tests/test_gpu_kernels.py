@@ -554,6 +554,56 @@ def test_partial_error_sum_in_the_stage6_launch(dev, kernel):
     assert torch.equal(K7a, K7b) and sa == sb and ba == bb == 0.0
 
 
+@pytest.mark.parametrize('H', [1, 16, 20, 33, 64, 65, 100, 128])
+def test_narrow_panel_rhs_is_one_launch_and_equals_the_composed_kernels(dev, H):
+    """H <= 128 (the README dynamics commands run H = 20): the whole ODEFunc - and the RK algebra consuming it - in ONE
+    launch of rhs_small.hip.  Same fma sequences as ndcn_spmm_f32 -> ndcn_linear_f32 -> the stage kernels: bit-identical
+    K, y_next, E; error sums to fp64 rounding; halo panel, ragged rows, a 150-entry row, empty rows."""
+    from ndcn_amd import hip, CsrOperator, _lib
+    n = 1500
+    m = rand_csr(n, n, 7, seed=H)
+    m = sp.vstack([m[:-1], sp.csr_matrix(np.ones((1, n), dtype=np.float32))[:, :]]).tocsr() if False else m
+    long_row = sp.random(1, n, density=0.1, random_state=np.random.RandomState(1), format='csr', dtype=np.float32)
+    m = sp.vstack([m[:700], long_row, m[701:]]).tocsr()
+    m.sort_indices()
+    A = CsrOperator.from_scipy(m, dev)
+    g = torch.Generator().manual_seed(H)
+    X, y0 = torch.randn(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(5)]
+    W = ((torch.rand(H, H, generator=g) - 0.5)).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5)).to(dev)
+    cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
+    ce = [np.float32(c) for c in (0.013, 0.021, -0.017, 0.009, -0.004, 0.025)]
+    lib = _lib.load()
+    nk = lib.ndcn_prof_kinds()
+    buf = (_lib.ctypes.c_double * (4 * nk))()
+    lib.ndcn_prof_enable(1)
+    lib.ndcn_prof_read(buf, nk)
+    K = hip.rhs(A, X, W, b)
+    torch.cuda.synchronize()
+    lib.ndcn_prof_enable(0)
+    lib.ndcn_prof_read(buf, nk)
+    launches = {name: int(buf[4 * i]) for i, name in enumerate(_lib.PROF_KINDS) if buf[4 * i]}
+    assert launches == {'rhs_fused': 1}, launches                          # one launch, none of spmm / linear
+    K_ref = hip.linear(hip.spmm(A, X), W, b, relu=True)
+    assert torch.equal(K, K_ref)
+    # halo split
+    got = hip.rhs(A, X[:900].contiguous(), W, b, X_halo=X[900:].contiguous())
+    assert torch.equal(got, K_ref)
+    for npv in (0, 1, 4, 5):
+        c = cs[:npv] + [cs[5]]
+        K1, yn, E = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], c, aux_cs=ce[:npv] + [ce[5]])
+        assert torch.equal(K1, K_ref) and torch.equal(yn, hip.combine(y0, ks[:npv] + [K_ref], c))
+        assert torch.equal(E, hip.combine(torch.zeros_like(y0), ks[:npv] + [K_ref], ce[:npv] + [ce[5]]))
+        K2, (s1, b1) = hip.rhs_rk(A, X, W, b, 'error', y0, ks[:npv], c, rtol=1e-2, atol=1e-3)
+        s2, b2 = hip.error(y0, X, ks[:npv] + [K_ref], c, 1e-2, 1e-3)
+        assert torch.equal(K2, K_ref) and abs(s1 - s2) <= 1e-12 * abs(s2) and b1 == b2 == 0.0
+    dt = np.float32(0.37)
+    for st in range(4):
+        K3, yn = hip.rhs_rk(A, X, W, b, 'rk4', y0, ks[:st], [dt])
+        assert torch.equal(K3, K_ref) and torch.equal(yn, hip.fixed_stage(2 + st, y0, *(ks[:st] + [K_ref]), dt=dt))
+
+
 def test_long_row_plan_equals_in_kernel_gather(dev):
     """Power-law graph: rows longer than the plan's threshold are evaluated by the segment SpMMs ahead of the fused
     kernel and enter it as one entry of a second panel - same results as gathering them inside the kernel."""
