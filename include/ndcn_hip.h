@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 7
+#define NDCN_ABI_VERSION 8
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -292,6 +292,55 @@ NDCN_API int ndcn_row_l1_normalize_f32(const float *X, float *Y, int64_t n_rows,
 NDCN_API int ndcn_row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int64_t n_rows, int H, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU transport (ndcn_halo_plan_create / exchange; 8e).  The path shards by node range, one rank per
+ * GPU: rank r owns rows [b_r, b_{r+1}) of the operator and of every panel; per right-hand side the X rows of remote
+ * column neighbours ("halo") arrive by ONE all-to-all-v - a grouped ncclSend / ncclRecv per peer over RCCL / xGMI, only
+ * the referenced rows travel - and the controller's 16-byte record is all-reduced.  The reference is single-device
+ * (SURVEY 8e); these calls are what its `A x` (neural_dynamics.py:29) and `torch.mean` / `norm` (misc.py:71-76,156)
+ * become when the node set is split.  librccl is bound at first use (dlopen): without it these calls return NDCN_EHIP. */
+typedef struct ndcn_comm ndcn_comm;
+typedef struct ndcn_halo_plan ndcn_halo_plan;
+/* rank 0: a 128-byte id to hand to every rank (over the caller's own channel), then every rank: create on its device */
+NDCN_API int ndcn_comm_unique_id(char h_id[128]);
+NDCN_API int ndcn_comm_create(const char h_id[128], int world, int rank, ndcn_comm **out);
+/* or adopt the caller's ncclComm_t (passed as void*; not destroyed by ndcn_comm_destroy) */
+NDCN_API int ndcn_comm_adopt(void *nccl_comm, int world, int rank, ndcn_comm **out);
+NDCN_API int ndcn_comm_destroy(ndcn_comm *c);
+/* d_buf[0..n) <- sum over ranks (in place, enqueued on `stream`; a no-op for world 1) */
+NDCN_API int ndcn_comm_allreduce_sum_f64(ndcn_comm *c, double *d_buf, int n, void *stream);
+/* h_send_counts / h_recv_counts: HOST arrays [world] of ROW counts per peer (a rank may list itself: rows routed through
+ * the exchange to itself); d_send_idx: DEVICE int32 rows of the own panel to pack, grouped by peer in rank order
+ * (sum of send counts entries; must outlive the plan); the halo panel receives peer 0's rows first, then peer 1's ...
+ * (sum of receive counts == n_halo).  any_rank_moves_rows: the caller's GLOBAL fact (an all-reduce at plan time) - the
+ * exchange is skipped only when no rank sends or receives, never on a rank-local test.                                */
+NDCN_API int ndcn_halo_plan_create(ndcn_comm *c, int64_t n_halo, const int64_t *h_send_counts, const int64_t *h_recv_counts,
+                                   const int32_t *d_send_idx, int any_rank_moves_rows, ndcn_halo_plan **out);
+NDCN_API int ndcn_halo_plan_destroy(ndcn_halo_plan *p);
+/* X_halo[n_halo, H] <- the rows of the peers' panels this rank references; d_pack: scratch of (sum of send counts) * H floats */
+NDCN_API int ndcn_halo_exchange_f32(ndcn_halo_plan *p, const float *X, int H, float *d_pack, float *X_halo, void *stream);
+
+/* How one rank's shard is evaluated by the device-resident solver (ndcn_solver_desc::shard).  desc.A is then an operator
+ * over the columns [own | halo] (n_cols = n_own + n_halo).  Three forms, all with the exchange on a side stream:
+ *   row split  (n_blocks > 0)  the shard's rows in up to 4 contiguous blocks; blocks with needs_halo == 0 (operator over
+ *              the own columns only) run while the halo is in flight, the others after it has landed.  Lattices: one long
+ *              interior block between two thin boundary bands.  desc.A is unused.
+ *   two-phase  (A_own.n_rows > 0)  S = A_own X during the exchange, then desc.A = [I | A_halo] over the panels
+ *              [S | X_halo] (the same fma sequence per row as one launch).  Scattered halos: small-world, power-law shards.
+ *   one launch (neither)       desc.A over [X | X_halo] after the exchange.
+ * n_global_rows: the node count of the whole graph (means and RMS norms of the controller are global).               */
+typedef struct ndcn_shard {
+    ndcn_comm      *comm;
+    ndcn_halo_plan *halo;
+    int64_t         n_global_rows;
+    int32_t         n_blocks;
+    struct { int64_t row_lo, row_hi; int32_t needs_halo; ndcn_csr A; } blocks[4];
+    ndcn_csr        A_own;
+    float          *X_halo;       /* nullable: where the halo rows land (n_halo x H floats).  An operator with a long-row
+                                     plan wants them directly in front of its hub rows (struct ndcn_csr: hub_S == X_halo +
+                                     n_halo * H); NULL: inside the solver's workspace                                    */
+} ndcn_shard;
+
+/* ------------------------------------------------------------------------------------------------
  * Device-resident integrator for the ODEFunc RHS (state, stage derivatives and dense-output coefficients
  * stay in HBM across steps; the host only reads the 16-byte error record per adaptive step).
  * Mirrors the reference's per-call solver object (odeint.py:71-72; dopri5.py:58-122; solvers.py:79-99).
@@ -315,6 +364,8 @@ typedef struct ndcn_solver_desc {
     double   safety, ifactor, dfactor;   /* dopri5 step-size controller (dopri5.py:60,72-74; misc.py:160-170); the
                                             reference's defaults pass through a float32 tensor: (double)0.9f, 10, (double)0.2f.
                                             Values <= 0 select those defaults.                                  */
+    const ndcn_shard *shard;  /* NULL: the whole graph on this device.  Otherwise this rank's shard of a node-range
+                                 sharded graph: A.n_rows = own rows, A.n_cols = own + halo columns (see ndcn_shard) */
 } ndcn_solver_desc;
 
 NDCN_API int64_t ndcn_solver_workspace_bytes(const ndcn_solver_desc *desc);

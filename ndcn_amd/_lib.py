@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 
 OK = 0
@@ -53,12 +53,23 @@ def empty_csr(n_rows):
     return v
 
 
+class ShardBlock(ctypes.Structure):
+    _fields_ = [('row_lo', ctypes.c_int64), ('row_hi', ctypes.c_int64), ('needs_halo', ctypes.c_int32), ('A', CsrView)]
+
+
+class ShardView(ctypes.Structure):
+    """struct ndcn_shard"""
+    _fields_ = [('comm', ctypes.c_void_p), ('halo', ctypes.c_void_p), ('n_global_rows', ctypes.c_int64),
+                ('n_blocks', ctypes.c_int32), ('blocks', ShardBlock * 4), ('A_own', CsrView), ('X_halo', ctypes.c_void_p)]
+
+
 class SolverDesc(ctypes.Structure):
     """struct ndcn_solver_desc"""
     _fields_ = [('method', ctypes.c_int), ('H', ctypes.c_int), ('rhs_flags', ctypes.c_uint32),
                 ('use_graph', ctypes.c_int), ('A', CsrView), ('W', ctypes.c_void_p), ('b', ctypes.c_void_p),
                 ('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('max_num_steps', ctypes.c_int64),
-                ('safety', ctypes.c_double), ('ifactor', ctypes.c_double), ('dfactor', ctypes.c_double)]
+                ('safety', ctypes.c_double), ('ifactor', ctypes.c_double), ('dfactor', ctypes.c_double),
+                ('shard', ctypes.POINTER(ShardView))]
 
 
 _P, _I, _L, _F, _D, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_uint32
@@ -99,6 +110,14 @@ SIGNATURES = {
     'ndcn_row_l1_normalize_bwd_f32': (_I, [_P, _P, _P, _L, _I, _P]),
     'ndcn_gene_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _P]),
     'ndcn_mutual_rhs_f32': (_I, [_CSR, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
+    'ndcn_comm_unique_id': (_I, [ctypes.c_char_p]),
+    'ndcn_comm_create': (_I, [ctypes.c_char_p, _I, _I, ctypes.POINTER(_P)]),
+    'ndcn_comm_adopt': (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
+    'ndcn_comm_destroy': (_I, [_P]),
+    'ndcn_comm_allreduce_sum_f64': (_I, [_P, _P, _I, _P]),
+    'ndcn_halo_plan_create': (_I, [_P, _L, ctypes.POINTER(_L), ctypes.POINTER(_L), _P, _I, ctypes.POINTER(_P)]),
+    'ndcn_halo_plan_destroy': (_I, [_P]),
+    'ndcn_halo_exchange_f32': (_I, [_P, _P, _I, _P, _P, _P]),
     'ndcn_solver_workspace_bytes': (_L, [ctypes.POINTER(SolverDesc)]),
     'ndcn_solver_create': (_I, [ctypes.POINTER(SolverDesc), _P, _L, ctypes.POINTER(_P)]),
     'ndcn_solver_destroy': (_I, [_P]),

@@ -119,6 +119,13 @@ int gene_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float f
 int mutual_rhs_f32(const ndcn_csr *A, const float *x, float *out, float b, float k, float c, float d, float e, float h,
                    hipStream_t st);
 
+// comm.hip
+int comm_world(const ndcn_comm *c);
+int comm_allreduce_sum_f64(ndcn_comm *c, double *d_buf, int n, hipStream_t st);
+int64_t halo_plan_n_halo(const ndcn_halo_plan *p);
+int64_t halo_plan_n_send(const ndcn_halo_plan *p);
+int halo_exchange_f32(ndcn_halo_plan *p, const float *X, int H, float *d_pack, float *X_halo, hipStream_t st);
+
 int64_t solver_workspace_bytes(const ndcn_solver_desc *desc);
 int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_bytes, ndcn_solver **out);
 int solver_destroy(ndcn_solver *s);

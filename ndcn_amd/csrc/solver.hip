@@ -90,6 +90,15 @@ struct ndcn_solver {
     float *d_dt = nullptr;         // device step size read by the captured stage kernels
     float *d_coef = nullptr, *d_beta = nullptr;   // replayed adaptive step: tableau entries and their dt-scaled image
     float h_beta[64] = {0};
+    // node-range sharded graph (ndcn_solver_desc::shard): exchange on a side stream, global reductions
+    bool sharded = false;
+    ndcn_shard shard;
+    int64_t n_own = 0, n_halo = 0, n_send = 0;
+    float *halo = nullptr, *pack = nullptr, *sbuf = nullptr;   // halo panel, send buffer, S = A_own X (two-phase)
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+    bool packed = false;           // `work` holds the packed weights of this solve
+    double n_mean = 0;             // element count behind the controller's means (global for a shard)
     int n_coef = 0;
     float *h_dt = nullptr;         // pinned ring of step sizes (async H2D source must stay untouched until consumed)
     int64_t g_step = 0;
@@ -112,7 +121,13 @@ int n_panels(const ndcn_solver_desc *d) {
 size_t workspace_bytes(const ndcn_solver_desc *d) {
     const size_t panel = align_up((size_t)d->A.n_rows * (size_t)d->H * sizeof(float) + 16);
     const size_t work = align_up((size_t)rhs_work_bytes(d->A.n_rows, d->H, d->rhs_flags) + 16);
-    return (size_t)n_panels(d) * panel + work + 2 * align_up((size_t)reduce_ws_bytes()) + 4096;
+    size_t shard = 0;
+    if (d->shard) {
+        const size_t rows = (size_t)halo_plan_n_halo(d->shard->halo) + (size_t)halo_plan_n_send(d->shard->halo) +
+                            (d->shard->A_own.n_rows > 0 ? (size_t)d->A.n_rows : 0);
+        shard = 3 * 256 + align_up(rows * (size_t)d->H * sizeof(float) + 48);
+    }
+    return (size_t)n_panels(d) * panel + work + 2 * align_up((size_t)reduce_ws_bytes()) + 4096 + shard;
 }
 
 int carve(ndcn_solver *s, size_t bytes, void **p) {
@@ -134,7 +149,11 @@ int alloc_panel(ndcn_solver *s, float **p) {
     return NDCN_OK;
 }
 
+int rhs_sharded(ndcn_solver *s, const float *x, float *K, int mode, const float *y0, const float *const *kp, const float *cp,
+                int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const RkOpt *opt);
+
 int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
+    if (s->sharded) return rhs_sharded(s, x, out, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st, nullptr);
     s->n_rhs++;
     if (s->fused2 && !s->rec_epi)
         return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, 0, nullptr,
@@ -149,6 +168,7 @@ int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
 int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0, const float *const *kp, const float *cp,
             int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st,
             const float *dt_dev = nullptr, const RkOpt *opt = nullptr) {
+    if (s->sharded) return rhs_sharded(s, x, K, mode, y0, kp, cp, n_prev, y_next, rtol, atol, d_out, d_ws, st, opt);
     s->n_rhs++;
     if (s->rec_epi) {
         // replay: cp holds the bare tableau entries; they join the solver's coefficient table, whose scaled image
@@ -175,6 +195,10 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
 
 // wait for the reduction record enqueued last on `st`
 int fetch_record(ndcn_solver *s, hipStream_t st, double &sum, double &bad) {
+    if (s->sharded) {                                   // every rank sees the same record: identical controller decisions
+        int rc = comm_allreduce_sum_f64(s->shard.comm, s->d_red, 2, st);
+        if (rc) return rc;
+    }
     NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     NDCN_HIP(hipEventRecord(s->ev, st));
     NDCN_HIP(hipEventSynchronize(s->ev));
@@ -192,7 +216,7 @@ int rms_scaled(ndcn_solver *s, const float *a, const float *b, const float *y, f
     if (rc) return rc;
     // misc.py:71-76: x.norm() / numel ** 0.5, a float32 0-d tensor divided by a python float
     const float nrm = (float)sqrt(sum);
-    rms = nrm / (float)sqrt((double)s->n_elem);
+    rms = nrm / (float)sqrt(s->n_mean);
     return NDCN_OK;
 }
 
@@ -231,6 +255,61 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     h_out = (double)(h100 < h1 ? h100 : h1);
     if (isnan(h100) || isnan(h1)) h_out = NAN;
     return NDCN_OK;
+}
+
+// One right-hand side (+ RK epilogue) of a shard: the halo exchange runs on the side stream while the launches that
+// need no halo run on `st`; see struct ndcn_shard for the three forms.  Every launch goes through rhs_rk_f32, i.e. the
+// same kernel selection as ndcn_rhs_rk_f32; split launches take their rows of every row-local panel by offset, the error
+// record by `y1` + accumulation (NDCN_F_ACCUM semantics).
+int rhs_sharded(ndcn_solver *s, const float *x, float *K, int mode, const float *y0, const float *const *kp, const float *cp,
+                int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const RkOpt *opt) {
+    s->n_rhs++;
+    const int H = s->d.H;
+    const uint32_t flags = s->d.rhs_flags | (s->packed ? NDCN_F_PACKED : 0u);
+    const ndcn_shard &sh = s->shard;
+    float *y_aux = opt ? opt->y_aux : nullptr;
+    const float *c_aux = opt ? opt->c_aux : nullptr;
+    auto launch = [&](const ndcn_csr *A, const float *X, const float *Xh, int64_t lo, bool first, const float *y1) -> int {
+        const size_t off = (size_t)lo * H;
+        const float *kpo[8];
+        for (int m = 0; m < n_prev; ++m) kpo[m] = kp[m] + off;
+        RkOpt o = {mode == NDCN_RK_ERROR ? y1 + off : nullptr, (mode == NDCN_RK_ERROR && !first) ? 1 : 0,
+                   y_aux ? y_aux + off : nullptr, c_aux};
+        return rhs_rk_f32(A, X, Xh, s->n_own, s->d.W, s->d.b, K + off, s->work, H, flags, mode, y0 ? y0 + off : nullptr, kpo, cp,
+                          n_prev, y_next ? y_next + off : nullptr, rtol, atol, d_out, d_ws, st, &o);
+    };
+    if (s->d.rhs_flags & NDCN_F_NO_GRAPH) return launch(&s->d.A, x, nullptr, 0, true, x);     // row-local: nothing to exchange
+    // x is complete on `st` -> the exchange may start on the side stream
+    NDCN_HIP(hipEventRecord(s->ev_x, st));
+    NDCN_HIP(hipStreamWaitEvent(s->cstream, s->ev_x, 0));
+    int rc = halo_exchange_f32(sh.halo, x, H, s->pack, s->halo, s->cstream);
+    if (rc) return rc;
+    NDCN_HIP(hipEventRecord(s->ev_halo, s->cstream));
+    if (sh.n_blocks > 0) {
+        bool first = true;
+        for (int b = 0; b < sh.n_blocks; ++b)
+            if (!sh.blocks[b].needs_halo) {
+                rc = launch(&sh.blocks[b].A, x, nullptr, sh.blocks[b].row_lo, first, x);
+                if (rc) return rc;
+                first = false;
+            }
+        NDCN_HIP(hipStreamWaitEvent(st, s->ev_halo, 0));
+        for (int b = 0; b < sh.n_blocks; ++b)
+            if (sh.blocks[b].needs_halo) {
+                rc = launch(&sh.blocks[b].A, x, s->halo, sh.blocks[b].row_lo, first, x);
+                if (rc) return rc;
+                first = false;
+            }
+        return NDCN_OK;
+    }
+    if (sh.A_own.n_rows > 0) {
+        rc = spmm_f32(&sh.A_own, x, nullptr, s->n_own, s->sbuf, H, 1.f, 0, st);               // phase 1 under the exchange
+        if (rc) return rc;
+        NDCN_HIP(hipStreamWaitEvent(st, s->ev_halo, 0));
+        return launch(&s->d.A, s->sbuf, s->halo, 0, true, x);                                  // phase 2: [I | A_halo] over [S | halo]
+    }
+    NDCN_HIP(hipStreamWaitEvent(st, s->ev_halo, 0));
+    return launch(&s->d.A, x, s->halo, 0, true, x);
 }
 
 void dt_coeffs(float dt32, const double *beta, int n, const float *const *kall, const float **kp, float *cp, int &m) {
@@ -365,7 +444,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
     rc = fetch_record(s, st, sum, bad);
     if (rc) return rc;
     // misc.py:156 mean in the state dtype; dopri5.py:109
-    const float ratio = (float)(sum / (double)s->n_elem);
+    const float ratio = (float)(sum / s->n_mean);
     const bool accept = ratio <= 1.f;
     // misc.py:160-170.  safety / dfactor passed through a float32 tensor in the reference (dopri5.py:72-74)
     const double safety = s->d.safety > 0 ? s->d.safety : (double)0.9f;
@@ -456,6 +535,19 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     s->d = *desc;
     s->n_rows = desc->A.n_rows;
     s->n_elem = s->n_rows * (int64_t)desc->H;
+    s->n_mean = (double)s->n_elem;
+    if (desc->shard) {
+        NDCN_CHECK_ARG(desc->shard->comm && desc->shard->halo && desc->shard->n_global_rows >= desc->A.n_rows &&
+                       desc->shard->n_blocks >= 0 && desc->shard->n_blocks <= 4, "bad shard descriptor");
+        s->sharded = true;
+        s->shard = *desc->shard;
+        s->d.shard = &s->shard;
+        s->n_halo = halo_plan_n_halo(s->shard.halo);
+        s->n_send = halo_plan_n_send(s->shard.halo);
+        s->n_own = desc->A.n_cols - s->n_halo;
+        s->n_mean = (double)s->shard.n_global_rows * (double)desc->H;
+        if (s->n_own != s->n_rows) { set_error("shard: operator has %lld rows, %lld own columns", (long long)s->n_rows, (long long)s->n_own); delete s; return NDCN_EINVAL; }
+    }
     if (workspace) {
         s->slab = workspace;
         s->slab_bytes = (size_t)ws_bytes;
@@ -482,6 +574,30 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
             s->work = static_cast<float *>(wq);
         }
         const bool both = !(desc->rhs_flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
+        if (s->sharded) {
+            // the stage algebra rides in the epilogues of whatever kernel ndcn_rhs_rk_f32 selects per launch
+            s->fused = both && rhs_fused_supported(desc->H, desc->rhs_flags);
+            s->fused2 = true;
+            void *q2 = nullptr;
+            if (s->shard.X_halo) {
+                s->halo = s->shard.X_halo;
+            } else {
+                if ((rc = carve(s, (size_t)s->n_halo * desc->H * sizeof(float) + 16, &q2))) return fail(rc);
+                s->halo = static_cast<float *>(q2);
+            }
+            if ((rc = carve(s, (size_t)s->n_send * desc->H * sizeof(float) + 16, &q2))) return fail(rc);
+            s->pack = static_cast<float *>(q2);
+            if (s->shard.A_own.n_rows > 0) {
+                if ((rc = carve(s, (size_t)s->n_elem * sizeof(float) + 16, &q2))) return fail(rc);
+                s->sbuf = static_cast<float *>(q2);
+            }
+            if (hipStreamCreateWithFlags(&s->cstream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming) != hipSuccess) {
+                set_error("creating the exchange stream failed");
+                return fail(NDCN_EHIP);
+            }
+        } else {
         s->fused = both && rhs_fused_supported(desc->H, desc->rhs_flags);
         s->fused2 = s->fused && rhs_fused2_supported(&desc->A, desc->H, desc->rhs_flags);
         if (!no_graph && no_ctl && spmm_rec_supported(&desc->A, desc->H) && s->n_rows * (int64_t)1024 < (1ll << 32)) {
@@ -493,6 +609,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
             // narrow panels: the adaptive step runs 1 combine + 6 launches; fixed-grid methods keep their replayed step,
             // whose right-hand sides go through the same kernel in plain mode (rhs_f32)
             s->fused2 = s->rec_epi = s->small_epi = true;
+        }
         }
     }
     const int nk = desc->method == NDCN_M_DOPRI5 ? 7 : desc->method == NDCN_M_RK4 ? 4 : 1;
@@ -524,7 +641,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     s->d_beta = s->d_coef + kCoefCap;
     // hipGraph replay pays off where the step is launch-bound.  The fused MFMA kernel takes dt by value (large
     // panels: never launch-bound); every other path reads it from device memory when replayed.
-    s->graph_on = desc->use_graph && !(s->fused2 && !s->rec_epi) &&
+    s->graph_on = !s->sharded && desc->use_graph && !(s->fused2 && !s->rec_epi) &&
                   !(s->rec_epi && desc->method != NDCN_M_DOPRI5);
     if (s->graph_on) {
         if (hipStreamCreateWithFlags(&s->gstream, hipStreamNonBlocking) != hipSuccess ||
@@ -547,6 +664,9 @@ int solver_destroy(ndcn_solver *s) {
     if (s->gev_in) (void)hipEventDestroy(s->gev_in);
     if (s->gev_out) (void)hipEventDestroy(s->gev_out);
     if (s->gstream) (void)hipStreamDestroy(s->gstream);
+    if (s->cstream) (void)hipStreamDestroy(s->cstream);
+    if (s->ev_x) (void)hipEventDestroy(s->ev_x);
+    if (s->ev_halo) (void)hipEventDestroy(s->ev_halo);
     if (s->h_dt) (void)hipHostFree(s->h_dt);
     delete s;
     return NDCN_OK;
@@ -567,6 +687,7 @@ int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st) {
     if (s->fused) {
         int rcp = pack_weight_256(s->d.W, s->work, st);
         if (rcp) return rcp;
+        s->packed = true;
     }
     if (s->d.method == NDCN_M_DOPRI5) {
         // dopri5.py:77-83

@@ -406,6 +406,121 @@ def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, ato
     return torch.stack([s[0] for s in sol])
 
 
+class DeviceShard:
+    """The C-ABI form of a HaloPlan (include/ndcn_hip.h: ndcn_comm / ndcn_halo_plan / ndcn_shard): an RCCL communicator
+    of the library's own (unique id from rank 0, handed out over torch.distributed), the halo plan, and the way the
+    shard is evaluated - row split for lattices, two-phase for scattered halos, one launch otherwise.  With it
+    `DeviceSolver(..., shard=)` steps the whole solve inside libndcn_hip.so: exchange on a side stream, launches, the
+    16-byte all-reduce and the controller - no Python between the evaluations."""
+
+    def __init__(self, plan, n_global_rows, group=None):
+        import ctypes
+        from . import _lib
+        self.plan = plan
+        self.lib = lib = _lib.load()
+        self.n_global_rows = int(n_global_rows)
+        dev = plan.device
+        # communicator: rank 0 draws the id, everybody learns it over the caller's process group
+        idbuf = ctypes.create_string_buffer(128)
+        if plan.rank == 0:
+            _lib.check(lib.ndcn_comm_unique_id(idbuf))
+        if plan.world > 1:
+            comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+            t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=comm_dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = ctypes.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        self.comm = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(lib.ndcn_comm_create(idbuf, plan.world, plan.rank, ctypes.byref(self.comm)))
+        L = ctypes.c_int64 * plan.world
+        self.send_idx = plan.send_idx.contiguous()
+        self.halo = ctypes.c_void_p()
+        _lib.check(lib.ndcn_halo_plan_create(self.comm, plan.n_halo, L(*plan.send_counts), L(*plan.recv_counts),
+                                             _lib.ptr(self.send_idx) if self.send_idx.numel() else None,
+                                             1 if plan.global_rows_moved > 0 else 0, ctypes.byref(self.halo)))
+        self._views = {}
+
+    def operator(self, H):
+        """The operator the solver descriptor carries: [I | A_halo] in the two-phase form, the whole shard otherwise."""
+        op = self.plan.two_phase[1] if self.plan.two_phase is not None else self.plan.local_op
+        return op.ensure_plans(H)
+
+    def view_ptr(self, H):
+        import ctypes
+        from . import _lib
+        v = self._views.get(H)
+        if v is None:
+            p = self.plan
+            v = _lib.ShardView()
+            v.comm, v.halo, v.n_global_rows = self.comm, self.halo, self.n_global_rows
+            keep = []
+            if p.ranges is not None:
+                v.n_blocks = len(p.ranges)
+                for i, (a, b, op, needs) in enumerate(p.ranges):
+                    op.ensure_plans(H)
+                    v.blocks[i].row_lo, v.blocks[i].row_hi, v.blocks[i].needs_halo = a, b, 1 if needs else 0
+                    v.blocks[i].A = op.view()
+                    keep.append(op)
+            elif p.two_phase is not None:
+                own = p.two_phase[0].ensure_plans(H)
+                v.A_own = own.view()
+                keep.append(own)
+            main = self.operator(H)
+            hub = getattr(main, 'hub', None)
+            if hub is not None and hub['H'] == H and hub['halo_S'].shape[0] == p.n_halo + hub['n']:
+                v.X_halo = hub['halo_S'].data_ptr()             # long-row plan: the halo lands in front of its hub rows
+            v._keep = keep
+            self._views[H] = v
+        return ctypes.pointer(v)
+
+    def close(self):
+        if self.halo:
+            self.lib.ndcn_halo_plan_destroy(self.halo)
+            self.halo = None
+        if self.comm:
+            self.lib.ndcn_comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedDeviceBench:
+    """bench.py's N > 1 workload on the device-resident sharded solver (the production form over RCCL): the counterpart of
+    ShardedBench without Python between the evaluations."""
+
+    def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, group=None):
+        from .torchdiffeq._impl.odeint import DeviceSolver
+        n_local = int(bounds[rank + 1] - bounds[rank])
+        sh = os.environ.get('NDCN_SELF_HALO', '0')
+        self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=sh if sh.startswith('scatter:') else int(sh))
+        self.local_nnz = self.plan.local_nnz
+        self.shard = DeviceShard(self.plan, int(bounds[-1]), group)
+        self.solver = DeviceSolver(odefunc, n_local, 'dopri5', rtol, atol, shard=self.shard)
+        self.x0 = torch.rand(n_local, odefunc.hidden_size, generator=torch.Generator().manual_seed(rank)).to(device)
+        self.out = torch.empty_like(self.x0)
+        self.T = T
+        self.nfe_done = 0
+        self.solver.begin(self.x0, 0.0)
+
+    def run_steps(self, k):
+        done = 0
+        while done < k:
+            before = self.solver.stats()['steps']
+            reached = self.solver.advance(self.T, self.out, step_budget=k - done)
+            done += int(self.solver.stats()['steps'] - before)
+            if reached:
+                self.nfe_done += int(self.solver.stats()['nfe'])
+                self.solver.begin(self.x0, 0.0)
+        return done
+
+    def nfe(self):
+        return self.nfe_done + int(self.solver.stats()['nfe'])
+
+
 class ShardedBench:
     """bench.py's N > 1 workload on ANY row-sharded operator: rank r owns rows [bounds[r], bounds[r+1]) of the global
     operator and is handed only that row block (global column indices)."""

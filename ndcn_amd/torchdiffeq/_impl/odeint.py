@@ -136,13 +136,20 @@ class DeviceSolver:
     """RAII wrapper of ndcn_solver_* for one (ODEFunc, method) pair; the workspace is a torch allocation."""
 
     def __init__(self, odefunc, n_rows, method, rtol=1e-7, atol=1e-9, max_num_steps=2 ** 31 - 1, use_graph=False,
-                 safety=core.SAFETY, ifactor=core.IFACTOR, dfactor=core.DFACTOR):
+                 safety=core.SAFETY, ifactor=core.IFACTOR, dfactor=core.DFACTOR, shard=None):
+        """shard: a ndcn_amd.sharding.DeviceShard - this rank's part of a node-range sharded graph; the operator is then
+        the shard's (own rows, [own | halo] columns) and `odefunc.A` is ignored."""
         from ...csr import as_csr
         self.lib = _lib.load()
         H = odefunc.hidden_size
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
         dev = odefunc.wt.weight.device
-        if odefunc.no_graph:
+        if shard is not None:
+            csr = shard.operator(H)
+            assert csr.shape[0] == n_rows
+            view = csr.view()
+            self._keep = (csr, shard)
+        elif odefunc.no_graph:
             view = _lib.empty_csr(n_rows)
             self._keep = ()
         else:
@@ -160,7 +167,7 @@ class DeviceSolver:
         self.desc = _lib.SolverDesc(_lib.METHODS[method], H, flags, 1 if use_graph else 0, view,
                                     W.data_ptr(), b.data_ptr() if b is not None else None,
                                     float(rtol), float(atol), int(max_num_steps), float(safety), float(ifactor),
-                                    float(dfactor))
+                                    float(dfactor), shard.view_ptr(H) if shard is not None else None)
         self.device = dev
         self.shape = (n_rows, H)
         nbytes = int(self.lib.ndcn_solver_workspace_bytes(ctypes.byref(self.desc)))

@@ -604,6 +604,46 @@ def test_narrow_panel_rhs_is_one_launch_and_equals_the_composed_kernels(dev, H):
         assert torch.equal(K3, K_ref) and torch.equal(yn, hip.fixed_stage(2 + st, y0, *(ks[:st] + [K_ref]), dt=dt))
 
 
+def test_halo_exchange_through_the_c_abi_only(dev):
+    """ndcn_comm_* / ndcn_halo_plan_* / ndcn_halo_exchange_f32 driven through ctypes alone (no torch.distributed): a
+    one-rank RCCL communicator whose plan routes rows of the own panel through the exchange to itself - the grouped
+    ncclSend / ncclRecv really executes on the 1-GPU box - plus the controller's all-reduce (identity at world 1)."""
+    import ctypes
+    from ndcn_amd import _lib
+    lib = _lib.load()
+    idbuf = ctypes.create_string_buffer(128)
+    _lib.check(lib.ndcn_comm_unique_id(idbuf))
+    comm = ctypes.c_void_p()
+    _lib.check(lib.ndcn_comm_create(idbuf, 1, 0, ctypes.byref(comm)))
+    try:
+        n, H, k = 5000, 256, 777
+        X = torch.randn(n, H, device=dev)
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(0))[:k].to(torch.int32).to(dev)
+        L1 = ctypes.c_int64 * 1
+        plan = ctypes.c_void_p()
+        _lib.check(lib.ndcn_halo_plan_create(comm, k, L1(k), L1(k), _lib.ptr(idx), 1, ctypes.byref(plan)))
+        pack = torch.empty(k, H, device=dev)
+        halo = torch.full((k, H), float('nan'), device=dev)
+        _lib.check(lib.ndcn_halo_exchange_f32(plan, _lib.ptr(X), H, _lib.ptr(pack), _lib.ptr(halo), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(halo, X[idx.long()])
+        # a plan nobody moves rows in skips the collective on every rank
+        plan0 = ctypes.c_void_p()
+        _lib.check(lib.ndcn_halo_plan_create(comm, 0, L1(0), L1(0), None, 0, ctypes.byref(plan0)))
+        _lib.check(lib.ndcn_halo_exchange_f32(plan0, _lib.ptr(X), H, None, None, _lib.stream_ptr()))
+        # receive counts must add up to n_halo
+        bad = ctypes.c_void_p()
+        assert lib.ndcn_halo_plan_create(comm, k + 1, L1(k), L1(k), _lib.ptr(idx), 1, ctypes.byref(bad)) == _lib.EINVAL
+        rec = torch.tensor([1.5, 2.0], dtype=torch.float64, device=dev)
+        _lib.check(lib.ndcn_comm_allreduce_sum_f64(comm, _lib.ptr(rec), 2, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert rec.tolist() == [1.5, 2.0]
+        lib.ndcn_halo_plan_destroy(plan)
+        lib.ndcn_halo_plan_destroy(plan0)
+    finally:
+        lib.ndcn_comm_destroy(comm)
+
+
 def test_long_row_plan_equals_in_kernel_gather(dev):
     """Power-law graph: rows longer than the plan's threshold are evaluated by the segment SpMMs ahead of the fused
     kernel and enter it as one entry of a second panel - same results as gathering them inside the kernel."""

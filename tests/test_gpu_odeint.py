@@ -415,6 +415,38 @@ def test_sharded_path_single_rank_equals_device_solver(dev):
         assert [r[2] for r in lc if r[0] != 'nfe'] == [r[2] for r in lb if r[0] != 'nfe']
         assert float((yc - yb).abs().max()) <= 1e-5 * float(ya.abs().max())
         assert float((yr - y4).abs().max()) <= 1e-5 * float(y4.abs().max())
+        # ---- the same shards through the C ABI: RCCL communicator + halo plan + sharded DEVICE-RESIDENT solver
+        # (ndcn_comm_* / ndcn_halo_plan_* / ndcn_solver_desc::shard): no Python between the evaluations.  Row-split form
+        # (lattice band), two-phase form (scattered self-halo), one-launch form (no halo): each must reproduce the
+        # Python-stepped sharded solve - same kernels, same order - and the unsharded solver within the path's tolerance.
+        from ndcn_amd.torchdiffeq._impl.odeint import DeviceSolver
+        plan3 = sharding.HaloPlan(L, [0, side * side], 0, dev, self_halo='scatter:500')
+        assert plan3.two_phase is not None and plan3.n_halo == 500
+        tt = [0.7, 2.0]
+        for pl in (plan2, plan3, plan):
+            shard = sharding.DeviceShard(pl, side * side)
+            solver = DeviceSolver(f, side * side, 'dopri5', .01, .001, shard=shard)
+            out = torch.empty(2, side * side, H, device=dev)
+            with torch.no_grad():
+                solver.begin(x0, 0.0)
+                solver.advance_many(tt, out)
+                lp = []
+                yp = sharding.sharded_odeint(hip, f, pl, side * side, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lp)
+            torch.cuda.synchronize()
+            ld = solver.steplog()
+            assert [r[2] for r in ld] == [r[2] for r in lp if r[0] != 'nfe'] == [r[2] for r in la[:-1]]
+            assert float((out - yp[1:]).abs().max()) <= 1e-6 * float(ya.abs().max())
+            assert float((out - ya[1:]).abs().max()) <= 1e-5 * float(ya.abs().max())
+            assert int(solver.stats()['nfe']) == dict([lp[-1]])['nfe']
+            # fixed grid on the shard: rk4 with the stage algebra in the split launches
+            rk = DeviceSolver(f, side * side, 'rk4', shard=shard)
+            o4 = torch.empty(3, side * side, H, device=dev)
+            with torch.no_grad():
+                rk.begin(x0, 0.0)
+                rk.advance_many(torch.linspace(0., 1., 4)[1:].tolist(), o4)
+            torch.cuda.synchronize()
+            assert float((o4 - y4[1:]).abs().max()) <= 1e-5 * float(y4.abs().max())
+            solver.close(); rk.close(); shard.close()
         # bench runner of the sharded path (with the hook: exchange timing is recorded)
         runner = sharding.ShardedGridBench(f, 48, 1, 0, dev, 5.0, .01, .001)
         assert runner.run_steps(3) == 3 and runner.nfe() >= 2 + 18
