@@ -77,7 +77,10 @@ def parse():
     p.add_argument('--cpu-threads', type=int, default=32, help='host threads of the CPU-baseline leg')
     p.add_argument('--cpu-nodes', type=int, default=0, help='nodes of the bounded CPU-baseline sample (0: per-configuration default)')
     p.add_argument('--no-profile-pass', action='store_true')
-    p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (needs torchrun, works with 1 rank)')
+    p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (works with 1 rank)')
+    p.add_argument('--sharded-impl', default='device', choices=['device', 'python'],
+                   help='N > 1: the sharded device-resident solver behind the C ABI (RCCL communicator of the library) or the '
+                        'Python-stepped path over torch.distributed (the only one the gloo test hook can run)')
     p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
     p.add_argument('--no-control', action='store_true', help='config M with ODEFunc(no_control=True): relu(A X), the pure HBM right-hand side (neural_dynamics.py:32)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')
@@ -338,10 +341,32 @@ def main():
         assert args.config in ('M', 'C4'), 'the sharded path runs the metric\'s grid or config 4\'s small world'
         torch.manual_seed(0)
         f = ODEFunc(H, None).to(dev).eval()                      # nn.Linear default init, seed 0
+        from ndcn_amd import sharding
+        device_impl = args.sharded_impl == 'device' and backend == 'nccl'
+
+        def make_runner(block, bounds):
+            """The sharded device-resident solver; if ANY rank cannot set it up (e.g. its RCCL communicator), every rank
+            falls back to the Python-stepped path together (the decision is all-reduced: no rank may wait in a collective
+            its peers never enter)."""
+            r, err = None, None
+            if device_impl:
+                try:
+                    r = sharding.ShardedDeviceBench(f, block, bounds, rank, dev, args.T, args.rtol, args.atol)
+                except Exception as e:                                  # noqa: BLE001 - reported below, then a collective decision
+                    err = e
+                ok = torch.tensor([0 if r is None else 1], device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    print('[bench] rank %d: device-resident sharded solver unavailable (%r) - Python-stepped path' % (rank, err),
+                          file=sys.stderr, flush=True)
+                    r = None
+            if r is None:
+                r = sharding.ShardedBench(f, block, bounds, rank, dev, args.T, args.rtol, args.atol)
+            return r
+
         if args.config == 'M':
             n_local = S * S
-            from ndcn_amd.sharding import ShardedGridBench
-            runner = ShardedGridBench(f, S, world, rank, dev, args.T, args.rtol, args.atol)
+            runner = make_runner(*sharding.grid_row_block(S, world, rank))
             nnz = runner.local_nnz
             what = ('NDCN ODEFunc relu(W(AX)+b), %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR nnz=%d '
                     'per GPU, H=%d, dopri5 rtol=%g atol=%g t in [0,%g], state X~U(0,1) seed = rank, nn.Linear default init seed 0'
@@ -349,12 +374,12 @@ def main():
         else:
             # weak scaling of config 4: a (500k x world)-node small world, node-range sharded; every rank generates the
             # same graph (O(n) generator, seed 0) and keeps its own rows of the normalised Laplacian
-            from ndcn_amd.sharding import ShardedBench, even_bounds
+            from ndcn_amd.sharding import even_bounds
             n_glob = C4_NODES_PER_GPU * world
             L = graphs.normalized_laplacian(graphs.make_graph('small_world', n_glob, seed=0)).tocsr()
             bounds = even_bounds(n_glob, world)
             n_local = int(bounds[rank + 1] - bounds[rank])
-            runner = ShardedBench(f, L[bounds[rank]:bounds[rank + 1]], bounds, rank, dev, args.T, args.rtol, args.atol)
+            runner = make_runner(L[bounds[rank]:bounds[rank + 1]], bounds)
             del L
             nnz = runner.local_nnz
             what = ('C4: NDCN ODEFunc relu(W(AX)+b), Newman-Watts-Strogatz small world k=5 p=0.5, %d nodes per GPU (N=%d nodes '
@@ -468,17 +493,20 @@ def main():
     halo = None
     if hasattr(runner, 'plan') and (world > 1 or runner.plan.n_halo > 0):
         hb = int(runner.plan.bytes_per_exchange(H))
+        # a short instrumented pass: per exchange, its duration on the side stream, the launch it hides behind, and what
+        # the main stream still waited for (exposed).  The device-resident solver is timed through its Python twin: the
+        # same plan, streams and launches, with events around them.
+        timed = runner.python_twin() if hasattr(runner, 'python_twin') else runner
         halo = {'bytes_received_per_rhs_per_gpu': hb, 'exchanges_per_step': 6,
-                'xgmi_peak_GBps_per_gpu': 7 * 153, 'overlapped_with_interior_rows': bool(runner.func.overlap),
-                'two_phase_own_columns_under_exchange': bool(runner.func.two_phase)}
-        # a short instrumented pass: per exchange, its duration on the side stream, the interior launch it hides
-        # behind, and what the main stream still waited for (exposed)
-        runner.func.timing = {}
+                'xgmi_peak_GBps_per_gpu': 7 * 153, 'overlapped_with_interior_rows': bool(timed.func.overlap),
+                'two_phase_own_columns_under_exchange': bool(timed.func.two_phase),
+                'solver': 'device-resident (C ABI, library-owned RCCL communicator)' if timed is not runner else 'python-stepped over torch.distributed'}
+        timed.func.timing = {}
         with torch.no_grad():
-            runner.run_steps(min(args.steps, 5))
+            timed.run_steps(min(args.steps, 5))
         torch.cuda.synchronize()
-        tm = runner.func.drain_timing() or {}
-        runner.func.timing = None
+        tm = timed.func.drain_timing() or {}
+        timed.func.timing = None
         if tm.get('n'):
             halo.update({'exchange_us': round(tm['exchange_us'] / tm['n'], 1), 'interior_us': round(tm['interior_us'] / tm['n'], 1),
                          'exposed_us': round(tm['exposed_us'] / tm['n'], 1), 'timed_exchanges': tm['n']})

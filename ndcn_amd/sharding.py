@@ -494,6 +494,7 @@ class ShardedDeviceBench:
 
     def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, group=None):
         from .torchdiffeq._impl.odeint import DeviceSolver
+        self.args = (odefunc, bounds, rank, device, T, rtol, atol, group)
         n_local = int(bounds[rank + 1] - bounds[rank])
         sh = os.environ.get('NDCN_SELF_HALO', '0')
         self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=sh if sh.startswith('scatter:') else int(sh))
@@ -520,18 +521,32 @@ class ShardedDeviceBench:
     def nfe(self):
         return self.nfe_done + int(self.solver.stats()['nfe'])
 
+    def python_twin(self):
+        """The same shard stepped from Python (ShardedBench on the same HaloPlan): bench.py's instrumented pass measures
+        the exchange / exposure times there (its streams and launches are the ones this solver issues)."""
+        odefunc, bounds, rank, device, T, rtol, atol, group = self.args
+        return ShardedBench(odefunc, None, bounds, rank, device, T, rtol, atol, group=group, plan=self.plan)
+
+
+def grid_row_block(S, world, rank):
+    """(row block, bounds) of the metric's weak-scaling grid: the (S * world) x S lattice, rank r owns lattice rows
+    [r S, (r + 1) S) and builds only its own rows."""
+    from . import graphs
+    return graphs.grid_operator_row_block(S * world, S, rank * S, (rank + 1) * S, 'norm_lap'), [r * S * S for r in range(world + 1)]
+
 
 class ShardedBench:
     """bench.py's N > 1 workload on ANY row-sharded operator: rank r owns rows [bounds[r], bounds[r+1]) of the global
     operator and is handed only that row block (global column indices)."""
 
-    def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, ops=None, group=None):
+    def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, ops=None, group=None, plan=None):
         from .torchdiffeq._impl import core
         if ops is None:
             from .ops import hip as ops
         n_local = int(bounds[rank + 1] - bounds[rank])
         sh = os.environ.get('NDCN_SELF_HALO', '0')
-        self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=sh if sh.startswith('scatter:') else int(sh))
+        self.plan = plan if plan is not None else HaloPlan(block, bounds, rank, device, group,
+                                                           self_halo=sh if sh.startswith('scatter:') else int(sh))
         self.local_nnz = self.plan.local_nnz
         self.func = ShardedODEFunc(odefunc, self.plan, ops)
         self.dops = DistOps(ops, int(bounds[-1]), n_local, group)
