@@ -5,6 +5,8 @@
 // (misc.py:25), products and sums are rounded separately and added left to right.  FP contraction is
 // therefore switched OFF for this translation unit - an fma here would change the last bit relative to
 // the reference's separate mul / add kernels.
+#include <stdlib.h>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -94,6 +96,9 @@ __device__ __forceinline__ void block_sum2(double &a, double &b) {
     }
 }
 
+constexpr int64_t kAtenNormMax = 1ll << 20;     // panels up to this many elements are reduced in ATen's float32 order
+constexpr int kAtenBlock = 2048;
+
 __device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.402823466e38f); }
 
 __device__ __forceinline__ float err_ratio_sq(float e, float a, float b, float rtol, float atol) {
@@ -101,6 +106,88 @@ __device__ __forceinline__ float err_ratio_sq(float e, float a, float b, float r
     const float tol = atol + rtol * max_nan(fabsf(a), fabsf(b));
     const float r = e / tol;
     return r * r;
+}
+
+// The mean squared error ratio in the order ATen's float32 `sum` forms it (torch.mean = sum / n on the CPU; SumKernel.cpp's
+// cascade sum, matched bit for bit against torch on random vectors like the norm above - tools/micro/aten_norm_order.py):
+//   the row is read as vectors of 8 lanes, 4 vectors interleaved ("ilp"): 32 independent running sums, sum (k, w) owning
+//   elements 32 i + 8 k + w; they are kept in 4 cascade LEVELS: level 0 takes the elements, after every `step` = 2^p of them
+//   (p = max(4, ceil_log2(n / 32) / 4)) it is added into level 1 and cleared, level 1 into level 2 after step^2 ... ; at the
+//   end the levels are added up (1, 2, 3 into 0), then the left-over vectors into ilp slot 0, the ilp slots 1..3 into slot
+//   0, and finally: the n % 8 tail elements, then the 8 lanes, left to right, starting from 0.
+// dopri5's accept / reject decision compares that mean with 1; at rtol 1e-7 the ratios sit close enough to 1 for the
+// last bit to matter, so panels up to kAtenNormMax elements are reduced in exactly this order (one workgroup: all threads
+// form r^2 of a 2048-element chunk in LDS, 32 lanes of the first wave run the cascade); larger panels keep the parallel
+// fp64 reduction, as do the error records formed inside the fused right-hand sides.
+__global__ __launch_bounds__(256) void rk_error_aten_kernel(const float *__restrict__ y0, const float *__restrict__ y1, Terms t,
+                                                            float rtol, float atol, int64_t n, double *__restrict__ out, int accum) {
+    apply_dt(t);
+    __shared__ float v[kAtenBlock];
+    __shared__ float lane32[32];
+    __shared__ int bad_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad_cnt = 0;
+    int bad = 0;
+    const int64_t nv = n / 8, size_ilp = nv / 4;
+    int lg = 1;                                                   // CeilLog2 of ATen: 1 for x <= 2
+    if (size_ilp > 2) { lg = 0; while ((1ll << lg) < size_ilp) ++lg; }
+    const int level_power = (lg / 4) > 4 ? (lg / 4) : 4;
+    const int64_t level_step = 1ll << level_power, level_mask = level_step - 1;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int64_t i = 0;                                                // cascade position in steps of 32 elements
+    int64_t in_level = 0;                                         // steps taken inside the current level-0 run
+    const int64_t n_main = size_ilp * 32;
+    auto ratio_sq = [&](int64_t e) {
+        const float b = y1[e];
+        bad += (int)nonfinite(b);
+        return err_ratio_sq(wsum1(t, e), y0[e], b, rtol, atol);
+    };
+    for (int64_t base = 0; base < n_main; base += kAtenBlock) {
+        const int cnt = (int)((n_main - base) < kAtenBlock ? (n_main - base) : kAtenBlock);
+        __syncthreads();
+        for (int q = tid; q < cnt; q += 256) v[q] = ratio_sq(base + q);
+        __syncthreads();
+        if (tid < 32) {
+            for (int q = tid; q < cnt; q += 32) {
+                // whole runs of level_step steps cascade upwards; a trailing partial run stays in level 0
+                a0 = a0 + v[q];
+                ++i; ++in_level;
+                if (in_level == level_step && i <= (size_ilp / level_step) * level_step) {
+                    in_level = 0;
+                    a1 = a1 + a0; a0 = 0.f;
+                    if ((i & (level_mask << level_power)) == 0) {
+                        a2 = a2 + a1; a1 = 0.f;
+                        if ((i & (level_mask << (2 * level_power))) == 0) { a3 = a3 + a2; a2 = 0.f; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        a0 = a0 + a1; a0 = a0 + a2; a0 = a0 + a3;
+        lane32[tid] = a0;
+    }
+    // the left-over elements (fewer than 32 + 8): r^2 into LDS, then the serial finish by one thread
+    const int n_left = (int)(n - n_main);
+    __syncthreads();
+    for (int q = tid; q < n_left; q += 256) v[q] = ratio_sq(n_main + q);
+    if (bad) atomicAdd(&bad_cnt, bad);
+    __syncthreads();
+    if (tid == 0) {
+        float p[8];
+        const int left_vecs = (int)(nv - size_ilp * 4);           // whole 8-lane vectors after the interleaved part: into ilp slot 0
+        for (int w = 0; w < 8; ++w) {
+            float s0 = lane32[w];
+            for (int u = 0; u < left_vecs; ++u) s0 = s0 + v[8 * u + w];
+            p[w] = ((s0 + lane32[8 + w]) + lane32[16 + w]) + lane32[24 + w];
+        }
+        float s = 0.f;
+        for (int q = 8 * left_vecs; q < n_left; ++q) s = s + v[q];  // the n % 8 tail first
+        for (int w = 0; w < 8; ++w) s = s + p[w];
+        out[0] = accum ? out[0] + (double)s : (double)s;
+        out[1] = accum ? out[1] + (double)bad_cnt : (double)bad_cnt;
+    }
 }
 
 template <bool VEC>
@@ -133,6 +220,58 @@ __device__ __forceinline__ float scaled_sq(float a, float b, float y, float rtol
     const float scale = atol + fabsf(y) * rtol;
     const float q = (a - b) / scale;
     return q * q;
+}
+
+// The same sum in the order ATen's float32 `norm` forms it (torch 2.x CPU, the build the fixtures were captured with;
+// found by matching torch's result bit for bit on 60 random vectors, tools/micro/aten_norm_order.py): EIGHT running sums -
+// lane j owns elements j, j + 8, j + 16, ... and accumulates acc_j = fma(q, q, acc_j) in index order - added up left to
+// right, then the n % 8 tail elements with fma.  The reference's initial step (misc.py:121-138) takes three such norms; at
+// rtol 1e-7 a 1-ulp difference there reshuffles later accept / reject decisions (the error estimate is then a cancellation
+// of O(1e-9) terms), so for panels up to kAtenNormMax elements the sum is formed in exactly that order: one workgroup,
+// q = (a - b) / scale computed by all threads into LDS, then 8 lanes walk their chains.  Larger panels keep the parallel
+// fp64 reduction (8 sequential chains over 10^8 elements would take tens of milliseconds per norm).
+template <bool HASB>
+__global__ __launch_bounds__(256) void scaled_sumsq_aten_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                const float *__restrict__ y, float rtol, float atol, int64_t n,
+                                                                double *__restrict__ out) {
+    __shared__ float q[kAtenBlock];
+    __shared__ float lane_sum[8];
+    __shared__ int bad_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad_cnt = 0;
+    float acc = 0.f;
+    int bad = 0;
+    const int64_t n8 = n - (n % 8);
+    for (int64_t base = 0; base < n8; base += kAtenBlock) {
+        const int cnt = (int)((n8 - base) < kAtenBlock ? (n8 - base) : kAtenBlock);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) {
+            const float av = a[base + i];
+            const float scale = atol + fabsf(y[base + i]) * rtol;
+            q[i] = HASB ? (av - b[base + i]) / scale : av / scale;
+            bad += (int)nonfinite(av);
+        }
+        __syncthreads();
+        if (tid < 8)
+            for (int i = tid; i < cnt; i += 8) acc = fmaf(q[i], q[i], acc);
+    }
+    if (tid < 8) lane_sum[tid] = acc;
+    if (bad) atomicAdd(&bad_cnt, bad);
+    __syncthreads();
+    if (tid == 0) {
+        float s = lane_sum[0];
+        for (int j = 1; j < 8; ++j) s = s + lane_sum[j];
+        int tb = bad_cnt;
+        for (int64_t i = n8; i < n; ++i) {
+            const float av = a[i];
+            const float scale = atol + fabsf(y[i]) * rtol;
+            const float qq = HASB ? (av - b[i]) / scale : av / scale;
+            s = fmaf(qq, qq, s);
+            tb += (int)nonfinite(av);
+        }
+        out[0] = (double)s;
+        out[1] = (double)tb;
+    }
 }
 
 template <bool VEC, bool HASB>
@@ -444,6 +583,11 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
     return NDCN_OK;
 }
 
+int64_t aten_order_max_elems() {
+    static const bool on = [] { const char *e = getenv("NDCN_ATEN_NORM"); return !(e && e[0] == '0'); }();
+    return on ? kAtenNormMax : 0;
+}
+
 int64_t rhs_fused2_partials_bytes();
 int64_t reduce_ws_bytes() {
     const int64_t a = (int64_t)kRedBlocks * 2 * sizeof(double), b = rhs_fused2_partials_bytes();
@@ -463,6 +607,13 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
     t.dt_dev = dt_dev;
     bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1);
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_error: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
+    static const bool aten_order = [] { const char *e = getenv("NDCN_ATEN_NORM"); return !(e && e[0] == '0'); }();
+    if (aten_order && n >= 8 && n <= kAtenNormMax) {
+        ProfScope prof(PROF_ERROR, st, 4.0 * n * (n_k + 2), 2.0 * n * (n_k + 4));
+        hipLaunchKernelGGL(rk_error_aten_kernel, dim3(1), dim3(256), 0, st, y0, y1, t, rtol, atol, n, d_out, accum);
+        NDCN_LAUNCH_CHECK();
+        return NDCN_OK;
+    }
     double *partial = static_cast<double *>(d_ws);
     const int64_t items = vec ? n / 4 : n;
     const int g = red_grid(items);
@@ -476,6 +627,14 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
 
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st) {
+    static const bool aten_order = [] { const char *e = getenv("NDCN_ATEN_NORM"); return !(e && e[0] == '0'); }();
+    if (aten_order && n > 0 && n <= kAtenNormMax) {
+        ProfScope prof(PROF_SUMSQ, st, 4.0 * n * (b ? 3 : 2), 6.0 * n);
+        if (b) hipLaunchKernelGGL(scaled_sumsq_aten_kernel<true>, dim3(1), dim3(256), 0, st, a, b, y, rtol, atol, n, d_out);
+        else hipLaunchKernelGGL(scaled_sumsq_aten_kernel<false>, dim3(1), dim3(256), 0, st, a, b, y, rtol, atol, n, d_out);
+        NDCN_LAUNCH_CHECK();
+        return NDCN_OK;
+    }
     const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(y) && (!b || aligned16(b));
     double *partial = static_cast<double *>(d_ws);
     const int64_t items = vec ? n / 4 : n;

@@ -248,8 +248,12 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
         const float a = 1e-6f, b = h0 * 1e-3f;
         h1 = a > b ? a : b;
     } else {
+        // `(0.01 / m) ** (1 / 5)` as torch evaluates it on a float32 0-d tensor (misc.py:141): python_scalar / tensor is
+        // tensor.reciprocal() * scalar - two float32 roundings - and tensor ** python_float runs std::pow in double with
+        // the exponent at full double precision, rounded to float32 once
         const float m = d1 > d2 ? d1 : d2;
-        h1 = powf(0.01f / m, (float)(1. / 5.));
+        const float a = (1.0f / m) * 0.01f;
+        h1 = (float)pow((double)a, 1. / 5.);
     }
     const float h100 = 100.f * h0;
     h_out = (double)(h100 < h1 ? h100 : h1);
@@ -344,7 +348,11 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         // (Replayed steps keep the one-launch form: their coefficients are fl(dt * c) of a device-resident dt, and E's
         // coefficient in the error launch is the constant 1.)
         static const bool aux_on = [] { const char *e = getenv("NDCN_ERR_PARTIAL"); return !(e && e[0] == '0'); }();
-        const bool use_aux = aux_on && !dt_dev;
+        // Small panels (<= 2^20 elements: the reference's own drivers, every fixture) form the error record in a launch
+        // of its own, in the summation order of ATen's float32 mean (rk.hip: rk_error_aten_kernel): at the truth solves'
+        // rtol 1e-7 the accept / reject decision hangs on the last bit of that mean.
+        const bool split_error = !s->sharded && s->n_elem >= 8 && s->n_elem <= aten_order_max_elems();
+        const bool use_aux = aux_on && !dt_dev && !split_error;
         float *e_panel = nullptr;
         float *in = s->ytmp;
         for (int i = 0; i < 6; ++i) {
@@ -377,6 +385,13 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
                              (i == 4 && use_aux) ? &opt : nullptr);
                 if (rc) return rc;
                 in = out;
+            } else if (split_error) {
+                rc = rhs(s, in, s->k[6], st);
+                if (rc) return rc;
+                dt_coeffs(dt32, kCErr, 7, s->k, kp, cp, m);
+                rc = rk_error_f32(s->ycur, s->ynext, kp, cp, m, (float)s->d.rtol, (float)s->d.atol, s->n_elem, s->d_red, s->d_ws, st,
+                                  dt_dev);
+                if (rc) return rc;
             } else {
                 int mp = 0;
                 if (e_panel) {

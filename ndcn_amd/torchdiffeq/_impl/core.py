@@ -187,7 +187,11 @@ def select_initial_step(ops, func, targ, t0, y0, order, rtol, atol, f0):
         h1 = max(f32(1e-6), f32(h0 * f32(1e-3)))
     else:
         m = max(d1 + d2)                       # list concatenation, as in the reference: max over both
-        h1 = f32(np.power(f32(f32(0.01) / m), f32(1. / float(order + 1))))
+        # `(0.01 / m) ** (1 / (order + 1))` as torch evaluates it on a float32 0-d tensor: python_scalar / tensor is
+        # tensor.reciprocal() * scalar (two float32 roundings), and tensor ** python_float runs std::pow in double with the
+        # exponent at full double precision, rounded to float32 once
+        a = f32(f32(f32(1.0) / m) * f32(0.01))
+        h1 = f32(math.pow(float(a), 1. / float(order + 1))) if a == a else f32('nan')
     h100 = f32(f32(100) * h0)
     if np.isnan(h100) or np.isnan(h1):
         return float('nan'), bad0

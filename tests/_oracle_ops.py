@@ -107,13 +107,18 @@ class OracleOps:
         err = _wsum(ks, cs)
         tol = atol + rtol * torch.max(torch.abs(y0), torch.abs(y1))
         r = err / tol
-        return float((r * r).double().sum()), _bad(y1)
+        # the float32 sum ATen forms for torch.mean (what the HIP kernel reproduces in ATen's cascade order for panels
+        # <= 2^20 elements); fp64 above that, like the product
+        v = r * r
+        return float(v.sum().double() if 8 <= v.numel() <= (1 << 20) else v.double().sum()), _bad(y1)
 
     @staticmethod
     def scaled_sumsq(a, b, y, rtol, atol):
         scale = atol + torch.abs(y) * rtol
         q = (a / scale) if b is None else ((a - b) / scale)
-        return float((q * q).double().sum()), _bad(a)
+        # the float32 norm ATen forms (what the HIP kernel reproduces in ATen's summation order for panels <= 2^20
+        # elements): returned as the double whose square root is that norm exactly
+        return float(q.norm().double() ** 2), _bad(a)
 
     @staticmethod
     def interp_fit(y0, y1, ks, cmid, dt):

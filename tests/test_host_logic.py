@@ -79,19 +79,13 @@ def test_dopri5_control_flow(name):
     ref = d['steplog']
     log = np.array(log)
     scale = max(1.0, np.abs(d['traj']).max())
-    if name == 'dopri5_tight':
-        # rtol 1e-7: the error estimate is a cancellation of O(1e-9) terms, so a 1-ulp difference in the
-        # initial step (torch's float32 norm vs the fp64-accumulated one) reshuffles later accept/reject
-        # decisions.  The solution itself is pinned; the step count only loosely.
-        assert abs(nfe - int(d['nfe'])) <= 0.1 * int(d['nfe'])
-        assert abs(log[0, 1] - ref[0, 1]) <= 1e-6 * ref[0, 1]
-        assert np.abs(y.numpy() - d['traj']).max() <= 1e-5 * scale
-        return
+    # The host logic forms every scalar the way torch does on 0-d tensors (python_scalar / tensor = reciprocal * scalar,
+    # tensor ** python_float in double, float32 means and norms in ATen's summation order - the ops double returns those):
+    # with the oracle's panel arithmetic underneath, the reference's run is reproduced to the last bit - every row of the
+    # per-attempt log and the trajectory, the rtol 1e-7 solve (dopri5_tight: 48 attempts, rejections) included.
     assert nfe == int(d['nfe'])
-    assert log.shape == ref.shape
-    assert np.array_equal(log[:, 2], ref[:, 2])
-    assert np.allclose(log[:, [0, 1, 4]], ref[:, [0, 1, 4]], rtol=2e-6, atol=0)
-    assert np.abs(y.numpy() - d['traj']).max() <= 2e-6 * scale
+    assert log.shape == ref.shape and np.array_equal(log, ref)
+    assert np.array_equal(y.numpy(), d['traj'])
 
 
 def test_tuple_state_and_time_dependent_func():
