@@ -183,7 +183,8 @@ def test_no_control_rhs_rk_epilogue_in_group_record_kernel(dev, shape):
             K, (s1, b1) = hip.rhs_rk(A, X, None, None, 'error', y0, ks[:npv], cs[:npv] + [cs[5]], rtol=1e-2, atol=1e-3,
                                      no_control=True)
             s2, b2 = hip.error(y0, X, ks[:npv] + [K_ref], cs[:npv] + [cs[5]], 1e-2, 1e-3)
-            assert torch.equal(K, K_ref) and abs(s1 - s2) <= 1e-9 * abs(s2) and b1 == b2 == 0.0
+            # (the stand-alone kernel sums a panel of this size in ATen's float32 order, the epilogue in fp64)
+            assert torch.equal(K, K_ref) and abs(s1 - s2) <= 1e-5 * abs(s2) and b1 == b2 == 0.0
         Xbad = X.clone()
         Xbad[5, 7] = float('inf')
         _, (_, bad) = hip.rhs_rk(A, Xbad, None, None, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3, no_control=True)
@@ -511,7 +512,9 @@ def test_error_record_split_over_row_blocks_accumulates(dev, H, no_control):
             assert (rec is None) == (i < len(cuts) - 1)
         assert bad == rec[1] == want_bad
         if want_bad == 0.0:
-            assert torch.equal(K, Ks) and abs(rec[0] - s) <= 1e-12 * abs(s)
+            # (fused epilogues: fp64 partial sums, any split gives the same bits to 1e-12; the composed path's stand-alone
+            # error kernel sums each block in ATen's float32 order: the split then differs by float32 rounding)
+            assert torch.equal(K, Ks) and abs(rec[0] - s) <= (1e-12 if H == 256 else 1e-5) * abs(s)
         else:
             assert np.isnan(rec[0]) and np.isnan(s)
 
@@ -597,7 +600,8 @@ def test_narrow_panel_rhs_is_one_launch_and_equals_the_composed_kernels(dev, H):
         assert torch.equal(E, hip.combine(torch.zeros_like(y0), ks[:npv] + [K_ref], ce[:npv] + [ce[5]]))
         K2, (s1, b1) = hip.rhs_rk(A, X, W, b, 'error', y0, ks[:npv], c, rtol=1e-2, atol=1e-3)
         s2, b2 = hip.error(y0, X, ks[:npv] + [K_ref], c, 1e-2, 1e-3)
-        assert torch.equal(K2, K_ref) and abs(s1 - s2) <= 1e-12 * abs(s2) and b1 == b2 == 0.0
+        # (the stand-alone kernel sums a panel of this size in ATen's float32 order, the epilogue in fp64)
+        assert torch.equal(K2, K_ref) and abs(s1 - s2) <= 1e-5 * abs(s2) and b1 == b2 == 0.0
     dt = np.float32(0.37)
     for st in range(4):
         K3, yn = hip.rhs_rk(A, X, W, b, 'rk4', y0, ks[:st], [dt])
@@ -732,7 +736,7 @@ def test_fused_rhs_tiny_and_ragged_sizes(dev, n):
     K3, (ss, bad) = hip.rhs_rk(A, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3)
     s_ref, bad_ref = hip.error(y0, X, ks + [K], cs, 1e-2, 1e-3)
     assert torch.equal(K3, K) and float(bad) == float(bad_ref) == 0.0
-    assert abs(float(ss) - float(s_ref)) <= 1e-9 * max(abs(float(s_ref)), 1e-30)
+    assert abs(float(ss) - float(s_ref)) <= 1e-5 * max(abs(float(s_ref)), 1e-30)    # (stand-alone: ATen float32 order below 2^20 elements)
 
 
 def test_fused_rk4_stage_epilogues_bitwise_vs_separate_kernels(dev):
@@ -867,13 +871,17 @@ def test_reductions(dev, n):
     g = lambda x: x.to(dev)
     s, bad = hip.error(g(y0), g(y1), [g(k) for k in ks], cs, 1e-2, 1e-3)
     rs, rbad = OracleOps.error(y0, y1, ks, cs, np.float32(1e-2), np.float32(1e-3))
-    assert bad == 0 and abs(s - rs) <= 1e-9 * abs(rs)
+    # n >= 8: the float32 sum torch.mean forms (ATen's cascade order), bit for bit; below that fp64 on both sides
+    assert bad == 0 and (s == rs if n >= 8 else abs(s - rs) <= 1e-9 * abs(rs))
+    # the float32 NORM (the square root of the sum) must equal torch's bit for bit: the kernel adds up in ATen's order
+    # (8 fma chains, then the tail) for panels up to 2^20 elements
+    nrm = lambda v: np.float32(np.sqrt(v))
     s, bad = hip.scaled_sumsq(g(a), g(b), g(y0), 1e-2, 1e-3)
-    rs, _ = OracleOps.scaled_sumsq(a, b, y0, np.float32(1e-2), np.float32(1e-3))
-    assert abs(s - rs) <= 1e-9 * abs(rs)
+    q = (a - b) / (np.float32(1e-3) + torch.abs(y0) * np.float32(1e-2))
+    assert nrm(s) == np.float32(q.norm().item())
     s, bad = hip.scaled_sumsq(g(a), None, g(y0), 1e-2, 1e-3)
-    rs, _ = OracleOps.scaled_sumsq(a, None, y0, np.float32(1e-2), np.float32(1e-3))
-    assert abs(s - rs) <= 1e-9 * abs(rs)
+    q = a / (np.float32(1e-3) + torch.abs(y0) * np.float32(1e-2))
+    assert nrm(s) == np.float32(q.norm().item())
     # determinism: same bits on a second run
     assert hip.scaled_sumsq(g(a), None, g(y0), 1e-2, 1e-3)[0] == s
     # non-finite detection
