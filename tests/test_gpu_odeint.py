@@ -172,9 +172,23 @@ def test_truth_dynamics_golden(dev, name):
         f = lambda t, x: hip.gene_rhs(A, x)
     else:
         f = lambda t, x: hip.mutual_rhs(A, x)
+    log = []
     with torch.no_grad():
-        y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), method='dopri5')
+        y = ode.odeint(f, T(d['x0']).to(dev), T(d['t']).to(dev), method='dopri5', step_log=log)
     check_traj(y.cpu().numpy(), d['traj'], l1=2e-5, mx=2e-4)
+    # the step sequence of the truth solve (rtol 1e-7 / atol 1e-9: every decision hangs on the last bits of the float32
+    # norms and means, which the kernels form in ATen's order): as many attempts, the same accept / reject sequence and
+    # the same number of evaluations as the reference-style solve of the oracle on the same inputs
+    Ao = orc.coo_from_csr(d['A_indptr'], d['A_indices'], d['A_data'], (n, n))
+    Lo = orc.coo_from_csr(d['L_indptr'], d['L_indices'], d['L_data'], (n, n))
+    fo = {'heat': lambda t, x: orc.heat_rhs(Lo, x), 'gene': lambda t, x: orc.gene_rhs(Ao, x),
+          'mutual': lambda t, x: orc.mutual_rhs(Ao, x)}[name.split('_')[1]]
+    lo = []
+    yo = orc.odeint(fo, T(d['x0']), T(d['t']), method='dopri5', step_log=lo)
+    check_traj(yo.numpy(), d['traj'], l1=2e-5, mx=2e-4)              # (x ** h runs a different vector pow on another host CPU)
+    nfe = dict([log.pop()])['nfe']
+    assert len(log) == len(lo) and nfe == 2 + 6 * len(lo)
+    assert [r[2] for r in log] == [r[2] for r in lo]
     if 'heat' in name:      # K1: closed form
         Ld = orc.dense_from_csr(d['L_indptr'], d['L_indices'], d['L_data'], (n, n)).numpy()
         exact = orc.heat_closed_form(Ld, d['x0'], d['t'])
