@@ -77,7 +77,8 @@ typedef struct ndcn_csr {
      *                                   after row in stored (column-ascending) order
      * The SpMM kernel moves every record and every distinct neighbour row into LDS by DMA at addresses it can form
      * without first loading streamed index data (ndcn_amd/csrc/spmm_rec.hip).  Supported shapes:
-     * {rec_rows, rec_cap, rec_kib} = {8, 32, 1} and {16, 40, 2}.                                             */
+     * {rec_rows, rec_cap, rec_kib} = {8, 32, 1}, {16, 40, 2} (lattice patches) and {8, 48, 2} (8 consecutive rows of a
+     * ring-plus-shortcuts graph: 12 ring columns + ~2 shortcut endpoints per row).                            */
     int32_t        rec_rows, rec_cap, rec_kib, rec_groups;
     const int32_t *rec;       /* [rec_groups][rec_kib * 256] */
     /* Optional long-row plan (hub_n = 0 when absent), built once per operator by the host

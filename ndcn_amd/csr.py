@@ -114,7 +114,7 @@ class CsrOperator:
         self._view = None
         return self
 
-    REC_SHAPES = ((8, 32, 1), (16, 40, 2))       # {rows per group, column-list capacity, record KiB}: spmm_rec.hip
+    REC_SHAPES = ((8, 32, 1), (16, 40, 2), (8, 48, 2))   # {rows per group, column-list capacity, record KiB}: spmm_rec.hip
 
     def build_rec_plan(self, rows_per_group=8, cap=32, kib=1):
         """Group-record plan (include/ndcn_hip.h, struct ndcn_csr::rec): per group of rows that are consecutive in the
@@ -349,7 +349,9 @@ class CsrOperator:
         avg = self.nnz / max(self.shape[0], 1)
         best = None
         hinted = self.group_order is not None or self.row_order is not None
-        for shape in (self.REC_SHAPES[::-1] if hinted else self.REC_SHAPES[:1]):
+        # with a walk order: the lattice shapes; without: 8 consecutive rows with a 32-column list, or - when that covers too
+        # few groups (ring neighbours + random shortcuts: a small world's 8 rows reference ~28 distinct columns) - 48
+        for shape in (self.REC_SHAPES[1::-1] if hinted else (self.REC_SHAPES[0], self.REC_SHAPES[2])):
             staged, loads = self.build_rec_plan(*shape)
             if staged >= 0.9 and loads <= 0.75 * avg and (best is None or loads < best[1]):
                 best = (self.rec, loads)

@@ -360,7 +360,8 @@ static int env_int_rec(const char *name, int dflt) {
 int spmm_rec_supported(const ndcn_csr *A, int H) {
     static const int enabled = env_int_rec("NDCN_SPMM_REC", 1);
     if (!enabled || H != 256 || !A || !A->rec || A->rec_groups <= 0) return 0;
-    return (A->rec_rows == 8 && A->rec_cap == 32 && A->rec_kib == 1) || (A->rec_rows == 16 && A->rec_cap == 40 && A->rec_kib == 2);
+    return (A->rec_rows == 8 && A->rec_cap == 32 && A->rec_kib == 1) || (A->rec_rows == 16 && A->rec_cap == 40 && A->rec_kib == 2) ||
+           (A->rec_rows == 8 && A->rec_cap == 48 && A->rec_kib == 2);      // ring + shortcuts: small-world graphs
 }
 
 int spmm_rec_variant(int mode, int n_prev) {
@@ -431,7 +432,8 @@ int spmm_rec_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_o
     ProfScope prof(mode == REC_PLAIN ? PROF_SPMM : PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256);
     dim3 grid;
     int rc;
-    if (A->rec_rows == 8) rc = launch_rec<8, 32, 1>(a, e, mode, Xh != nullptr, st, grid);
+    if (A->rec_rows == 8 && A->rec_cap == 48) rc = launch_rec<8, 48, 2>(a, e, mode, Xh != nullptr, st, grid);
+    else if (A->rec_rows == 8) rc = launch_rec<8, 32, 1>(a, e, mode, Xh != nullptr, st, grid);
     else rc = launch_rec<16, 40, 2>(a, e, mode, Xh != nullptr, st, grid);
     if (rc) return rc;
     if (mode == REC_ERROR) return partials_finish(e.partials, (int)grid.x * kRecWC, d_out, st, (opt && opt->accum) ? 1 : 0);

@@ -104,7 +104,7 @@ def _no_plan(A):
     return A
 
 
-@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2)])
+@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2), (8, 48, 2)])
 @pytest.mark.parametrize('side', [45, 64])
 def test_spmm_group_record_kernel(dev, shape, side):
     """H = 256 with a group-record plan (spmm_rec.hip): staged groups, groups the record cannot hold (direct gather
@@ -137,6 +137,32 @@ def test_spmm_group_record_kernel(dev, shape, side):
     assert np.abs(hip.spmm(CsrOperator.from_scipy(grid, dev), X).cpu().numpy() - ref64).max() < 1e-4
 
 
+def test_small_world_operator_gets_the_ring_plan_automatically(dev):
+    """Newman-Watts-Strogatz graphs (config C4, gene_dynamics.py:99,103): 8 consecutive rows share their ring neighbours
+    (12 columns) and add ~2 random shortcut endpoints each - too many for the 32-column record, fine for {8, 48, 2}:
+    ensure_plans attaches it, the SpMM and the no_control RHS + RK epilogue run the group-record kernel, bit-equal to the
+    plan-free row kernel."""
+    from ndcn_amd import hip, CsrOperator, graphs
+    n, H = 30000, 256
+    m = graphs.normalized_laplacian(graphs.make_graph('small_world', n, seed=0)).tocsr()
+    A = CsrOperator.from_scipy(m, dev)
+    A.ensure_plans(H)
+    assert A.rec is not None and (A.rec['rows'], A.rec['cap'], A.rec['kib']) == (8, 48, 2) and A.rec['staged'] > 0.9
+    P = _no_plan(CsrOperator.from_scipy(m, dev))
+    g = torch.Generator().manual_seed(1)
+    X, y0 = torch.rand(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    ks = [torch.randn(n, H, generator=g).to(dev) for _ in range(2)]
+    assert torch.equal(hip.spmm(A, X), hip.spmm(P, X))
+    cs = [np.float32(0.2), np.float32(-0.1), np.float32(0.3)]
+    K1, y1 = hip.rhs_rk(A, X, None, None, 'combine', y0, ks, cs, no_control=True)
+    K2, y2 = hip.rhs_rk(P, X, None, None, 'combine', y0, ks, cs, no_control=True)
+    assert torch.equal(K1, K2) and torch.equal(y1, y2)
+    # an Erdos-Renyi graph of the same density shares nothing: no plan
+    B = CsrOperator.from_scipy(graphs.normalized_laplacian(graphs.make_graph('random', 5000, seed=0, mean_degree=7)).tocsr(), dev)
+    B.ensure_plans(H)
+    assert B.rec is None
+
+
 def test_lattice_operator_gets_patch_plan_automatically(dev):
     """A lattice operator handed over as a plain tensor (the reference's way) is recognised and gets the 16-row patch
     plan; a random graph gets none."""
@@ -152,7 +178,7 @@ def test_lattice_operator_gets_patch_plan_automatically(dev):
     assert torch.equal(hip.spmm(A, X), hip.spmm(_no_plan(CsrOperator.from_scipy(L, dev)), X))
 
 
-@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2), None])
+@pytest.mark.parametrize('shape', [(8, 32, 1), (16, 40, 2), (8, 48, 2), None])
 def test_no_control_rhs_rk_epilogue_in_group_record_kernel(dev, shape):
     """relu(A X) with the stage algebra in the SpMM's epilogue (the no_control RHS of the dgnn README command):
     COMBINE with 0..5 earlier stages, ERROR, RK4 stages 0..3 - bit-identical to SpMM + the separate stage kernels.
