@@ -441,6 +441,27 @@ static int dispatch_lpr(int slots, const ndcn_csr *A, const float *X, const floa
 int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
              uint32_t flags, hipStream_t st) {
     const bool vec = (H % 4 == 0) && aligned16(X) && aligned16(Y) && (Xh == nullptr || aligned16(Xh));
+    // Long-row plan (struct ndcn_csr): a 3900-entry hub row of a power-law graph is one wave's sequential work in the row
+    // kernels - the tail of the launch.  As in the fused right-hand side: the hubs' rows are formed ahead by two small SpMMs
+    // (<= 256-entry segments, then their sums in order) and the launch proper runs on the light operator, which reads each
+    // hub's finished row as ONE entry of a second panel.
+    static const int use_hub = env_int("NDCN_SPMM_HUB", 1);
+    if (use_hub && vec && !Xh && A->hub_n > 0 && A->hub_H == H && A->hub_S && A->hub_Sseg && A->lt_rowptr) {
+        ndcn_csr seg = {};
+        seg.n_rows = A->hub_nseg; seg.n_cols = A->n_cols; seg.nnz = A->hub_nnz;
+        seg.rowptr = A->hub_seg_rowptr; seg.colidx = A->hub_colidx; seg.val = A->hub_val;
+        int rc = spmm_f32(&seg, X, nullptr, A->n_cols, A->hub_Sseg, H, 1.f, 0, st);
+        if (rc) return rc;
+        ndcn_csr cmb = {};
+        cmb.n_rows = A->hub_n; cmb.n_cols = A->hub_nseg; cmb.nnz = A->hub_nseg;
+        cmb.rowptr = A->hub_cmb_rowptr; cmb.colidx = A->hub_cmb_colidx; cmb.val = A->hub_cmb_val;
+        rc = spmm_f32(&cmb, A->hub_Sseg, nullptr, A->hub_nseg, A->hub_S, H, 1.f, 0, st);
+        if (rc) return rc;
+        ndcn_csr light = {};
+        light.n_rows = A->n_rows; light.n_cols = A->n_cols + A->hub_n; light.nnz = A->lt_nnz;
+        light.rowptr = A->lt_rowptr; light.colidx = A->lt_colidx; light.val = A->lt_val;
+        return spmm_f32(&light, X, A->hub_S, A->n_cols, Y, H, alpha, flags, st);
+    }
     if (vec && spmm_rec_supported(A, H) && A->n_rows * (int64_t)1024 < (1ll << 32))     // operator carries a group-record plan
         return spmm_rec_f32(A, X, Xh, n_own, Y, alpha, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr,
                             nullptr, st);
