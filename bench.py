@@ -38,11 +38,23 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 d
 SPLIT_PRODUCTS = 6             # the fused H = 256 kernels form W S from 3-way bf16 splits: 6 bf16 MFMA products per fp32 product
 
 
-KERNEL_FAMILY = {'rhs_fused': 'rhs_fused', 'spmm': 'spmm_', 'combine': 'combine_kernel', 'linear': 'linear_',
-                 'error': 'rk_error_kernel'}
+def in_family(kind, kernel_name):
+    """Does a rocprofv3 kernel name belong to a ProfScope kind of the library?  'rhs_fused' = every launch that carries the
+    right-hand side WITH an epilogue or the Linear: the fused MFMA kernels, rhs_small, and the SpMM kernels in a non-plain
+    mode (their last template argument: the no_control RHS + RK epilogue)."""
+    import re
+    if kind == 'rhs_fused':
+        if 'rhs_fused' in kernel_name or 'rhs_small' in kernel_name:
+            return True
+        m = re.search(r'spmm_(rec|wide)_kernel<([^>]*)>', kernel_name)
+        return bool(m) and m.group(2).split(',')[-1].strip() != '0'
+    if kind == 'spmm':
+        m = re.search(r'spmm_(rec|wide)_kernel<([^>]*)>', kernel_name)
+        return 'spmm_csr' in kernel_name or (bool(m) and m.group(2).split(',')[-1].strip() == '0')
+    return {'combine': 'combine_kernel', 'linear': 'linear_', 'error': 'rk_error'}.get(kind, kind) in kernel_name
 
 
-def pmc_traffic(family, cfg):
+def pmc_traffic(kind, cfg):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary OF THIS CONFIGURATION
     (profiles/*_traffic_pmc_<cfg>.json, produced by tools/gpu.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  Launch-weighted mean over the family's kernels; (None, None)
@@ -57,7 +69,7 @@ def pmc_traffic(family, cfg):
         return None, None
     num = den = 0
     for name, v in d.items():
-        if family in name and 'finish' not in name:
+        if in_family(kind, name) and 'finish' not in name:
             num += v['hbm_bytes_per_launch'] * v['launches']
             den += v['launches']
     return (int(num / den), os.path.relpath(files[-1], ROOT)) if den else (None, None)
@@ -335,7 +347,12 @@ def main():
             byt = graphs.spmm_bytes(n_local, nnz, H)
             spmm_line = {'avg_ms': round(ms, 4), 'alg_bytes': byt, 'GBps': round(byt / ms / 1e6, 1),
                          'frac_of_hbm_peak': round(byt / ms / 1e6 / HBM_PEAK_GBS, 4),
-                         'plan': None if A_op.rec is None else 'group-record %d rows / %d columns' % (A_op.rec['rows'], A_op.rec['cap'])}
+                         'plan': None if A_op.rec is None else 'group-record %d rows / %d columns' % (A_op.rec['rows'], A_op.rec['cap']),
+                         'long_row_plan': None if getattr(A_op, 'hub', None) is None else '%d hub rows' % A_op.hub['n']}
+            cfg_spmm = 'NC' if (args.config == 'M' and args.no_control) else args.config
+            tr, src = pmc_traffic('spmm', cfg_spmm)
+            if tr:
+                spmm_line.update({'traffic': tr, 'traffic_source': src, 'traffic_over_algorithmic': round(tr / byt, 3)})
             del Y
     else:
         assert args.config in ('M', 'C4'), 'the sharded path runs the metric\'s grid or config 4\'s small world'
@@ -456,7 +473,7 @@ def main():
                 roofline = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': round(ach / HBM_PEAK_GBS, 4)}
             cfg_name = 'NC' if (args.config == 'M' and args.no_control) else args.config
-            traffic, src = pmc_traffic(KERNEL_FAMILY.get(dom, dom), cfg_name) if (world == 1 and not args.sharded) else (None, None)
+            traffic, src = pmc_traffic(dom, cfg_name) if (world == 1 and not args.sharded) else (None, None)
             roofline.update({'traffic': traffic, 'traffic_source': src, 'mfma_roof': mfma_what,
                              'traffic_over_algorithmic': round(traffic / (byt / cnt), 3) if traffic else None,
                              'kernel': dom, 'launches': int(cnt),

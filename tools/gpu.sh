@@ -55,9 +55,9 @@ PY
 }
 
 pmc_passes() {          # $1 = TAG, $2 = cfg
-  local a; a=$(bench_args "$2")
-  for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_${1}_${2}_$c" -o p -- \
+  local a ctr; a=$(bench_args "$2")
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_${1}_${2}_$ctr" -o p -- \
        python "$GRAFT_REPO_ROOT/bench.py" $a --no-cpu-baseline --no-profile-pass --steps 6 --warmup 1 > /dev/null 2>&1)
   done
   pmc_summary "$1" "$2" "profiles/${1}_traffic_pmc_${2}.json"
