@@ -66,7 +66,7 @@ pmc_passes() {          # $1 = TAG, $2 = cfg
 
 kernel_stats() {        # $1 = label, rest = bench flags ; prints per-variant averages of the RHS kernels
   local lab=$1; shift
-  (cd /tmp && rm -rf /tmp/p_$lab && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$lab -o x -- \
+  (cd /tmp && rm -rf /tmp/p_$lab && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$lab -o x -- \
      python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-profile-pass "$@" > /tmp/p_$lab.log 2>&1)
   grep -o '"ms_per_step": [0-9.]*' /tmp/p_$lab.log
   local f; f=$(find /tmp/p_$lab -name "*kernel_stats.csv" | head -1)
@@ -122,7 +122,7 @@ ab)
   ;;
 abbuild)
   run() {
-    python -m pytest tests/test_gpu_kernels.py tests/test_gpu_odeint.py -m gpu -x -q 2>&1 | grep -E "passed|failed" | head -3
+    timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_odeint.py -m gpu -x -q 2>&1 | grep -E "passed|failed" | head -3   # (a variant build may hang: bounded)
     kernel_stats "$1"
   }
   { echo "=== default"; run build_default
