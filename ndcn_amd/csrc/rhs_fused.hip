@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "split16.h"
 
 namespace ndcn {
 
@@ -233,9 +234,53 @@ int rhs_fused_supported(int H, uint32_t flags) {
 // packed fp32 weights (256 KiB) followed by the split bf16 weights (384 KiB)
 int64_t rhs_fused_work_bytes(int H) { return (int64_t)H * H * sizeof(float) + (int64_t)H * H * 3 * 2; }
 
+// Split weights for the fp16 consumers (split16.h): one global power-of-two scale that brings max |W| into [0.5, 1), then
+// every scaled weight as two fp16 pieces (round to nearest, then the exact remainder rounded to nearest), MFMA 32x32x16
+// B-operand order:  Wh[(((j * 16 + s) * 2 + p) * 64 + lane) * 8 + e] = piece p of W[32 j + (lane & 31)][16 s + 8 (lane >> 5) + e];
+// behind the planes: float {scale, 1 / scale}.
+__global__ __launch_bounds__(256) void weight_scale_256_kernel(const float *__restrict__ W, float *__restrict__ tail) {
+    __shared__ unsigned smax[256];
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < kH * kH; i += 256) {
+        const unsigned b = __builtin_bit_cast(unsigned, W[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + w] ? smax[threadIdx.x] : smax[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned sb, ub;
+        s16_scale_bits(smax[0], sb, ub);
+        tail[0] = __builtin_bit_cast(float, sb);
+        tail[1] = __builtin_bit_cast(float, ub);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ Wh,
+                                                                  const float *__restrict__ tail) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;            // one (j, s, lane): 8 * 16 * 64 = 8192
+    if (idx >= 8 * 16 * 64) return;
+    const float sc = tail[0];
+    const int lane = idx & 63, s = (idx >> 6) & 15, j = idx >> 10;
+    const float *src = W + (32 * j + (lane & 31)) * kH + 16 * s + 8 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float w = src[e] * sc;
+        const _Float16 g0 = (_Float16)w;
+        const _Float16 g1 = (_Float16)(w - (float)g0);
+        Wh[((((size_t)j * 16 + s) * 2 + 0) * 64 + lane) * 8 + e] = g0;
+        Wh[((((size_t)j * 16 + s) * 2 + 1) * 64 + lane) * 8 + e] = g1;
+    }
+}
+
 int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
     hipLaunchKernelGGL(pack_weight_256_kernel, dim3(64), dim3(256), 0, st, W, Wp);
-    hipLaunchKernelGGL(pack_weight_256_split_kernel, dim3(32), dim3(256), 0, st, W, reinterpret_cast<unsigned short *>(Wp + kH * kH));
+    float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(Wp + kH * kH) + kS16Bytes);
+    hipLaunchKernelGGL(weight_scale_256_kernel, dim3(1), dim3(256), 0, st, W, tail);
+    hipLaunchKernelGGL(pack_weight_256_f16_kernel, dim3(32), dim3(256), 0, st, W, reinterpret_cast<_Float16 *>(Wp + kH * kH), tail);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

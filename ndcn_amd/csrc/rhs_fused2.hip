@@ -37,6 +37,7 @@
 
 #include "kernels.h"
 #include "gather.h"
+#include "split16.h"
 
 #pragma clang fp contract(off)   // the RK algebra below must round like the reference's separate mul / add ops
 
@@ -119,6 +120,9 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
         return e;
     };
     __shared__ __attribute__((aligned(16))) float s_tile[2 * kTileFloats2];
+    // per S-tile row: the power-of-two scale of the fp16 split (split16.h) and 1 / (row scale * weight scale)
+    __shared__ __attribute__((aligned(16))) float s_sc[2 * kTile2], s_un[2 * kTile2];
+    const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Wq) + kS16Bytes)[1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -300,7 +304,17 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
                 }
                 epi_finish(ea, r, buf + lr * kLd2, e[k & 1]);
             }
-            if (do_gather) *reinterpret_cast<f32x4 *>(buf + lr * kLd2 + 4 * lane) = acc;
+            if (do_gather) {
+                *reinterpret_cast<f32x4 *>(buf + lr * kLd2 + 4 * lane) = acc;
+                // the row's scale for the fp16 split: a power of two from its largest magnitude (this wave holds the row)
+                unsigned sb, ub;
+                s16_scale_bits(s16_wave_umax(s16_row_max_bits(acc)), sb, ub);
+                if (lane == 0) {
+                    const int slot = (buf == s_tile ? 0 : kTile2) + lr;
+                    s_sc[slot] = __builtin_bit_cast(float, sb);
+                    s_un[slot] = __builtin_bit_cast(float, ub) * w_unscale;
+                }
+            }
         }
     };
 
@@ -387,51 +401,34 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
         }
     };
 #if NDCN_SPLIT
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    // split weights: block (n-tile j, k-step s of 16, plane p) = 64 lanes x 16 bytes (8 bf16: W[32 j + (lane & 31)][16 s +
-    // 8 (lane >> 5) + 0..7]); ring of kRingQ k-steps x {2 n-tiles of this wave} x 3 planes, refilled right after use
-    constexpr int kRingQ = 3;
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, 8 * 16 * 3 * 1024, 0x00020000);
-    const int q_slab = (2 * (wave & 3)) * 16 * 3 * 1024;
+    // split weights (split16.h): block (n-tile j, k-step s of 16, plane p of 2) = 64 lanes x 16 bytes (8 fp16:
+    // W[32 j + (lane & 31)][16 s + 8 (lane >> 5) + 0..7]); ring of kRingQ k-steps x {2 n-tiles of this wave} x 2 planes,
+    // refilled right after use
+    constexpr int kRingQ = 4;
+    constexpr int kPl = kS16Planes;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, kS16Bytes, 0x00020000);
+    const int q_slab = (2 * (wave & 3)) * 16 * kPl * 1024;
     auto ldq = [&](int jj, int ks, int pl) {
         int ws = q_slab;
         asm volatile("" : "+s"(ws));
-        return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, ws + ((jj * 16 + ks) * 3 + pl) * 1024, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, ws + ((jj * 16 + ks) * kPl + pl) * 1024, 0);
     };
-    u32x4 Bq[kRingQ][2][3];
+    u32x4 Bq[kRingQ][2][kPl];
     auto ring_fill_q = [&]() {
 #pragma unroll
         for (int u = 0; u < kRingQ; ++u)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, u, pl);
+                for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, u, pl);
     };
-    auto cvt_pk = [](float lo, float hi) {
-        unsigned r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
-    };
-    // 8 consecutive fp32 -> three bf16x8 pieces whose sum is the input, exactly (round to nearest even each time)
-    auto split8 = [&](f32x4 r0, f32x4 r1, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
-        const float x[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float va = x[2 * q], vb = x[2 * q + 1];
-            const unsigned h = cvt_pk(va, vb);
-            const float ra = va - __builtin_bit_cast(float, h << 16), rb = vb - __builtin_bit_cast(float, h & 0xffff0000u);
-            const unsigned m = cvt_pk(ra, rb);
-            const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
-            p1[q] = h; p2[q] = m; p3[q] = cvt_pk(sa, sb);
-        }
-    };
-    // (A hand-built software pipeline of the split - stages of block b + 1 placed between the product groups of block b -
-    // and a two-k-step ring were measured too: same launch times; the loop runs at ~70 % of the matrix-pipe rate alone
-    // (17.7 k cycles per tile) and at 24-34 k next to the gather waves, whose fetches its weight fetches queue behind.)
-    auto mfma_tile_split = [&](const float *src) {
+    // every fp32 S value times its row's power-of-two scale, split error-free into two fp16 pieces; three partial products
+    // per k-step, small terms first (split16.h; the same sequence as rhs_fused3.hip: bit-equal results)
+    auto mfma_tile_split = [&](const float *src, int tb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
         const float *ap = src + (lane & 31) * kLd2 + 8 * (lane >> 5);
+        const float sc[2] = {s_sc[tb * kTile2 + (lane & 31)], s_sc[tb * kTile2 + 32 + (lane & 31)]};
         f32x4 n0 = *reinterpret_cast<const f32x4 *>(ap), n1 = *reinterpret_cast<const f32x4 *>(ap + 4);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -446,18 +443,14 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
                         n1 = *reinterpret_cast<const f32x4 *>(ap + nm * 32 * kLd2 + 16 * nk + 4);
                     }
                 }
-                u32x4 A0, A1, A2;
-                split8(r0, r1, A0, A1, A2);
-                auto mm = [&](f32x16 &acc, u32x4 av, u32x4 bv) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
-                };
+                u32x4 A0, A1;
+                s16_split8(r0, r1, sc[mt], A0, A1);
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     f32x16 &acc = mt == 0 ? (jj == 0 ? acc00 : acc01) : (jj == 0 ? acc10 : acc11);
-                    // small products first
-                    mm(acc, A0, Bq[u][jj][2]); mm(acc, A2, Bq[u][jj][0]); mm(acc, A1, Bq[u][jj][1]);
-                    mm(acc, A0, Bq[u][jj][1]); mm(acc, A1, Bq[u][jj][0]);
-                    mm(acc, A0, Bq[u][jj][0]);
+                    s16_mfma(acc, A1, Bq[u][jj][0]);
+                    s16_mfma(acc, A0, Bq[u][jj][1]);
+                    s16_mfma(acc, A0, Bq[u][jj][0]);
                 }
             }
             if (!(a.dbg & 64)) {
@@ -465,26 +458,33 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kn, pl);
+                    for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, kn, pl);
             }
         }
     };
 #endif
-    auto dump_tile = [&](float *dst) {
-        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]
+    auto dump_tile = [&](float *dst, int tb) {
+        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; with the split product row m is multiplied back by
+        // 1 / (row scale * weight scale) (16 rows per lane and m-tile: four 16-byte LDS reads)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int col = 64 * wave + 32 * n + (lane & 31);
-            const float bv = a.bias ? a.bias[col] : 0.f;
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 un[4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int q = 0; q < 4; ++q)
+                un[q] = NDCN_SPLIT ? *reinterpret_cast<const f32x4 *>(s_un + tb * kTile2 + 32 * mt + 8 * q + 4 * (lane >> 5))
+                                   : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = 64 * wave + 32 * n + (lane & 31);
+                const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float o = (mt == 0 ? (n == 0 ? acc00[r] : acc01[r]) : (n == 0 ? acc10[r] : acc11[r])) + bv;
+                    float o = (mt == 0 ? (n == 0 ? acc00[r] : acc01[r]) : (n == 0 ? acc10[r] : acc11[r])) * un[r >> 2][r & 3] + bv;
                     if (a.relu) o = relu_nan(o);
                     dst[m * kLd2 + col] = o;
                 }
+            }
         }
     };
 
@@ -536,14 +536,14 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
             float *cur = s_tile + (it & 1) * kTileFloats2;
             const unsigned long long c0 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
 #if NDCN_SPLIT
-            if (!(a.dbg & 1)) mfma_tile_split(cur);
+            if (!(a.dbg & 1)) mfma_tile_split(cur, it & 1);
 #else
             if (!(a.dbg & 1)) mfma_tile(cur);
 #endif
             const unsigned long long c1 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();                                   // every consumer is done reading `cur`
             const unsigned long long c2 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
-            dump_tile(cur);
+            dump_tile(cur, it & 1);
             const unsigned long long c3 = a.dbg_cycles ? __builtin_readcyclecounter() : 0;
             __syncthreads();
             if (a.dbg_cycles) {

@@ -36,6 +36,7 @@
 #include "kernels.h"
 #include "gather.h"
 #include "rec_common.h"
+#include "split16.h"
 
 #pragma clang fp contract(off)   // the RK algebra must round like the reference's separate mul / add ops
 
@@ -60,7 +61,7 @@ constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this 
 #define NDCN_F3_PIPE 0
 #endif
 #ifndef NDCN_F3_RESIDENT
-#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? (NDCN_F3_PIPE ? 4 : 5) : 1)
+#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 8 : 2)     // two fp16 planes: 8 registers per resident k-step
 #endif
 #ifndef NDCN_F3_PRODUCERS
 #define NDCN_F3_PRODUCERS 8
@@ -75,7 +76,9 @@ constexpr unsigned kF3OffS = kF3OffRec + kF3NRec * kF3RecW * 1024;
 constexpr unsigned kF3OffRow = kF3OffS + 2 * kF3Tile * kF3Ld * 4;
 constexpr unsigned kF3OffSync = kF3OffRow + 2 * kF3Tile * 4;
 constexpr unsigned kF3OffBias = kF3OffSync + 16;
-constexpr unsigned kF3Lds = kF3OffBias + 256 * 4;
+constexpr unsigned kF3OffScale = kF3OffBias + 256 * 4;        // per S-tile row: the power-of-two scale of the fp16 split (split16.h)
+constexpr unsigned kF3OffUnscale = kF3OffScale + 2 * kF3Tile * 4;   // ... and 1 / (row scale * weight scale)
+constexpr unsigned kF3Lds = kF3OffUnscale + 2 * kF3Tile * 4;
 
 // workgroup barrier: this wave's LDS traffic has been performed first, and hipcc moves no memory access across it
 __device__ __forceinline__ void f3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     int *s_rowid = reinterpret_cast<int *>(lds) + kF3OffRow / 4;
     unsigned *s_sync = reinterpret_cast<unsigned *>(lds) + kF3OffSync / 4;
     float *s_bias = lds + kF3OffBias / 4;          // a fetch issued from inside the MFMA loop queues behind the producers' requests
+    float *s_scale = lds + kF3OffScale / 4, *s_unscale = lds + kF3OffUnscale / 4;
 
     // groups of this workgroup: XCD x owns a contiguous chunk, its workgroups take the chunk's groups round-robin
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wpx = gridDim.x / kXcds;
@@ -156,47 +160,31 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         constexpr int kRes = NDCN_F3_RESIDENT;              // k-steps [0, kRes) of the wave's weights never leave its registers
         constexpr int kNS = 16 - kRes;                       // streamed k-steps per tile
         static_assert(kRing <= kNS, "ring");
-        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, 8 * 16 * 3 * 1024, 0x00020000);
-        const int q_slab = (kNT * mw) * 16 * 3 * 1024;
+        constexpr int kPl = kS16Planes;                     // two fp16 pieces per weight (split16.h)
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, kS16Bytes, 0x00020000);
+        const int q_slab = (kNT * mw) * 16 * kPl * 1024;
         auto ldq = [&](int jj, int ks, int pl) {
             int ws = q_slab;
             asm volatile("" : "+s"(ws));
-            return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, ws + ((jj * 16 + ks) * 3 + pl) * 1024, 0);
+            return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, ws + ((jj * 16 + ks) * kPl + pl) * 1024, 0);
         };
-        u32x4 Bq[kRing][kNT][3];
-        u32x4 Br[kRes > 0 ? kRes : 1][kNT][3];
+        u32x4 Bq[kRing][kNT][kPl];
+        u32x4 Br[kRes > 0 ? kRes : 1][kNT][kPl];
 #pragma unroll
         for (int k = 0; k < kRes; ++k)
 #pragma unroll
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Br[k][jj][pl] = ldq(jj, k, pl);
+                for (int pl = 0; pl < kPl; ++pl) Br[k][jj][pl] = ldq(jj, k, pl);
 #pragma unroll
         for (int u = 0; u < kRing; ++u)
 #pragma unroll
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kRes + u, pl);
-        // 8 consecutive fp32 -> three bf16x8 pieces whose sum is the input, exactly (round to nearest even each time).
-        // Two elements per instruction: v_cvt_pk_bf16_f32, the two halves widened back (shift / mask), v_pk_add_f32.
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        auto split8 = [&](f32x4 r0, f32x4 r1, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
-            const f32x2 x[4] = {{r0.x, r0.y}, {r0.z, r0.w}, {r1.x, r1.y}, {r1.z, r1.w}};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(x[q], bf16x2));
-                const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
-                const f32x2 ra = x[q] - hf;
-                const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, bf16x2));
-                const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
-                const f32x2 sa = ra - mf;
-                p1[q] = h; p2[q] = m; p3[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(sa, bf16x2));
-            }
-        };
+                for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, kRes + u, pl);
         f32x16 acc[kNT];
-        // k-steps [8 HALF, 8 HALF + 8) of the tile at `src`
-        auto mfma_half = [&](const float *src, auto half_tag) {
+        // k-steps [8 HALF, 8 HALF + 8) of the tile at `src` (tile index tb = 0 | 1 selects its rows' scales)
+        auto mfma_half = [&](const float *src, int tb, auto half_tag) {
             constexpr int HALF = decltype(half_tag)::value;
             // per-lane addresses are re-derived from a laundered lane id at every use: hoisted out of the step loop they
             // occupy registers the ring needs, and hipcc then parks them in scratch - whose reloads queue behind the
@@ -204,60 +192,29 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const float *ap = src + (ln & 31) * kF3Ld + 8 * (ln >> 5) + 128 * HALF;
-            auto mm = [&](f32x16 &c, u32x4 av, u32x4 bv) {
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-            };
-            // NDCN_F3_PIPE = 1 (measured, not the default): the split of k-step i + 1 interleaved with the products of
-            // k-step i (sched_group_barrier: one MFMA, then a slice of the split's 38 VALU instructions, six times) - the
-            // ISA comes out as intended, but with two MFMA waves per SIMD the other wave already fills those gaps:
-            // 11.36 -> 11.55 ms/step, and 0.66 -> 0.76 ms for the plain launch with the weight stream switched off.
-            constexpr bool kPipe = NDCN_F3_PIPE;
+            const float sc = s_scale[tb * kF3Tile + (ln & 31)];          // this lane's row: power of two, max |s| -> [0.5, 1)
             f32x4 r0 = *reinterpret_cast<const f32x4 *>(ap), r1 = *reinterpret_cast<const f32x4 *>(ap + 4);
-            u32x4 A0, A1, A2;
-            if (kPipe) split8(r0, r1, A0, A1, A2);
+            u32x4 A0, A1;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                constexpr int dummy = 0; (void)dummy;
                 const int ks = 8 * HALF + i;
                 const bool res = ks < kRes;
                 const int u = res ? 0 : (ks - kRes) % kRing;
                 auto bq = [&](int jj, int pl) -> const u32x4 & { return res ? Br[res ? ks : 0][jj][pl] : Bq[u][jj][pl]; };
-                u32x4 N0 = A0, N1 = A1, N2 = A2;
-                if (!kPipe) {
-                    if (a.dbg & 128) { A0 = __builtin_bit_cast(u32x4, r0); A1 = __builtin_bit_cast(u32x4, r1); A2 = A0; }   // timing: no split
-                    else split8(r0, r1, A0, A1, A2);
-                    if (i + 1 < 8) {                                // the next block's A values leave LDS while these products run
-                        r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
-                        r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
-                    }
-                } else if (i + 1 < 8) {
+                if (a.dbg & 128) { A0 = __builtin_bit_cast(u32x4, r0); A1 = __builtin_bit_cast(u32x4, r1); }   // timing: no split
+                else s16_split8(r0, r1, sc, A0, A1);
+                if (i + 1 < 8) {                                // the next block's A values leave LDS while these products run
                     r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
                     r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
-                    split8(r0, r1, N0, N1, N2);
                 }
                 // small products first (the order of rhs_fused2.hip: identical rounding); the n-tiles alternate
 #pragma unroll
-                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 2));
+                for (int jj = 0; jj < kNT; ++jj) s16_mfma(acc[jj], A1, bq(jj, 0));
 #pragma unroll
-                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A2, bq(jj, 0));
+                for (int jj = 0; jj < kNT; ++jj) s16_mfma(acc[jj], A0, bq(jj, 1));
 #pragma unroll
-                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A1, bq(jj, 1));
-#pragma unroll
-                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 1));
-#pragma unroll
-                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A1, bq(jj, 0));
-#pragma unroll
-                for (int jj = 0; jj < kNT; ++jj) mm(acc[jj], A0, bq(jj, 0));
-                if (kPipe) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the two LDS reads of the next block first
-#pragma unroll
-                    for (int g = 0; g < 6 * kNT; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, (38 + 6 * kNT - 1) / (6 * kNT), 0);   // a slice of the split
-                    }
-                    A0 = N0; A1 = N1; A2 = N2;
-                }
-                __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot (hoisted, they need 12 more registers)
+                for (int jj = 0; jj < kNT; ++jj) s16_mfma(acc[jj], A0, bq(jj, 0));
+                __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot (hoisted, they need more registers)
                 if (!res && !(a.dbg & 64)) {
                     // streamed k-step j = ks - kRes: its slot is refilled with j + kRing or, for the last kRing of a tile,
                     // with streamed k-step (slot index) of the NEXT tile
@@ -266,15 +223,18 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
 #pragma unroll
                     for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) Bq[u][jj][pl] = ldq(jj, kn, pl);
+                        for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, kn, pl);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto dump_tile = [&](float *dst) {
-            // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]
+        auto dump_tile = [&](float *dst, int tb) {
+            // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; row m is multiplied back by 1 / (row scale * weight scale)
             int ln = lane;
             asm volatile("" : "+v"(ln));
+            f32x4 un[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) un[q] = *reinterpret_cast<const f32x4 *>(s_unscale + tb * kF3Tile + 8 * q + 4 * (ln >> 5));
 #pragma unroll
             for (int jj = 0; jj < kNT; ++jj) {
                 const int col = 32 * (kNT * mw + jj) + (ln & 31);
@@ -282,7 +242,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-                    float o = acc[jj][r] + bv;
+                    float o = acc[jj][r] * un[r >> 2][r & 3] + bv;
                     if (a.relu) o = relu_nan(o);
                     dst[m * kF3Ld + col] = o;
                 }
@@ -309,15 +269,15 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[jj][i] = 0.f;
-            if (!(a.dbg & 1)) mfma_half(tile, std::integral_constant<int, 0>{});
+            if (!(a.dbg & 1)) mfma_half(tile, t & 1, std::integral_constant<int, 0>{});
             barrier_t();                                            // [A_(2t+3)]
-            if (!(a.dbg & 1)) mfma_half(tile, std::integral_constant<int, 1>{});
+            if (!(a.dbg & 1)) mfma_half(tile, t & 1, std::integral_constant<int, 1>{});
             // every MFMA wave has read its last S value before anyone overwrites the tile with K
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(s_sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             while (__hip_atomic_load(s_sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(kF3WM * (t + 1)))
                 __builtin_amdgcn_s_sleep(1);
-            dump_tile(tile);
+            dump_tile(tile, t & 1);
         }
         barrier_t();                                                // the two steps in which the producers finish the last tile's K rows
         barrier_t();
@@ -350,6 +310,8 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     if (lane < 2 * kF3Tile / kF3WP) s_rowid[pw * (2 * kF3Tile / kF3WP) + lane] = -1;     // 64 slots
     if (pw == 0 && lane == 0) *s_sync = 0u;
     if (pw < 4) s_bias[64 * pw + lane] = a.bias ? a.bias[64 * pw + lane] : 0.f;
+    // 1 / (global weight scale), written behind the packed planes by pack_weight_256 (split16.h)
+    const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Wq) + kS16Bytes)[1];
 
     auto dma_rec = [&](int it) {
         if (pw < kF3RecW && it < my) {
@@ -522,7 +484,16 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             float *srow = s_tiles + sl * kF3Ld + 4 * lane;
             if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p[q]); arrived(pan[q]); }
             if (er >= 0 && !(a.dbg & 4)) epilogue(er, *reinterpret_cast<const f32x4 *>(srow), pan[q]);
-            if (row >= 0) *reinterpret_cast<f32x4 *>(srow) = acc;
+            if (row >= 0) {
+                *reinterpret_cast<f32x4 *>(srow) = acc;
+                // the row's scale for the fp16 split: a power of two from its largest magnitude (this wave holds the row)
+                unsigned sb, ub;
+                s16_scale_bits(s16_wave_umax(s16_row_max_bits(acc)), sb, ub);
+                if (lane == 0) {
+                    s_scale[sl] = __builtin_bit_cast(float, sb);
+                    s_unscale[sl] = __builtin_bit_cast(float, ub) * w_unscale;
+                }
+            }
             s_rowid[sl] = row;
             // the panels of this slot in the NEXT step (its K rows were staged 3 steps ago)
             if (MODE != F3_PLAIN) { request(s + 1 < n_steps ? rowid_at(slot_of(s + 1, q)) : -1, pan[q]); since_p[q] = 0; }
