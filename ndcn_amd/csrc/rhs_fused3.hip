@@ -61,7 +61,7 @@ constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this 
 #define NDCN_F3_PIPE 0
 #endif
 #ifndef NDCN_F3_RESIDENT
-#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 8 : 2)     // two fp16 planes: 8 registers per resident k-step
+#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 9 : 2)     // two fp16 planes: 8 registers per resident k-step (9 + ring 2 = 128 registers, no spill; 8: 9.82, 9: 9.66, 10 + ring 1: 9.81 ms/step)
 #endif
 #ifndef NDCN_F3_PRODUCERS
 #define NDCN_F3_PRODUCERS 8
