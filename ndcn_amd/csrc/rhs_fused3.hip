@@ -61,7 +61,7 @@ constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this 
 #define NDCN_F3_PIPE 0
 #endif
 #ifndef NDCN_F3_RESIDENT
-#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 9 : 2)     // two fp16 planes: 8 registers per resident k-step (9 + ring 2 = 128 registers, no spill; 8: 9.82, 9: 9.66, 10 + ring 1: 9.81 ms/step)
+#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 10 : 2)    // two fp16 planes: 8 registers per resident k-step
 #endif
 #ifndef NDCN_F3_PRODUCERS
 #define NDCN_F3_PRODUCERS 8
@@ -76,8 +76,7 @@ constexpr unsigned kF3OffS = kF3OffRec + kF3NRec * kF3RecW * 1024;
 constexpr unsigned kF3OffRow = kF3OffS + 2 * kF3Tile * kF3Ld * 4;
 constexpr unsigned kF3OffSync = kF3OffRow + 2 * kF3Tile * 4;
 constexpr unsigned kF3OffBias = kF3OffSync + 16;
-constexpr unsigned kF3OffScale = kF3OffBias + 256 * 4;        // per S-tile row: the power-of-two scale of the fp16 split (split16.h)
-constexpr unsigned kF3OffUnscale = kF3OffScale + 2 * kF3Tile * 4;   // ... and 1 / (row scale * weight scale)
+constexpr unsigned kF3OffUnscale = kF3OffBias + 256 * 4;      // per S-tile row: 1 / (row scale * weight scale) of the fp16 split (split16.h)
 constexpr unsigned kF3Lds = kF3OffUnscale + 2 * kF3Tile * 4;
 
 // workgroup barrier: this wave's LDS traffic has been performed first, and hipcc moves no memory access across it
@@ -89,6 +88,23 @@ constexpr bool kF3Timing = true;
 #else
 constexpr bool kF3Timing = false;
 #endif
+
+// Which of a tile's 16 k-steps keep their weights in registers.  The accumulation order stays k = 0 .. 15; with at most
+// 8 streamed k-steps they are the EVEN ones (0, 2, ..), so that a ring slot refilled right after its k-step 2 j is read
+// again at k-step 2 (j + ring): 2 ring - 1 k-steps of products cover the L2 round trip (in a block behind the resident ones
+// it was ring - 1).
+template <int NS>
+struct F3Order {
+    static constexpr bool kInterleaved = NS <= 8;
+    static constexpr bool streamed(int ks) { return kInterleaved ? ((ks & 1) == 0 && ks / 2 < NS) : ks >= 16 - NS; }
+    static constexpr int stream_index(int ks) { return kInterleaved ? ks / 2 : ks - (16 - NS); }
+    static constexpr int stream_ks(int j) { return kInterleaved ? 2 * j : 16 - NS + j; }
+    static constexpr int res_index(int ks) {                  // position among the resident k-steps, in k order
+        int n = 0;
+        for (int q = 0; q < ks; ++q) n += streamed(q) ? 0 : 1;
+        return n;
+    }
+};
 
 enum { F3_PLAIN = 0, F3_COMBINE = 1, F3_ERROR = 2, F3_RK4 = 3 };
 
@@ -104,8 +120,10 @@ struct F3Args {
     const int *rowptr, *colidx;      // direct gather of groups the plan could not stage
     const float *val;
     unsigned long long *dbg_cycles;  // NDCN_FUSED3_TIMING: per (block, wave) {cycles between barriers, cycles inside barriers}
-    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 64 no weight refills, 128 no bf16 split
+    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 64 no weight refills
 };
+// the experiment switches exist in timing builds only (in the product they would cost scalar registers and branches)
+__device__ __forceinline__ int f3_dbg(const F3Args &a) { return kF3Timing ? a.dbg : 0; }
 struct F3Epi {
     const float *y0;
     const float *kprev[kF3MaxPrev];
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     int *s_rowid = reinterpret_cast<int *>(lds) + kF3OffRow / 4;
     unsigned *s_sync = reinterpret_cast<unsigned *>(lds) + kF3OffSync / 4;
     float *s_bias = lds + kF3OffBias / 4;          // a fetch issued from inside the MFMA loop queues behind the producers' requests
-    float *s_scale = lds + kF3OffScale / 4, *s_unscale = lds + kF3OffUnscale / 4;
+    float *s_unscale = lds + kF3OffUnscale / 4;     // per S-tile row: 1 / (row scale * weight scale) of the fp16 split
 
     // groups of this workgroup: XCD x owns a contiguous chunk, its workgroups take the chunk's groups round-robin
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wpx = gridDim.x / kXcds;
@@ -171,17 +189,18 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         u32x4 Bq[kRing][kNT][kPl];
         u32x4 Br[kRes > 0 ? kRes : 1][kNT][kPl];
 #pragma unroll
-        for (int k = 0; k < kRes; ++k)
+        for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
-                for (int pl = 0; pl < kPl; ++pl) Br[k][jj][pl] = ldq(jj, k, pl);
+                for (int pl = 0; pl < kPl; ++pl)
+                    if (!F3Order<kNS>::streamed(ks)) Br[F3Order<kNS>::res_index(ks)][jj][pl] = ldq(jj, ks, pl);
 #pragma unroll
         for (int u = 0; u < kRing; ++u)
 #pragma unroll
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
-                for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, kRes + u, pl);
+                for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, F3Order<kNS>::stream_ks(u), pl);
         f32x16 acc[kNT];
         // k-steps [8 HALF, 8 HALF + 8) of the tile at `src` (tile index tb = 0 | 1 selects its rows' scales)
         auto mfma_half = [&](const float *src, int tb, auto half_tag) {
@@ -191,35 +210,35 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             // producers' requests like every other vector-memory operation of this CU
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            const float *ap = src + (ln & 31) * kF3Ld + 8 * (ln >> 5) + 128 * HALF;
-            const float sc = s_scale[tb * kF3Tile + (ln & 31)];          // this lane's row: power of two, max |s| -> [0.5, 1)
-            f32x4 r0 = *reinterpret_cast<const f32x4 *>(ap), r1 = *reinterpret_cast<const f32x4 *>(ap + 4);
-            u32x4 A0, A1;
+            // S row m of the tile = [256 fp16 high pieces | 256 fp16 low pieces] (written by the wave that folded the row):
+            // this lane's A operands of k-step ks are the 16 bytes at 32 ks + 16 (lane >> 5) of either half of row lane & 31
+            const char *ap = reinterpret_cast<const char *>(src) + (ln & 31) * (kF3Ld * 4) + 16 * (ln >> 5) + 256 * HALF;
+            u32x4 A0 = *reinterpret_cast<const u32x4 *>(ap), A1 = *reinterpret_cast<const u32x4 *>(ap + 512);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int ks = 8 * HALF + i;
-                const bool res = ks < kRes;
-                const int u = res ? 0 : (ks - kRes) % kRing;
-                auto bq = [&](int jj, int pl) -> const u32x4 & { return res ? Br[res ? ks : 0][jj][pl] : Bq[u][jj][pl]; };
-                if (a.dbg & 128) { A0 = __builtin_bit_cast(u32x4, r0); A1 = __builtin_bit_cast(u32x4, r1); }   // timing: no split
-                else s16_split8(r0, r1, sc, A0, A1);
-                if (i + 1 < 8) {                                // the next block's A values leave LDS while these products run
-                    r0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1));
-                    r1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (i + 1) + 4);
-                }
-                // small products first (the order of rhs_fused2.hip: identical rounding); the n-tiles alternate
+                const bool res = !F3Order<kNS>::streamed(ks);
+                const int j = res ? 0 : F3Order<kNS>::stream_index(ks);          // streamed k-step number j of the tile
+                const int u = j % kRing;
+                auto bq = [&](int jj, int pl) -> const u32x4 & { return res ? Br[res ? F3Order<kNS>::res_index(ks) : 0][jj][pl] : Bq[u][jj][pl]; };
+                // small products first (the order of rhs_fused2.hip: identical rounding).  The next k-step's pieces are
+                // requested from LDS into the SAME registers as soon as their last product has been issued (a second pair of
+                // operand registers would cost a resident k-step)
 #pragma unroll
                 for (int jj = 0; jj < kNT; ++jj) s16_mfma(acc[jj], A1, bq(jj, 0));
+                __builtin_amdgcn_sched_barrier(0);      // (pinned: a hoisted LDS read takes a second register set)
+                if (i + 1 < 8) A1 = *reinterpret_cast<const u32x4 *>(ap + 32 * (i + 1) + 512);
 #pragma unroll
                 for (int jj = 0; jj < kNT; ++jj) s16_mfma(acc[jj], A0, bq(jj, 1));
 #pragma unroll
                 for (int jj = 0; jj < kNT; ++jj) s16_mfma(acc[jj], A0, bq(jj, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < 8) A0 = *reinterpret_cast<const u32x4 *>(ap + 32 * (i + 1));
                 __builtin_amdgcn_sched_barrier(0);      // the refills stay BEHIND the products that read the slot (hoisted, they need more registers)
-                if (!res && !(a.dbg & 64)) {
-                    // streamed k-step j = ks - kRes: its slot is refilled with j + kRing or, for the last kRing of a tile,
+                if (!res && !(f3_dbg(a) & 64)) {
+                    // streamed k-step j: its slot is refilled with streamed k-step j + kRing or, for the last kRing of a tile,
                     // with streamed k-step (slot index) of the NEXT tile
-                    const int j = ks - kRes;
-                    const int kn = kRes + (j + kRing < kNS ? j + kRing : u);
+                    const int kn = F3Order<kNS>::stream_ks(j + kRing < kNS ? j + kRing : u);
 #pragma unroll
                     for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
@@ -232,19 +251,20 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; row m is multiplied back by 1 / (row scale * weight scale)
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            f32x4 un[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) un[q] = *reinterpret_cast<const f32x4 *>(s_unscale + tb * kF3Tile + 8 * q + 4 * (ln >> 5));
+            for (int q = 0; q < 4; ++q) {                           // (one scale at a time: the ring's registers are live here)
+                const float *unp = s_unscale + tb * kF3Tile + 8 * q + 4 * (ln >> 5);
 #pragma unroll
-            for (int jj = 0; jj < kNT; ++jj) {
-                const int col = 32 * (kNT * mw + jj) + (ln & 31);
-                const float bv = s_bias[col];
+                for (int jj = 0; jj < kNT; ++jj) {
+                    const int col = 32 * (kNT * mw + jj) + (ln & 31);
+                    const float bv = s_bias[col];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-                    float o = acc[jj][r] * un[r >> 2][r & 3] + bv;
-                    if (a.relu) o = relu_nan(o);
-                    dst[m * kF3Ld + col] = o;
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int m = rr + 8 * q + 4 * (ln >> 5);
+                        float o = acc[jj][4 * q + rr] * unp[rr] + bv;
+                        if (a.relu) o = relu_nan(o);
+                        dst[m * kF3Ld + col] = o;
+                    }
                 }
             }
         };
@@ -269,9 +289,9 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[jj][i] = 0.f;
-            if (!(a.dbg & 1)) mfma_half(tile, t & 1, std::integral_constant<int, 0>{});
+            if (!(f3_dbg(a) & 1)) mfma_half(tile, t & 1, std::integral_constant<int, 0>{});
             barrier_t();                                            // [A_(2t+3)]
-            if (!(a.dbg & 1)) mfma_half(tile, t & 1, std::integral_constant<int, 1>{});
+            if (!(f3_dbg(a) & 1)) mfma_half(tile, t & 1, std::integral_constant<int, 1>{});
             // every MFMA wave has read its last S value before anyone overwrites the tile with K
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(s_sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         const int row = __builtin_amdgcn_readfirstlane(r[kF3Cap + 2 * i]);
         const int meta = __builtin_amdgcn_readfirstlane(r[kF3Cap + 2 * i + 1]);
         acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (row < 0 || (a.dbg & 2)) return row;
+        if (row < 0 || (f3_dbg(a) & 2)) return row;
         const int cnt = meta & 0xffff, ofs = meta >> 16;
         if (cnt != 0xffff) {
             int es = 0;
@@ -483,16 +503,18 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             if (s < my) row = fold(s, pw + kF3WP * q, acc);
             float *srow = s_tiles + sl * kF3Ld + 4 * lane;
             if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p[q]); arrived(pan[q]); }
-            if (er >= 0 && !(a.dbg & 4)) epilogue(er, *reinterpret_cast<const f32x4 *>(srow), pan[q]);
+            if (er >= 0 && !(f3_dbg(a) & 4)) epilogue(er, *reinterpret_cast<const f32x4 *>(srow), pan[q]);
             if (row >= 0) {
-                *reinterpret_cast<f32x4 *>(srow) = acc;
-                // the row's scale for the fp16 split: a power of two from its largest magnitude (this wave holds the row)
+                // the row leaves this wave as its two fp16 pieces (split16.h), scaled by a power of two from its largest
+                // magnitude: [256 high | 256 low] in the 1 KiB the fp32 row (and later its K row) occupies
                 unsigned sb, ub;
                 s16_scale_bits(s16_wave_umax(s16_row_max_bits(acc)), sb, ub);
-                if (lane == 0) {
-                    s_scale[sl] = __builtin_bit_cast(float, sb);
-                    s_unscale[sl] = __builtin_bit_cast(float, ub) * w_unscale;
-                }
+                u32x2_s16 h0, h1;
+                s16_split4(acc, __builtin_bit_cast(float, sb), h0, h1);
+                char *hrow = reinterpret_cast<char *>(s_tiles + sl * kF3Ld) + 8 * lane;
+                *reinterpret_cast<u32x2_s16 *>(hrow) = h0;
+                *reinterpret_cast<u32x2_s16 *>(hrow + 512) = h1;
+                if (lane == 0) s_unscale[sl] = __builtin_bit_cast(float, ub) * w_unscale;
             }
             s_rowid[sl] = row;
             // the panels of this slot in the NEXT step (its K rows were staged 3 steps ago)

@@ -70,6 +70,21 @@ __device__ __forceinline__ void s16_split8(f32x4_s16 r0, f32x4_s16 r1, float sc,
     }
 }
 
+// 4 consecutive fp32 of one S row -> the two fp16x4 pieces (element for element the arithmetic of s16_split8)
+typedef unsigned u32x2_s16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void s16_split4(f32x4_s16 r, float sc, u32x2_s16 &A0, u32x2_s16 &A1) {
+    const f32x2_s16 x[2] = {{r.x, r.y}, {r.z, r.w}};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2_s16 xs = x[q] * sc;
+        const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(xs.x, xs.y));
+        const f32x2_s16 hf = {(float)h.x, (float)h.y};
+        const f32x2_s16 ra = xs - hf;
+        A0[q] = __builtin_bit_cast(unsigned, h);
+        A1[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra.x, ra.y));
+    }
+}
+
 __device__ __forceinline__ void s16_mfma(float __attribute__((ext_vector_type(16))) &c, u32x4_s16 a, u32x4_s16 b) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
