@@ -195,7 +195,7 @@ class CsrOperator:
         self._view = None
         return self.rec['staged'], loads
 
-    def detect_stencil_order(self, px=4, py=4):
+    def detect_stencil_order(self, px=4, py=4, n_chunks=8):
         """If the operator is a 2-D lattice stencil in row-major node order (every entry's column is the row plus
         a * S + b with |a|, |b| <= 2 for one stride S - the reference's grid graphs, utils_in_learn_dynamics.py:137-157,
         handed over as plain tensors), return the group order that visits the lattice in px x py patches (the rows of a
@@ -238,6 +238,19 @@ class CsrOperator:
         y = (np.arange(PY)[None, :, None, None] * py + np.arange(py)[None, None, None, :])
         node = x * S + y
         node = np.where((x < x_hi) & (y < S) & (node >= row_base) & (node < row_base + n), node - row_base, -1)
+        node = node.reshape(PX * PY, px * py)
+        # Order of the patches: the group kernels (spmm_rec.hip, rhs_fused3.hip) give each of the 8 XCDs a contiguous
+        # range of the walk and its 32 workgroups take the range round-robin - 32 consecutive patches run concurrently.
+        # Row-major, those are 32 patches of one lattice row band and the band below comes PY patches later: its two
+        # shared node rows have left the XCD's 4 MiB L2 by then (measured: X fetched 1.55 times per launch).  Inside
+        # every XCD range the patches are therefore walked in strips `strip` patches wide, top to bottom: what runs
+        # concurrently is one row of a strip, and the next iteration is the row right below it.
+        strip = int(os.environ.get('NDCN_PATCH_STRIP', '32'))
+        if strip > 0 and PX > 1 and PY > strip:
+            t = np.arange(PX * PY, dtype=np.int64)
+            X, Y = t // PY, t % PY
+            per = (PX * PY + n_chunks - 1) // n_chunks
+            node = node[np.lexsort((Y % strip, X, Y // strip, t // per))]
         return node.reshape(-1).astype(np.int32)
 
     def lattice_tile_order(self, S, block_rows=32, n_chunks=8):

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         constexpr int kRing = NDCN_F3_RING;
         constexpr int kRes = NDCN_F3_RESIDENT;              // k-steps [0, kRes) of the wave's weights never leave its registers
         constexpr int kNS = 16 - kRes;                       // streamed k-steps per tile
-        static_assert(kRing <= kNS, "ring");
+        static_assert(kNS == 0 || kRing <= kNS, "ring");
         constexpr int kPl = kS16Planes;                     // two fp16 pieces per weight (split16.h)
         const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.Wq), 0, kS16Bytes, 0x00020000);
         const int q_slab = (kNT * mw) * 16 * kPl * 1024;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
                 for (int pl = 0; pl < kPl; ++pl)
                     if (!F3Order<kNS>::streamed(ks)) Br[F3Order<kNS>::res_index(ks)][jj][pl] = ldq(jj, ks, pl);
 #pragma unroll
-        for (int u = 0; u < kRing; ++u)
+        for (int u = 0; u < (kNS > 0 ? kRing : 0); ++u)
 #pragma unroll
             for (int jj = 0; jj < kNT; ++jj)
 #pragma unroll

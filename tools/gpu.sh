@@ -131,6 +131,33 @@ abbuild)
     cp /tmp/default.so ndcn_amd/libndcn_hip.so
   } 2>&1 | tee gpurun_out/exp_ab.log
   ;;
+gaps)
+  # timeline of one bench run: idle time between consecutive kernels (host round trips of the adaptive controller)
+  (cd /tmp && rm -rf /tmp/p_gaps && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_gaps -o x -- \
+     python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-profile-pass "$@" > /tmp/p_gaps.log 2>&1)
+  grep -o '"ms_per_step": [0-9.]*' /tmp/p_gaps.log
+  f=$(find /tmp/p_gaps -name "*kernel_trace.csv" | head -1)
+  python - "$f" <<'PY' | tee gpurun_out/gaps.txt
+import csv, sys, collections
+rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ndcn::', '')[:44]) for r in csv.DictReader(open(sys.argv[1]))]
+rows.sort()
+# the timed region: the last 20 * 6 fused launches and what lies between them
+idx = [i for i, r in enumerate(rows) if 'rhs_fused3_kernel<false, 2, 1>' in r[2] or 'rhs_fused3_kernel<false, 2, 5>' in r[2]]
+lo = idx[-21] + 1 if len(idx) > 21 else 0
+sel = rows[lo:idx[-1] + 1]
+busy = sum(e - s for s, e, _ in sel)
+span = sel[-1][1] - sel[0][0]
+print('timed-region kernels %d  span %.3f ms  busy %.3f ms  idle %.3f ms (%.1f %%)' % (len(sel), span / 1e6, busy / 1e6, (span - busy) / 1e6, 100.0 * (span - busy) / span))
+gap_after = collections.defaultdict(list)
+for (s0, e0, n0), (s1, e1, n1) in zip(sel, sel[1:]):
+    gap_after[n0 + ' -> ' + n1].append(s1 - e0)
+for k, v in sorted(gap_after.items(), key=lambda kv: -sum(kv[1])):
+    print('  %-96s n=%3d  avg gap %7.1f us  total %.3f ms' % (k, len(v), sum(v) / len(v) / 1e3, sum(v) / 1e6))
+print('one step:')
+for s, e, n in sel[:14]:
+    print('   %-46s start %+9.1f us  dur %7.1f us' % (n, (s - sel[0][0]) / 1e3, (e - s) / 1e3))
+PY
+  ;;
 timing)
   for d in ${DBG_LIST:-0 6 70 1}; do
     echo "== NDCN_FUSED3_DBG=$d"
