@@ -353,22 +353,45 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         // rtol 1e-7 the accept / reject decision hangs on the last bit of that mean.
         const bool split_error = !s->sharded && s->n_elem >= 8 && s->n_elem <= aten_order_max_elems();
         const bool use_aux = aux_on && !dt_dev && !split_error;
-        float *e_panel = nullptr;
+        // The launch that produces k4 (i == 2) holds k1, k2, k3 in its epilogue: besides the stage-5 input it writes
+        // P = dt (beta_61 k1 + beta_62 k2 + beta_63 k3 + beta_64 k4) - the first four terms of the stage-6 sum, left to right -
+        // into the panel that will hold y1 two launches later; the launch that produces k5 then reads {y0, P} and forms
+        // y0 + (1 * P + dt beta_65 k5), the same roundings, instead of {y0, k1, k2, k3, k4}: 2 panels less per step.
+        static const bool partial_on = [] { const char *e = getenv("NDCN_STAGE_PARTIAL"); return !(e && e[0] == '0'); }();
+        const bool use_partial = partial_on && !dt_dev;
+        float *e_panel = nullptr, *p_panel = nullptr;
         float *in = s->ytmp;
         for (int i = 0; i < 6; ++i) {
             if (i < 5) {
                 float *out = (i == 4) ? s->ynext : (in == s->ytmp ? s->ytmp2 : s->ytmp);   // stage-6 input IS y1
                 int mp = 0;
-                for (int j = 0; j <= i; ++j) {                 // previous stages k[0..i] with non-zero coefficients
-                    const float bj = (float)kBeta[i + 1][j];
-                    if (bj == 0.f) continue;
-                    kp[mp] = s->k[j];
-                    cp[mp] = dt32 * bj;
-                    ++mp;
+                if (i == 3 && p_panel) {
+                    kp[0] = p_panel;
+                    cp[0] = 1.f;
+                    mp = 1;
+                } else {
+                    for (int j = 0; j <= i; ++j) {             // previous stages k[0..i] with non-zero coefficients
+                        const float bj = (float)kBeta[i + 1][j];
+                        if (bj == 0.f) continue;
+                        kp[mp] = s->k[j];
+                        cp[mp] = dt32 * bj;
+                        ++mp;
+                    }
                 }
                 cp[mp] = dt32 * (float)kBeta[i + 1][i + 1];   // the K being produced, last term
                 RkOpt opt = {nullptr, 0, nullptr, nullptr};
                 float c2[8];
+                if (i == 2 && use_partial) {
+                    // rows 4 and 5 of the tableau are dense: the same stages in the same order as this launch's own sum
+                    bool dense = true;
+                    for (int j = 0; j <= 3; ++j) dense = dense && (float)kBeta[3][j] != 0.f && (float)kBeta[4][j] != 0.f;
+                    if (dense) {
+                        for (int j = 0; j <= 3; ++j) c2[j] = dt32 * (float)kBeta[4][j];
+                        p_panel = s->ynext;
+                        opt.y_aux = p_panel;
+                        opt.c_aux = c2;
+                    }
+                }
                 if (i == 4 && use_aux) {
                     // the same stages in the same order: beta[5][j] and c_err[j] vanish for the same j (= 1) only
                     int m2 = 0;
@@ -382,7 +405,7 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
                     opt.c_aux = c2;
                 }
                 rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st, dt_dev,
-                             (i == 4 && use_aux) ? &opt : nullptr);
+                             opt.y_aux ? &opt : nullptr);
                 if (rc) return rc;
                 in = out;
             } else if (split_error) {
