@@ -238,10 +238,27 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     const float cp[1] = {h0};
     rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, 1, s->n_elem, st);
     if (rc) return rc;
-    rc = rhs(s, s->ytmp, s->k[1], st);
-    if (rc) return rc;
-    rc = rms_scaled(s, s->k[1], s->k[0], s->ycur, rtol, atol, st, d2, bad);
-    if (rc) return rc;
+    // d2 = || (f1 - f0) / scale || (misc.py:131-134).  On the paths whose RHS carries an epilogue the sum rides in the launch
+    // that produces f1, as its error record: stages {f0, f1} with coefficients {-1, 1} - (-f0) + f1 is the float32 value of
+    // f1 - f0 - over the tolerance of the pair (y0, y0), i.e. atol + rtol |y0|; squares summed in double like
+    // scaled_sumsq_f32.  (Panels small enough for ATen's float32 summation order keep the separate launch: section 2.)
+    static const bool fuse_d2_on = [] { const char *e = getenv("NDCN_INIT_FUSED"); return !(e && e[0] == '0'); }();
+    if (fuse_d2_on && s->fused2 && (s->sharded || s->n_elem > aten_order_max_elems())) {
+        const float *kq[1] = {s->k[0]};
+        const float cq[2] = {-1.f, 1.f};
+        const RkOpt opt = {s->ycur, 0, nullptr, nullptr};
+        rc = rhs_epi(s, s->ytmp, s->k[1], 2, s->ycur, kq, cq, 1, nullptr, rtol, atol, s->d_red, s->d_ws2, st, nullptr, &opt);
+        if (rc) return rc;
+        double sum;
+        rc = fetch_record(s, st, sum, bad);
+        if (rc) return rc;
+        d2 = (float)sqrt(sum) / (float)sqrt(s->n_mean);
+    } else {
+        rc = rhs(s, s->ytmp, s->k[1], st);
+        if (rc) return rc;
+        rc = rms_scaled(s, s->k[1], s->k[0], s->ycur, rtol, atol, st, d2, bad);
+        if (rc) return rc;
+    }
     d2 = d2 / h0;
     float h1;
     if (d1 <= 1e-15 && d2 <= 1e-15) {
@@ -275,6 +292,7 @@ int rhs_sharded(ndcn_solver *s, const float *x, float *K, int mode, const float 
     const float *c_aux = opt ? opt->c_aux : nullptr;
     auto launch = [&](const ndcn_csr *A, const float *X, const float *Xh, int64_t lo, bool first, const float *y1) -> int {
         const size_t off = (size_t)lo * H;
+        if (opt && opt->y1) y1 = opt->y1;                     // the caller names the second state of the error tolerance
         const float *kpo[8];
         for (int m = 0; m < n_prev; ++m) kpo[m] = kp[m] + off;
         RkOpt o = {mode == NDCN_RK_ERROR ? y1 + off : nullptr, (mode == NDCN_RK_ERROR && !first) ? 1 : 0,
