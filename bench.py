@@ -110,7 +110,7 @@ class SingleGpuRunner:
         self.x0, self.T, self.method = x0, T, method
         self.ticks = [float(v) for v in (ticks if ticks is not None else [0.0, T])]
         self.out = torch.empty_like(x0)
-        self.solver.begin(x0, self.ticks[0])
+        self.solver.begin(x0, self.ticks[0], borrow=True)      # as odeint() hands the initial state over
         self.pos = 1                                     # next tick to reach
         self.solve_steps = 0                             # attempted steps of one whole solve (known after the first)
         self.traj = torch.empty((len(self.ticks) - 1,) + tuple(x0.shape), device=x0.device) if len(self.ticks) > 2 and method == 'dopri5' else None
@@ -138,7 +138,7 @@ class SingleGpuRunner:
             if reached_end:
                 self.solve_steps = int(self.solver.stats()['steps'])
                 self.nfe_done += int(self.solver.stats()['nfe'])
-                self.solver.begin(self.x0, self.ticks[0])        # resets the solver's own counters
+                self.solver.begin(self.x0, self.ticks[0], borrow=True)        # resets the solver's own counters
                 self.pos = 1
                 self.restarts += 1
         return done

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 8
+#define NDCN_ABI_VERSION 9
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -375,6 +375,11 @@ NDCN_API int ndcn_solver_create(const ndcn_solver_desc *desc, void *workspace, i
 NDCN_API int ndcn_solver_destroy(ndcn_solver *s);
 /* Start at (t0, y0): copies y0 in; dopri5 also evaluates f0 and the initial step (dopri5.py:77-83).   */
 NDCN_API int ndcn_solver_begin(ndcn_solver *s, const float *y0, double t0, void *stream);
+/* As ndcn_solver_begin, without the copy (dopri5; other methods and replay mode copy as above): the solver reads the
+ * initial state where it lies - odeint.py:39-41 hands y0 over and never writes it - until its second accepted step.
+ * y0 must stay valid and unchanged until the next ndcn_solver_begin* / ndcn_solver_destroy on `s`, and no `out` of
+ * ndcn_solver_advance / _advance_many may overlap it (refused with NDCN_EINVAL).                       */
+NDCN_API int ndcn_solver_begin_borrowed(ndcn_solver *s, const float *y0, double t0, void *stream);
 /* Integrate to next_t and write y(next_t) to `out` (n_rows x H).
  * fixed grid: ONE step of size next_t - t (solvers.py:89-97).
  * dopri5: adaptive steps until t1 >= next_t, at most `step_budget` of them (<= 0: unlimited), then the

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 
 OK = 0
@@ -122,6 +122,7 @@ SIGNATURES = {
     'ndcn_solver_create': (_I, [ctypes.POINTER(SolverDesc), _P, _L, ctypes.POINTER(_P)]),
     'ndcn_solver_destroy': (_I, [_P]),
     'ndcn_solver_begin': (_I, [_P, _P, _D, _P]),
+    'ndcn_solver_begin_borrowed': (_I, [_P, _P, _D, _P]),
     'ndcn_solver_advance': (_I, [_P, _D, _P, _L, _P]),
     'ndcn_solver_advance_many': (_I, [_P, ctypes.POINTER(_D), _L, _P, _P]),
     'ndcn_solver_stats': (_I, [_P, ctypes.POINTER(_D)]),

@@ -271,6 +271,7 @@ int ndcn_solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t wo
 }
 int ndcn_solver_destroy(ndcn_solver *s) { return solver_destroy(s); }
 int ndcn_solver_begin(ndcn_solver *s, const float *y0, double t0, void *stream) { return solver_begin(s, y0, t0, ST(stream)); }
+int ndcn_solver_begin_borrowed(ndcn_solver *s, const float *y0, double t0, void *stream) { return solver_begin(s, y0, t0, ST(stream), true); }
 int ndcn_solver_advance(ndcn_solver *s, double next_t, float *out, int64_t step_budget, void *stream) {
     return solver_advance(s, next_t, out, step_budget, ST(stream));
 }

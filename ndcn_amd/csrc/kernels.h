@@ -130,7 +130,7 @@ int halo_exchange_f32(ndcn_halo_plan *p, const float *X, int H, float *d_pack, f
 int64_t solver_workspace_bytes(const ndcn_solver_desc *desc);
 int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_bytes, ndcn_solver **out);
 int solver_destroy(ndcn_solver *s);
-int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st);
+int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st, bool borrow = false);
 int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st);
 int solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, float *out, hipStream_t st);
 int solver_stats(const ndcn_solver *s, double h[6]);

@@ -78,6 +78,9 @@ struct ndcn_solver {
     float fit_dt = 0;
     bool cur_is_borrowed = false;  // ycur points into a caller buffer (fixed grid)
     float *ycur_own = nullptr;
+    float *own3[3] = {};           // dopri5: the solver's three state panels {ycur_own, ynext, yold as allocated}
+    const float *borrowed = nullptr;   // dopri5, ndcn_solver_begin_borrowed: the caller's y0 stands in for a state panel ...
+    float *spare = nullptr;        // ... and this one of the solver's own takes its place when it leaves the rotation
     int64_t n_attempt = 0, n_accept = 0, n_rhs = 0;
     double last_ratio = 0;
     int64_t pending_bad = 0;       // non-finite elements seen in the state that starts the next step
@@ -552,6 +555,11 @@ int rotate_after_accept(ndcn_solver *s, hipStream_t st) {
         return NDCN_OK;
     }
     float *old = s->yold;
+    if (s->borrowed && old == s->borrowed) {          // the caller's y0 leaves the rotation: never written by the solver
+        old = s->spare;
+        s->borrowed = nullptr;
+        s->spare = nullptr;
+    }
     s->yold = s->ycur;       // becomes "e" if this step gets fitted
     s->ycur = s->ynext;
     s->ynext = old;
@@ -674,6 +682,7 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     if (desc->method == NDCN_M_DOPRI5) {
         if ((rc = alloc_panel(s, &s->ynext))) return fail(rc);
         if ((rc = alloc_panel(s, &s->yold))) return fail(rc);
+        s->own3[0] = s->ycur_own; s->own3[1] = s->ynext; s->own3[2] = s->yold;
         if ((rc = alloc_panel(s, &s->ca))) return fail(rc);
         if ((rc = alloc_panel(s, &s->cb))) return fail(rc);
         if ((rc = alloc_panel(s, &s->cc))) return fail(rc);
@@ -728,11 +737,25 @@ int solver_destroy(ndcn_solver *s) {
     return NDCN_OK;
 }
 
-int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st) {
+int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st, bool borrow) {
     NDCN_CHECK_ARG(s && y0, "null argument");
     s->ycur = s->ycur_own;
     s->cur_is_borrowed = false;
-    NDCN_HIP(hipMemcpyAsync(s->ycur, y0, (size_t)s->n_elem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    s->borrowed = nullptr;
+    s->spare = nullptr;
+    if (s->d.method == NDCN_M_DOPRI5) {               // the names go back to the panels they were allocated as
+        s->ynext = s->own3[1];
+        s->yold = s->own3[2];
+    }
+    if (borrow && s->d.method == NDCN_M_DOPRI5 && !s->d.use_graph) {
+        // the first step reads y0 where the caller keeps it (one panel copy less per solve); when the panel would come
+        // up for writing - two accepted steps later, as y1 - the solver's own spare takes its place (rotate_after_accept)
+        s->ycur = const_cast<float *>(y0);
+        s->borrowed = y0;
+        s->spare = s->own3[0];
+    } else {
+        NDCN_HIP(hipMemcpyAsync(s->ycur, y0, (size_t)s->n_elem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     s->n_attempt = s->n_accept = s->n_rhs = 0;
     s->log.clear();
     s->fit_pending = s->fit_valid = false;
@@ -932,9 +955,21 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
 
 static int dopri5_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st);
 
+// ndcn_solver_begin_borrowed: results must not land in the initial state the solver still reads
+static bool overlaps_borrowed(const ndcn_solver *s, const float *out, int64_t n_panels) {
+    if (!s->borrowed || !out || n_panels <= 0) return false;
+    const float *lo = s->borrowed, *hi = s->borrowed + s->n_elem;
+    if (out < hi && out + n_panels * s->n_elem > lo) {
+        set_error("the output overlaps the initial state handed to ndcn_solver_begin_borrowed");
+        return true;
+    }
+    return false;
+}
+
 int solver_advance(ndcn_solver *s, double next_t, float *out, int64_t budget, hipStream_t st) {
     NDCN_CHECK_ARG(s, "null solver");
     if (!s->begun) { set_error("ndcn_solver_advance before ndcn_solver_begin"); return NDCN_ESTATE; }
+    if (overlaps_borrowed(s, out, 1)) return NDCN_EINVAL;
     if (s->d.method != NDCN_M_DOPRI5) return fixed_advance(s, next_t, out, st);
     // replay mode: the captured attempt is launched into the caller's stream like any other work (capture needed a
     // stream of its own, replay does not)
@@ -995,6 +1030,7 @@ static int dopri5_advance(ndcn_solver *s, double next_t, float *out, int64_t bud
 int solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, float *out, hipStream_t st) {
     NDCN_CHECK_ARG(s && (n_ticks == 0 || (h_ticks && out)), "null argument");
     if (!s->begun) { set_error("ndcn_solver_advance_many before ndcn_solver_begin"); return NDCN_ESTATE; }
+    if (overlaps_borrowed(s, out, n_ticks)) return NDCN_EINVAL;
     const size_t stride = (size_t)s->n_elem;
     int64_t i = 0;
     while (i < n_ticks) {

@@ -505,7 +505,7 @@ class ShardedDeviceBench:
         self.out = torch.empty_like(self.x0)
         self.T = T
         self.nfe_done = 0
-        self.solver.begin(self.x0, 0.0)
+        self.solver.begin(self.x0, 0.0, borrow=True)
 
     def run_steps(self, k):
         done = 0
@@ -515,7 +515,7 @@ class ShardedDeviceBench:
             done += int(self.solver.stats()['steps'] - before)
             if reached:
                 self.nfe_done += int(self.solver.stats()['nfe'])
-                self.solver.begin(self.x0, 0.0)
+                self.solver.begin(self.x0, 0.0, borrow=True)
         return done
 
     def nfe(self):

@@ -177,11 +177,15 @@ class DeviceSolver:
             _lib.check(self.lib.ndcn_solver_create(ctypes.byref(self.desc), _lib.ptr(self.workspace), nbytes,
                                                    ctypes.byref(self.handle)))
 
-    def begin(self, y0, t0):
+    def begin(self, y0, t0, borrow=False):
+        """borrow=True (ndcn_solver_begin_borrowed): dopri5 reads y0 in place instead of copying it - the caller leaves
+        the tensor alone until the solve is over and never passes an `out` that overlaps it (this object keeps it alive)."""
         y0 = _lib.require_device(y0, 'state y0').contiguous()
         assert tuple(y0.shape) == self.shape
+        self._y0 = y0 if borrow else None
+        entry = self.lib.ndcn_solver_begin_borrowed if borrow else self.lib.ndcn_solver_begin
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ndcn_solver_begin(self.handle, _lib.ptr(y0), float(t0), _lib.stream_ptr()))
+            _lib.check(entry(self.handle, _lib.ptr(y0), float(t0), _lib.stream_ptr()))
 
     def advance(self, next_t, out=None, step_budget=0):
         """Returns True when next_t was reached (and `out` written), False when the step budget ran out."""
@@ -237,7 +241,7 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     try:
         out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         out[0].copy_(y0)
-        solver.begin(y0, tt[0])
+        solver.begin(out[0], tt[0], borrow=True)           # the solution's first panel IS the initial state: read in place
         try:
             if len(tt) > 1:
                 solver.advance_many(tt[1:], out[1:])               # one library call for the whole time vector

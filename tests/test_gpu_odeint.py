@@ -355,6 +355,51 @@ def test_dopri5_hipgraph_replay_equals_eager(dev, case):
         check_traj(outs[1].cpu().numpy(), d['traj'], l1=1e-5, mx=2e-4)
 
 
+def test_borrowed_initial_state_equals_the_copied_one(dev):
+    """ndcn_solver_begin_borrowed (ABI 9): dopri5 reads y0 where the caller keeps it - odeint() hands over the first
+    panel of its solution - until the panel would come up for writing; same launches, same results, y0 untouched; an
+    output that overlaps the borrowed panel is refused; restarts (fewer than two accepted steps, then many) stay exact."""
+    from ndcn_amd import _lib, graphs
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq._impl.odeint import DeviceSolver
+    A = graphs.to_device(graphs.normalized_laplacian(graphs.grid_8_neighbor(40)), dev)
+    torch.manual_seed(4)
+    f = ODEFunc(256, A).to(dev).eval()
+    x0 = torch.rand(1600, 256, device=dev)
+    keep = x0.clone()
+    ticks = [0.05, 0.4, 1.5, 4.0, 9.0]                       # the first two fall into the first accepted step
+    res = {}
+    for borrow in (False, True):
+        s = DeviceSolver(f, 1600, 'dopri5', .01, .001)
+        outs = []
+        for rep in range(3):                                 # restarts: after one tick (no rotation yet), then full solves
+            s.begin(x0, 0.0, borrow=borrow)
+            o = torch.empty((len(ticks),) + tuple(x0.shape), device=dev)
+            if rep == 0:
+                s.advance(ticks[0], o[0])
+            else:
+                s.advance_many(ticks, o)
+            torch.cuda.synchronize()
+            outs.append((o[:1].clone() if rep == 0 else o, s.steplog()))
+        if borrow:
+            s.begin(x0, 0.0, borrow=True)
+            with pytest.raises(_lib.NdcnHipError, match='overlaps the initial state'):
+                s.advance(1.0, x0)
+            big = torch.empty((3,) + tuple(x0.shape), device=dev)
+            big[1].copy_(x0)
+            s.begin(big[1], 0.0, borrow=True)
+            with pytest.raises(_lib.NdcnHipError, match='overlaps the initial state'):
+                s.advance_many([1.0, 2.0], big[:2])
+            s.advance_many([1.0], big[2:])                   # the panel right behind it is fine
+        s.close()
+        res[borrow] = outs
+    assert torch.equal(x0, keep)
+    assert len(res[True][1][1]) >= 4                         # several accepted steps: the caller's panel left the rotation
+    for (a, la), (b, lb) in zip(res[False], res[True]):
+        assert la == lb and torch.equal(a, b)
+    assert torch.equal(res[True][1][0], res[True][2][0])
+
+
 @pytest.mark.parametrize('side', [48, 55, 64])       # 48: some workgroups of the persistent grid get no tile
 def test_fused_epilogue_solver_equals_generic_path(dev, side):
     """H = 256: the device-resident solver runs the stage algebra / error norm inside the fused RHS epilogue
