@@ -34,8 +34,8 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
-SPLIT_PRODUCTS = 6             # the fused H = 256 kernels form W S from 3-way bf16 splits: 6 bf16 MFMA products per fp32 product
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 / _bf16 dense peak (no sparsity)
+SPLIT_PRODUCTS = 3             # the fused H = 256 kernels form W S from two fp16 pieces per operand: 3 fp16 MFMA products per fp32 product (split16.h)
 
 
 def in_family(kind, kernel_name):
@@ -453,14 +453,14 @@ def main():
             i = _lib.PROF_KINDS.index(dom)
             cnt, ms, byt, fl = buf[4 * i:4 * i + 4]
             # which roof is nearer: time the launch would take at the HBM peak vs on the matrix cores.  The fused H = 256
-            # kernels issue bf16 MFMAs - 6 products of 3-way splits per fp32 product - so their matrix work is priced as
-            # 6 x the Linear's flops at the dense bf16 peak; every other kernel with a GEMM runs the fp32 MFMA.
+            # kernels issue fp16 MFMAs - 3 products of two-piece splits per fp32 product - so their matrix work is priced as
+            # 3 x the Linear's flops at the dense fp16 peak; every other kernel with a GEMM runs the fp32 MFMA.
             t_hbm = byt / cnt / (HBM_PEAK_GBS * 1e9)
             split = dom == 'rhs_fused' and H == 256 and not f.no_control and not f.no_graph
             lin_flops = 2.0 * n_local * H * H if split else 0.0
             if split:
-                mfma_peak, mfma_what = MFMA_BF16_PEAK_TFLOPS, 'bf16 32x32x16, %d split products per fp32 product' % SPLIT_PRODUCTS
-                t_mfma = SPLIT_PRODUCTS * lin_flops / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+                mfma_peak, mfma_what = MFMA_F16_PEAK_TFLOPS, 'fp16 32x32x16, %d split products per fp32 product' % SPLIT_PRODUCTS
+                t_mfma = SPLIT_PRODUCTS * lin_flops / (MFMA_F16_PEAK_TFLOPS * 1e12)
             else:
                 mfma_peak, mfma_what = MFMA_F32_PEAK_TFLOPS, 'fp32 32x32x2'
                 t_mfma = fl / cnt / (MFMA_F32_PEAK_TFLOPS * 1e12)

@@ -44,34 +44,6 @@ __global__ __launch_bounds__(256) void pack_weight_256_kernel(const float *__res
     reinterpret_cast<f32x4 *>(Wp)[idx] = v;
 }
 
-// Split weights for the bf16 consumer of rhs_fused2.hip: every fp32 weight as three bf16 pieces whose sum is the weight
-// (round to nearest even each time: 8 + 8 + 8 significand bits), in MFMA 32x32x16 B-operand order:
-//   Wq[(((j * 16 + s) * 3 + p) * 64 + lane) * 8 + e] = piece p of W[32 j + (lane & 31)][16 s + 8 (lane >> 5) + e]
-__device__ __forceinline__ unsigned short bf16_rne(float x) {
-    unsigned b = __builtin_bit_cast(unsigned, x);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (unsigned short)(b >> 16);
-}
-__device__ __forceinline__ float bf16_val(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
-
-__global__ __launch_bounds__(256) void pack_weight_256_split_kernel(const float *__restrict__ W, unsigned short *__restrict__ Wq) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;            // one (j, s, lane) each: 8 * 16 * 64 = 8192
-    if (idx >= 8 * 16 * 64) return;
-    const int lane = idx & 63, ks = (idx >> 6) & 15, j = idx >> 10;
-    const float *w = W + (32 * j + (lane & 31)) * kH + 16 * ks + 8 * (lane >> 5);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = w[e];
-        const unsigned short h = bf16_rne(v);
-        const float r1 = v - bf16_val(h);
-        const unsigned short m = bf16_rne(r1);
-        const float r2 = r1 - bf16_val(m);
-        const unsigned short pieces[3] = {h, m, bf16_rne(r2)};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) Wq[((((size_t)j * 16 + ks) * 3 + p) * 64 + lane) * 8 + e] = pieces[p];
-    }
-}
-
 template <int U, bool HALO>
 __device__ __forceinline__ void gather_batch(int c, float v, int i, const f32x4 *__restrict__ X,
                                              const f32x4 *__restrict__ Xh, int n_own, int lane, f32x4 &acc) {
@@ -231,7 +203,7 @@ int rhs_fused_supported(int H, uint32_t flags) {
     return H == kH ? 1 : 0;
 }
 
-// packed fp32 weights (256 KiB) followed by the split bf16 weights (384 KiB)
+// packed fp32 weights (256 KiB) followed by the split fp16 weights (two planes, 256 KiB, + their scale pair; sized for three)
 int64_t rhs_fused_work_bytes(int H) { return (int64_t)H * H * sizeof(float) + (int64_t)H * H * 3 * 2; }
 
 // Split weights for the fp16 consumers (split16.h): one global power-of-two scale that brings max |W| into [0.5, 1), then

@@ -49,17 +49,15 @@ constexpr int kH2 = 256;
 constexpr int kTile2 = 64;
 constexpr int kLd2 = kH2 + 4;              // +4 floats: row m starts on 16-byte slot (4 m) mod 64 -> conflict-free b128
 constexpr int kTileFloats2 = kTile2 * kLd2;
-// NDCN_SPLIT = 1 (default): the dense 256 x 256 product runs on the bf16 matrix cores with fp32 operands split
-// error-free into three bf16 pieces each (x = x1 + x2 + x3, 8 + 8 + 8 significand bits) and the six partial products
-// with i + j <= 4 accumulated in fp32 - measured (tools/micro/gemm_split_lab.hip, profiles/r02c_gemm_split_lab.txt): max
-// error against fp64 2.0e-6 vs 2.3e-6 for the fp32-MFMA chain on the same data (the dropped products are ~2^-24 of a
-// product, below the rounding of the fp32 accumulation both variants share; 8 or all 9 products give the identical
-// error) at 6/16 of the fp32 MFMA's matrix-pipe time.  NDCN_SPLIT = 0 builds the fp32-MFMA consumer (A/B reference).
+// NDCN_SPLIT = 1 (default): the dense 256 x 256 product runs on the fp16 matrix cores with fp32-grade results - every operand
+// split error-free into two fp16 pieces behind a power-of-two scale, three partial products accumulated in fp32 (split16.h:
+// measured against fp64, 1.9e-7 of sum |s w| vs 2.3e-7 for the fp32-MFMA chain on the same data) at 3/16 of the fp32 MFMA's
+// matrix-pipe time.  NDCN_SPLIT = 0 builds the fp32-MFMA consumer (A/B reference).
 #ifndef NDCN_SPLIT
 #define NDCN_SPLIT 1
 #endif
 // gather waves: 12 beside the fp32 MFMA waves (16 waves per CU, 128 registers each); 8 beside the split consumer, whose
-// three-k-step weight ring needs ~160 registers (12 waves per CU, 168 each)
+// four-k-step weight ring needs ~160 registers (12 waves per CU, 168 each)
 constexpr int kProd = NDCN_SPLIT ? 8 : 12;
 constexpr int kWaves = 4 + kProd;
 constexpr int kRowsPerProd = (kTile2 + kProd - 1) / kProd;  // rows p, p+12, ... < 64 of every tile: 6 (p < 4) or 5
@@ -89,7 +87,7 @@ struct Fused2Args {
     unsigned x_bytes, xh_bytes;             // sizes of the gathered panels (buffer descriptors: < 2^32)
     int n_own;
     const float *Wp, *bias;
-    const void *Wq;                         // split weights (pack_weight_256: three bf16 planes in MFMA B-operand order)
+    const void *Wq;                         // split weights (pack_weight_256: two fp16 planes in MFMA B-operand order + scales)
     float *K;                               // relu(...) output panel
     int n_rows, n_tiles, relu;
     const int *tile_order;                  // nullable: walk position -> 64-row tile (ndcn_csr::tile_order)

@@ -1,33 +1,34 @@
 // The whole ODEFunc  K = relu(W (A X) + b)  (neural_dynamics.py:27-36) plus the Runge-Kutta algebra that consumes K
 // (rk_common.py:45-60,72-78; misc.py:22-25,146-157), H = 256, for operators that carry the 16-row group-record plan
-// (ndcn_csr::rec, csr.py:build_rec_plan): the gather side of spmm_rec.hip feeding the split-bf16 MFMA product of
-// rhs_fused2.hip, one persistent workgroup per CU.
+// (ndcn_csr::rec, csr.py:build_rec_plan): the gather side of spmm_rec.hip feeding the split-fp16 MFMA product of split16.h,
+// one persistent workgroup per CU.
 //
 // Why (profiles/r02g_fused_timing.txt): rhs_fused2's gather waves fetch every neighbour row through the vector-memory
 // path into registers - 9 fetches of 1 KiB per output row on the 8-neighbour lattice, 9 GB per launch L2 -> CU - and
-// that path, not HBM and not the matrix pipe, bounds its low-stage launches (1.7 M cycles per launch with the MFMA
-// waves idle; twice the fetches in flight change nothing).  The group-record plan stages each DISTINCT neighbour row of
-// a 4 x 4 lattice patch once (36 rows for 16 outputs: 2.25 fetches per row) by LDS-DMA, no register round trip; the
-// LDS that costs is found by shrinking the S tile from 64 to 32 rows (the weights are then streamed twice as often:
-// 12 KiB per row from L2, still less than the 9 KiB per row of fetches it replaces plus the 6 KiB it had).
+// that path, not HBM and not the matrix pipe, bounds its low-stage launches.  The group-record plan stages each DISTINCT
+// neighbour row of a 4 x 4 lattice patch once (36 rows for 16 outputs: 2.25 fetches per row) by LDS-DMA, no register round
+// trip; the LDS that costs is found by shrinking the S tile from 64 to 32 rows.
 //
-//   12 waves: 8 producer | 4 MFMA, in lock-step over "steps" (one 16-row group each), ONE workgroup barrier per step
+//   16 waves: 8 producer | 8 MFMA, in lock-step over "steps" (one 16-row group each), ONE workgroup barrier per step
 //     producer step s: own LDS-DMA requests of group s landed (counted vmcnt); barrier; request record s + 2 and its
 //              share (5 of 40) of the union rows of group s + 1 (column ids out of the record that landed a step
 //              earlier); then two rows: fold the row's (slot, value) entries over the staged union rows (stored order:
-//              bit-identical to a sequential loop) -> row 16 (s & 1) + i of S tile (s / 2) & 1.  The slot it overwrites
-//              holds K of the tile staged 4 steps earlier: that row's RK epilogue (K out, y_next / error sums) comes
-//              first; its row-local panels were requested half a step ahead.
-//     MFMA     step s: half (s & 1) of the 16 k-steps of tile s / 2 - 1 (the other S buffer): wave w owns output
-//              columns [64 w, 64 w + 64); fp32 operands split error-free into 3 bf16 pieces, 6 partial products
-//              (rhs_fused2.hip).  After the second half the four waves meet on an LDS counter (everyone has read S) and
-//              drop K = relu(. + b) into the tile they consumed.
-//   (Measured on the way: 4 DMA + 8 compute + 4 MFMA waves (16 waves: 128 registers, a two-k-step weight ring) ran the
-//   MFMA side at 22 k cycles per 32-row tile, 3.6 x its matrix-pipe time - every k-step waited an L2 round trip for its
-//   weights - while the producer side alone was at the HBM floor of every launch; 8 producer + 8 MFMA waves (one n-tile
-//   each, two per SIMD) took 13 k cycles per tile even with the weight fetches switched off: eight waves each splitting
-//   the whole A tile into bf16 pieces make the loop VALU-bound.)
-//   LDS: 2 union buffers (40 KiB) + 3 records (2 KiB) + 2 S tiles (32 x 260 floats) + row ids = 151 KiB.
+//              bit-identical to a sequential loop), form the row's power-of-two scale (DPP max over the wave) and write the
+//              row as its two fp16 pieces [256 high | 256 low] -> row 16 (s & 1) + i of S tile (s / 2) & 1: the 1 KiB the
+//              fp32 row would occupy.  The slot it overwrites holds K (fp32) of the tile staged 4 steps earlier: that row's
+//              RK epilogue (K out, y_next / error sums) comes first; its row-local panels were requested a step ahead.
+//     MFMA     step s: half (s & 1) of the 16 k-steps of tile s / 2 - 1 (the other S buffer): wave w owns output columns
+//              [32 w, 32 w + 32): per k-step two ds_read_b128 (ready A operands - no VALU in the loop) and three
+//              v_mfma_f32_32x32x16_f16 (low x high, high x low, high x high; small terms first).  The weights of 10 k-steps
+//              stay in registers, the other 6 (the even ones) stream from L2 through a two-slot ring refilled right after
+//              use, three k-steps of products ahead of the next use.  After the second half the eight waves meet on an LDS
+//              counter (everyone has read S) and drop K = relu(unscale * acc + b) into the tile they consumed.
+//   History: rounds 1-2 split every S value into three bf16 pieces INSIDE each MFMA wave (six products,
+//   38 VALU per split, eight waves each splitting the whole tile: the loop was VALU-bound, 13 k cycles per 32-row tile); two
+//   fp16 pieces make the split planes exactly as large as the fp32 tile, so the producer that holds the row splits it once.
+//   12-wave configurations (4 producers + 8 MFMA waves with ALL weights resident, 8 + 4) hang on the hardware: not shipped.
+//   LDS: 2 union buffers (80 KiB) + 3 records (6 KiB) + 2 S tiles (32 x 260 floats each, 65 KiB) + row ids / bias / scales
+//   = 153 KiB.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -43,23 +44,19 @@
 namespace ndcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this kernel is written for
-// MFMA waves: 4 (two n-tiles each, 12 waves per CU: 168 registers) or 8 (one n-tile each, two per SIMD, 128 registers)
+// MFMA waves: 8 (one n-tile each, two per SIMD, 128 registers); the 4-wave form (two n-tiles each) compiles but hangs
 #ifndef NDCN_F3_MFMA_WAVES
 #define NDCN_F3_MFMA_WAVES 8
 #endif
 #ifndef NDCN_F3_RING
 #define NDCN_F3_RING 2
 #endif
-// The weight stream (12 KiB per row from L2), not HBM, bounds this kernel: with the refills switched off the dopri5 step
-// of the metric case takes 6.2 ms instead of 11.9.  Whatever registers the MFMA waves have left hold the first k-steps of
-// their weights for good.
-// the bf16 split of the next k-step interleaved with this k-step's products (experiment, see mfma_half)
-#ifndef NDCN_F3_PIPE
-#define NDCN_F3_PIPE 0
-#endif
+// The L2 -> CU weight stream competes with the producers' requests for the vector-memory path (round 2, bf16: 12 KiB per row;
+// with the refills switched off the dopri5 step of the metric case took 6.2 ms instead of 11.9).  Whatever registers the MFMA
+// waves have left hold k-steps of their weights for good: 10 of 16 (3 KiB per row still streamed; 8: 9.82, 9: 9.66 ms/step
+// with the split still in the MFMA waves; 10 + ring 2 = 123 registers with ready operands: 9.21 on the same box class).
 #ifndef NDCN_F3_RESIDENT
 #define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 10 : 2)    // two fp16 planes: 8 registers per resident k-step
 #endif
@@ -113,7 +110,7 @@ struct F3Args {
     int n_groups;
     const float *X, *Xh;
     int n_own;
-    const void *Wq;                  // split weights (pack_weight_256: three bf16 planes in MFMA B-operand order)
+    const void *Wq;                  // split weights (pack_weight_256: two fp16 planes in MFMA B-operand order + scales)
     const float *bias;
     float *K;
     int relu;

@@ -935,7 +935,7 @@ def test_truth_rhs_kernels(dev):
 
 
 def test_packed_weight_cache_follows_weight_updates(dev):
-    """ops keeps the packed (split-bf16) image of W between no-grad calls (NDCN_F_PACKED); an in-place update of W must
+    """ops keeps the packed (split-fp16) image of W between no-grad calls (NDCN_F_PACKED); an in-place update of W must
     be seen by the next call."""
     from ndcn_amd import hip, CsrOperator, graphs
     H = 256

@@ -6,9 +6,10 @@ SpMM and the row SpMM carrying the no_control RHS, and the composed SpMM + Linea
   (b) a NaN BORN INSIDE the evaluation: (+Inf) + (-Inf) in the accumulation of A X,
   (c) an overflow inside A X (finite inputs) that the Linear turns into NaN,
 and compared with oracle.odefunc_rhs element class by element class (NaN / +Inf / -Inf / finite value).
-One documented difference: the H = 256 fused kernels form W S on the bf16 matrix cores from error-free
-three-way splits of both operands; an INFINITE entry of S = A X then makes its whole K row NaN (Inf times the residual
-planes of W has both signs), where the reference's fp32 chain gives +Inf / 0 after the ReLU per output column.  Both rows
+One documented difference: the H = 256 fused kernels form W S on the fp16 matrix cores from error-free
+two-piece splits of both operands (split16.h); an INFINITE entry of S = A X then makes its whole K row NaN (the row's
+pieces come out Inf / NaN, and Inf times the low plane of W has both signs), where the reference's fp32 chain gives
++Inf / 0 after the ReLU per output column.  Both rows
 are non-finite - what the solver's assertions look at - so for those kernels rows are compared as finite / non-finite and
 every reference NaN must be a NaN."""
 import numpy as np
