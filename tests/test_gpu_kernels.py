@@ -581,6 +581,14 @@ def test_partial_error_sum_in_the_stage6_launch(dev, kernel):
     K7a, (sa, ba) = hip.rhs_rk(A, y1, W, b, 'error', y0, [E], [np.float32(1.0), ce[5]], rtol=1e-2, atol=1e-3, **kw)
     K7b, (sb, bb) = hip.rhs_rk(A, y1, W, b, 'error', y0, ks[:4] + [K6], ce[:4] + [ce[4], ce[5]], rtol=1e-2, atol=1e-3, **kw)
     assert torch.equal(K7a, K7b) and sa == sb and ba == bb == 0.0
+    # the stage-6 hand-over (solver.hip: enqueue_attempt): the launch that produces k4 also writes
+    # P = c1 k1 + c2 k2 + c3 k3 + c4 k4 of the NEXT stage's sum; the launch that produces k5 then forms y0 + (1 * P + c5 k5)
+    # from {y0, P} - bit for bit what it forms from {y0, k1, k2, k3, k4}
+    b5 = [np.float32(c) for c in (2.846275, -10.757576, 8.906423, 0.278409, -0.273531)]
+    K4, y5, P = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:3], cs[:3] + [cs[5]], aux_cs=b5[:4], **kw)
+    K5a, y6a = hip.rhs_rk(A, y5, W, b, 'combine', y0, [P], [np.float32(1.0), b5[4]], **kw)
+    K5b, y6b = hip.rhs_rk(A, y5, W, b, 'combine', y0, ks[:3] + [K4], b5, **kw)
+    assert torch.equal(K5a, K5b) and torch.equal(y6a, y6b)
 
 
 @pytest.mark.parametrize('H', [1, 16, 20, 33, 64, 65, 100, 128])
