@@ -342,12 +342,23 @@ class Dopri5:
         kk, cs = dt_terms(dt32, DP_BETA[0], k)
         x = self.ops.combine(y0, kk, cs)
         aux = bool(getattr(self.fused, 'supports_aux', False))
-        E = None
+        E = P = None
         for i in range(1, 6):
             # the evaluation producing k[i] also forms the input of stage i+1: y0 + dt * sum beta[i][m] k[m]
             prev, cp = dt_terms(dt32, DP_BETA[i][:i], k)
             c_new = f32(dt32 * f32(DP_BETA[i][i]))
             self.nfe += 1
+            if i == 4 and P is not None:
+                prev, cp = [P], [f32(1.0)]                         # y0 + (1 * P + dt beta_65 k5): the same roundings
+            if i == 3 and aux and len(cp) == 3:
+                # holding k1, k2, k3: the first four terms of the stage-6 sum, P = dt sum_{j<=4} beta_6j k_j, handed to the
+                # next evaluation, which then reads {y0, P} instead of {y0, k1..k4} (solver.hip: enqueue_attempt)
+                _, c6 = dt_terms(dt32, DP_BETA[4][:4], k + [None])
+                if len(c6) == 4:
+                    k_new, x_next, P = self.fused.rhs_rk(x, 'combine', y0, prev, cp + [c_new], 0.0, 0.0, aux_cs=c6)
+                    k.append(k_new)
+                    x = x_next
+                    continue
             if i == 5 and aux:
                 # ... and, holding k1, k3, k4, k5 already, the partial error sum E = dt sum_{j<=6} c_err[j] k_j (the same
                 # stages in the same order: beta[5][j] and c_err[j] vanish for the same j), so that the error evaluation
