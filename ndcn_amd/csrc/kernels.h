@@ -101,6 +101,8 @@ extern thread_local int g_last_rhs_path;     // ndcn_debug_last_rhs_path     // 
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st);
 int64_t reduce_ws_bytes();
+int scaled_sumsq_pair_f32(const float *f, const float *y, float rtol, float atol, int64_t n, double *d_out4, void *d_ws,
+                          void *d_ws2, hipStream_t st);
 int64_t aten_order_max_elems();   // rk_error_f32 / scaled_sumsq_f32 reduce panels up to this size in ATen's float32 order (0: disabled)
 int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt, float *a,
                    float *b, float *c, float *d, int64_t n, hipStream_t st);

@@ -313,6 +313,36 @@ __global__ __launch_bounds__(256) void scaled_sumsq_kernel(const float *__restri
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s; partial[2 * blockIdx.x + 1] = bad; }
 }
 
+// d0 and d1 of the initial step (misc.py:121-127) in ONE pass over {y0, f0}: sum (y0 / scale)^2 and sum (f0 / scale)^2 with
+// scale = atol + |y0| rtol, element for element the arithmetic of scaled_sumsq_kernel<., false>; two partial arrays
+template <bool VEC>
+__global__ __launch_bounds__(256) void scaled_sumsq_pair_kernel(const float *__restrict__ f, const float *__restrict__ y,
+                                                                float rtol, float atol, int64_t n_items,
+                                                                double *__restrict__ partial_y, double *__restrict__ partial_f) {
+    double sy = 0.0, by = 0.0, sf = 0.0, bf = 0.0;
+    auto one = [&](float fv, float yv) {
+        const float scale = atol + fabsf(yv) * rtol;
+        const float qy = yv / scale, qf = fv / scale;
+        sy += (double)(qy * qy);
+        sf += (double)(qf * qf);
+        by += (double)(int)nonfinite(yv);
+        bf += (double)(int)nonfinite(fv);
+    };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const float4 fv = ld4(f, i), yv = ld4(y, i);
+            one(fv.x, yv.x); one(fv.y, yv.y); one(fv.z, yv.z); one(fv.w, yv.w);
+        } else {
+            one(f[i], y[i]);
+        }
+    }
+    block_sum2(sy, by);
+    if (threadIdx.x == 0) { partial_y[2 * blockIdx.x] = sy; partial_y[2 * blockIdx.x + 1] = by; }
+    __syncthreads();
+    block_sum2(sf, bf);
+    if (threadIdx.x == 0) { partial_f[2 * blockIdx.x] = sf; partial_f[2 * blockIdx.x + 1] = bf; }
+}
+
 // fixed-order final sum of the per-block partials
 __global__ __launch_bounds__(256) void reduce_finish_kernel(const double *__restrict__ partial, int n_partial,
                                                             double *__restrict__ out, int accum) {
@@ -645,6 +675,22 @@ int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol,
     else { if (b) NDCN_SS(false, true); else NDCN_SS(false, false); }
 #undef NDCN_SS
     hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, partial, g, d_out, 0);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+// {sum (y / scale)^2, non-finite y, sum (f / scale)^2, non-finite f} -> d_out4; d_ws, d_ws2: two reduction workspaces
+int scaled_sumsq_pair_f32(const float *f, const float *y, float rtol, float atol, int64_t n, double *d_out4, void *d_ws,
+                          void *d_ws2, hipStream_t st) {
+    const bool vec = (n % 4 == 0) && aligned16(f) && aligned16(y);
+    const int64_t items = vec ? n / 4 : n;
+    const int g = red_grid(items);
+    double *py = static_cast<double *>(d_ws), *pf = static_cast<double *>(d_ws2);
+    ProfScope prof(PROF_SUMSQ, st, 4.0 * n * 2, 12.0 * n);
+    if (vec) hipLaunchKernelGGL((scaled_sumsq_pair_kernel<true>), dim3(g), dim3(256), 0, st, f, y, rtol, atol, items, py, pf);
+    else hipLaunchKernelGGL((scaled_sumsq_pair_kernel<false>), dim3(g), dim3(256), 0, st, f, y, rtol, atol, items, py, pf);
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, py, g, d_out4, 0);
+    hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(256), 0, st, pf, g, d_out4 + 2, 0);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

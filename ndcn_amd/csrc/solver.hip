@@ -228,11 +228,31 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     const float rtol = (float)s->d.rtol, atol = (float)s->d.atol;
     float d0, d1, d2;
     double bad0, bad;
-    int rc = rms_scaled(s, s->ycur, nullptr, s->ycur, rtol, atol, st, d0, bad0);
-    if (rc) return rc;
-    s->pending_bad = (int64_t)bad0;
-    rc = rms_scaled(s, s->k[0], nullptr, s->ycur, rtol, atol, st, d1, bad);
-    if (rc) return rc;
+    int rc;
+    static const bool fuse_on = [] { const char *e = getenv("NDCN_INIT_FUSED"); return !(e && e[0] == '0'); }();
+    if (fuse_on && (s->sharded || s->n_elem > aten_order_max_elems())) {
+        // d0 = || y0 / scale || and d1 = || f0 / scale || in one pass over {y0, f0}, one read-back (large panels: the
+        // double-precision sums of scaled_sumsq_f32; small ones keep ATen's float32 order, section 2)
+        rc = scaled_sumsq_pair_f32(s->k[0], s->ycur, rtol, atol, s->n_elem, s->d_red, s->d_ws, s->d_ws2, st);
+        if (rc) return rc;
+        if (s->sharded) {
+            rc = comm_allreduce_sum_f64(s->shard.comm, s->d_red, 4, st);
+            if (rc) return rc;
+        }
+        NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        NDCN_HIP(hipEventRecord(s->ev, st));
+        NDCN_HIP(hipEventSynchronize(s->ev));
+        bad0 = s->h_red[1];
+        d0 = (float)sqrt(s->h_red[0]) / (float)sqrt(s->n_mean);
+        d1 = (float)sqrt(s->h_red[2]) / (float)sqrt(s->n_mean);
+        s->pending_bad = (int64_t)bad0;
+    } else {
+        rc = rms_scaled(s, s->ycur, nullptr, s->ycur, rtol, atol, st, d0, bad0);
+        if (rc) return rc;
+        s->pending_bad = (int64_t)bad0;
+        rc = rms_scaled(s, s->k[0], nullptr, s->ycur, rtol, atol, st, d1, bad);
+        if (rc) return rc;
+    }
     float h0;
     if (d0 < 1e-5 || d1 < 1e-5) h0 = 1e-6f;
     else h0 = 0.01f * (d0 / d1);
@@ -245,8 +265,7 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     // that produces f1, as its error record: stages {f0, f1} with coefficients {-1, 1} - (-f0) + f1 is the float32 value of
     // f1 - f0 - over the tolerance of the pair (y0, y0), i.e. atol + rtol |y0|; squares summed in double like
     // scaled_sumsq_f32.  (Panels small enough for ATen's float32 summation order keep the separate launch: section 2.)
-    static const bool fuse_d2_on = [] { const char *e = getenv("NDCN_INIT_FUSED"); return !(e && e[0] == '0'); }();
-    if (fuse_d2_on && s->fused2 && (s->sharded || s->n_elem > aten_order_max_elems())) {
+    if (fuse_on && s->fused2 && (s->sharded || s->n_elem > aten_order_max_elems())) {
         const float *kq[1] = {s->k[0]};
         const float cq[2] = {-1.f, 1.f};
         const RkOpt opt = {s->ycur, 0, nullptr, nullptr};
@@ -689,13 +708,13 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         if ((rc = alloc_panel(s, &s->cd))) return fail(rc);
     }
     void *q = nullptr;
-    if ((rc = carve(s, 2 * sizeof(double), &q))) return fail(rc);
+    if ((rc = carve(s, 4 * sizeof(double), &q))) return fail(rc);     // {sum, non-finite} (x 2 for the initial step's norm pair)
     s->d_red = static_cast<double *>(q);
     if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);
     s->d_ws = q;
     if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);      // partials of any RHS epilogue
     s->d_ws2 = q;
-    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 2 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         return fail(NDCN_EHIP);
     }
