@@ -139,7 +139,9 @@ NDCN_API int ndcn_linear_f32(const float *S, const float *W, const float *b, flo
  *   gW [H_out, H_in]  = gZ^T S             (nullable; reduction over rows split into chunks, partials summed in a fixed
  *                                           order: deterministic, no atomics)
  *   gb [H_out]        = column sums of gZ  (nullable)
- * S: the forward input (needed for gW).  work: ndcn_linear_bwd_work_bytes() bytes of device scratch (gW / gb).       */
+ * S: the forward input (needed for gW).  work: ndcn_linear_bwd_work_bytes() bytes of device scratch (gW / gb; with
+ * H_in = H_out = 256 also gS: given scratch, the product runs on the fp16 matrix cores from two-piece splits of both
+ * operands - fp32-grade, as the forward kernels - and the planes of W^T are packed there; without it, the fp32 MFMA).   */
 NDCN_API int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW,
                                  float *gb, void *work, int64_t n, int H_in, int H_out, void *stream);
 NDCN_API int64_t ndcn_linear_bwd_work_bytes(int64_t n, int H_in, int H_out);

@@ -13,12 +13,17 @@
 //
 // MFMA operand map (32x32x2 f32): A lane l = A[m = l & 31][k = l >> 5]; B lane l = B[k = l >> 5][n = l & 31];
 // D reg r = D[m = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][n = l & 31].
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
+#include "split16.h"
 
 namespace ndcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGwWaves = 8;          // o-strips of 32 per workgroup (Ho <= 256 per pass)
 constexpr int kGwMaxNI = 8;          // i-tiles of 32 per wave (Hi <= 256 per pass)
@@ -176,6 +181,103 @@ __global__ __launch_bounds__(256) void linear_gs_kernel(const float *__restrict_
     }
 }
 
+// gS for Hi = Ho = 256 (the ODEFunc's Linear under autograd) on the fp16 matrix cores with fp32-grade results: the product of
+// the forward kernels (split16.h: two fp16 pieces per operand behind a per-row power-of-two scale, three partial products in one
+// fp32 accumulator) with B = W instead of W^T.  One workgroup = 64 rows: the masked gZ tile is staged in LDS once (each wave
+// 16 rows: mask, row maximum by DPP, scale), wave w then owns output columns [64 w, 64 w + 64) of both 32-row m-tiles; the
+// packed weights (pack_weight_256_t16: planes of W^T in MFMA B-operand order, 256 KiB, L2-resident) come through a four-k-step
+// register ring.  fp32 MFMA version (linear_gs_kernel<256>): 0.44 ms at n = 10^5; this one is bound by its 0.3 GB of HBM traffic.
+constexpr int kGsRows = 64, kGsLd = 260;
+__global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *__restrict__ g, const float *__restrict__ Y,
+                                                                  const void *__restrict__ Wq, float *__restrict__ gS, int64_t n) {
+    __shared__ __attribute__((aligned(16))) float s_A[kGsRows * kGsLd];
+    __shared__ float s_sc[kGsRows], s_un[kGsRows];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * kGsRows;
+    const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Wq) + kS16Bytes)[1];
+    for (int i = 0; i < 16; ++i) {
+        const int r = 16 * wave + i;
+        const int64_t gr = row0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < n) {
+            v = *reinterpret_cast<const f32x4 *>(g + gr * 256 + 4 * lane);
+            if (Y) {
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(Y + gr * 256 + 4 * lane);
+                if (!(y.x > 0.f)) v.x = 0.f;
+                if (!(y.y > 0.f)) v.y = 0.f;
+                if (!(y.z > 0.f)) v.z = 0.f;
+                if (!(y.w > 0.f)) v.w = 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4 *>(s_A + r * kGsLd + 4 * lane) = v;
+        unsigned sb, ub;
+        s16_scale_bits(s16_wave_umax(s16_row_max_bits(v)), sb, ub);
+        if (lane == 0) {
+            s_sc[r] = __builtin_bit_cast(float, sb);
+            s_un[r] = __builtin_bit_cast(float, ub) * w_unscale;
+        }
+    }
+    constexpr int kRingQ = 4, kPl = kS16Planes;
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wq), 0, kS16Bytes, 0x00020000);
+    const int lane_off = lane * 16;
+    const int q_slab = (2 * wave) * 16 * kPl * 1024;
+    auto ldq = [&](int jj, int ks, int pl) {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane_off, q_slab + ((jj * 16 + ks) * kPl + pl) * 1024, 0);
+    };
+    u32x4_s16 Bq[kRingQ][2][kPl];
+#pragma unroll
+    for (int u = 0; u < kRingQ; ++u)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, u, pl);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][jj][i] = 0.f;
+    __syncthreads();
+    const float *ap = s_A + (lane & 31) * kGsLd + 8 * (lane >> 5);
+    const float sc[2] = {s_sc[lane & 31], s_sc[32 + (lane & 31)]};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int u = ks % kRingQ;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(ap + mt * 32 * kGsLd + 16 * ks);
+            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(ap + mt * 32 * kGsLd + 16 * ks + 4);
+            u32x4_s16 A0, A1;
+            s16_split8(r0, r1, sc[mt], A0, A1);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                s16_mfma(acc[mt][jj], A1, Bq[u][jj][0]);
+                s16_mfma(acc[mt][jj], A0, Bq[u][jj][1]);
+                s16_mfma(acc[mt][jj], A0, Bq[u][jj][0]);
+            }
+        }
+        if (ks + kRingQ < 16) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, ks + kRingQ, pl);
+        }
+    }
+    // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31], multiplied back by 1 / (row scale * weight scale)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int64_t gr = row0 + m;
+            if (gr >= n) continue;
+            const float un = s_un[m];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) gS[gr * 256 + 64 * wave + 32 * jj + (lane & 31)] = acc[mt][jj][r] * un;
+        }
+}
+
 __global__ __launch_bounds__(256) void linear_gs_small_kernel(const float *__restrict__ g, const float *__restrict__ Y,
                                                               const float *__restrict__ W, float *__restrict__ gS, int64_t n,
                                                               int Hi, int Ho) {
@@ -195,8 +297,13 @@ static int64_t wgrad_chunks(int64_t n) {
     return c < 1 ? 1 : c;
 }
 
+static int64_t wgrad_work_bytes(int64_t n, int Hi, int Ho) {
+    return (wgrad_chunks(n) * ((int64_t)Ho * Hi + Ho) * (int64_t)sizeof(float) + 256 + 255) / 256 * 256;
+}
+
+// partial gW / gb blocks, then (Hi = Ho = 256) the packed fp16 planes of W^T for the gS product
 int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho) {
-    return wgrad_chunks(n) * ((int64_t)Ho * Hi + Ho) * (int64_t)sizeof(float) + 256;
+    return wgrad_work_bytes(n, Hi, Ho) + ((Hi == 256 && Ho == 256) ? (int64_t)kS16Bytes + 256 : 0);
 }
 
 int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb, void *work,
@@ -209,8 +316,16 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
     const bool small = Hi < 16 || Ho < 16;
     if (gS) {
         ProfScope prof(PROF_LINEAR, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * Hi * Ho, 2.0 * n * (double)Hi * Ho);
+        static const bool split_on = [] { const char *e = getenv("NDCN_GS_SPLIT"); return !(e && e[0] == '0'); }();
+        const bool a16 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(gS)) & 15) == 0;
         if (small) {
             hipLaunchKernelGGL(linear_gs_small_kernel, dim3(stream_grid(n * (int64_t)Hi, 256)), dim3(256), 0, st, g, Y, W, gS, n, Hi, Ho);
+        } else if (split_on && Hi == 256 && Ho == 256 && work && a16) {
+            // (a caller without scratch - gS only, older bindings - keeps the fp32 MFMA kernel below)
+            void *Wq = static_cast<char *>(work) + wgrad_work_bytes(n, Hi, Ho);
+            int rcp = pack_weight_256_t16(W, Wq, st);
+            if (rcp) return rcp;
+            hipLaunchKernelGGL(linear_gs_256_split_kernel, dim3((unsigned)((n + kGsRows - 1) / kGsRows)), dim3(256), 0, st, g, Y, Wq, gS, n);
         } else {
             const unsigned gx = (unsigned)((n + kBM2 - 1) / kBM2);
             if (Hi > 128) hipLaunchKernelGGL((linear_gs_kernel<256>), dim3(gx, (unsigned)((Hi + 255) / 256)), dim3(256), 0, st, g, Y, W, gS, n, Hi, Ho);

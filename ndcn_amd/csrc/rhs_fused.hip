@@ -231,16 +231,18 @@ __global__ __launch_bounds__(256) void weight_scale_256_kernel(const float *__re
     }
 }
 
+// TRANSPOSED: the planes of W^T (the B operand of gS = gZ W, linear_bwd.hip)
+template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ Wh,
                                                                   const float *__restrict__ tail) {
     const int idx = blockIdx.x * 256 + threadIdx.x;            // one (j, s, lane): 8 * 16 * 64 = 8192
     if (idx >= 8 * 16 * 64) return;
     const float sc = tail[0];
     const int lane = idx & 63, s = (idx >> 6) & 15, j = idx >> 10;
-    const float *src = W + (32 * j + (lane & 31)) * kH + 16 * s + 8 * (lane >> 5);
+    const int row = 32 * j + (lane & 31), col = 16 * s + 8 * (lane >> 5);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float w = src[e] * sc;
+        const float w = (TRANSPOSED ? W[(col + e) * kH + row] : W[row * kH + col + e]) * sc;
         const _Float16 g0 = (_Float16)w;
         const _Float16 g1 = (_Float16)(w - (float)g0);
         Wh[((((size_t)j * 16 + s) * 2 + 0) * 64 + lane) * 8 + e] = g0;
@@ -252,7 +254,16 @@ int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
     hipLaunchKernelGGL(pack_weight_256_kernel, dim3(64), dim3(256), 0, st, W, Wp);
     float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(Wp + kH * kH) + kS16Bytes);
     hipLaunchKernelGGL(weight_scale_256_kernel, dim3(1), dim3(256), 0, st, W, tail);
-    hipLaunchKernelGGL(pack_weight_256_f16_kernel, dim3(32), dim3(256), 0, st, W, reinterpret_cast<_Float16 *>(Wp + kH * kH), tail);
+    hipLaunchKernelGGL(pack_weight_256_f16_kernel<false>, dim3(32), dim3(256), 0, st, W, reinterpret_cast<_Float16 *>(Wp + kH * kH), tail);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+// Wq <- the fp16 planes of W^T + {scale, 1 / scale} (kS16Bytes + 8 bytes)
+int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st) {
+    float *tail = reinterpret_cast<float *>(static_cast<char *>(Wq) + kS16Bytes);
+    hipLaunchKernelGGL(weight_scale_256_kernel, dim3(1), dim3(256), 0, st, W, tail);
+    hipLaunchKernelGGL(pack_weight_256_f16_kernel<true>, dim3(32), dim3(256), 0, st, W, static_cast<_Float16 *>(Wq), tail);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }

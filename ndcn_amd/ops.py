@@ -189,7 +189,7 @@ class HipOps:
         gW = torch.empty((Ho, Hi), dtype=torch.float32, device=g.device) if need_gW else None
         gb = torch.empty((Ho,), dtype=torch.float32, device=g.device) if need_gb else None
         work = None
-        if need_gW or need_gb:
+        if need_gW or need_gb or (need_gS and Hi == 256 and Ho == 256):      # (H = 256: gS packs the planes of W^T there)
             work = torch.empty(int(lib.ndcn_linear_bwd_work_bytes(n, Hi, Ho)), dtype=torch.uint8, device=g.device)
         with torch.cuda.device(g.device):
             check(lib.ndcn_linear_bwd_f32(ptr(g2), ptr(Y2), ptr(S2 if S2 is not None else g2), ptr(W), ptr(gS), ptr(gW), ptr(gb),
