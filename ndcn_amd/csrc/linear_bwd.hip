@@ -317,7 +317,7 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
     if (gS) {
         ProfScope prof(PROF_LINEAR, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * Hi * Ho, 2.0 * n * (double)Hi * Ho);
         static const bool split_on = [] { const char *e = getenv("NDCN_GS_SPLIT"); return !(e && e[0] == '0'); }();
-        const bool a16 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(gS)) & 15) == 0;
+        const bool a16 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(gS) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
         if (small) {
             hipLaunchKernelGGL(linear_gs_small_kernel, dim3(stream_grid(n * (int64_t)Hi, 256)), dim3(256), 0, st, g, Y, W, gS, n, Hi, Ho);
         } else if (split_on && Hi == 256 && Ho == 256 && work && a16) {

@@ -210,11 +210,14 @@ int64_t rhs_fused_work_bytes(int H) { return (int64_t)H * H * sizeof(float) + (i
 // every scaled weight as two fp16 pieces (round to nearest, then the exact remainder rounded to nearest), MFMA 32x32x16
 // B-operand order:  Wh[(((j * 16 + s) * 2 + p) * 64 + lane) * 8 + e] = piece p of W[32 j + (lane & 31)][16 s + 8 (lane >> 5) + e];
 // behind the planes: float {scale, 1 / scale}.
-__global__ __launch_bounds__(256) void weight_scale_256_kernel(const float *__restrict__ W, float *__restrict__ tail) {
+// max |W| over the 256 x 256 weights as a bit pattern, by every thread of a 256-thread block (each block of the pack kernel
+// forms it for itself: 256 KiB out of L2, cheaper than a launch of its own in front)
+__device__ __forceinline__ unsigned weight_max_bits_256(const float *__restrict__ W) {
     __shared__ unsigned smax[256];
     unsigned m = 0;
-    for (int i = threadIdx.x; i < kH * kH; i += 256) {
-        const unsigned b = __builtin_bit_cast(unsigned, W[i]) & 0x7fffffffu;
+    for (int i = threadIdx.x; i < kH * kH / 4; i += 256) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(W)[i];
+        const unsigned b = s16_row_max_bits(v);
         m = b > m ? b : m;
     }
     smax[threadIdx.x] = m;
@@ -223,21 +226,22 @@ __global__ __launch_bounds__(256) void weight_scale_256_kernel(const float *__re
         if (threadIdx.x < w) smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + w] ? smax[threadIdx.x] : smax[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        unsigned sb, ub;
-        s16_scale_bits(smax[0], sb, ub);
-        tail[0] = __builtin_bit_cast(float, sb);
-        tail[1] = __builtin_bit_cast(float, ub);
-    }
+    return smax[0];
 }
 
 // TRANSPOSED: the planes of W^T (the B operand of gS = gZ W, linear_bwd.hip)
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ Wh,
-                                                                  const float *__restrict__ tail) {
+                                                                  float *__restrict__ tail) {
+    unsigned sb, ub;
+    s16_scale_bits(weight_max_bits_256(W), sb, ub);
+    const float sc = __builtin_bit_cast(float, sb);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tail[0] = sc;
+        tail[1] = __builtin_bit_cast(float, ub);
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;            // one (j, s, lane): 8 * 16 * 64 = 8192
     if (idx >= 8 * 16 * 64) return;
-    const float sc = tail[0];
     const int lane = idx & 63, s = (idx >> 6) & 15, j = idx >> 10;
     const int row = 32 * j + (lane & 31), col = 16 * s + 8 * (lane >> 5);
 #pragma unroll
@@ -253,7 +257,6 @@ __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *_
 int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
     hipLaunchKernelGGL(pack_weight_256_kernel, dim3(64), dim3(256), 0, st, W, Wp);
     float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(Wp + kH * kH) + kS16Bytes);
-    hipLaunchKernelGGL(weight_scale_256_kernel, dim3(1), dim3(256), 0, st, W, tail);
     hipLaunchKernelGGL(pack_weight_256_f16_kernel<false>, dim3(32), dim3(256), 0, st, W, reinterpret_cast<_Float16 *>(Wp + kH * kH), tail);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
@@ -262,7 +265,6 @@ int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
 // Wq <- the fp16 planes of W^T + {scale, 1 / scale} (kS16Bytes + 8 bytes)
 int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st) {
     float *tail = reinterpret_cast<float *>(static_cast<char *>(Wq) + kS16Bytes);
-    hipLaunchKernelGGL(weight_scale_256_kernel, dim3(1), dim3(256), 0, st, W, tail);
     hipLaunchKernelGGL(pack_weight_256_f16_kernel<true>, dim3(32), dim3(256), 0, st, W, static_cast<_Float16 *>(Wq), tail);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
