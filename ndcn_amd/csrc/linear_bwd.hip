@@ -93,6 +93,142 @@ __global__ __launch_bounds__(64 * kGwWaves) void linear_wgrad_kernel(const float
     }
 }
 
+// ---- gW, gb for Hi = Ho = 256 on the bf16 matrix cores with fp32-grade results.  The reduction runs over the ROWS, where the
+// per-row power-of-two scale of the fp16 pieces (split16.h) cannot follow, and column scales would cost a pass of their own
+// (measured: 0.117 ms - the whole budget).  bf16 has fp32's exponent range: every operand is split error-free into THREE bf16
+// pieces (8 + 8 + 8 significand bits) and the six partial products with i + j <= 4 are accumulated in fp32, small terms first -
+// the product of rounds 1-2 (profiles/r02c_gemm_split_lab.txt: 2.0e-7 of sum |a b| against fp64, fp32 MFMA chain 2.3e-7).
+// One workgroup (8 waves) per row chunk, the whole 256 x 256 block: per k-step of 16 rows thread (column c, row half h)
+// fetches gZ[8 rows][c] and S[8 rows][c] (a wave's fetch = 64 consecutive columns of one row; a pair of k-steps ahead), splits
+// them and writes the 16-byte operand chunks - A[m = c][k = 8 h ..] and B[k = 8 h ..][n = c] have the SAME lane layout - into
+// LDS ([k-step of the pair][plane][h][column][16 B]: conflict-free b128 on both sides); wave w then owns the o-strip
+// [32 w, 32 w + 32) against all eight i-tiles: 3 + 24 ds_read_b128 and 48 MFMAs per k-step.
+typedef __bf16 bf16x8_gw __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned gw_cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void gw_split8(const float *x, u32x4_s16 &p1, u32x4_s16 &p2, u32x4_s16 &p3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = x[2 * q], b = x[2 * q + 1];
+        const unsigned h = gw_cvt_pk_bf16(a, b);
+        const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+        const unsigned m = gw_cvt_pk_bf16(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+        p1[q] = h; p2[q] = m; p3[q] = gw_cvt_pk_bf16(sa, sb);
+    }
+}
+__device__ __forceinline__ void gw_mfma(f32x16 &c, u32x4_s16 a, u32x4_s16 b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_gw, a), __builtin_bit_cast(bf16x8_gw, b), c, 0, 0, 0);
+}
+
+constexpr int kWsPlane = 2 * 256 * 16;          // bytes of one operand plane of one k-step
+__global__ __launch_bounds__(512) void linear_wgrad_256_split_kernel(const float *__restrict__ g, const float *__restrict__ Y,
+                                                                     const float *__restrict__ S, float *__restrict__ part_w,
+                                                                     float *__restrict__ part_b, int64_t n,
+                                                                     int64_t rows_per_chunk) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 6 * kWsPlane];        // 96 KiB: 2 buffers x {A1..3, B1..3}
+    __shared__ float s_b[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = tid & 255, half = tid >> 8;
+    const int64_t r_lo = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t r_hi = r_lo + rows_per_chunk < n ? r_lo + rows_per_chunk : n;
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float bsum = 0.f;
+    const int n_steps = r_hi > r_lo ? (int)((r_hi - r_lo + 15) / 16) : 0;
+    // a PAIR of k-steps (32 rows) is fetched at a time: 32 + 16 requests per thread in flight under the pair's 96 products
+    struct Rows { float gv[2][8], sv[2][8], yv[2][8]; };
+    const int n_pairs = (n_steps + 1) / 2;
+    // every request is unconditional (rows past the chunk re-read its last row and are zeroed in stage()): a predicated
+    // load is waited for where its value merges with the zero - 48 round trips in a row (measured: 0.128 ms for the fetches
+    // alone)
+    auto fetch = [&](int pair, Rows &q) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r0 = r_lo + 32 * (int64_t)pair + 16 * u + 8 * half;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int64_t r = r0 + e;
+                r = r < r_hi ? r : r_hi - 1;
+                q.gv[u][e] = g[r * 256 + col];
+                q.sv[u][e] = S[r * 256 + col];
+                q.yv[u][e] = Y ? Y[r * 256 + col] : 1.f;
+            }
+        }
+    };
+    auto stage = [&](const Rows &q, int pair) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r0 = r_lo + 32 * (int64_t)pair + 16 * u + 8 * half;
+            float gz[8], sz[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = r0 + e < r_hi;
+                gz[e] = (ok && q.yv[u][e] > 0.f) ? q.gv[u][e] : 0.f;         // gZ = g where Y > 0 (masked())
+                sz[e] = ok ? q.sv[u][e] : 0.f;
+                bsum += gz[e];
+            }
+            u32x4_s16 P[6];
+            gw_split8(gz, P[0], P[1], P[2]);
+            gw_split8(sz, P[3], P[4], P[5]);
+            unsigned char *base = lds + u * 6 * kWsPlane + half * 4096 + col * 16;
+#pragma unroll
+            for (int pl = 0; pl < 6; ++pl) *reinterpret_cast<u32x4_s16 *>(base + pl * kWsPlane) = P[pl];
+        }
+    };
+    auto products = [&](int buf) {
+        const unsigned char *rb = lds + buf * 6 * kWsPlane + (lane >> 5) * 4096 + (lane & 31) * 16;
+        u32x4_s16 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const u32x4_s16 *>(rb + pl * kWsPlane + (32 * wave) * 16);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            u32x4_s16 b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4_s16 *>(rb + (3 + pl) * kWsPlane + (32 * t) * 16);
+            gw_mfma(acc[t], a[2], b[0]);          // pieces (3,1) (1,3) (2,2) (2,1) (1,2) (1,1): small terms first
+            gw_mfma(acc[t], a[0], b[2]);
+            gw_mfma(acc[t], a[1], b[1]);
+            gw_mfma(acc[t], a[1], b[0]);
+            gw_mfma(acc[t], a[0], b[1]);
+            gw_mfma(acc[t], a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);       // (all 24 operand reads hoisted to the top cost 96 registers: spills)
+        }
+    };
+    Rows q;
+    if (n_pairs > 0) fetch(0, q);
+    for (int pair = 0; pair < n_pairs; ++pair) {
+        stage(q, pair);                                          // (waits for the pair's requests)
+        __syncthreads();
+        if (pair + 1 < n_pairs) fetch(pair + 1, q);
+        products(0);
+        products(1);
+        __syncthreads();                                         // everyone has read the pair before it is overwritten
+    }
+    // D[m = o][n = i], o = 32 wave + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), i = 32 t + (lane & 31)
+    float *pw = part_w + (size_t)blockIdx.x * 256 * 256;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int i = 32 * t + (lane & 31);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int oo = 32 * wave + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+            pw[(size_t)oo * 256 + i] = acc[t][rr];
+        }
+    }
+    if (part_b) {
+        s_b[tid] = bsum;
+        __syncthreads();
+        if (half == 0) part_b[(size_t)blockIdx.x * 256 + col] = s_b[col] + s_b[256 + col];
+    }
+}
+
 // narrow shapes (encoder Linear(1, H), decoder Linear(H, 1), H < 16): one thread per output element of the chunk
 __global__ __launch_bounds__(256) void linear_wgrad_small_kernel(const float *__restrict__ g, const float *__restrict__ Y,
                                                                  const float *__restrict__ S, float *__restrict__ part_w,
@@ -120,7 +256,15 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float *__restrict_
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n_elem) return;
     float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n_elem + e];
+    int c = 0;
+    for (; c + 8 <= n_chunks; c += 8) {                        // eight requests in flight, added in chunk order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * n_elem + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < n_chunks; ++c) s += part[(size_t)c * n_elem + e];
     out[e] = s;
 }
 
@@ -195,26 +339,33 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * kGsRows;
     const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Wq) + kS16Bytes)[1];
-    for (int i = 0; i < 16; ++i) {
-        const int r = 16 * wave + i;
-        const int64_t gr = row0 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gr < n) {
-            v = *reinterpret_cast<const f32x4 *>(g + gr * 256 + 4 * lane);
-            if (Y) {
-                const f32x4 y = *reinterpret_cast<const f32x4 *>(Y + gr * 256 + 4 * lane);
-                if (!(y.x > 0.f)) v.x = 0.f;
-                if (!(y.y > 0.f)) v.y = 0.f;
-                if (!(y.z > 0.f)) v.z = 0.f;
-                if (!(y.w > 0.f)) v.w = 0.f;
-            }
+    // eight rows' requests fly together, unconditionally (rows past n re-read row n - 1 and are zeroed afterwards)
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 8) {
+        f32x4 gv[8], yv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int64_t gr = row0 + 16 * wave + i0 + i;
+            gr = gr < n ? gr : n - 1;
+            gv[i] = *reinterpret_cast<const f32x4 *>(g + gr * 256 + 4 * lane);
+            yv[i] = Y ? *reinterpret_cast<const f32x4 *>(Y + gr * 256 + 4 * lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
         }
-        *reinterpret_cast<f32x4 *>(s_A + r * kGsLd + 4 * lane) = v;
-        unsigned sb, ub;
-        s16_scale_bits(s16_wave_umax(s16_row_max_bits(v)), sb, ub);
-        if (lane == 0) {
-            s_sc[r] = __builtin_bit_cast(float, sb);
-            s_un[r] = __builtin_bit_cast(float, ub) * w_unscale;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 16 * wave + i0 + i;
+            const bool ok = row0 + r < n;
+            f32x4 v;
+            v.x = (ok && yv[i].x > 0.f) ? gv[i].x : 0.f;
+            v.y = (ok && yv[i].y > 0.f) ? gv[i].y : 0.f;
+            v.z = (ok && yv[i].z > 0.f) ? gv[i].z : 0.f;
+            v.w = (ok && yv[i].w > 0.f) ? gv[i].w : 0.f;
+            *reinterpret_cast<f32x4 *>(s_A + r * kGsLd + 4 * lane) = v;
+            unsigned sb, ub;
+            s16_scale_bits(s16_wave_umax(s16_row_max_bits(v)), sb, ub);
+            if (lane == 0) {
+                s_sc[r] = __builtin_bit_cast(float, sb);
+                s_un[r] = __builtin_bit_cast(float, ub) * w_unscale;
+            }
         }
     }
     constexpr int kRingQ = 4, kPl = kS16Planes;
@@ -343,8 +494,12 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
         float *part_w = static_cast<float *>(work);
         float *part_b = part_w + (size_t)used * Ho * Hi;
         ProfScope prof(PROF_LINEAR, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * (used + 1) * (double)Hi * Ho, 2.0 * n * (double)Hi * Ho);
+        static const bool wsplit_on = [] { const char *e = getenv("NDCN_GW_SPLIT"); return !(e && e[0] == '0'); }();
         if (small) {
             hipLaunchKernelGGL(linear_wgrad_small_kernel, dim3((unsigned)used), dim3(256), 0, st, g, Y, S, part_w, gb ? part_b : nullptr, n, Hi, Ho, rpc);
+        } else if (wsplit_on && Hi == 256 && Ho == 256) {
+            hipLaunchKernelGGL(linear_wgrad_256_split_kernel, dim3((unsigned)used), dim3(512), 0, st, g, Y, S, part_w,
+                               gb ? part_b : nullptr, n, rpc);
         } else {
             const dim3 grid((unsigned)used, (unsigned)((Ho + 255) / 256), (unsigned)((Hi + 255) / 256));
             const int ni = Hi >= 256 ? 8 : (Hi + 31) / 32;
