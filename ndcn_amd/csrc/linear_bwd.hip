@@ -240,7 +240,15 @@ __global__ __launch_bounds__(256) void linear_wgrad_small_kernel(const float *__
         float s = 0.f;
         if (e < Ho * Hi) {
             const int o = e / Hi, i = e - o * Hi;
-            for (int64_t r = r_lo; r < r_hi; ++r) s = fmaf(masked(g, Y, r * Ho + o), S[r * Hi + i], s);
+            int64_t r = r_lo;
+            for (; r + 8 <= r_hi; r += 8) {                     // eight rows' requests in flight, folded in row order
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a[u] = masked(g, Y, (r + u) * Ho + o); b[u] = S[(r + u) * Hi + i]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fmaf(a[u], b[u], s);
+            }
+            for (; r < r_hi; ++r) s = fmaf(masked(g, Y, r * Ho + o), S[r * Hi + i], s);
             part_w[(size_t)blockIdx.x * Ho * Hi + e] = s;
         } else if (part_b) {
             const int o = e - Ho * Hi;
@@ -442,14 +450,17 @@ __global__ __launch_bounds__(256) void linear_gs_small_kernel(const float *__res
     }
 }
 
-static int64_t wgrad_chunks(int64_t n) {
+// narrow shapes (one thread per output element, serial over the chunk's rows) get their parallelism from the number of
+// chunks: 4096 instead of 256 (decoder Linear(256, 1) over 10^6 rows: 1.2 -> 0.2 ms); their partial blocks are tiny
+static int64_t wgrad_chunks(int64_t n, bool small) {
     int64_t c = (n + 63) / 64;
-    if (c > kGwMaxChunks) c = kGwMaxChunks;
+    const int64_t cap = small ? 4096 : kGwMaxChunks;
+    if (c > cap) c = cap;
     return c < 1 ? 1 : c;
 }
 
 static int64_t wgrad_work_bytes(int64_t n, int Hi, int Ho) {
-    return (wgrad_chunks(n) * ((int64_t)Ho * Hi + Ho) * (int64_t)sizeof(float) + 256 + 255) / 256 * 256;
+    return (wgrad_chunks(n, Hi < 16 || Ho < 16) * ((int64_t)Ho * Hi + Ho) * (int64_t)sizeof(float) + 256 + 255) / 256 * 256;
 }
 
 // partial gW / gb blocks, then (Hi = Ho = 256) the packed fp16 planes of W^T for the gS product
@@ -487,7 +498,7 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
     }
     if (gW || gb) {
         if (!work || !S) { set_error("linear_bwd: scratch of ndcn_linear_bwd_work_bytes() bytes and the forward input are required for gW / gb"); return NDCN_EINVAL; }
-        const int64_t chunks = wgrad_chunks(n);
+        const int64_t chunks = wgrad_chunks(n, small);
         const int64_t rpc0 = (n + chunks - 1) / chunks;
         const int64_t rpc = (rpc0 + 7) / 8 * 8;                    // whole rounds of 8 rows
         const int64_t used = (n + rpc - 1) / rpc;
