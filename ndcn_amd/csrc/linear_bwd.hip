@@ -3,12 +3,13 @@
 // Linears :143-148).  With gZ = g (.) [Y > 0] when the ReLU output Y is given (mask fused into the operand loads, no
 // separate pass), gZ = g otherwise:
 //
-//   gS [n, Hi]  = gZ W                fp32 MFMA GEMM, W read transposed while it is staged (no W^T copy)
-//   gW [Ho, Hi] = gZ^T S              fp32 MFMA "split-K": the reduction runs over the n rows; each workgroup owns a
-//                                     contiguous chunk of rows and writes one partial Ho x Hi block, summed afterwards in
-//                                     a FIXED order (deterministic gradients, no atomics).  Both operands are read
-//                                     straight from HBM in MFMA operand order: A[m = o][k = row] = gZ[row][o] and
-//                                     B[k = row][n = i] = S[row][i] are 128-byte coalesced per half-wave as they lie.
+//   gS [n, Hi]  = gZ W                fp32 MFMA GEMM, W read transposed while it is staged (no W^T copy); Hi = Ho = 256: the
+//                                     forward's two-piece fp16 product with the planes of W^T (linear_gs_256_split_kernel)
+//   gW [Ho, Hi] = gZ^T S              "split-K": the reduction runs over the n rows; each workgroup owns a contiguous chunk of
+//                                     rows and writes one partial Ho x Hi block, summed afterwards in a FIXED order
+//                                     (deterministic gradients, no atomics).  fp32 MFMA with both operands read straight from
+//                                     HBM in operand order; Hi = Ho = 256: three bf16 pieces per operand, staged once per
+//                                     16 rows in LDS (linear_wgrad_256_split_kernel)
 //   gb [Ho]     = column sums of gZ   rides in the gW kernel (the A operand passes through the lanes anyway)
 //
 // MFMA operand map (32x32x2 f32): A lane l = A[m = l & 31][k = l >> 5]; B lane l = B[k = l >> 5][n = l & 31];
