@@ -73,6 +73,7 @@ int spmm_wide_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t
                      const RkOpt *opt = nullptr);
 // rhs_small.hip: the whole ODEFunc (+ RK epilogue, modes as rhs_fused2_f32) in one launch for H <= 128
 int rhs_small_supported(const ndcn_csr *A, int H, uint32_t flags);
+int rhs_small_wanted(int64_t n_rows, int H, uint32_t flags);      // the same decision from the sizes alone (rhs_work_bytes)
 int rhs_small_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *K,
                   int H, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr,

@@ -22,7 +22,7 @@ int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) {
     const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
     if (!(graph && ctl)) return 0;
     if (rhs_fused_supported(H, flags)) return rhs_fused_work_bytes(H);       // packed weights
-    if (H <= 128) return 16;                                                   // rhs_small.hip needs none (a token size keeps callers' pointers non-null)
+    if (rhs_small_wanted(n_rows, H, flags)) return 16;                          // rhs_small.hip needs none (a token size keeps callers' pointers non-null)
     return n_rows * (int64_t)H * (int64_t)sizeof(float);                        // S = A X between the two kernels
 }
 

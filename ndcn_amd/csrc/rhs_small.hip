@@ -13,6 +13,8 @@
 //              consecutive words) and S[h] as an LDS broadcast
 //     epilogue row-local panels at column o: the stage algebra in the reference's operator order (separate mul / add)
 //   => results are bit-identical to the composed path  ndcn_spmm_f32 -> ndcn_linear_f32 -> rk kernel.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #pragma clang fp contract(off)
@@ -174,11 +176,21 @@ __global__ __launch_bounds__(256) void rhs_small_kernel(SmallArgs a, SmallEpi e)
     }
 }
 
-int rhs_small_supported(const ndcn_csr *A, int H, uint32_t flags) {
+// The one-launch form pays where a step is launch- and latency-bound; a wave's Linear is a serial fma chain per row (that is
+// what makes it bit-identical to the composed kernels), so beyond a few thousand rows the composed path - row SpMM into a
+// scratch panel, MFMA Linear, stage kernel - is faster (10^5-node grid, H = 128: 0.72 ms here, 0.08 ms composed; measured
+// crossovers, tools/micro/rhs_small_time.py: H = 128 between 2 000 and 5 000 rows, H = 64 at 10 000, H = 20 between 10 000 and
+// 32 000: n H <= 2^18).  Both give the same bits, so the switch is invisible; rhs_work_bytes() asks the same question to size
+// the scratch.
+int rhs_small_wanted(int64_t n_rows, int H, uint32_t flags) {
     static const bool enabled = [] { const char *e = getenv("NDCN_RHS_SMALL"); return !(e && e[0] == '0'); }();
-    if (!enabled || !A || H < 1 || H > kSmMaxH) return 0;
-    return (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) ? 0 : 1;
+    static const int64_t max_elems = [] { const char *e = getenv("NDCN_RHS_SMALL_MAX"); return (e && *e) ? atoll(e) : (int64_t)1 << 18; }();
+    if (!enabled || H < 1 || H > kSmMaxH) return 0;
+    if (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) return 0;
+    return n_rows * (int64_t)H <= max_elems ? 1 : 0;
 }
+
+int rhs_small_supported(const ndcn_csr *A, int H, uint32_t flags) { return A ? rhs_small_wanted(A->n_rows, H, flags) : 0; }
 
 int rhs_small_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b, float *K,
                   int H, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,

@@ -591,6 +591,44 @@ def test_partial_error_sum_in_the_stage6_launch(dev, kernel):
     assert torch.equal(K5a, K5b) and torch.equal(y6a, y6b)
 
 
+@pytest.mark.parametrize('n,H', [(20000, 20), (20000, 64), (6000, 128)])
+def test_narrow_panels_beyond_the_one_launch_range_take_the_composed_path(dev, n, H):
+    """rhs_small.hip serves n H <= 2^18 (launch-bound sizes); larger narrow panels run row SpMM -> scratch -> MFMA Linear
+    (-> stage kernel), whose scratch ndcn_rhs_work_bytes must size from the same decision (it returned the one-launch
+    token for every H <= 128: with the one-launch kernel switched off the composed path wrote past it).  Values against
+    fp64; the switch NDCN_RHS_SMALL=0 on a small panel in a fresh process."""
+    import subprocess, sys
+    from ndcn_amd import hip, CsrOperator, _lib
+    assert int(_lib.load().ndcn_rhs_work_bytes(n, H, _lib.F_RELU)) == n * H * 4
+    assert int(_lib.load().ndcn_rhs_work_bytes(400, H, _lib.F_RELU)) == 16
+    m = rand_csr(n, n, 6, seed=H)
+    A = CsrOperator.from_scipy(m, dev)
+    g = torch.Generator().manual_seed(H)
+    X, y0 = torch.randn(n, H, generator=g).to(dev), torch.rand(n, H, generator=g).to(dev)
+    k1 = torch.randn(n, H, generator=g).to(dev)
+    W = ((torch.rand(H, H, generator=g) - 0.5)).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5)).to(dev)
+    ref = np.maximum((m.astype(np.float64) @ X.double().cpu().numpy()) @ W.double().cpu().numpy().T + b.double().cpu().numpy(), 0.0)
+    K = hip.rhs(A, X, W, b)
+    assert float(np.abs(K.double().cpu().numpy() - ref).max()) < 1e-4
+    K2, yn = hip.rhs_rk(A, X, W, b, 'combine', y0, [k1], [np.float32(0.3), np.float32(-0.2)])
+    assert torch.equal(K2, K)
+    assert torch.equal(yn, y0 + (k1 * np.float32(0.3) + K * np.float32(-0.2)))
+    code = ("import torch, numpy as np, scipy.sparse as sp\n"
+            "from ndcn_amd import hip, CsrOperator\n"
+            "dev = torch.device('cuda:0')\n"
+            "m = sp.random(400, 400, density=0.02, random_state=np.random.RandomState(0), format='csr', dtype=np.float32)\n"
+            "A = CsrOperator.from_scipy(m, dev)\n"
+            "X = torch.rand(400, %d, device=dev); W = torch.rand(%d, %d, device=dev) - .5; b = torch.rand(%d, device=dev)\n"
+            "K = hip.rhs(A, X, W, b); torch.cuda.synchronize()\n"
+            "ref = torch.relu((torch.from_numpy(m.toarray()).to(dev).double() @ X.double()) @ W.double().t() + b.double())\n"
+            "assert float((K.double() - ref).abs().max()) < 1e-4\n"
+            "print('ok')\n" % (H, H, H, H))
+    env = dict(os.environ, NDCN_RHS_SMALL='0', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize('H', [1, 16, 20, 33, 64, 65, 100, 128])
 def test_narrow_panel_rhs_is_one_launch_and_equals_the_composed_kernels(dev, H):
     """H <= 128 (the README dynamics commands run H = 20): the whole ODEFunc - and the RK algebra consuming it - in ONE
