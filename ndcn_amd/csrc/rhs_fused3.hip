@@ -26,7 +26,8 @@
 //   History: rounds 1-2 split every S value into three bf16 pieces INSIDE each MFMA wave (six products,
 //   38 VALU per split, eight waves each splitting the whole tile: the loop was VALU-bound, 13 k cycles per 32-row tile); two
 //   fp16 pieces make the split planes exactly as large as the fp32 tile, so the producer that holds the row splits it once.
-//   12-wave configurations (4 producers + 8 MFMA waves with ALL weights resident, 8 + 4) hang on the hardware: not shipped.
+//   -DNDCN_F3_PRODUCERS=4 -DNDCN_F3_RESIDENT=16 -DNDCN_F3_RING=1 builds the 12-wave form (ALL weights resident, 154 registers): correct,
+//   faster on the 3-4-stage launches, slower on the whole dopri5 step (its light launches become producer-bound).
 //   LDS: 2 union buffers (80 KiB) + 3 records (6 KiB) + 2 S tiles (32 x 260 floats each, 65 KiB) + row ids / bias / scales
 //   = 153 KiB.
 #include <stdio.h>
@@ -46,7 +47,7 @@ namespace ndcn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this kernel is written for
-// MFMA waves: 8 (one n-tile each, two per SIMD, 128 registers); the 4-wave form (two n-tiles each) compiles but hangs
+// MFMA waves: 8 (one n-tile each, two per SIMD, 128 registers); 4 (two n-tiles each) is not maintained
 #ifndef NDCN_F3_MFMA_WAVES
 #define NDCN_F3_MFMA_WAVES 8
 #endif
@@ -133,8 +134,23 @@ struct F3Epi {
     float c2[kF3MaxPrev + 1];
 };
 
+// The epilogue arguments (8 pointers, 14 scalars) are NOT read through the kernel-parameter object: the compiler would keep all
+// of them live in SGPRs across the producer loop - the variants with >= 2 earlier stages then spill 8-43 scalar registers
+// into VGPR lanes, which costs every wave of the kernel registers (the MFMA waves' resident weights) - but from the kernarg
+// segment where they are used, through a laundered pointer the compiler cannot hoist (a handful of s_loads per K row; as
+// rhs_fused2.hip).
+typedef const __attribute__((address_space(4))) F3Epi *F3EpiPtr;
+constexpr int kF3EpiKernargOffset = (int)((sizeof(F3Args) + 7) / 8 * 8);       // kernel parameters: F3Args, F3Epi (both 8-aligned)
+
 template <bool HALO, int MODE, int NP>
-__global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3Epi e) {
+__global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
+    (void)epi_by_kernarg_only;
+    auto epi_args = [&]() -> F3EpiPtr {
+        auto base = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+        F3EpiPtr q = (F3EpiPtr)(base + kF3EpiKernargOffset);
+        asm volatile("" : "+s"(q));                           // a fresh pointer per call: the loads stay where they are used
+        return q;
+    };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -158,8 +174,9 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     const int n_steps = 2 * n_tiles + 4;                       // + 2 for the MFMA lag, + 2 for the epilogue lag
     if (my == 0) {
         if (MODE == F3_ERROR && wave < kF3WP && lane == 0) {  // the finish kernel sums EVERY slot
-            e.partials[2 * (blockIdx.x * kF3WP + wave)] = 0.0;
-            e.partials[2 * (blockIdx.x * kF3WP + wave) + 1] = 0.0;
+            double *partials = epi_args()->partials;
+            partials[2 * (blockIdx.x * kF3WP + wave)] = 0.0;
+            partials[2 * (blockIdx.x * kF3WP + wave) + 1] = 0.0;
         }
         return;
     }
@@ -360,10 +377,11 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
     // is the target of an in-flight fetch must be assigned on ONE path only, or hipcc copies it around
     auto request = [&](int row, Panels &p) {
         const int voff = (max(row, 0) << 10) + lane_off;           // panels < 4 GiB (launcher check)
+        const F3EpiPtr e = epi_args();
 #pragma unroll
-        for (int m = 0; m < NP; ++m) p.km[m] = ldp(e.kprev[m], voff);
-        p.y0v = ldp(e.y0, voff);
-        if (MODE == F3_ERROR) p.y1v = ldp(e.y1, voff);              // the input of this evaluation is y1 (own rows)
+        for (int m = 0; m < NP; ++m) p.km[m] = ldp(e->kprev[m], voff);
+        p.y0v = ldp(e->y0, voff);
+        if (MODE == F3_ERROR) p.y1v = ldp(e->y1, voff);             // the input of this evaluation is y1 (own rows)
         issued(kLoads);
     };
     auto arrived = [&](Panels &p) {
@@ -382,45 +400,46 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         stp(a.K, voff, kn);
         issued(1);
         if (MODE == F3_PLAIN) return;
+        const F3EpiPtr e = epi_args();
         if (MODE == F3_RK4) {
             // rk4_alt_step_func (rk_common.py:72-78), same operator order as fixed_stage_kernel ops 2-5
-            const float dt = e.c[0];
+            const float dt = e->c[0];
             f32x4 s;
             if (NP == 0) s = (kn * dt) / 3.f;
             else if (NP == 1) s = (p.km[0] / -3.f + kn) * dt;
             else if (NP == 2) s = ((p.km[0] - p.km[NP > 1 ? 1 : 0]) + kn) * dt;
             else s = (((p.km[0] + p.km[NP > 1 ? 1 : 0] * 3.f) + p.km[NP > 2 ? 2 : 0] * 3.f) + kn) * (dt / 8.f);
-            stp(e.y_next, voff, p.y0v + s);
+            stp(e->y_next, voff, p.y0v + s);
             issued(1);
             return;
         }
         // sum of the stages left to right, the new one last (misc.py:22-25), each product rounded on its own
-        f32x4 s = kn * e.c[NP];
+        f32x4 s = kn * e->c[NP];
         if (NP > 0) {
-            f32x4 u = p.km[0] * e.c[0];
+            f32x4 u = p.km[0] * e->c[0];
 #pragma unroll
-            for (int m = 1; m < NP; ++m) u = u + p.km[m] * e.c[m];
+            for (int m = 1; m < NP; ++m) u = u + p.km[m] * e->c[m];
             s = u + s;
         }
         if (MODE == F3_COMBINE) {
-            stp(e.y_next, voff, p.y0v + s);
+            stp(e->y_next, voff, p.y0v + s);
             issued(1);
-            if (e.y_aux) {                                          // wave-uniform
-                f32x4 w2 = kn * e.c2[NP];
+            if (e->y_aux) {                                          // wave-uniform
+                f32x4 w2 = kn * e->c2[NP];
                 if (NP > 0) {
-                    f32x4 u2 = p.km[0] * e.c2[0];
+                    f32x4 u2 = p.km[0] * e->c2[0];
 #pragma unroll
-                    for (int m = 1; m < NP; ++m) u2 = u2 + p.km[m] * e.c2[m];
+                    for (int m = 1; m < NP; ++m) u2 = u2 + p.km[m] * e->c2[m];
                     w2 = u2 + w2;
                 }
-                stp(e.y_aux, voff, w2);
+                stp(e->y_aux, voff, w2);
                 issued(1);
             }
             return;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float tol = e.atol + e.rtol * max_nan(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
+            const float tol = e->atol + e->rtol * max_nan(fabsf(p.y0v[q]), fabsf(p.y1v[q]));
             const float z = s[q] / tol;
             err_sum += (double)(z * z);
             err_bad += (double)(int)(!(fabsf(p.y1v[q]) <= 3.402823466e38f));
@@ -534,8 +553,9 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
             err_bad += __shfl_down(err_bad, off, 64);
         }
         if (lane == 0) {
-            e.partials[2 * (blockIdx.x * kF3WP + pw)] = err_sum;
-            e.partials[2 * (blockIdx.x * kF3WP + pw) + 1] = err_bad;
+            double *partials = epi_args()->partials;
+            partials[2 * (blockIdx.x * kF3WP + pw)] = err_sum;
+            partials[2 * (blockIdx.x * kF3WP + pw) + 1] = err_bad;
         }
     }
 }
