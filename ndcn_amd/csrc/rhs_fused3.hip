@@ -26,8 +26,7 @@
 //   History: rounds 1-2 split every S value into three bf16 pieces INSIDE each MFMA wave (six products,
 //   38 VALU per split, eight waves each splitting the whole tile: the loop was VALU-bound, 13 k cycles per 32-row tile); two
 //   fp16 pieces make the split planes exactly as large as the fp32 tile, so the producer that holds the row splits it once.
-//   -DNDCN_F3_PRODUCERS=4 -DNDCN_F3_RESIDENT=16 -DNDCN_F3_RING=1 builds the 12-wave form (ALL weights resident, 154 registers): correct,
-//   faster on the 3-4-stage launches, slower on the whole dopri5 step (its light launches become producer-bound).
+//   A 12-wave form (4 producers | 8 MFMA waves, ALL weights resident) is a build option (f3_producers): correct, not faster.
 //   LDS: 2 union buffers (80 KiB) + 3 records (6 KiB) + 2 S tiles (32 x 260 floats each, 65 KiB) + row ids / bias / scales
 //   = 153 KiB.
 #include <stdio.h>
@@ -47,10 +46,6 @@ namespace ndcn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this kernel is written for
-// MFMA waves: 8 (one n-tile each, two per SIMD, 128 registers); 4 (two n-tiles each) is not maintained
-#ifndef NDCN_F3_MFMA_WAVES
-#define NDCN_F3_MFMA_WAVES 8
-#endif
 #ifndef NDCN_F3_RING
 #define NDCN_F3_RING 2
 #endif
@@ -59,16 +54,30 @@ constexpr int kF3R = 16, kF3Cap = 40, kF3RecW = 2;       // the plan shape this 
 // waves have left hold k-steps of their weights for good: 10 of 16 (3 KiB per row still streamed; 8: 9.82, 9: 9.66 ms/step
 // with the split still in the MFMA waves; 10 + ring 2 = 123 registers with ready operands: 9.21 on the same box class).
 #ifndef NDCN_F3_RESIDENT
-#define NDCN_F3_RESIDENT (NDCN_F3_MFMA_WAVES == 8 ? 10 : 2)    // two fp16 planes: 8 registers per resident k-step
+#define NDCN_F3_RESIDENT 10    // two fp16 planes: 8 registers per resident k-step
 #endif
 #ifndef NDCN_F3_PRODUCERS
 #define NDCN_F3_PRODUCERS 8
 #endif
-constexpr int kF3WP = NDCN_F3_PRODUCERS, kF3WM = NDCN_F3_MFMA_WAVES, kF3Waves = kF3WP + kF3WM;    // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
+#ifndef NDCN_F3_HEAVY_4P
+#define NDCN_F3_HEAVY_4P 0
+#endif
+enum { F3_PLAIN = 0, F3_COMBINE = 1, F3_ERROR = 2, F3_RK4 = 3 };
+// The wave split is a function of the variant (f3_producers).  Shipped: 16 waves everywhere (8 producers | 8 MFMA waves, 128
+// registers: 10 resident weight k-steps).  NDCN_F3_HEAVY_4P = 1 gives the launches with >= 3 earlier stages the 12-wave form
+// (4 producers | 8 MFMA waves, 168 registers: ALL 16 k-steps resident, no weight stream at all) - correct since the epilogue
+// arguments stopped spilling scalar registers, but not faster: alternating runs on one box 8.92-8.94 (shipped) vs 8.98-9.00
+// ms/step; the 12-wave form for EVERY launch 9.36 vs 9.03 (its light launches become producer-bound).  Single A/B pairs had
+// suggested a gain on the heavy launches: the boxes differ by 4 % among themselves, repeats on one box by 0.3 %.
+constexpr int kF3WM = 8;                                    // MFMA waves: one 32-column n-tile each
+constexpr int f3_producers(int mode, int np) {
+    return (NDCN_F3_HEAVY_4P && ((mode == F3_COMBINE && np >= 3) || (mode == F3_ERROR && np == 5))) ? 4 : NDCN_F3_PRODUCERS;
+}
+constexpr int kF3WavesMax = 16;
 constexpr int kF3NBuf = 2, kF3NRec = 3;                  // one group in flight ahead of the one being folded
 constexpr int kF3Tile = 32, kF3Ld = 260;                 // S tile: 2 groups; +4 floats per row: conflict-free b128
 constexpr int kF3MaxPrev = 5;
-constexpr int kF3CapD = kF3Cap / kF3WP, kF3E0 = kF3Cap + 2 * kF3R;
+constexpr int kF3E0 = kF3Cap + 2 * kF3R;
 constexpr unsigned kF3OffRec = kF3NBuf * kF3Cap * 1024;
 constexpr unsigned kF3OffS = kF3OffRec + kF3NRec * kF3RecW * 1024;
 constexpr unsigned kF3OffRow = kF3OffS + 2 * kF3Tile * kF3Ld * 4;
@@ -104,8 +113,6 @@ struct F3Order {
     }
 };
 
-enum { F3_PLAIN = 0, F3_COMBINE = 1, F3_ERROR = 2, F3_RK4 = 3 };
-
 struct F3Args {
     const int *rec;
     int n_groups;
@@ -126,7 +133,7 @@ struct F3Epi {
     const float *y0;
     const float *kprev[kF3MaxPrev];
     float *y_next;
-    double *partials;                // ERROR: [gridDim.x * kF3WP][2]
+    double *partials;                // ERROR: [gridDim.x * producer waves][2]
     float c[kF3MaxPrev + 1];         // c[0 .. n_prev-1] for kprev, c[n_prev] for the new K ; RK4: c[0] = dt
     float rtol, atol;
     const float *y1;                 // ERROR: the state of the error record, by row of this launch
@@ -143,8 +150,11 @@ typedef const __attribute__((address_space(4))) F3Epi *F3EpiPtr;
 constexpr int kF3EpiKernargOffset = (int)((sizeof(F3Args) + 7) / 8 * 8);       // kernel parameters: F3Args, F3Epi (both 8-aligned)
 
 template <bool HALO, int MODE, int NP>
-__global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
+__global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
     (void)epi_by_kernarg_only;
+    constexpr int kF3WP = f3_producers(MODE, NP), kF3Waves = kF3WP + kF3WM;   // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
+    constexpr int kF3CapD = kF3Cap / kF3WP;
+    static_assert(kF3Cap % kF3WP == 0 && kF3R % kF3WP == 0 && kF3WP >= 4, "wave split");
     auto epi_args = [&]() -> F3EpiPtr {
         auto base = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
         F3EpiPtr q = (F3EpiPtr)(base + kF3EpiKernargOffset);
@@ -188,8 +198,8 @@ __global__ __launch_bounds__(64 * kF3Waves) void rhs_fused3_kernel(F3Args a, F3E
         // refilled right after use.  The ring runs on across halves and tiles: the weights are the same for every tile.
         const int mw = wave - kF3WP;
         constexpr int kNT = 8 / kF3WM;
-        constexpr int kRing = NDCN_F3_RING;
-        constexpr int kRes = NDCN_F3_RESIDENT;              // k-steps [0, kRes) of the wave's weights never leave its registers
+        constexpr int kRing = kF3WP == 4 ? 1 : NDCN_F3_RING;
+        constexpr int kRes = kF3WP == 4 ? 16 : NDCN_F3_RESIDENT;    // resident k-steps: their weights never leave the registers
         constexpr int kNS = 16 - kRes;                       // streamed k-steps per tile
         static_assert(kNS == 0 || kRing <= kNS, "ring");
         constexpr int kPl = kS16Planes;                     // two fp16 pieces per weight (split16.h)
@@ -588,7 +598,7 @@ static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st)
         NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * kF3Waves), kF3Lds, st, a, e);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * (f3_producers(MODE, NP) + kF3WM)), kF3Lds, st, a, e);
     return NDCN_OK;
 }
 
@@ -607,7 +617,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     static const int timing = kF3Timing ? env_int_f3("NDCN_FUSED3_TIMING", 0) : 0;
     static unsigned long long *d_cyc = nullptr;
     static int timing_prints = 0;
-    if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * kF3Waves * 2 * sizeof(unsigned long long));
+    if (timing && !d_cyc) (void)hipMalloc(&d_cyc, (size_t)kCus * kF3WavesMax * 2 * sizeof(unsigned long long));
     a.dbg_cycles = timing ? d_cyc : nullptr;
     F3Epi e = {};
     e.y0 = y0; e.y_next = y_next; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
@@ -655,16 +665,17 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     NDCN_LAUNCH_CHECK();
     if (timing && timing_prints < timing) {                          // debugging aid: cycle accounting of workgroup 100
         (void)hipStreamSynchronize(st);
-        unsigned long long h[2 * kF3Waves];
-        (void)hipMemcpy(h, d_cyc + (size_t)100 * 2 * kF3Waves, sizeof(h), hipMemcpyDeviceToHost);
+        const int wp = f3_producers(mode, n_prev), nw = wp + kF3WM;
+        unsigned long long h[2 * kF3WavesMax];
+        (void)hipMemcpy(h, d_cyc + (size_t)100 * 2 * nw, 2 * nw * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double pw = 0, pq = 0, pd = 0, mw = 0, mq = 0;
-        for (int w = 0; w < kF3WP; ++w) { pw += h[2 * w] / (double)kF3WP; pq += (h[2 * w + 1] & 0xffffffffull) / (double)kF3WP; pd += (h[2 * w + 1] >> 32) / (double)kF3WP; }
-        for (int w = kF3WP; w < kF3Waves; ++w) { mw += h[2 * w] / (double)kF3WM; mq += h[2 * w + 1] / (double)kF3WM; }
+        for (int w = 0; w < wp; ++w) { pw += h[2 * w] / (double)wp; pq += (h[2 * w + 1] & 0xffffffffull) / (double)wp; pd += (h[2 * w + 1] >> 32) / (double)wp; }
+        for (int w = wp; w < nw; ++w) { mw += h[2 * w] / (double)kF3WM; mq += h[2 * w + 1] / (double)kF3WM; }
         fprintf(stderr, "[fused3 timing] mode %d n_prev %d block 100: producer waves work %.0f dma-wait %.0f barrier %.0f | mfma waves work %.0f barrier %.0f\n",
                 mode, n_prev, pw, pd, pq, mw, mq);
         ++timing_prints;
     }
-    if (mode == F3_ERROR) return partials_finish(e.partials, (int)grid.x * kF3WP, d_out, st, (opt && opt->accum) ? 1 : 0);
+    if (mode == F3_ERROR) return partials_finish(e.partials, (int)grid.x * f3_producers(mode, n_prev), d_out, st, (opt && opt->accum) ? 1 : 0);
     return NDCN_OK;
 }
 
