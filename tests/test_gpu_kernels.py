@@ -580,7 +580,9 @@ def test_partial_error_sum_in_the_stage6_launch(dev, kernel):
     K6, y1, E = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:4], cs[:4] + [cs[5]], aux_cs=ce[:4] + [ce[4]], **kw)
     K7a, (sa, ba) = hip.rhs_rk(A, y1, W, b, 'error', y0, [E], [np.float32(1.0), ce[5]], rtol=1e-2, atol=1e-3, **kw)
     K7b, (sb, bb) = hip.rhs_rk(A, y1, W, b, 'error', y0, ks[:4] + [K6], ce[:4] + [ce[4], ce[5]], rtol=1e-2, atol=1e-3, **kw)
-    assert torch.equal(K7a, K7b) and sa == sb and ba == bb == 0.0
+    # (the record is a double-precision sum of per-wave partials: identical terms, and identical bits as long as both launches
+    # run the same wave split - rhs_fused3.hip: f3_producers)
+    assert torch.equal(K7a, K7b) and abs(sa - sb) <= 1e-12 * abs(sb) and ba == bb == 0.0
     # the stage-6 hand-over (solver.hip: enqueue_attempt): the launch that produces k4 also writes
     # P = c1 k1 + c2 k2 + c3 k3 + c4 k4 of the NEXT stage's sum; the launch that produces k5 then forms y0 + (1 * P + c5 k5)
     # from {y0, P} - bit for bit what it forms from {y0, k1, k2, k3, k4}
