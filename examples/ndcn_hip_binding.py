@@ -15,7 +15,7 @@ class Csr(ctypes.Structure):                    # struct ndcn_csr (ABI 6): the o
                 ('hub_seg_rowptr', _p), ('hub_colidx', _p), ('hub_val', _p),
                 ('hub_cmb_rowptr', _p), ('hub_cmb_colidx', _p), ('hub_cmb_val', _p),
                 ('lt_rowptr', _p), ('lt_colidx', _p), ('lt_val', _p), ('hub_Sseg', _p), ('hub_S', _p)]
-assert _lib.ndcn_abi_version() == 9
+assert _lib.ndcn_abi_version() == 10
 
 def _check(rc):
     if rc < 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 9
+#define NDCN_ABI_VERSION 10
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -221,6 +221,16 @@ NDCN_API int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_h
                              int rk_mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
                              float *y_next, const float *y1, float *y_aux, const float *h_c_aux, float rtol, float atol,
                              double *d_out, void *d_ws, void *stream);
+/* The evaluation that OPENS a dopri5 step (rk_common.py:45-51 with i = 0): K = f(X + x_add_c * x_add), and in the same pass
+ * y_next = y0 + (h_c[0] * k_prev + h_c[1] * K) - i.e. ndcn_rk_combine_f32(tmp, X, {x_add}, {x_add_c}) followed by
+ * ndcn_rhs_rk_f32(..., tmp, ..., NDCN_RK_COMBINE, y0, {k_prev}, h_c, 1, y_next) without the temporary: the sum is formed on
+ * the neighbour rows the kernel stages (one product, one sum per element: the same bits), 3 panels of traffic less.  For the
+ * operators / widths ndcn_rhs_xadd_supported() accepts (H = 256, a 2-D lattice's group-record plan, no halo panel,
+ * NDCN_RK_COMBINE with n_prev = 1); NDCN_EINVAL otherwise.  In the dopri5 step X = y0, x_add = k_prev = k1.             */
+NDCN_API int ndcn_rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int rk_mode, int n_prev);
+NDCN_API int ndcn_rhs_rk_xadd_f32(const ndcn_csr *A, const float *X, const float *x_add, float x_add_c, const float *W,
+                                  const float *b, float *K, float *work, int H, uint32_t flags, const float *y0,
+                                  const float *k_prev, const float *h_c, float *y_next, void *stream);
 
 /* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
 NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);

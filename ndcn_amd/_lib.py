@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 
 OK = 0
@@ -97,6 +97,8 @@ SIGNATURES = {
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
                         _P, _P, _P, ctypes.POINTER(_F), _F, _F, _P, _P, _P]),
+    'ndcn_rhs_xadd_supported': (_I, [_CSR, _I, _U, _I, _I]),
+    'ndcn_rhs_rk_xadd_f32': (_I, [_CSR, _P, _P, _F, _P, _P, _P, _P, _I, _U, _P, _P, ctypes.POINTER(_F), _P, _P]),
     'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
     'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),

@@ -156,10 +156,11 @@ int ndcn_row_l1_normalize_bwd_f32(const float *G, const float *X, float *GX, int
     return row_l1_normalize_bwd_f32(G, X, GX, n_rows, H, ST(stream));
 }
 
-int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
-                    float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
-                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float *y_aux,
-                    const float *h_c_aux, float rtol, float atol, double *d_out, void *d_ws, void *stream) {
+static int rhs_rk_entry(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
+                        float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
+                        const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float *y_aux,
+                        const float *h_c_aux, float rtol, float atol, double *d_out, void *d_ws, const float *x_add, float x_add_c,
+                        void *stream) {
     NDCN_CHECK_ARG(A, "null operator descriptor");
     NDCN_CHECK_ARG(H > 0, "H must be positive");
     NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 3, "rk_mode must be 0, NDCN_RK_COMBINE, NDCN_RK_ERROR or NDCN_RK_RK4");
@@ -180,9 +181,34 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
     }
     NDCN_CHECK_ARG(!y_aux || (rk_mode == NDCN_RK_COMBINE && h_c_aux && y_aux != y_next && y_aux != K && y_aux != X),
                    "y_aux: NDCN_RK_COMBINE only, with h_c_aux, not aliasing X / K / y_next");
-    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0, y_aux, h_c_aux};
+    if (x_add) {
+        NDCN_CHECK_ARG(!X_halo && x_add != K && x_add != y_next && rhs_xadd_supported(A, H, flags, rk_mode, n_prev),
+                       "x_add: not supported for this operator / mode (ndcn_rhs_xadd_supported), or aliased");
+    }
+    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0, y_aux, h_c_aux, x_add, x_add_c};
     return rhs_rk_f32(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                       d_out, d_ws, ST(stream), &opt);
+}
+
+int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own, const float *W, const float *b,
+                    float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
+                    const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float *y_aux,
+                    const float *h_c_aux, float rtol, float atol, double *d_out, void *d_ws, void *stream) {
+    return rhs_rk_entry(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, y1, y_aux, h_c_aux,
+                        rtol, atol, d_out, d_ws, nullptr, 0.f, stream);
+}
+
+int ndcn_rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int rk_mode, int n_prev) {
+    return A ? rhs_xadd_supported(A, H, flags, rk_mode, n_prev) : 0;
+}
+
+int ndcn_rhs_rk_xadd_f32(const ndcn_csr *A, const float *X, const float *x_add, float x_add_c, const float *W, const float *b,
+                         float *K, float *work, int H, uint32_t flags, const float *y0, const float *k_prev, const float *h_c,
+                         float *y_next, void *stream) {
+    NDCN_CHECK_ARG(x_add && k_prev, "null panel");
+    const float *kp[1] = {k_prev};
+    return rhs_rk_entry(A, X, nullptr, A ? A->n_cols : 0, W, b, K, work, H, flags, NDCN_RK_COMBINE, y0, kp, h_c, 1, y_next, nullptr,
+                        nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, x_add, x_add_c, stream);
 }
 
 int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream) {

@@ -16,7 +16,10 @@ namespace ndcn {
 //          dopri5 uses it to form E = dt sum_{j<=6} c_err[j] k_j in the launch that produces k6 - where k1, k3, k4, k5
 //          are in registers anyway - so that the error launch reads {y0, E, y1} instead of {y0, k1, k3, k4, k5, k6, y1}:
 //          3 P less traffic per step for 1 P written, the same sum in the same order (E holds the partial sum exactly).
-struct RkOpt { const float *y1; int accum; float *y_aux; const float *c_aux; };
+//   xadd / xadd_c (plain and COMBINE with one earlier stage, operators on the rhs_fused3 path without a halo panel -
+//          rhs_xadd_supported()): the evaluation's input is X + xadd_c * xadd, formed on the rows the kernel stages instead of by a
+//          combine launch in front (3 panels); same product-then-sum rounding per element.
+struct RkOpt { const float *y1; int accum; float *y_aux; const float *c_aux; const float *xadd; float xadd_c; };
 
 int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
              uint32_t flags, hipStream_t st);
@@ -52,6 +55,7 @@ int partials_finish(const double *partials, int n, double *d_out, hipStream_t st
 // rhs_fused3.hip: the same contract as rhs_fused2_f32 for operators that carry the 16-row group-record plan (Wq: the
 // split weights of pack_weight_256, i.e. Wp + 256 * 256 floats)
 int rhs_fused3_supported(const ndcn_csr *A);
+int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev);   // RkOpt::xadd can be honoured
 int rhs_fused3_variant(int mode, int n_prev);
 int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
                    uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,

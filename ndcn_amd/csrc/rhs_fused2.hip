@@ -650,6 +650,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         return rhs_fused3_f32(A, X, Xh, n_own, Wp + kH2 * kH2, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out,
                               d_ws, st, opt);
     }
+    if (opt && opt->xadd) { set_error("rhs_fused2: RkOpt::xadd needs the rhs_fused3 path (rhs_xadd_supported)"); return NDCN_EINVAL; }
     g_last_rhs_path = NDCN_PATH_FUSED2 | path_bits;
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;

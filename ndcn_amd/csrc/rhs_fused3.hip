@@ -117,6 +117,8 @@ struct F3Args {
     const int *rec;
     int n_groups;
     const float *X, *Xh;
+    const float *Xadd;               // XADD variants: the evaluation's input is X + xadd_c * Xadd, formed on the staged rows
+    float xadd_c;
     int n_own;
     const void *Wq;                  // split weights (pack_weight_256: two fp16 planes in MFMA B-operand order + scales)
     const float *bias;
@@ -149,8 +151,13 @@ struct F3Epi {
 typedef const __attribute__((address_space(4))) F3Epi *F3EpiPtr;
 constexpr int kF3EpiKernargOffset = (int)((sizeof(F3Args) + 7) / 8 * 8);       // kernel parameters: F3Args, F3Epi (both 8-aligned)
 
-template <bool HALO, int MODE, int NP>
+// XADD: the input of the evaluation is X + c Xadd (dopri5's first stage input y0 + dt beta_21 k1),
+// formed where it is needed instead of by a kernel of its own (3 panels): every wave fetches the Xadd rows of the union rows
+// it stages, a step ahead like them, and adds them into its LDS rows - one product, one sum per element, the roundings of
+// combine_kernel - before the barrier that hands the group to the fold.  One more gather (1.07 panels) instead of 3 panels.
+template <bool HALO, int MODE, int NP, bool XADD = false>
 __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
+    static_assert(!(XADD && HALO), "the halo rows of Xadd are not exchanged");
     (void)epi_by_kernarg_only;
     constexpr int kF3WP = f3_producers(MODE, NP), kF3Waves = kF3WP + kF3WM;   // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
     constexpr int kF3CapD = kF3Cap / kF3WP;
@@ -364,6 +371,7 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
             issued(1);
         }
     };
+    f32x4 xk[XADD ? kF3CapD : 1];
     auto dma_x = [&](int it) {
         const int *r = rbuf + (it % kF3NRec) * kF3RecW * 256 + pw * kF3CapD;
         int cc[kF3CapD];
@@ -377,6 +385,21 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
             dma_row(base + (size_t)c * 256, lds_x + (unsigned)(((it % kF3NBuf) * kF3Cap + pw * kF3CapD + k) * 1024), lane_off);
         }
         issued(kF3CapD);
+        if (XADD) {
+#pragma unroll
+            for (int k = 0; k < kF3CapD; ++k)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xk[k]) : "v"((cc[k] << 10) + lane_off), "s"(a.Xadd) : "memory");
+            issued(kF3CapD);
+        }
+    };
+    // XADD: the staged rows of group `it` (this wave's share) become X + c Xadd; called once its requests have landed
+    auto xadd_rows = [&](int it) {
+        f32x4 *xb = reinterpret_cast<f32x4 *>(lds) + ((it % kF3NBuf) * kF3Cap + pw * kF3CapD) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < kF3CapD; ++k) {
+            asm volatile("" : "+v"(xk[k]));
+            xb[k * 64] = xb[k * 64] + xk[k] * a.xadd_c;
+        }
     };
     auto ldp = [&](const float *base /*uniform*/, int voff) {
         f32x4 v;
@@ -487,6 +510,11 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
                     if (HALO && c >= a.n_own) { p = a.Xh; c -= a.n_own; }
                     f32x4 v;
                     asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(lane_off), "s"(p + (size_t)c * 256) : "memory");
+                    if (XADD) {
+                        f32x4 w;
+                        asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(lane_off), "s"(a.Xadd + (size_t)c * 256) : "memory");
+                        v = v + w * a.xadd_c;
+                    }
                     return v;
                 }, acc);
             }
@@ -514,6 +542,7 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
     for (int s = 0; s < n_steps; ++s) {
         const unsigned long long ca = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
         rec_wait_vmcnt_rt(since_dma);                               // this wave's share of group s (and of record s + 1) has landed
+        if (XADD && s < my) xadd_rows(s);
         const unsigned long long cb = (kF3Timing && a.dbg_cycles) ? __builtin_readcyclecounter() : 0;
         f3_barrier();                                               // [A_s]
         if (kF3Timing && a.dbg_cycles) { const unsigned long long ce = __builtin_readcyclecounter(); cyc_work += ca - c_prev; cyc_dma += cb - ca; cyc_wait += ce - cb; c_prev = ce; }
@@ -590,9 +619,17 @@ int rhs_fused3_variant(int mode, int n_prev) {
     return mode == F3_ERROR && (n_prev == kF3MaxPrev || n_prev == 1);
 }
 
-template <bool HALO, int MODE, int NP>
+// RkOpt::xadd: the lattice plan, no halo panel, the launch that opens a dopri5 step (COMBINE with one earlier stage: k2)
+int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev) {
+    static const int enabled = env_int_f3("NDCN_F3_XADD", 1);
+    if (!enabled || H != 256 || (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) || !rhs_fused3_supported(A)) return 0;
+    if (A->hub_n > 0 || A->n_rows != A->n_cols) return 0;              // no second panel (hub sums, halo rows)
+    return (mode == F3_COMBINE && n_prev == 1) ? 1 : 0;
+}
+
+template <bool HALO, int MODE, int NP, bool XADD = false>
 static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st) {
-    auto kern = rhs_fused3_kernel<HALO, MODE, NP>;
+    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XADD>;
     static bool attr_set = false;
     if (!attr_set) {
         NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
@@ -610,6 +647,12 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (!rhs_fused3_variant(mode, n_prev)) { set_error("rhs_fused3: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     F3Args a;
     a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
+    a.Xadd = (opt && opt->xadd) ? opt->xadd : nullptr;
+    a.xadd_c = a.Xadd ? opt->xadd_c : 0.f;
+    if (a.Xadd && (Xh || !(mode == F3_COMBINE && n_prev == 1) || A->n_rows != A->n_cols)) {
+        set_error("rhs_fused3: X + c Xadd is formed in the one-stage COMBINE launch of an operator without a halo panel");
+        return NDCN_EINVAL;
+    }
     a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
     a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val;
     static const int dbg = env_int_f3("NDCN_FUSED3_DBG", 0);
@@ -635,6 +678,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * 256 * (double)(A->n_rows + A->n_cols) + 4.0 * 256 * 256;
     if (mode != F3_PLAIN) bytes += P * (n_prev + 2);
     if (e.y_aux) bytes += P;
+    if (a.Xadd) bytes += P;                                          // the second gather
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
     int rc = NDCN_OK;
 #define NDCN_F3(HALO_, MODE_, NP_) rc = launch_f3<HALO_, MODE_, NP_>(a, e, grid, st)
@@ -657,7 +701,8 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
             default: NDCN_F3(HALO_, F3_COMBINE, 5); break;            \
         }                                                             \
     } while (0)
-    if (Xh) NDCN_F3_DISPATCH(true);
+    if (a.Xadd) rc = launch_f3<false, F3_COMBINE, 1, true>(a, e, grid, st);
+    else if (Xh) NDCN_F3_DISPATCH(true);
     else NDCN_F3_DISPATCH(false);
 #undef NDCN_F3_DISPATCH
 #undef NDCN_F3

@@ -379,9 +379,17 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
     if (s->fused2) {
         // Stage algebra rides in the RHS epilogues: the evaluation that produces k[i+1] also forms the NEXT stage
         // input y0 + dt * sum_m beta[i+1][m] k[m] (its own K as the last term), the last one the error record.
+        // The first stage input y0 + dt beta_21 k1 is a kernel of its own (3 panels) - unless the launch that produces k2 can
+        // form it on the rows it stages (RkOpt::xadd: the lattice plan of rhs_fused3.hip, one more gather instead)
+        static const bool xadd_on = [] { const char *e = getenv("NDCN_STAGE_XADD"); return !(e && e[0] == '0'); }();
+        const bool xadd = xadd_on && !dt_dev && !s->sharded && !s->rec_epi &&
+                          rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 1, 1);
         dt_coeffs(dt32, kBeta[0], 1, s->k, kp, cp, m);
-        rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st, dt_dev);
-        if (rc) return rc;
+        const float xadd_c = cp[0];
+        if (!xadd) {
+            rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st, dt_dev);
+            if (rc) return rc;
+        }
         // The launch that produces k6 (i == 4) holds k1, k3, k4, k5 in its epilogue: it also forms the partial error sum
         // E = dt (c_err1 k1 + c_err3 k3 + c_err4 k4 + c_err5 k5 + c_err6 k6) - left to right like the reference's sum - into
         // the stage-input buffer that is free at that point; the error launch reads {y0, E, y1} instead of 7 panels.
@@ -400,10 +408,10 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         static const bool partial_on = [] { const char *e = getenv("NDCN_STAGE_PARTIAL"); return !(e && e[0] == '0'); }();
         const bool use_partial = partial_on && !dt_dev;
         float *e_panel = nullptr, *p_panel = nullptr;
-        float *in = s->ytmp;
+        float *in = xadd ? s->ycur : s->ytmp;
         for (int i = 0; i < 6; ++i) {
             if (i < 5) {
-                float *out = (i == 4) ? s->ynext : (in == s->ytmp ? s->ytmp2 : s->ytmp);   // stage-6 input IS y1
+                float *out = (i == 4) ? s->ynext : (in == s->ytmp ? s->ytmp2 : s->ytmp);   // stage-6 input IS y1 (in == ycur: ytmp)
                 int mp = 0;
                 if (i == 3 && p_panel) {
                     kp[0] = p_panel;
@@ -419,8 +427,12 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
                     }
                 }
                 cp[mp] = dt32 * (float)kBeta[i + 1][i + 1];   // the K being produced, last term
-                RkOpt opt = {nullptr, 0, nullptr, nullptr};
+                RkOpt opt = {nullptr, 0, nullptr, nullptr, nullptr, 0.f};
                 float c2[8];
+                if (i == 0 && xadd) {
+                    opt.xadd = s->k[0];
+                    opt.xadd_c = xadd_c;
+                }
                 if (i == 2 && use_partial) {
                     // rows 4 and 5 of the tableau are dense: the same stages in the same order as this launch's own sum
                     bool dense = true;
@@ -445,7 +457,7 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
                     opt.c_aux = c2;
                 }
                 rc = rhs_epi(s, in, s->k[i + 1], 1, s->ycur, kp, cp, mp, out, 0.f, 0.f, nullptr, nullptr, st, dt_dev,
-                             opt.y_aux ? &opt : nullptr);
+                             (opt.y_aux || opt.xadd) ? &opt : nullptr);
                 if (rc) return rc;
                 in = out;
             } else if (split_error) {

@@ -332,6 +332,31 @@ class HipOps:
             return K, (red.fetch() if fetch else None)
 
     @staticmethod
+    def rhs_rk_xadd(A, X, xadd, xadd_c, W, b, y0, k_prev, cs):
+        """The evaluation that opens a dopri5 step (ndcn_rhs_rk_xadd_f32): K = ODEFunc(X + xadd_c * xadd) and
+        y_next = y0 + (cs[0] * k_prev + cs[1] * K) in one pass, the input formed on the rows the kernel stages - the bits of
+        combine(X, [xadd], [xadd_c]) followed by rhs_rk(..., 'combine', y0, [k_prev], cs).  Returns (K, y_next), or None where
+        the operator has no such kernel (ndcn_rhs_xadd_supported)."""
+        X, xadd, y0, k_prev = _panel(X), _panel(xadd), _panel(y0), _panel(k_prev)
+        W = _panel(W, 'weight')
+        b = _panel(b, 'bias') if b is not None else None
+        H = X.shape[1]
+        A = as_csr(A)
+        A.ensure_plans(H)
+        lib = _lib.load()
+        flags = _lib.F_RELU
+        if not int(lib.ndcn_rhs_xadd_supported(A.view_ref(), H, flags, _lib.RK_COMBINE, 1)):
+            return None
+        assert len(cs) == 2
+        K, y_next = torch.empty_like(X), torch.empty_like(X)
+        work = torch.empty(int(lib.ndcn_rhs_work_bytes(A.shape[0], H, flags)), dtype=torch.uint8, device=X.device)
+        arr_c = (_F * 2)(float(cs[0]), float(cs[1]))
+        with torch.cuda.device(X.device):
+            check(lib.ndcn_rhs_rk_xadd_f32(A.view_ref(), ptr(X), ptr(xadd), float(xadd_c), ptr(W), ptr(b), ptr(K), ptr(work), H, flags,
+                                           ptr(y0), ptr(k_prev), arr_c, ptr(y_next), stream_ptr()))
+        return K, y_next
+
+    @staticmethod
     def gather_rows(X, idx):
         X = _panel(X)
         assert idx.dtype == torch.int32 and idx.is_cuda

@@ -593,6 +593,56 @@ def test_partial_error_sum_in_the_stage6_launch(dev, kernel):
     assert torch.equal(K5a, K5b) and torch.equal(y6a, y6b)
 
 
+@pytest.mark.parametrize('side', [40, 47, 64])
+def test_first_stage_input_formed_on_the_staged_rows(dev, side):
+    """ndcn_rhs_rk_xadd_f32 (ABI 10): the launch that opens a dopri5 step evaluates f(X + c Xadd) with the sum formed on the
+    neighbour rows it stages - bit for bit combine(X, [Xadd], [c]) followed by the one-stage COMBINE launch (K and y_next),
+    also where groups are not staged (a plan built without the lattice hint is refused: no such kernel), repeated
+    (a premature read of an Xadd row would be a race); refused with a halo panel / other modes."""
+    from ndcn_amd import hip, CsrOperator, graphs, _lib
+    n = side * side
+    m = graphs.normalized_laplacian(graphs.grid_8_neighbor(side)).tocsr()
+    A = CsrOperator.from_scipy(m, dev)
+    g = torch.Generator().manual_seed(side)
+    X, y0 = torch.rand(n, 256, generator=g).to(dev), torch.rand(n, 256, generator=g).to(dev)
+    k1 = torch.randn(n, 256, generator=g).to(dev)
+    W = ((torch.rand(256, 256, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(256, generator=g) - 0.5) / 8).to(dev)
+    c, cs = np.float32(0.0371), [np.float32(0.11), np.float32(-0.23)]
+    tmp = hip.combine(X, [k1], [c])
+    K0, y0n = hip.rhs_rk(A, tmp, W, b, 'combine', y0, [k1], cs)
+    assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3
+    for _ in range(3):
+        got = hip.rhs_rk_xadd(A, X, k1, c, W, b, y0, k1, cs)
+        assert got is not None
+        assert torch.equal(got[0], K0) and torch.equal(got[1], y0n)
+    # a different added panel than the earlier stage
+    z = torch.randn(n, 256, generator=g).to(dev)
+    K1, y1n = hip.rhs_rk(A, hip.combine(X, [z], [c]), W, b, 'combine', y0, [k1], cs)
+    got = hip.rhs_rk_xadd(A, X, z, c, W, b, y0, k1, cs)
+    assert torch.equal(got[0], K1) and torch.equal(got[1], y1n)
+    # groups the record cannot hold (rows with far-away entries): gathered directly inside the kernel, same bits
+    rs = np.random.RandomState(side)
+    hot = np.repeat(rs.choice(n, 6, replace=False), 12)                     # six rows with 12 far-away entries each
+    extra = sp.csr_matrix((rs.rand(72).astype(np.float32), (hot, rs.randint(0, n, 72))), shape=(n, n))
+    m2 = (m + extra).tocsr()
+    m2.sort_indices()
+    A2 = _no_plan(CsrOperator.from_scipy(m2, dev))
+    A2.group_order = torch.as_tensor(A.detect_stencil_order() if A.group_order is None else A.group_order.cpu().numpy(), dtype=torch.int32).to(dev)
+    staged, _ = A2.build_rec_plan(16, 40, 2)
+    assert 0.5 < staged < 1.0
+    K2, y2n = hip.rhs_rk(A2, tmp, W, b, 'combine', y0, [k1], cs)
+    assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3
+    got = hip.rhs_rk_xadd(A2, X, k1, c, W, b, y0, k1, cs)
+    assert got is not None and torch.equal(got[0], K2) and torch.equal(got[1], y2n)
+    # no lattice plan: no such kernel
+    P = _no_plan(CsrOperator.from_scipy(m, dev))
+    assert hip.rhs_rk_xadd(P, X, k1, c, W, b, y0, k1, cs) is None
+    lib = _lib.load()
+    assert int(lib.ndcn_rhs_xadd_supported(A.view_ref(), 256, _lib.F_RELU, _lib.RK_COMBINE, 2)) == 0
+    assert int(lib.ndcn_rhs_xadd_supported(A.view_ref(), 256, _lib.F_RELU, _lib.RK_ERROR, 1)) == 0
+
+
 @pytest.mark.parametrize('n,H', [(20000, 20), (20000, 64), (6000, 128)])
 def test_narrow_panels_beyond_the_one_launch_range_take_the_composed_path(dev, n, H):
     """rhs_small.hip serves n H <= 2^18 (launch-bound sizes); larger narrow panels run row SpMM -> scratch -> MFMA Linear
