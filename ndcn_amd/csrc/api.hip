@@ -182,7 +182,7 @@ static int rhs_rk_entry(const ndcn_csr *A, const float *X, const float *X_halo, 
     NDCN_CHECK_ARG(!y_aux || (rk_mode == NDCN_RK_COMBINE && h_c_aux && y_aux != y_next && y_aux != K && y_aux != X),
                    "y_aux: NDCN_RK_COMBINE only, with h_c_aux, not aliasing X / K / y_next");
     if (x_add) {
-        NDCN_CHECK_ARG(!X_halo && x_add != K && x_add != y_next && rhs_xadd_supported(A, H, flags, rk_mode, n_prev),
+        NDCN_CHECK_ARG(!X_halo && x_add != K && x_add != y_next && rk_mode == NDCN_RK_COMBINE && rhs_xadd_supported(A, H, flags, rk_mode, n_prev),
                        "x_add: not supported for this operator / mode (ndcn_rhs_xadd_supported), or aliased");
     }
     const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0, y_aux, h_c_aux, x_add, x_add_c};
@@ -199,7 +199,7 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
 }
 
 int ndcn_rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int rk_mode, int n_prev) {
-    return A ? rhs_xadd_supported(A, H, flags, rk_mode, n_prev) : 0;
+    return (A && rk_mode == NDCN_RK_COMBINE) ? rhs_xadd_supported(A, H, flags, rk_mode, n_prev) : 0;
 }
 
 int ndcn_rhs_rk_xadd_f32(const ndcn_csr *A, const float *X, const float *x_add, float x_add_c, const float *W, const float *b,

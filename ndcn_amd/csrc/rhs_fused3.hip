@@ -581,6 +581,10 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
 #pragma unroll
         for (int q = 0; q < kRPW; ++q) arrived(pan[q]);
     }
+    if (XADD) {                                                     // (their registers stay reserved up to the wait above)
+#pragma unroll
+        for (int k = 0; k < kF3CapD; ++k) asm volatile("" : "+v"(xk[k]));
+    }
     if (kF3Timing && a.dbg_cycles && lane == 0) {
         a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave)] = cyc_work;
         a.dbg_cycles[2 * (blockIdx.x * kF3Waves + wave) + 1] = cyc_wait + (cyc_dma << 32);
@@ -619,12 +623,13 @@ int rhs_fused3_variant(int mode, int n_prev) {
     return mode == F3_ERROR && (n_prev == kF3MaxPrev || n_prev == 1);
 }
 
-// RkOpt::xadd: the lattice plan, no halo panel, the launch that opens a dopri5 step (COMBINE with one earlier stage: k2)
+// RkOpt::xadd: the lattice plan, no halo panel, the launch that opens a dopri5 step (COMBINE with one earlier stage: k2) and the
+// second evaluation of the initial step (ERROR with one earlier stage: f(y0 + h0 f0) carrying the d2 norm)
 int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev) {
     static const int enabled = env_int_f3("NDCN_F3_XADD", 1);
     if (!enabled || H != 256 || (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) || !rhs_fused3_supported(A)) return 0;
     if (A->hub_n > 0 || A->n_rows != A->n_cols) return 0;              // no second panel (hub sums, halo rows)
-    return (mode == F3_COMBINE && n_prev == 1) ? 1 : 0;
+    return ((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) ? 1 : 0;
 }
 
 template <bool HALO, int MODE, int NP, bool XADD = false>
@@ -649,8 +654,8 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
     a.Xadd = (opt && opt->xadd) ? opt->xadd : nullptr;
     a.xadd_c = a.Xadd ? opt->xadd_c : 0.f;
-    if (a.Xadd && (Xh || !(mode == F3_COMBINE && n_prev == 1) || A->n_rows != A->n_cols)) {
-        set_error("rhs_fused3: X + c Xadd is formed in the one-stage COMBINE launch of an operator without a halo panel");
+    if (a.Xadd && (Xh || !((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) || A->n_rows != A->n_cols)) {
+        set_error("rhs_fused3: X + c Xadd is formed in the one-stage COMBINE / ERROR launches of an operator without a halo panel");
         return NDCN_EINVAL;
     }
     a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
@@ -701,8 +706,10 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
             default: NDCN_F3(HALO_, F3_COMBINE, 5); break;            \
         }                                                             \
     } while (0)
-    if (a.Xadd) rc = launch_f3<false, F3_COMBINE, 1, true>(a, e, grid, st);
-    else if (Xh) NDCN_F3_DISPATCH(true);
+    if (a.Xadd) {
+        if (mode == F3_COMBINE) rc = launch_f3<false, F3_COMBINE, 1, true>(a, e, grid, st);
+        else rc = launch_f3<false, F3_ERROR, 1, true>(a, e, grid, st);
+    } else if (Xh) NDCN_F3_DISPATCH(true);
     else NDCN_F3_DISPATCH(false);
 #undef NDCN_F3_DISPATCH
 #undef NDCN_F3

@@ -259,17 +259,24 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     // y1 = y0 + h0 * f0 ; f1 = f(t0 + h0, y1)
     const float *kp[1] = {s->k[0]};
     const float cp[1] = {h0};
-    rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, 1, s->n_elem, st);
-    if (rc) return rc;
+    // (on the lattice plan the launch that produces f1 forms y0 + h0 f0 on the rows it stages: RkOpt::xadd)
+    const bool fuse_d2 = fuse_on && s->fused2 && (s->sharded || s->n_elem > aten_order_max_elems());
+    static const bool xadd_on = [] { const char *e = getenv("NDCN_STAGE_XADD"); return !(e && e[0] == '0'); }();
+    const bool xadd = xadd_on && fuse_d2 && !s->sharded && !s->rec_epi && rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 2, 1);
+    if (!xadd) {
+        rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, 1, s->n_elem, st);
+        if (rc) return rc;
+    }
     // d2 = || (f1 - f0) / scale || (misc.py:131-134).  On the paths whose RHS carries an epilogue the sum rides in the launch
     // that produces f1, as its error record: stages {f0, f1} with coefficients {-1, 1} - (-f0) + f1 is the float32 value of
     // f1 - f0 - over the tolerance of the pair (y0, y0), i.e. atol + rtol |y0|; squares summed in double like
     // scaled_sumsq_f32.  (Panels small enough for ATen's float32 summation order keep the separate launch: section 2.)
-    if (fuse_on && s->fused2 && (s->sharded || s->n_elem > aten_order_max_elems())) {
+    if (fuse_d2) {
         const float *kq[1] = {s->k[0]};
         const float cq[2] = {-1.f, 1.f};
-        const RkOpt opt = {s->ycur, 0, nullptr, nullptr};
-        rc = rhs_epi(s, s->ytmp, s->k[1], 2, s->ycur, kq, cq, 1, nullptr, rtol, atol, s->d_red, s->d_ws2, st, nullptr, &opt);
+        const RkOpt opt = {s->ycur, 0, nullptr, nullptr, xadd ? s->k[0] : nullptr, xadd ? h0 : 0.f};
+        rc = rhs_epi(s, xadd ? s->ycur : s->ytmp, s->k[1], 2, s->ycur, kq, cq, 1, nullptr, rtol, atol, s->d_red, s->d_ws2, st, nullptr,
+                     &opt);
         if (rc) return rc;
         double sum;
         rc = fetch_record(s, st, sum, bad);
