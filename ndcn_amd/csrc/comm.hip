@@ -107,6 +107,7 @@ int comm_allreduce_sum_f64(ndcn_comm *c, double *d_buf, int n, hipStream_t st) {
 
 int64_t halo_plan_n_halo(const ndcn_halo_plan *p) { return p ? p->n_halo : 0; }
 int64_t halo_plan_n_send(const ndcn_halo_plan *p) { return p ? p->n_send : 0; }
+const int32_t *halo_plan_send_idx(const ndcn_halo_plan *p) { return p ? p->d_send_idx : nullptr; }
 
 int halo_exchange_f32(ndcn_halo_plan *p, const float *X, int H, float *d_pack, float *X_halo, hipStream_t st) {
     if (!p->any) return NDCN_OK;

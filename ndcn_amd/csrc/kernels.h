@@ -133,6 +133,7 @@ int comm_world(const ndcn_comm *c);
 int comm_allreduce_sum_f64(ndcn_comm *c, double *d_buf, int n, hipStream_t st);
 int64_t halo_plan_n_halo(const ndcn_halo_plan *p);
 int64_t halo_plan_n_send(const ndcn_halo_plan *p);
+const int32_t *halo_plan_send_idx(const ndcn_halo_plan *p);        // device array of n_send own-row indices
 int halo_exchange_f32(ndcn_halo_plan *p, const float *X, int H, float *d_pack, float *X_halo, hipStream_t st);
 
 int64_t solver_workspace_bytes(const ndcn_solver_desc *desc);

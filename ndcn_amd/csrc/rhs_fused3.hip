@@ -628,7 +628,8 @@ int rhs_fused3_variant(int mode, int n_prev) {
 int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev) {
     static const int enabled = env_int_f3("NDCN_F3_XADD", 1);
     if (!enabled || H != 256 || (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) || !rhs_fused3_supported(A)) return 0;
-    if (A->hub_n > 0 || A->n_rows != A->n_cols) return 0;              // no second panel (hub sums, halo rows)
+    if (A->hub_n > 0) return 0;                                          // no second panel (hub sums); the caller vouches that
+                                                                         // every column lies in the panels it passes (no X_halo)
     return ((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) ? 1 : 0;
 }
 
@@ -654,7 +655,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
     a.Xadd = (opt && opt->xadd) ? opt->xadd : nullptr;
     a.xadd_c = a.Xadd ? opt->xadd_c : 0.f;
-    if (a.Xadd && (Xh || !((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) || A->n_rows != A->n_cols)) {
+    if (a.Xadd && (Xh || !((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1))) {
         set_error("rhs_fused3: X + c Xadd is formed in the one-stage COMBINE / ERROR launches of an operator without a halo panel");
         return NDCN_EINVAL;
     }

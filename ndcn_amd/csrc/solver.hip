@@ -12,6 +12,8 @@
 #include <math.h>
 #include <stdlib.h>
 #include <new>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -100,6 +102,10 @@ struct ndcn_solver {
     float *halo = nullptr, *pack = nullptr, *sbuf = nullptr;   // halo panel, send buffer, S = A_own X (two-phase)
     hipStream_t cstream = nullptr;
     hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+    // row-split shards: the own rows whose first stage input the boundary launches and the exchange read (merged ranges);
+    // everything else of it is formed inside the interior launch (RkOpt::xadd)
+    std::vector<std::pair<int64_t, int64_t>> xadd_ranges;
+    int xadd_block = -1;           // an interior block whose operator has the XADD kernel (-1: none)
     bool packed = false;           // `work` holds the packed weights of this solve
     double n_mean = 0;             // element count behind the controller's means (global for a shard)
     int n_coef = 0;
@@ -319,13 +325,15 @@ int rhs_sharded(ndcn_solver *s, const float *x, float *K, int mode, const float 
     const ndcn_shard &sh = s->shard;
     float *y_aux = opt ? opt->y_aux : nullptr;
     const float *c_aux = opt ? opt->c_aux : nullptr;
-    auto launch = [&](const ndcn_csr *A, const float *X, const float *Xh, int64_t lo, bool first, const float *y1) -> int {
+    const bool xadd = opt && opt->xadd;                       // x = y0, the input is x + xadd_c * xadd (row-split shards only)
+    auto launch = [&](const ndcn_csr *A, const float *X, const float *Xh, int64_t lo, bool first, const float *y1,
+                      bool with_xadd = false) -> int {
         const size_t off = (size_t)lo * H;
         if (opt && opt->y1) y1 = opt->y1;                     // the caller names the second state of the error tolerance
         const float *kpo[8];
         for (int m = 0; m < n_prev; ++m) kpo[m] = kp[m] + off;
         RkOpt o = {mode == NDCN_RK_ERROR ? y1 + off : nullptr, (mode == NDCN_RK_ERROR && !first) ? 1 : 0,
-                   y_aux ? y_aux + off : nullptr, c_aux};
+                   y_aux ? y_aux + off : nullptr, c_aux, with_xadd ? opt->xadd : nullptr, with_xadd ? opt->xadd_c : 0.f};
         return rhs_rk_f32(A, X, Xh, s->n_own, s->d.W, s->d.b, K + off, s->work, H, flags, mode, y0 ? y0 + off : nullptr, kpo, cp,
                           n_prev, y_next ? y_next + off : nullptr, rtol, atol, d_out, d_ws, st, &o);
     };
@@ -333,21 +341,23 @@ int rhs_sharded(ndcn_solver *s, const float *x, float *K, int mode, const float 
     // x is complete on `st` -> the exchange may start on the side stream
     NDCN_HIP(hipEventRecord(s->ev_x, st));
     NDCN_HIP(hipStreamWaitEvent(s->cstream, s->ev_x, 0));
-    int rc = halo_exchange_f32(sh.halo, x, H, s->pack, s->halo, s->cstream);
+    // xadd: the rows the exchange packs and the boundary launches gather were formed in s->ytmp by the caller
+    const float *xs = xadd ? s->ytmp : x;
+    int rc = halo_exchange_f32(sh.halo, xs, H, s->pack, s->halo, s->cstream);
     if (rc) return rc;
     NDCN_HIP(hipEventRecord(s->ev_halo, s->cstream));
     if (sh.n_blocks > 0) {
         bool first = true;
         for (int b = 0; b < sh.n_blocks; ++b)
             if (!sh.blocks[b].needs_halo) {
-                rc = launch(&sh.blocks[b].A, x, nullptr, sh.blocks[b].row_lo, first, x);
+                rc = launch(&sh.blocks[b].A, x, nullptr, sh.blocks[b].row_lo, first, x, xadd);
                 if (rc) return rc;
                 first = false;
             }
         NDCN_HIP(hipStreamWaitEvent(st, s->ev_halo, 0));
         for (int b = 0; b < sh.n_blocks; ++b)
             if (sh.blocks[b].needs_halo) {
-                rc = launch(&sh.blocks[b].A, x, s->halo, sh.blocks[b].row_lo, first, x);
+                rc = launch(&sh.blocks[b].A, xs, s->halo, sh.blocks[b].row_lo, first, x);
                 if (rc) return rc;
                 first = false;
             }
@@ -389,13 +399,22 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         // The first stage input y0 + dt beta_21 k1 is a kernel of its own (3 panels) - unless the launch that produces k2 can
         // form it on the rows it stages (RkOpt::xadd: the lattice plan of rhs_fused3.hip, one more gather instead)
         static const bool xadd_on = [] { const char *e = getenv("NDCN_STAGE_XADD"); return !(e && e[0] == '0'); }();
-        const bool xadd = xadd_on && !dt_dev && !s->sharded && !s->rec_epi &&
-                          rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 1, 1);
+        const bool xadd = xadd_on && !dt_dev && !s->rec_epi &&
+                          (s->sharded ? s->xadd_block >= 0 : rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 1, 1));
         dt_coeffs(dt32, kBeta[0], 1, s->k, kp, cp, m);
         const float xadd_c = cp[0];
         if (!xadd) {
             rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, m, s->n_elem, st, dt_dev);
             if (rc) return rc;
+        } else if (s->sharded) {
+            // row-split shard: the boundary launches and the exchange still read the stage input from a panel - formed on the
+            // few lattice rows they touch; the interior launch forms the rest on its staged rows
+            for (const auto &r : s->xadd_ranges) {
+                const size_t off = (size_t)r.first * s->d.H;
+                const float *kq[1] = {s->k[0] + off};
+                rc = rk_combine_f32(s->ytmp + off, s->ycur + off, kq, cp, 1, (r.second - r.first) * (int64_t)s->d.H, st, nullptr);
+                if (rc) return rc;
+            }
         }
         // The launch that produces k6 (i == 4) holds k1, k3, k4, k5 in its epilogue: it also forms the partial error sum
         // E = dt (c_err1 k1 + c_err3 k3 + c_err4 k4 + c_err5 k5 + c_err6 k6) - left to right like the reference's sum - into
@@ -418,7 +437,8 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         float *in = xadd ? s->ycur : s->ytmp;
         for (int i = 0; i < 6; ++i) {
             if (i < 5) {
-                float *out = (i == 4) ? s->ynext : (in == s->ytmp ? s->ytmp2 : s->ytmp);   // stage-6 input IS y1 (in == ycur: ytmp)
+                // stage-6 input IS y1; a sharded XADD launch still gathers its boundary rows from ytmp: its output goes to ytmp2
+                float *out = (i == 4) ? s->ynext : ((in == s->ytmp || (i == 0 && xadd && s->sharded)) ? s->ytmp2 : s->ytmp);
                 int mp = 0;
                 if (i == 3 && p_panel) {
                     kp[0] = p_panel;
@@ -649,6 +669,38 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
         s->n_own = desc->A.n_cols - s->n_halo;
         s->n_mean = (double)s->shard.n_global_rows * (double)desc->H;
         if (s->n_own != s->n_rows) { set_error("shard: operator has %lld rows, %lld own columns", (long long)s->n_rows, (long long)s->n_own); delete s; return NDCN_EINVAL; }
+        // Row-split shards (lattices): which own rows of a stage input do the boundary launches and the exchange read?  One-off,
+        // from the boundary blocks' column lists and the send list (a few thousand entries).  With an interior block on the
+        // XADD kernel the first stage input of a dopri5 step is then formed on those rows only (enqueue_attempt).
+        if (s->shard.n_blocks > 0 && desc->method == NDCN_M_DOPRI5 && !desc->use_graph) {
+            std::vector<std::pair<int64_t, int64_t>> rs;
+            auto add_range = [&](const int32_t *d_idx, int64_t n_idx) -> int {
+                if (n_idx <= 0 || !d_idx) return NDCN_OK;
+                std::vector<int32_t> h((size_t)n_idx);
+                NDCN_HIP(hipMemcpy(h.data(), d_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyDeviceToHost));
+                int64_t lo = -1, hi = -1;
+                for (int32_t c : h)
+                    if (c >= 0 && c < s->n_own) { lo = lo < 0 || c < lo ? c : lo; hi = c > hi ? c : hi; }
+                if (lo >= 0) rs.emplace_back(lo, hi + 1);
+                return NDCN_OK;
+            };
+            int rcx = add_range(halo_plan_send_idx(s->shard.halo), s->n_send);
+            for (int b = 0; b < s->shard.n_blocks && !rcx; ++b) {
+                const auto &blk = s->shard.blocks[b];
+                if (blk.needs_halo) rcx = add_range(blk.A.colidx, blk.A.nnz);
+                else if (s->xadd_block < 0 && rhs_xadd_supported(&blk.A, desc->H, desc->rhs_flags, 1, 1)) s->xadd_block = b;
+            }
+            if (rcx) { delete s; return rcx; }
+            std::sort(rs.begin(), rs.end());
+            for (const auto &r : rs) {
+                if (!s->xadd_ranges.empty() && r.first <= s->xadd_ranges.back().second)
+                    s->xadd_ranges.back().second = std::max(s->xadd_ranges.back().second, r.second);
+                else s->xadd_ranges.push_back(r);
+            }
+            // every interior block must be able to form the input itself
+            for (int b = 0; b < s->shard.n_blocks; ++b)
+                if (!s->shard.blocks[b].needs_halo && !rhs_xadd_supported(&s->shard.blocks[b].A, desc->H, desc->rhs_flags, 1, 1)) s->xadd_block = -1;
+        }
     }
     if (workspace) {
         s->slab = workspace;
