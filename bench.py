@@ -88,11 +88,13 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-threads', type=int, default=32, help='host threads of the CPU-baseline leg')
     p.add_argument('--cpu-nodes', type=int, default=0, help='nodes of the bounded CPU-baseline sample (0: per-configuration default)')
+    p.add_argument('--no-at-scale', action='store_true', help='skip cpu_baseline.at_scale (one oracle RHS + one solver step at ~10^5 nodes)')
     p.add_argument('--no-profile-pass', action='store_true')
     p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (works with 1 rank)')
-    p.add_argument('--sharded-impl', default='device', choices=['device', 'python'],
-                   help='N > 1: the sharded device-resident solver behind the C ABI (RCCL communicator of the library) or the '
-                        'Python-stepped path over torch.distributed (the only one the gloo test hook can run)')
+    p.add_argument('--sharded-impl', default=os.environ.get('NDCN_SHARDED_IMPL', 'python'), choices=['device', 'python'],
+                   help='N > 1: the Python-stepped path over torch.distributed (default: its collectives are PyTorch\'s own '
+                        'RCCL calls, and it is the form the 2- and 8-rank tests run) or the sharded device-resident solver behind '
+                        'the C ABI (RCCL communicator of the library; has run with one rank only - opt in on a multi-GPU box)')
     p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
     p.add_argument('--no-control', action='store_true', help='config M with ODEFunc(no_control=True): relu(A X), the pure HBM right-hand side (neural_dynamics.py:32)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')
@@ -172,46 +174,118 @@ def cpu_workload(cfg, H, n, T):
     return m, True, 'dopri5', torch.linspace(0., 1.2, 16).tolist(), 'Pubmed topology, FULL size (%d nodes), 16 ticks' % int(g['n'])
 
 
-def cpu_baseline(cfg, H, T, rtol, atol, threads, runs=5, nodes=0):
-    """The CPU oracle (torch-CPU restatement of the reference path: torch.sparse.mm on COO + F.linear + the restated
-    solver loops, checked against fixtures of the reference itself) on a BOUNDED sample of this configuration's workload:
-    the same generators, seeds, H, tolerances and time grid at a node count that one solve finishes in seconds (C5: the
-    full workload).  Protocol (BASELINE.md section 3): two warm-up solves, `runs` >= 5 timed solves, median.
-    node-states/s is a per-node rate: the figure at the sample's N stands in for the full N (the reference-style solver
-    needs ~40 panels of temporaries per step - ~40 GB at 10^6 x 256 - and minutes per solve there; BASELINE.md measured
-    4.8 k node-states/s at N = 10^5 on 8 cores)."""
+AT_SCALE_NODES = {'M': 316 * 316, 'NC': 316 * 316, 'C2': 100000, 'C3': 100000, 'C4': 100000, 'C5': 0}
+
+
+def _oracle_case(cfg, H, n, T, rtol, atol):
+    """(oracle ODEFunc, x0, ticks, method, rtol, atol, description, scipy operator, Linear) of configuration cfg at n nodes."""
     from oracle import ndcn_oracle as orc
-    # the reference's op-per-term solver issues ~300 small tensor ops per step: beyond a few dozen threads the
-    # fork/join cost of each op outweighs the work, so the leg uses a bounded thread count and says which
-    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
-    n = nodes or CPU_SAMPLE[cfg]
     L, no_control, method, ticks, what = cpu_workload(cfg, H, n, T)
-    n = L.shape[0]
     if cfg == 'C5':
         rtol, atol = .1, .1
     A = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
     torch.manual_seed(0)
     lin = torch.nn.Linear(H, H)
     f = orc.OracleODEFunc(A, lin.weight.detach(), lin.bias.detach(), no_control=no_control)
-    x0 = torch.rand(n, H, generator=torch.Generator().manual_seed(0))
-    tt = torch.tensor(ticks)
-    times, steps = [], 0
+    x0 = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(0))
+    return f, x0, torch.tensor(ticks), method, rtol, atol, what, L, lin
+
+
+def cpu_at_scale(cfg, H, T, rtol, atol):
+    """BASELINE.md section 3's fall-back for sizes the reference-style solver cannot finish in minutes: ONE timed right-hand
+    side and ONE timed solver step of the oracle at the configuration's full node count - or at 10^5 nodes where the full
+    count needs ~40 GB of temporaries and minutes per step (M, C3, C4) - extrapolated to node-states/s as N / step time.
+    dopri5: the timed unit is a solve to a tick inside the first step, i.e. the initial-step selection (2 evaluations and
+    three norms) + one attempted step (6 evaluations, stage sums, error ratio) + the dense-output evaluation; rk4: the
+    first grid step."""
+    from oracle import ndcn_oracle as orc
+    n = AT_SCALE_NODES[cfg]
+    if not n:
+        return None
+    f, x0, tt, method, rtol, atol, what, L, _ = _oracle_case(cfg, H, n, T, rtol, atol)
+    n = L.shape[0]
+    f(0.0, x0)                                                       # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        f(0.0, x0)
+    rhs_s = (time.perf_counter() - t0) / 3
+    one = torch.tensor([0., 1e-4]) if method == 'dopri5' else tt[:2]
+    log = []
+    nfe0 = f.nfe
+    t0 = time.perf_counter()
+    orc.odeint(f, x0, one, rtol=rtol, atol=atol, method=method, step_log=log if method == 'dopri5' else None)
+    step_s = time.perf_counter() - t0
+    steps = len([r for r in log if r[0] != 'nfe']) if method == 'dopri5' else 1
+    return {'nodes': n, 'what': what, 'rhs_s': round(rhs_s, 4), 'node_rhs_per_s': round(n / rhs_s, 1),
+            'one_step_solve_s': round(step_s, 3), 'steps_in_it': steps, 'rhs_evals_in_it': f.nfe - nfe0,
+            'share_of_time_outside_the_rhs': round(1.0 - (f.nfe - nfe0) * rhs_s / step_s, 3),
+            'value_extrapolated': round(n * steps / step_s, 1), 'unit': 'node-states/s',
+            'note': 'single samples (one solve after one warm-up evaluation); the reference-style solver at N >= 10^6 needs '
+                    '~40 panels of temporaries per step'}
+
+
+def gpu_parity(f_or, x0, tt, method, rtol, atol, ref, ref_log, dev):
+    """The HIP path on the CPU leg's own sample (same operator, weights, x0, ticks, tolerances): trajectory L1 / max-abs
+    against the oracle's and equality of the dopri5 accept / reject sequence (SURVEY 8d "parity gate"; north_star: L1 < 1e-4)."""
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    A = f_or.A.coalesce()
+    idx = A.indices()
+    op = CsrOperator.from_coo(idx[0].to(dev), idx[1].to(dev), A.values().to(dev), A.shape)
+    H = x0.shape[1]
+    g = ODEFunc(H, op, no_control=f_or.no_control).to(dev).eval()
+    g.load_state_dict({'wt.weight': f_or.W, 'wt.bias': f_or.b})
+    log = []
+    with torch.no_grad():
+        y = ode.odeint(g, x0.to(dev), tt.to(dev), rtol=rtol, atol=atol, method=method, step_log=log if method == 'dopri5' else None)
+    err = (y.cpu() - ref).abs()
+    mine = [bool(r[2]) for r in log if r[0] != 'nfe']
+    theirs = [bool(r[2]) for r in ref_log if r[0] != 'nfe']
+    return {'l1': float(err.mean()), 'max_abs': float(err.max()), 'ref_max_abs': float(ref.abs().max()),
+            'steps_equal': (mine == theirs) if method == 'dopri5' else None,
+            'attempts': len(mine) if method == 'dopri5' else len(tt) - 1, 'l1_bound': 1e-4}
+
+
+def cpu_baseline(cfg, H, T, rtol, atol, threads, runs=5, nodes=0, dev=None, at_scale=True):
+    """The CPU oracle (torch-CPU restatement of the reference path: torch.sparse.mm on COO + F.linear + the restated
+    solver loops, checked against fixtures of the reference itself) on a BOUNDED sample of this configuration's workload:
+    the same generators, seeds, H, tolerances and time grid at a node count that one solve finishes in seconds (C5: the
+    full workload).  Protocol (BASELINE.md section 3): two warm-up solves, `runs` >= 5 timed solves, median.
+    node-states/s is a per-node rate measured at the sample's N; `at_scale` (cpu_at_scale) is the single-step figure at
+    the full node count (or 10^5 nodes), where the reference-style solver falls out of the caches - BASELINE.md measured
+    4.8 k node-states/s at N = 10^5 on 8 cores.  Returns (cpu_baseline, parity): parity = the HIP path on the very sample."""
+    from oracle import ndcn_oracle as orc
+    # the reference's op-per-term solver issues ~300 small tensor ops per step: beyond a few dozen threads the
+    # fork/join cost of each op outweighs the work, so the leg uses a bounded thread count and says which
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
+    n = nodes or CPU_SAMPLE[cfg]
+    f, x0, tt, method, rtol, atol, what, L, _ = _oracle_case(cfg, H, n, T, rtol, atol)
+    n = L.shape[0]
+    times, steps, ref, log = [], 0, None, []
     for r in range(2 + max(runs, 5)):
         log = []
         nfe0 = f.nfe
         t0 = time.perf_counter()
-        orc.odeint(f, x0, tt, rtol=rtol, atol=atol, method=method, step_log=log if method == 'dopri5' else None)
+        ref = orc.odeint(f, x0, tt, rtol=rtol, atol=atol, method=method, step_log=log if method == 'dopri5' else None)
         dt = time.perf_counter() - t0
         if r >= 2:
             times.append(dt)
         nfe = f.nfe - nfe0
-        steps = len([row for row in log if row[0] != 'nfe']) if method == 'dopri5' else len(ticks) - 1
+        steps = len([row for row in log if row[0] != 'nfe']) if method == 'dopri5' else len(tt) - 1
     med = float(np.median(times))
-    return {'value': n * steps / med, 'unit': 'node-states/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '2 warm-ups + %d timed %s solves on %s (N=%d, H=%d, same generators / seeds / tolerances / time grid as '
-                      'the GPU run): %d steps, %d RHS evals per solve, median %.2f s (all: %s); per-node rate, stands in for '
-                      'the full node count' % (len(times), method, what, n, H, steps, nfe, med,
-                                               ', '.join('%.2f' % v for v in times))}
+    sample = ('2 warm-ups + %d timed %s solves on %s (N=%d, H=%d, same generators / seeds / tolerances / time grid as '
+              'the GPU run): %d steps, %d RHS evals per solve, median %.2f s (all: %s); per-node rate at the sample\'s N - see '
+              'at_scale for the full node count' % (len(times), method, what, n, H, steps, nfe, med,
+                                                    ', '.join('%.2f' % v for v in times)))
+    parity = None
+    if dev is not None:
+        parity = gpu_parity(f, x0, tt, method, rtol, atol, ref, log, dev)
+        parity['sample'] = '%s, N=%d, H=%d, %s, %d ticks: the CPU leg\'s own sample' % (what, n, H, method, len(tt))
+    base = {'value': n * steps / med, 'unit': 'node-states/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'sample': sample}
+    if at_scale:
+        base['at_scale'] = cpu_at_scale(cfg, H, T, rtol, atol)
+    return base, parity
 
 
 C4_NODES_PER_GPU = int(os.environ.get('NDCN_C4_NODES', '500000'))    # BASELINE config 4: a 4M-node small world over 8 GPUs (override: tests)
@@ -362,23 +436,33 @@ def main():
         device_impl = args.sharded_impl == 'device' and backend == 'nccl'
 
         def make_runner(block, bounds):
-            """The sharded device-resident solver; if ANY rank cannot set it up (e.g. its RCCL communicator), every rank
-            falls back to the Python-stepped path together (the decision is all-reduced: no rank may wait in a collective
-            its peers never enter)."""
+            """The Python-stepped sharded path over torch.distributed (default) or the sharded device-resident solver
+            behind the C ABI.  Every step towards the latter that can fail on ONE rank is a rank-local test whose outcome is
+            all-reduced BEFORE any rank enters a collective of that path: no rank may wait in a collective its peers never
+            enter.  (1) the plan: a collective of the torch group both paths need - every rank builds it; (2) librccl binds
+            and draws an id on every rank (local) -> all-reduce; (3) DeviceShard: its broadcast is reached by every rank
+            whatever happened on rank 0 (sharding.py), ncclCommInitRank is entered by all or none; (4) the outcome of
+            (3) and of the solver set-up is all-reduced again before the first step."""
+            plan = sharding.bench_plan(block, bounds, rank, dev)
             r, err = None, None
             if device_impl:
-                try:
-                    r = sharding.ShardedDeviceBench(f, block, bounds, rank, dev, args.T, args.rtol, args.atol)
-                except Exception as e:                                  # noqa: BLE001 - reported below, then a collective decision
-                    err = e
-                ok = torch.tensor([0 if r is None else 1], device=dev)
+                ok = torch.tensor([1 if sharding.rccl_usable() else 0], device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    try:
+                        r = sharding.ShardedDeviceBench(f, block, bounds, rank, dev, args.T, args.rtol, args.atol, plan=plan)
+                    except Exception as e:                              # noqa: BLE001 - reported below, then a collective decision
+                        err = e
+                    ok = torch.tensor([0 if r is None else 1], device=dev)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                else:
+                    err = 'librccl not usable on some rank'
                 if int(ok.item()) == 0:
                     print('[bench] rank %d: device-resident sharded solver unavailable (%r) - Python-stepped path' % (rank, err),
                           file=sys.stderr, flush=True)
                     r = None
             if r is None:
-                r = sharding.ShardedBench(f, block, bounds, rank, dev, args.T, args.rtol, args.atol)
+                r = sharding.ShardedBench(f, block, bounds, rank, dev, args.T, args.rtol, args.atol, plan=plan)
             return r
 
         if args.config == 'M':
@@ -557,9 +641,10 @@ def main():
     }
     if world == 1 and not args.sharded and not args.no_cpu_baseline:
         cfg_name = 'NC' if (args.config == 'M' and args.no_control) else args.config
-        out['cpu_baseline'] = cpu_baseline(cfg_name, H, args.T, args.rtol, args.atol, args.cpu_threads, args.cpu_runs, args.cpu_nodes)
+        out['cpu_baseline'], out['parity'] = cpu_baseline(cfg_name, H, args.T, args.rtol, args.atol, args.cpu_threads,
+                                                           args.cpu_runs, args.cpu_nodes, dev=dev, at_scale=not args.no_at_scale)
     else:
-        out['cpu_baseline'] = None
+        out['cpu_baseline'] = out['parity'] = None
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

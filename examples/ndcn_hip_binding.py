@@ -7,7 +7,7 @@ import os
 _lib = ctypes.CDLL(os.environ.get('NDCN_HIP_LIB', 'libndcn_hip.so'))   # import torch first: the library binds to torch's HIP runtime
 
 _i32, _i64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
-class Csr(ctypes.Structure):                    # struct ndcn_csr (ABI 6): the optional plans stay zero = absent
+class Csr(ctypes.Structure):                    # struct ndcn_csr (ABI 10): the optional plans stay zero = absent
     _fields_ = [('n_rows', _i64), ('n_cols', _i64), ('nnz', _i64), ('rowptr', _p), ('colidx', _p), ('val', _p),
                 ('row_order', _p), ('tile_order', _p),
                 ('rec_rows', _i32), ('rec_cap', _i32), ('rec_kib', _i32), ('rec_groups', _i32), ('rec', _p),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 10
+#define NDCN_ABI_VERSION 11
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -66,8 +66,8 @@ typedef struct ndcn_csr {
                                  identical for any permutation                                              */
     const int32_t *tile_order; /* [ceil(n_rows / 64)] or NULL: the order in which the fused RHS kernel walks its 64-row
                                  tiles (a permutation; locality hint like row_order - results are identical)      */
-    /* Optional "group record" plan (rec = NULL when absent), built once per operator by the host
-     * (ndcn_amd/csr.py:build_rec_plan) for H = 256 panels.  The rows are cut into groups of rec_rows rows that are
+    /* Optional "group record" plan (rec = NULL when absent), built once per operator by ndcn_csr_create
+     * (ndcn_amd/csrc/csr_plan.hip) for H = 256 panels.  The rows are cut into groups of rec_rows rows that are
      * consecutive in the operator's walk order (row_order, or 0..n-1); group g owns the fixed-size record
      * rec[g * rec_kib * 256 ...) of 32-bit words:
      *   [0, rec_cap)                    the DISTINCT columns the group's rows reference, ascending, padded by repetition
@@ -81,8 +81,8 @@ typedef struct ndcn_csr {
      * ring-plus-shortcuts graph: 12 ring columns + ~2 shortcut endpoints per row).                            */
     int32_t        rec_rows, rec_cap, rec_kib, rec_groups;
     const int32_t *rec;       /* [rec_groups][rec_kib * 256] */
-    /* Optional long-row plan (hub_n = 0 when absent), built once per operator by the host
-     * (ndcn_amd/csr.py:build_hub_plan) for graphs with a skewed degree distribution.  Rows with more than the
+    /* Optional long-row plan (hub_n = 0 when absent), built once per operator by ndcn_csr_create
+     * (ndcn_amd/csrc/csr_plan.hip) for graphs with a skewed degree distribution.  Rows with more than the
      * plan's threshold of entries ("hubs": a 3900-entry row of a 10^6-node Barabasi-Albert graph is otherwise
      * one wave's sequential work inside the fused RHS kernel) are evaluated ahead of that kernel:
      *   hub_seg_* : CSR over SEGMENTS of the hub rows (<= 256 entries each; columns as in colidx),
@@ -109,6 +109,63 @@ typedef struct ndcn_csr {
     float         *hub_Sseg;        /* [hub_nseg][hub_H] */
     float         *hub_S;           /* [hub_n][hub_H] */
 } ndcn_csr;
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator handle.  The reference holds its operator `A` by reference on the module (neural_dynamics.py:9-18: `self.A = A`)
+ * and the caller converts it once, before model construction (heat_dynamics.py:170-175: dense -> sparse COO, .to(device)).
+ * The counterpart: hand the CSR arrays over ONCE and keep the handle next to the model.  ndcn_csr_create builds - on the
+ * device, from the arrays alone - every plan the H = 256 kernels select on (struct ndcn_csr above: the group-record plan
+ * with its lattice walk orders, the long-row plan), so a caller that binds nothing but this header reaches the same kernels
+ * (rhs_fused3, spmm_rec) as the Python package, whose ndcn_amd/csr.py is a binding of these calls.
+ *   rowptr / colidx / val   DEVICE arrays owned by the caller; they must outlive the handle (the view points into them)
+ *   H                       panel width the operator will be applied to (plans exist for H = 256; other widths: a bare view)
+ *   hints                   nullable; zero-initialise, then set what applies:
+ *     lattice_row_base / lattice_n_own   this operator is a ROW BLOCK of a node-range shard: row r is node row_base + r of the
+ *                           shard, columns < n_own are the shard's own nodes, columns >= n_own halo rows (lattice_n_own = 0:
+ *                           a whole graph; stencil detection then requires a square operator)
+ *     n_halo                rows of the halo panel that will be passed next to X: the long-row plan lays the hubs' scratch
+ *                           rows out directly behind them ([halo | hub rows], ndcn_csr_halo_panel)
+ *     row_order             [n_rows] walk order given by the caller (the view's row_order; also groups the records)
+ *     group_order / n_group_order   row ids (-1 = empty slot) in the order the records group them, e.g. a lattice's patches
+ *     rec_rows / rec_cap / rec_kib  != 0: build exactly this record shape and keep it whatever it covers (default: the
+ *                           shapes are tried and one is kept only if it holds >= 90 % of the entries and stages <= 3/4 of
+ *                           the rows a direct gather would fetch)
+ *     hub_threshold         > 0: rows longer than this leave the fused kernel; 0: automatic (the lowest of 32 / 64 / 128 that
+ *                           moves <= 5 % of the rows); < 0: no long-row plan
+ *     flags                 NDCN_PLAN_*
+ * Allocates the plans with hipMalloc (synchronises); every other call takes ndcn_csr_view(handle).  `stream` orders the
+ * plan kernels; the call returns after they have finished.                                                              */
+typedef struct ndcn_csr_handle ndcn_csr_handle;
+typedef struct ndcn_csr_hints {
+    int64_t        lattice_row_base, lattice_n_own;
+    int64_t        n_halo;
+    const int32_t *row_order;
+    const int32_t *group_order;
+    int64_t        n_group_order;
+    int32_t        rec_rows, rec_cap, rec_kib;
+    int32_t        hub_threshold;
+    uint32_t       flags;
+} ndcn_csr_hints;
+#define NDCN_PLAN_NO_REC            1u   /* no group-record plan                                                     */
+#define NDCN_PLAN_NO_STENCIL        2u   /* do not look for a lattice stencil (records group consecutive rows)        */
+#define NDCN_PLAN_NO_TILE_ORDER     4u   /* no tile walk order for the fused kernel                                   */
+#define NDCN_PLAN_NO_HUB            8u   /* no long-row plan                                                          */
+#define NDCN_PLAN_EXTERNAL_SCRATCH 16u   /* the caller provides the long-row plan's scratch (ndcn_csr_set_hub_scratch) */
+NDCN_API int ndcn_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colidx,
+                             const float *val, int H, const ndcn_csr_hints *hints, void *stream, ndcn_csr_handle **out);
+NDCN_API int ndcn_csr_destroy(ndcn_csr_handle *h);
+/* the struct every other entry point takes; valid until ndcn_csr_destroy */
+NDCN_API const ndcn_csr *ndcn_csr_view(const ndcn_csr_handle *h);
+/* h_out = {rec_rows, rec_cap, rec_kib, rec_groups, entries held by records, distinct columns staged by them, lattice stride
+ * (0: none), slots of the group order, hub_n, hub_nseg, hub threshold, hub_nnz, lt_nnz, n_halo, has tile order, H}     */
+NDCN_API int ndcn_csr_info(const ndcn_csr_handle *h, int64_t h_out[16]);
+/* the group order the records were built on when the library found it (a detected lattice): [info[7]] int32, or NULL    */
+NDCN_API const int32_t *ndcn_csr_group_order(const ndcn_csr_handle *h);
+/* long-row plan: the [n_halo + hub_n][H] buffer whose head receives the halo rows and whose tail holds the hubs' rows - pass
+ * it as X_halo (NULL without a long-row plan, or before ndcn_csr_set_hub_scratch under NDCN_PLAN_EXTERNAL_SCRATCH)        */
+NDCN_API float *ndcn_csr_halo_panel(const ndcn_csr_handle *h);
+/* NDCN_PLAN_EXTERNAL_SCRATCH: Sseg [hub_nseg][H] and halo_S [n_halo + hub_n][H], 16-byte aligned, owned by the caller     */
+NDCN_API int ndcn_csr_set_hub_scratch(ndcn_csr_handle *h, float *Sseg, float *halo_S);
 
 NDCN_API int         ndcn_abi_version(void);
 NDCN_API const char *ndcn_last_error(void);            /* thread-local, valid until the next failing call */

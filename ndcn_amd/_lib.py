@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
 
 OK = 0
@@ -44,6 +44,17 @@ class CsrView(ctypes.Structure):
                 ('hub_cmb_rowptr', ctypes.c_void_p), ('hub_cmb_colidx', ctypes.c_void_p), ('hub_cmb_val', ctypes.c_void_p),
                 ('lt_rowptr', ctypes.c_void_p), ('lt_colidx', ctypes.c_void_p), ('lt_val', ctypes.c_void_p),
                 ('hub_Sseg', ctypes.c_void_p), ('hub_S', ctypes.c_void_p)]
+
+
+class CsrHints(ctypes.Structure):
+    """struct ndcn_csr_hints"""
+    _fields_ = [('lattice_row_base', ctypes.c_int64), ('lattice_n_own', ctypes.c_int64), ('n_halo', ctypes.c_int64),
+                ('row_order', ctypes.c_void_p), ('group_order', ctypes.c_void_p), ('n_group_order', ctypes.c_int64),
+                ('rec_rows', ctypes.c_int32), ('rec_cap', ctypes.c_int32), ('rec_kib', ctypes.c_int32),
+                ('hub_threshold', ctypes.c_int32), ('flags', ctypes.c_uint32)]
+
+
+PLAN_NO_REC, PLAN_NO_STENCIL, PLAN_NO_TILE_ORDER, PLAN_NO_HUB, PLAN_EXTERNAL_SCRATCH = 1, 2, 4, 8, 16
 
 
 def empty_csr(n_rows):
@@ -80,6 +91,13 @@ SIGNATURES = {
     'ndcn_abi_version': (_I, []),
     'ndcn_last_error': (ctypes.c_char_p, []),
     'ndcn_device_info': (_I, [ctypes.POINTER(_L)]),
+    'ndcn_csr_create': (_I, [_L, _L, _L, _P, _P, _P, _I, ctypes.POINTER(CsrHints), _P, ctypes.POINTER(_P)]),
+    'ndcn_csr_destroy': (_I, [_P]),
+    'ndcn_csr_view': (_CSR, [_P]),
+    'ndcn_csr_info': (_I, [_P, ctypes.POINTER(_L)]),
+    'ndcn_csr_group_order': (_P, [_P]),
+    'ndcn_csr_halo_panel': (_P, [_P]),
+    'ndcn_csr_set_hub_scratch': (_I, [_P, _P, _P]),
     'ndcn_spmm_f32': (_I, [_CSR, _P, _P, _L, _P, _I, _F, _U, _P]),
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
     'ndcn_linear_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

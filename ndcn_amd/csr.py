@@ -216,7 +216,7 @@ class CsrOperator:
         if off.numel() > 25 or off.numel() == 0:
             return None
         off = off.cpu().numpy()
-        big = off[off > 2]
+        big = np.abs(off)[np.abs(off) > 2]      # (a boundary band of a shard may see only the lattice row ABOVE it among its own columns)
         if big.size == 0:
             return None
         # the smallest large offset is S - b_max with b_max <= 2: of the three strides that allows take the one that

@@ -119,13 +119,26 @@ int halo_exchange_f32(ndcn_halo_plan *p, const float *X, int H, float *d_pack, f
     }
     const int world = p->c->world;
     NDCN_NCCL(rccl().GroupStart());
-    for (int q = 0; q < world; ++q) {
-        if (p->send_counts[q] > 0)
-            NDCN_NCCL(rccl().Send(d_pack + p->send_off[q] * H, (size_t)(p->send_counts[q] * H), kNcclFloat32, q, p->c->comm, st));
-        if (p->recv_counts[q] > 0)
-            NDCN_NCCL(rccl().Recv(X_halo + p->recv_off[q] * H, (size_t)(p->recv_counts[q] * H), kNcclFloat32, q, p->c->comm, st));
+    // a failing Send / Recv must not leave the group open (every later RCCL call of this thread would join it): remember the
+    // first failure, close the group, then report
+    int bad = kNcclSuccess;
+    const char *what = "";
+    for (int q = 0; q < world && bad == kNcclSuccess; ++q) {
+        if (p->send_counts[q] > 0) {
+            bad = rccl().Send(d_pack + p->send_off[q] * H, (size_t)(p->send_counts[q] * H), kNcclFloat32, q, p->c->comm, st);
+            what = "ncclSend";
+        }
+        if (bad == kNcclSuccess && p->recv_counts[q] > 0) {
+            bad = rccl().Recv(X_halo + p->recv_off[q] * H, (size_t)(p->recv_counts[q] * H), kNcclFloat32, q, p->c->comm, st);
+            what = "ncclRecv";
+        }
     }
-    NDCN_NCCL(rccl().GroupEnd());
+    const int end = rccl().GroupEnd();
+    if (bad != kNcclSuccess) {
+        ndcn::set_error("%s: %s failed: %s", __func__, what, rccl().GetErrorString ? rccl().GetErrorString(bad) : "?");
+        return NDCN_EHIP;
+    }
+    NDCN_NCCL(end);
     return NDCN_OK;
 }
 

@@ -96,7 +96,15 @@ __device__ __forceinline__ void block_sum2(double &a, double &b) {
     }
 }
 
-constexpr int64_t kAtenNormMax = 1ll << 20;     // panels up to this many elements are reduced in ATen's float32 order
+// Panels up to this many elements are reduced in ATen's float32 order - the order of ONE torch CPU build: torch 2.10.0, x86-64
+// AVX2 kernels (8-lane vectors, 4 interleaved accumulators, the cascade sum of SumKernel.cpp), which is what the reference's
+// Python executed when the fixtures under tests/golden were captured; an AVX-512 dispatch or another torch version sums in
+// another order and these kernels would then match IT no better than any parallel reduction does.  The one-workgroup serial
+// form costs ~4 ns per element and lane group (2^18 elements: ~0.13 ms), so it is confined to the sizes where a last-bit
+// difference of the mean can flip an accept / reject decision and a reference run exists to compare with: 2^18 elements
+// covers every reference-sized solve (the README commands: 400 x 20; Cora 2708 x 64).  NDCN_ATEN_NORM_MAX=<elements> moves
+// the bound (0 or NDCN_ATEN_NORM=0: parallel fp64 reductions everywhere).
+constexpr int64_t kAtenNormMaxDefault = 1ll << 18;
 constexpr int kAtenBlock = 2048;
 
 __device__ __forceinline__ bool nonfinite(float v) { return !(fabsf(v) <= 3.402823466e38f); }
@@ -116,7 +124,7 @@ __device__ __forceinline__ float err_ratio_sq(float e, float a, float b, float r
 //   end the levels are added up (1, 2, 3 into 0), then the left-over vectors into ilp slot 0, the ilp slots 1..3 into slot
 //   0, and finally: the n % 8 tail elements, then the 8 lanes, left to right, starting from 0.
 // dopri5's accept / reject decision compares that mean with 1; at rtol 1e-7 the ratios sit close enough to 1 for the
-// last bit to matter, so panels up to kAtenNormMax elements are reduced in exactly this order (one workgroup: all threads
+// last bit to matter, so panels up to aten_order_max_elems() elements are reduced in exactly this order (one workgroup: all threads
 // form r^2 of a 2048-element chunk in LDS, 32 lanes of the first wave run the cascade); larger panels keep the parallel
 // fp64 reduction, as do the error records formed inside the fused right-hand sides.
 __global__ __launch_bounds__(256) void rk_error_aten_kernel(const float *__restrict__ y0, const float *__restrict__ y1, Terms t,
@@ -227,7 +235,7 @@ __device__ __forceinline__ float scaled_sq(float a, float b, float y, float rtol
 // lane j owns elements j, j + 8, j + 16, ... and accumulates acc_j = fma(q, q, acc_j) in index order - added up left to
 // right, then the n % 8 tail elements with fma.  The reference's initial step (misc.py:121-138) takes three such norms; at
 // rtol 1e-7 a 1-ulp difference there reshuffles later accept / reject decisions (the error estimate is then a cancellation
-// of O(1e-9) terms), so for panels up to kAtenNormMax elements the sum is formed in exactly that order: one workgroup,
+// of O(1e-9) terms), so for panels up to aten_order_max_elems() elements the sum is formed in exactly that order: one workgroup,
 // q = (a - b) / scale computed by all threads into LDS, then 8 lanes walk their chains.  Larger panels keep the parallel
 // fp64 reduction (8 sequential chains over 10^8 elements would take tens of milliseconds per norm).
 template <bool HASB>
@@ -614,8 +622,15 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
 }
 
 int64_t aten_order_max_elems() {
-    static const bool on = [] { const char *e = getenv("NDCN_ATEN_NORM"); return !(e && e[0] == '0'); }();
-    return on ? kAtenNormMax : 0;
+    static const int64_t bound = []() -> int64_t {
+        const char *e = getenv("NDCN_ATEN_NORM");
+        if (e && e[0] == '0') return (int64_t)0;
+        const char *m = getenv("NDCN_ATEN_NORM_MAX");
+        const int64_t v = m ? atoll(m) : kAtenNormMaxDefault;
+        const int64_t cap = (int64_t)1 << 24;
+        return v < 0 ? (int64_t)0 : (v > cap ? cap : v);
+    }();
+    return bound;
 }
 
 int64_t rhs_fused2_partials_bytes();
@@ -637,8 +652,7 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
     t.dt_dev = dt_dev;
     bool vec = (n % 4 == 0) && aligned16(y0) && aligned16(y1);
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_error: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
-    static const bool aten_order = [] { const char *e = getenv("NDCN_ATEN_NORM"); return !(e && e[0] == '0'); }();
-    if (aten_order && n >= 8 && n <= kAtenNormMax) {
+    if (n >= 8 && n <= aten_order_max_elems()) {
         ProfScope prof(PROF_ERROR, st, 4.0 * n * (n_k + 2), 2.0 * n * (n_k + 4));
         hipLaunchKernelGGL(rk_error_aten_kernel, dim3(1), dim3(256), 0, st, y0, y1, t, rtol, atol, n, d_out, accum);
         NDCN_LAUNCH_CHECK();
@@ -657,8 +671,7 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
 
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st) {
-    static const bool aten_order = [] { const char *e = getenv("NDCN_ATEN_NORM"); return !(e && e[0] == '0'); }();
-    if (aten_order && n > 0 && n <= kAtenNormMax) {
+    if (n > 0 && n <= aten_order_max_elems()) {
         ProfScope prof(PROF_SUMSQ, st, 4.0 * n * (b ? 3 : 2), 6.0 * n);
         if (b) hipLaunchKernelGGL(scaled_sumsq_aten_kernel<true>, dim3(1), dim3(256), 0, st, a, b, y, rtol, atol, n, d_out);
         else hipLaunchKernelGGL(scaled_sumsq_aten_kernel<false>, dim3(1), dim3(256), 0, st, a, b, y, rtol, atol, n, d_out);

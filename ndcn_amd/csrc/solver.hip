@@ -678,10 +678,21 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
                 if (n_idx <= 0 || !d_idx) return NDCN_OK;
                 std::vector<int32_t> h((size_t)n_idx);
                 NDCN_HIP(hipMemcpy(h.data(), d_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyDeviceToHost));
-                int64_t lo = -1, hi = -1;
+                // the own rows an index list touches, as bands: sorted, cut wherever two neighbours lie more than a few lattice
+                // rows apart.  (An interior rank's send list holds rows at BOTH ends of the shard - for the upper and the
+                // lower neighbour: one [min, max] range would cover the whole shard and turn the thin combine into a full pass.)
+                std::vector<int32_t> own;
+                own.reserve(h.size());
                 for (int32_t c : h)
-                    if (c >= 0 && c < s->n_own) { lo = lo < 0 || c < lo ? c : lo; hi = c > hi ? c : hi; }
-                if (lo >= 0) rs.emplace_back(lo, hi + 1);
+                    if (c >= 0 && c < s->n_own) own.push_back(c);
+                std::sort(own.begin(), own.end());
+                const int64_t gap = 8192;
+                for (size_t i = 0; i < own.size();) {
+                    size_t j = i;
+                    while (j + 1 < own.size() && (int64_t)own[j + 1] - own[j] <= gap) ++j;
+                    rs.emplace_back((int64_t)own[i], (int64_t)own[j] + 1);
+                    i = j + 1;
+                }
                 return NDCN_OK;
             };
             int rcx = add_range(halo_plan_send_idx(s->shard.halo), s->n_send);
@@ -700,6 +711,11 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
             // every interior block must be able to form the input itself
             for (int b = 0; b < s->shard.n_blocks; ++b)
                 if (!s->shard.blocks[b].needs_halo && !rhs_xadd_supported(&s->shard.blocks[b].A, desc->H, desc->rhs_flags, 1, 1)) s->xadd_block = -1;
+            // bands that add up to most of the shard: the combine launch over the whole panel is cheaper than the gather
+            // inside the interior launch plus a near-full band pass
+            int64_t covered = 0;
+            for (const auto &r : s->xadd_ranges) covered += r.second - r.first;
+            if (2 * covered > s->n_own) { s->xadd_block = -1; s->xadd_ranges.clear(); }
         }
     }
     if (workspace) {

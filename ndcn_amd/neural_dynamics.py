@@ -54,51 +54,44 @@ class ODEFunc(nn.Module):
         return hip.rhs(self.A, x, self.wt.weight, self.wt.bias, no_graph=self.no_graph, no_control=self.no_control)
 
 
-class ODEBlock(nn.Module):
-    """reference neural_dynamics.py:42-79."""
+class _OdeBlock(nn.Module):
+    """What the reference's two block classes share (neural_dynamics.py:42-119): a right-hand side module held as
+    `.odefunc` (the state_dict prefix `odefunc.`), the solver settings as plain attributes, and one solve per forward -
+    `odeint_adjoint` when `adjoint` is set, the whole trajectory or its last tick."""
+
+    def _configure(self, odefunc, rtol, atol, method, adjoint, terminal):
+        self.odefunc = odefunc
+        self.rtol, self.atol, self.method = rtol, atol, method
+        self.adjoint, self.terminal = adjoint, terminal
+
+    def _solve(self, x, vt):
+        solve = ode.odeint_adjoint if self.adjoint else ode.odeint
+        out = solve(self.odefunc, x, vt.type_as(x), rtol=self.rtol, atol=self.atol, method=self.method)
+        return out[-1] if self.terminal else out
+
+
+class ODEBlock(_OdeBlock):
+    """forward(vt, x): the time vector arrives with every call (neural_dynamics.py:42-79; NDCN's block)."""
 
     def __init__(self, odefunc, rtol=.01, atol=.001, method='dopri5', adjoint=False, terminal=False):
-        super(ODEBlock, self).__init__()
-        self.odefunc = odefunc
-        self.rtol = rtol
-        self.atol = atol
-        self.method = method
-        self.adjoint = adjoint
-        self.terminal = terminal
+        super().__init__()
+        self._configure(odefunc, rtol, atol, method, adjoint, terminal)
 
     def forward(self, vt, x):
-        integration_time_vector = vt.type_as(x)
-        if self.adjoint:
-            out = ode.odeint_adjoint(self.odefunc, x, integration_time_vector,
-                                     rtol=self.rtol, atol=self.atol, method=self.method)
-        else:
-            out = ode.odeint(self.odefunc, x, integration_time_vector,
-                             rtol=self.rtol, atol=self.atol, method=self.method)
-        return out[-1] if self.terminal else out
+        return self._solve(x, vt)
 
 
-class ODEBlock2(nn.Module):
-    """reference neural_dynamics.py:82-119 (the time vector is fixed at construction)."""
+class ODEBlock2(_OdeBlock):
+    """forward(x): the time vector is fixed at construction as `.integration_time_vector` - a plain attribute, not a
+    buffer, so `.to(device)` leaves it where the caller put it (neural_dynamics.py:82-119; dgnn.py's Sequential)."""
 
     def __init__(self, odefunc, vt, rtol=.01, atol=.001, method='dopri5', adjoint=False, terminal=False):
-        super(ODEBlock2, self).__init__()
-        self.odefunc = odefunc
+        super().__init__()
+        self._configure(odefunc, rtol, atol, method, adjoint, terminal)
         self.integration_time_vector = vt
-        self.rtol = rtol
-        self.atol = atol
-        self.method = method
-        self.adjoint = adjoint
-        self.terminal = terminal
 
     def forward(self, x):
-        integration_time_vector = self.integration_time_vector.type_as(x)
-        if self.adjoint:
-            out = ode.odeint_adjoint(self.odefunc, x, integration_time_vector,
-                                     rtol=self.rtol, atol=self.atol, method=self.method)
-        else:
-            out = ode.odeint(self.odefunc, x, integration_time_vector,
-                             rtol=self.rtol, atol=self.atol, method=self.method)
-        return out[-1] if self.terminal else out
+        return self._solve(x, self.integration_time_vector)
 
 
 class _HipLinear(nn.Linear):
@@ -112,37 +105,28 @@ class _HipLinear(nn.Linear):
 
 
 class NDCN(nn.Module):
-    """encoder -> graph ODE -> decoder   -- reference neural_dynamics.py:122-160."""
+    """encoder -> graph ODE -> decoder   -- reference neural_dynamics.py:122-160.  Submodule names (and with them the
+    state_dict keys input_layer.{0,2}.*, neural_dynamic_layer.odefunc.wt.*, output_layer.*) and the constructor's
+    arguments, kept as attributes, are the contract; the three Linears run on the MFMA kernel."""
 
     def __init__(self, input_size, hidden_size, A, num_classes, dropout=0.0,
                  no_embed=False, no_graph=False, no_control=False,
                  rtol=.01, atol=.001, method='dopri5'):
-        super(NDCN, self).__init__()
-        self.input_size = input_size
-        self.hidden_size = hidden_size
-        self.A = A
-        self.num_classes = num_classes
-        self.dropout = dropout
+        super().__init__()
+        for name, value in (('input_size', input_size), ('hidden_size', hidden_size), ('A', A), ('num_classes', num_classes),
+                            ('dropout', dropout), ('no_embed', no_embed), ('no_graph', no_graph), ('no_control', no_control),
+                            ('rtol', rtol), ('atol', atol), ('method', method)):
+            setattr(self, name, value)
         self.dropout_layer = nn.Dropout(dropout)
-        self.no_embed = no_embed
-        self.no_graph = no_graph
-        self.no_control = no_control
-        self.rtol = rtol
-        self.atol = atol
-        self.method = method
-        self.input_layer = nn.Sequential(_HipLinear(input_size, hidden_size, bias=True), nn.Tanh(),
-                                         _HipLinear(hidden_size, hidden_size, bias=True))
-        self.neural_dynamic_layer = ODEBlock(
-            ODEFunc(hidden_size, A, dropout=dropout, no_graph=no_graph, no_control=no_control),
-            rtol=rtol, atol=atol, method=method)
-        self.output_layer = _HipLinear(hidden_size, num_classes, bias=True)
+        # construction order = parameter order = the order nn.Linear draws its initial weights in (seeded parity)
+        self.input_layer = nn.Sequential(_HipLinear(input_size, hidden_size), nn.Tanh(), _HipLinear(hidden_size, hidden_size))
+        func = ODEFunc(hidden_size, A, dropout=dropout, no_graph=no_graph, no_control=no_control)
+        self.neural_dynamic_layer = ODEBlock(func, rtol=rtol, atol=atol, method=method)
+        self.output_layer = _HipLinear(hidden_size, num_classes)
 
     def forward(self, vt, x):
-        if not self.no_embed:
-            x = self.input_layer(x)
-        hvx = self.neural_dynamic_layer(vt, x)
-        output = self.output_layer(hvx)
-        return output
+        h = x if self.no_embed else self.input_layer(x)
+        return self.output_layer(self.neural_dynamic_layer(vt, h))
 
 
 class GraphConvolution(nn.Module):

@@ -64,6 +64,19 @@ class _Reducer:
         return float(self.host[0]), float(self.host[1])
 
 
+class ErrorRecord:
+    """A caller-owned {sum of squared error ratios, non-finite count} record: two doubles on the device + a pinned host
+    mirror.  An error evaluation that is split into several launches (row blocks of a shard: NDCN_F_ACCUM) accumulates
+    into ITS OWN record - the per-device one of _Reducer is shared with every other reduction of the process, and the
+    lock is released between the launches of a split."""
+
+    def __init__(self, device):
+        self.out = torch.zeros(2, dtype=torch.float64, device=device)
+        self.host = torch.zeros(2, dtype=torch.float64).pin_memory()
+
+    fetch = _Reducer.fetch
+
+
 class _PackedWeights:
     """The fused H = 256 kernels read W in a packed, split form that ndcn_rhs_f32 / ndcn_rhs_rk_f32 build in their
     scratch at every call (two small launches in front of the big one).  A solver calls them thousands of times with
@@ -265,8 +278,10 @@ class HipOps:
 
     @staticmethod
     def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None, record=None):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
+        record (mode 'error'): an ErrorRecord of the caller's that receives / accumulates the result instead of the
+        per-device one (split evaluations: new_error_record()).
         mode 'combine': returns (K, y0 + sum cs[m] kprev[m] + cs[-1] K); mode 'error': returns
         (K, (sum of squared error ratios, non-finite count of X)) - the dopri5 error record with X = y1;
         mode 'rk4': stage len(kprev) of the 3/8-rule step, cs = [dt]: returns (K, next stage input / step result).
@@ -324,12 +339,16 @@ class HipOps:
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                       ptr(None if no_control else b), ptr(K), ptr(work), H, flags, rk, ptr(y0), arr_k,
                                       arr_c, len(kprev), ptr(y_next), ptr(y1), ptr(y_aux), arr_c2, float(rtol), float(atol),
-                                      ptr(red.out), ptr(red.ws), stream_ptr()))
+                                      ptr((record or red).out), ptr(red.ws), stream_ptr()))
             if aux_cs is not None:
                 return K, y_next, y_aux
             if mode in ('combine', 'rk4'):
                 return K, y_next
-            return K, (red.fetch() if fetch else None)
+            return K, ((record or red).fetch() if fetch else None)
+
+    @staticmethod
+    def new_error_record(device):
+        return ErrorRecord(device)
 
     @staticmethod
     def rhs_rk_xadd(A, X, xadd, xadd_c, W, b, y0, k_prev, cs):

@@ -207,6 +207,7 @@ class ShardedODEFunc(nn.Module):
         self.overlap = overlap and plan.ranges is not None
         self.two_phase = overlap and plan.two_phase is not None
         self.comm = None                  # side stream of the exchange (created on first use, CUDA only)
+        self._err_record = None           # this function's own error record (split launches accumulate into it)
         self.timing = None                # when a dict: accumulates {exchange_us, interior_us, exposed_us, n}
 
     # -- exchange on the side stream; returns (halo, event-or-None)
@@ -322,9 +323,11 @@ class ShardedODEFunc(nn.Module):
 
             def call(op, halo, a, b, first, last):
                 if mode == 'error':
+                    if self._err_record is None:
+                        self._err_record = self.ops.new_error_record(x.device)
                     return self.ops.rhs_rk(op, x, W, bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
                                            no_control=f.no_control, X_halo=halo, out_K=k[a:b], y1=x[a:b], accum=not first,
-                                           fetch=last)[1]
+                                           fetch=last, record=self._err_record)[1]
                 self.ops.rhs_rk(op, x, W, bias, mode, y0[a:b], [kp[a:b] for kp in kprev], cs, rtol, atol,
                                 no_control=f.no_control, X_halo=halo, out_K=k[a:b], out_y=y_next[a:b], **akw(a, b))
             out = self._split_eval(x, call)
@@ -389,8 +392,10 @@ class DistOps:
 
 
 def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, atol=1e-9, method='dopri5', step_log=None,
-                   group=None, fused=True):
-    """odeint on this rank's rows of the global system; returns (len(t), n_local, H)."""
+                   group=None, fused=True, stats=None):
+    """odeint on this rank's rows of the global system; returns (len(t), n_local, H).
+    stats (a dict, optional) receives which evaluation form ran and what travelled: {'form': 'row_split' | 'two_phase' |
+    'one_launch', 'nfe', 'halo_bytes' (sent + received over the solve), 'halo_rows_received_per_rhs'}."""
     from .torchdiffeq._impl import core
     f = ShardedODEFunc(odefunc, plan, ops)
     dops = DistOps(ops, n_global_rows, x_local.shape[0], group)
@@ -403,6 +408,9 @@ def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, ato
                                     fused=f if (fused and not decreasing) else None)
     else:
         sol = core.integrate_fixed(dops, func, y0, tt, method, autonomous=True)
+    if stats is not None:
+        stats.update(form='row_split' if f.overlap else 'two_phase' if f.two_phase else 'one_launch', nfe=f.nfe,
+                     halo_bytes=f.halo_bytes, halo_rows_received_per_rhs=plan.n_halo)
     return torch.stack([s[0] for s in sol])
 
 
@@ -420,15 +428,21 @@ class DeviceShard:
         self.lib = lib = _lib.load()
         self.n_global_rows = int(n_global_rows)
         dev = plan.device
-        # communicator: rank 0 draws the id, everybody learns it over the caller's process group
+        # communicator: rank 0 draws the id, everybody learns it over the caller's process group.  Every rank reaches the
+        # broadcast whatever happened before it (a rank that raised earlier would leave its peers waiting in it): rank 0's
+        # failure travels as an all-zero id with a set flag byte, and then every rank raises together.
         idbuf = ctypes.create_string_buffer(128)
-        if plan.rank == 0:
-            _lib.check(lib.ndcn_comm_unique_id(idbuf))
+        rc0 = lib.ndcn_comm_unique_id(idbuf) if plan.rank == 0 else 0
         if plan.world > 1:
             comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-            t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=comm_dev)
+            t = torch.tensor(list(idbuf.raw) + [1 if rc0 != 0 else 0], dtype=torch.uint8, device=comm_dev)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            idbuf = ctypes.create_string_buffer(bytes(t.cpu().tolist()), 128)
+            raw = bytes(t.cpu().tolist())
+            if raw[128]:
+                raise _lib.NdcnHipError(_lib.EHIP, 'rank 0 could not draw an RCCL unique id')
+            idbuf = ctypes.create_string_buffer(raw[:128], 128)
+        else:
+            _lib.check(rc0)
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(dev):
             _lib.check(lib.ndcn_comm_create(idbuf, plan.world, plan.rank, ctypes.byref(self.comm)))
@@ -492,12 +506,11 @@ class ShardedDeviceBench:
     """bench.py's N > 1 workload on the device-resident sharded solver (the production form over RCCL): the counterpart of
     ShardedBench without Python between the evaluations."""
 
-    def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, group=None):
+    def __init__(self, odefunc, block, bounds, rank, device, T, rtol, atol, group=None, plan=None):
         from .torchdiffeq._impl.odeint import DeviceSolver
         self.args = (odefunc, bounds, rank, device, T, rtol, atol, group)
         n_local = int(bounds[rank + 1] - bounds[rank])
-        sh = os.environ.get('NDCN_SELF_HALO', '0')
-        self.plan = HaloPlan(block, bounds, rank, device, group, self_halo=sh if sh.startswith('scatter:') else int(sh))
+        self.plan = plan if plan is not None else bench_plan(block, bounds, rank, device, group)
         self.local_nnz = self.plan.local_nnz
         self.shard = DeviceShard(self.plan, int(bounds[-1]), group)
         self.solver = DeviceSolver(odefunc, n_local, 'dopri5', rtol, atol, shard=self.shard)
@@ -528,6 +541,24 @@ class ShardedDeviceBench:
         return ShardedBench(odefunc, None, bounds, rank, device, T, rtol, atol, group=group, plan=self.plan)
 
 
+def bench_plan(block, bounds, rank, device, group=None):
+    """The HaloPlan of a bench shard (collective on `group`: every rank builds its plan at the same time), honouring the
+    NDCN_SELF_HALO test hook."""
+    sh = os.environ.get('NDCN_SELF_HALO', '0')
+    return HaloPlan(block, bounds, rank, device, group, self_halo=sh if sh.startswith('scatter:') else int(sh))
+
+
+def rccl_usable():
+    """A rank-LOCAL fact (no collective): can this process bind librccl and draw a unique id?  What bench.py all-reduces
+    before any rank enters a collective of the device-resident sharded path."""
+    import ctypes
+    from . import _lib
+    try:
+        return _lib.load().ndcn_comm_unique_id(ctypes.create_string_buffer(128)) == 0
+    except Exception:
+        return False
+
+
 def grid_row_block(S, world, rank):
     """(row block, bounds) of the metric's weak-scaling grid: the (S * world) x S lattice, rank r owns lattice rows
     [r S, (r + 1) S) and builds only its own rows."""
@@ -544,9 +575,7 @@ class ShardedBench:
         if ops is None:
             from .ops import hip as ops
         n_local = int(bounds[rank + 1] - bounds[rank])
-        sh = os.environ.get('NDCN_SELF_HALO', '0')
-        self.plan = plan if plan is not None else HaloPlan(block, bounds, rank, device, group,
-                                                           self_halo=sh if sh.startswith('scatter:') else int(sh))
+        self.plan = plan if plan is not None else bench_plan(block, bounds, rank, device, group)
         self.local_nnz = self.plan.local_nnz
         self.func = ShardedODEFunc(odefunc, self.plan, ops)
         self.dops = DistOps(ops, int(bounds[-1]), n_local, group)

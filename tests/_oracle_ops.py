@@ -66,7 +66,7 @@ class OracleOps:
 
     @classmethod
     def rhs_rk(cls, A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None, record=None):
         k = cls.rhs(A, X, W, b, no_graph=no_graph, no_control=no_control, X_halo=X_halo)
         ks = list(kprev) + [k]
         if out_K is not None:
@@ -87,8 +87,13 @@ class OracleOps:
                 out_y.copy_(y)
             return k, y
         s, bad = cls.error(y0, X if y1 is None else y1, ks, cs, rtol, atol)
-        cls._record = [cls._record[0] + s, cls._record[1] + bad] if accum else [s, bad]
-        return k, (tuple(cls._record) if fetch else None)
+        rec = record if record is not None else cls._record
+        rec[:] = [rec[0] + s, rec[1] + bad] if accum else [s, bad]
+        return k, (tuple(rec) if fetch else None)
+
+    @staticmethod
+    def new_error_record(device):
+        return [0.0, 0.0]
 
     @staticmethod
     def scale(x, w):

@@ -211,7 +211,7 @@ sharded)
   tail -6 gpurun_out/pytest_sharded.log | cut -c1-300
   for spec in "M 0" "M 2000" "C4 0" "C4 scatter:200000"; do
     set -- $spec
-    NDCN_SELF_HALO=$2 timeout 900 python bench.py --gpus 1 --sharded --config $1 --steps 10 --warmup 2 --no-cpu-baseline 2> gpurun_out/bench_sharded_$1_${2/:/_}.err | grep '^{"metric' > gpurun_out/${R}_bench_sharded_$1_${2/:/_}.json
+    NDCN_SELF_HALO=$2 timeout 900 python bench.py --gpus 1 --sharded --sharded-impl device --config $1 --steps 10 --warmup 2 --no-cpu-baseline 2> gpurun_out/bench_sharded_$1_${2/:/_}.err | grep '^{"metric' > gpurun_out/${R}_bench_sharded_$1_${2/:/_}.json
     python -c "import json; d=json.load(open('gpurun_out/${R}_bench_sharded_$1_${2/:/_}.json')); print('$1 self_halo $2', d['ms_per_step'], d['halo_exchange'])"
     tail -2 gpurun_out/bench_sharded_$1_${2/:/_}.err | cut -c1-200
   done

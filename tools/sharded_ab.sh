@@ -16,5 +16,5 @@ for r in (csv.DictReader(open(fs[0])) if fs else []):
 PY
 }
 FLAGS="" run single X=0
-FLAGS="--gpus 1 --sharded" run sharded0 NDCN_SELF_HALO=0
-FLAGS="--gpus 1 --sharded" run sharded2000 NDCN_SELF_HALO=2000
+FLAGS="--gpus 1 --sharded --sharded-impl device" run sharded0 NDCN_SELF_HALO=0
+FLAGS="--gpus 1 --sharded --sharded-impl device" run sharded2000 NDCN_SELF_HALO=2000
