@@ -151,6 +151,7 @@ typedef struct ndcn_csr_hints {
 #define NDCN_PLAN_NO_TILE_ORDER     4u   /* no tile walk order for the fused kernel                                   */
 #define NDCN_PLAN_NO_HUB            8u   /* no long-row plan                                                          */
 #define NDCN_PLAN_EXTERNAL_SCRATCH 16u   /* the caller provides the long-row plan's scratch (ndcn_csr_set_hub_scratch) */
+#define NDCN_PLAN_ORDER_ONLY       32u   /* lattice detection and walk orders only, no records                        */
 NDCN_API int ndcn_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colidx,
                              const float *val, int H, const ndcn_csr_hints *hints, void *stream, ndcn_csr_handle **out);
 NDCN_API int ndcn_csr_destroy(ndcn_csr_handle *h);

@@ -54,7 +54,7 @@ class CsrHints(ctypes.Structure):
                 ('hub_threshold', ctypes.c_int32), ('flags', ctypes.c_uint32)]
 
 
-PLAN_NO_REC, PLAN_NO_STENCIL, PLAN_NO_TILE_ORDER, PLAN_NO_HUB, PLAN_EXTERNAL_SCRATCH = 1, 2, 4, 8, 16
+PLAN_NO_REC, PLAN_NO_STENCIL, PLAN_NO_TILE_ORDER, PLAN_NO_HUB, PLAN_EXTERNAL_SCRATCH, PLAN_ORDER_ONLY = 1, 2, 4, 8, 16, 32
 
 
 def empty_csr(n_rows):

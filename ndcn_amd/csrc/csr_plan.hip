@@ -568,7 +568,8 @@ int csr_create(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream
         if ((rc = choose_hub_threshold(h, hi.hub_threshold, &thr, st))) return rc;
         if (thr > 0 && (rc = build_hub_plan(h, H, thr, hi.flags & NDCN_PLAN_EXTERNAL_SCRATCH, st))) return rc;
     }
-    if ((hi.flags & NDCN_PLAN_NO_REC) || env_off("NDCN_REC_PLAN") || A.nnz == 0) return NDCN_OK;
+    const bool order_only = hi.flags & NDCN_PLAN_ORDER_ONLY;
+    if (A.nnz == 0 || (!order_only && ((hi.flags & NDCN_PLAN_NO_REC) || env_off("NDCN_REC_PLAN")))) return NDCN_OK;
     // ---- walk order: the caller's, or the patches of a detected lattice
     const int32_t *order = nullptr;
     int64_t M = A.n_rows;
@@ -588,6 +589,7 @@ int csr_create(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream
                 return rc;
         }
     }
+    if (order_only) return NDCN_OK;
     // ---- record shapes: with a walk order the lattice shapes; without, 8 consecutive rows with a 32-column list, or -
     // when that covers too few groups (ring neighbours + random shortcuts reference ~28 distinct columns) - 48.  A shape is
     // kept when it covers the operator and stages clearly fewer rows than a direct gather fetches.

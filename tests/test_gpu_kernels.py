@@ -935,7 +935,8 @@ def test_first_generation_fused_kernel_still_serves_as_fallback(dev):
 
 def test_integration_stub_runs(dev):
     """the ~40-line ctypes stub a reference maintainer would add (examples/ndcn_hip_binding.py,
-    no ndcn_amd import) against the reference's own expression on a torch COO operator."""
+    no ndcn_amd import: ndcn_csr_create on the arrays of a torch COO operator, then ndcn_rhs_f32 on the handle's view)
+    against the reference's own output on the 20 x 20 grid - and it must reach rhs_fused3 at H = 256."""
     import importlib.util
     from ndcn_amd import _lib
     os.environ['NDCN_HIP_LIB'] = _lib.LIB_PATH
@@ -944,13 +945,15 @@ def test_integration_stub_runs(dev):
     spec.loader.exec_module(stub)
     d = load_golden('rhs_grid400_H256_default_coo')
     A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape']).to(dev)
-    csr, keep = stub.to_csr(A)
-    out = stub.odefunc_forward(csr, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev))
+    op = stub.Operator(A, 256)
+    out = stub.odefunc_forward(op, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev))
     assert np.abs(out.cpu().numpy() - d['out']).max() <= 2e-5
+    # the handle built the lattice's group-record plan inside the library: the binding lands on the kernel the bench times
+    assert stub.last_rhs_path() == 2                                       # NDCN_PATH_FUSED3
     d = load_golden('rhs_grid400_H20_no_control_coo')
     A = orc.coo_from_csr(d['indptr'], d['indices'], d['data'], d['shape']).to(dev)
-    csr, keep = stub.to_csr(A)
-    out = stub.odefunc_forward(csr, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev), no_control=True)
+    op = stub.Operator(A, 20)
+    out = stub.odefunc_forward(op, T(d['x']).to(dev), T(d['W']).to(dev), T(d['b']).to(dev), no_control=True)
     assert np.abs(out.cpu().numpy() - d['out']).max() <= 2e-5
 
 
@@ -1002,7 +1005,8 @@ def test_reductions(dev, n):
     # the float32 NORM (the square root of the sum) must equal torch's bit for bit in that range: the kernel adds up in
     # ATen's order (8 fma chains, then the tail)
     nrm = lambda v: np.float32(np.sqrt(v))
-    same = (lambda u, v: u == v) if n <= (1 << 18) else (lambda u, v: abs(float(u) - float(v)) <= 2e-6 * abs(float(v)))
+    # (beyond the range the kernel sums in fp64; torch's own float32 chains are then the less accurate side: ~1e-5 at 10^6 terms)
+    same = (lambda u, v: u == v) if n <= (1 << 18) else (lambda u, v: abs(float(u) - float(v)) <= 1e-4 * abs(float(v)))
     s, bad = hip.scaled_sumsq(g(a), g(b), g(y0), 1e-2, 1e-3)
     q = (a - b) / (np.float32(1e-3) + torch.abs(y0) * np.float32(1e-2))
     assert same(nrm(s), np.float32(q.norm().item()))

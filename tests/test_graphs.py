@@ -106,11 +106,20 @@ def _decode_rec(A):
 
 
 def test_group_record_plan_reconstructs_the_operator():
-    """CsrOperator.build_rec_plan (include/ndcn_hip.h, ndcn_csr::rec): every row appears once, staged rows decode to
-    their CSR entries, groups that do not fit are flagged; lattice detection yields whole patches."""
+    """The plan restatement the GPU plan tests compare the library with (tests/_plan_reference.py; the layout of
+    include/ndcn_hip.h, ndcn_csr::rec): every row appears once, staged rows decode to their CSR entries, groups that do
+    not fit are flagged; lattice detection yields whole patches."""
     import torch
-    from ndcn_amd import CsrOperator
+    from ndcn_amd import CsrOperator as _Csr
+    from _plan_reference import PlanReference
     import scipy.sparse as sp
+
+    class CsrOperator:
+        REC_SHAPES = _Csr.REC_SHAPES
+
+        @staticmethod
+        def from_scipy(m):
+            return PlanReference.of(_Csr.from_scipy(m))
     rng = np.random.RandomState(0)
     grid = graphs.normalized_laplacian(graphs.grid_8_neighbor(37))          # side not a multiple of the patch
     rnd = sp.random(1369, 1369, density=0.01, random_state=rng, format='csr', dtype=np.float32)
