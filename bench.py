@@ -98,6 +98,9 @@ def parse():
     p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
     p.add_argument('--no-control', action='store_true', help='config M with ODEFunc(no_control=True): relu(A X), the pure HBM right-hand side (neural_dynamics.py:32)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')
+    p.add_argument('--method', default='dopri5', choices=['dopri5', 'euler', 'rk4'],
+                   help='config M: the integrator (dopri5 = the judged line; euler - the reference drivers\' default, heat_dynamics.py:20-22 - '
+                        'and rk4 step along t = linspace(0, T, 100), heat_dynamics.py:35,123)')
     p.add_argument('--cpu-runs', type=int, default=5, help='timed solves of the CPU-baseline leg (after two warm-ups; BASELINE.md section 3)')
     return p.parse_args()
 
@@ -153,14 +156,20 @@ class SingleGpuRunner:
 CPU_SAMPLE = {'M': 128 * 128, 'NC': 128 * 128, 'C2': 8000, 'C3': 16000, 'C4': 16000, 'C5': 0}
 
 
+FIXED_GRID_METHOD = None         # set by main(): config M with --method euler / rk4
+
+
 def cpu_workload(cfg, H, n, T):
     """(operator as scipy CSR, no_control, method, ticks, description) of configuration cfg at n nodes - the same
     generators, seeds and solver settings as build_workload."""
     from ndcn_amd import graphs
     if cfg in ('M', 'NC'):
         side = int(round(n ** 0.5))
-        return (graphs.normalized_laplacian(graphs.grid_8_neighbor(side)), cfg == 'NC', 'dopri5', [0., T],
-                '%dx%d grid' % (side, side))
+        L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+        if FIXED_GRID_METHOD:
+            return (L, cfg == 'NC', FIXED_GRID_METHOD, torch.linspace(0., T, 100)[:21].tolist(),
+                    '%dx%d grid, the first 20 of the 99 %s steps' % (side, side, FIXED_GRID_METHOD))
+        return L, cfg == 'NC', 'dopri5', [0., T], '%dx%d grid' % (side, side)
     if cfg == 'C2':
         return (graphs.normalized_laplacian(graphs.make_graph('random', n, seed=0)), False, 'rk4',
                 torch.linspace(0., 5., 100)[:21].tolist(), 'G(n,p) n=%d mean degree 39.9, the first 20 of the 99 RK4 steps' % n)
@@ -302,10 +311,19 @@ def build_workload(args, dev):
         L = graphs.normalized_laplacian(graphs.grid_8_neighbor(S))
         A = graphs.to_device(L, dev)
         f = ODEFunc(H, A, no_control=args.no_control).to(dev).eval()
-        kw = dict(T=args.T, rtol=args.rtol, atol=args.atol, method='dopri5')
-        what = (('NDCN ODEFunc(no_control) relu(AX)' if args.no_control else 'NDCN ODEFunc relu(W(AX)+b)') + ', %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR '
-                'nnz=%d per GPU, H=%d, dopri5 rtol=%g atol=%g t in [0,%g]' % (S, S, S * S, L.nnz, H, args.rtol, args.atol, args.T))
-        step = 'one attempted dopri5 step (6 RHS evals + stage algebra + error norm + controller)'
+        name = ('NDCN ODEFunc(no_control) relu(AX)' if args.no_control else 'NDCN ODEFunc relu(W(AX)+b)')
+        if args.method == 'dopri5':
+            kw = dict(T=args.T, rtol=args.rtol, atol=args.atol, method='dopri5')
+            what = (name + ', %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR '
+                    'nnz=%d per GPU, H=%d, dopri5 rtol=%g atol=%g t in [0,%g]' % (S, S, S * S, L.nnz, H, args.rtol, args.atol, args.T))
+            step = 'one attempted dopri5 step (6 RHS evals + stage algebra + error norm + controller)'
+        else:
+            kw = dict(T=args.T, rtol=args.rtol, atol=args.atol, method=args.method, ticks=torch.linspace(0., args.T, 100).tolist())
+            what = (name + ', %dx%d 8-neighbour grid per GPU (N=%d nodes total), normalised-Laplacian CSR nnz=%d per GPU, H=%d, '
+                    'fixed-step %s on t = linspace(0,%g,100) (heat_dynamics.py:35,123)'
+                    % (S, S, S * S, L.nnz, H, {'euler': 'Euler (the reference drivers\' default method)', 'rk4': 'RK4 (3/8 rule)'}[args.method], args.T))
+            step = {'euler': 'one Euler step (1 RHS eval with the update in its epilogue)',
+                    'rk4': 'one RK4 step (4 RHS evals with the stage algebra in their epilogues)'}[args.method]
     elif args.config == 'C2':
         G = graphs.make_graph('random', 100000, seed=0, layout=args.layout)
         L = graphs.normalized_laplacian(G)
@@ -371,6 +389,10 @@ def self_launch(args):
 
 def main():
     args = parse()
+    global FIXED_GRID_METHOD
+    if args.method != 'dopri5':
+        assert args.config == 'M' and args.gpus == 1, '--method applies to the single-GPU config M'
+        FIXED_GRID_METHOD = args.method
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -557,6 +579,8 @@ def main():
                 roofline = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': round(ach / HBM_PEAK_GBS, 4)}
             cfg_name = 'NC' if (args.config == 'M' and args.no_control) else args.config
+            if args.method != 'dopri5':
+                cfg_name += '_' + args.method                 # its own PMC summary (profiles/*_traffic_pmc_M_euler.json) or none
             traffic, src = pmc_traffic(dom, cfg_name) if (world == 1 and not args.sharded) else (None, None)
             roofline.update({'traffic': traffic, 'traffic_source': src, 'mfma_roof': mfma_what,
                              'traffic_over_algorithmic': round(traffic / (byt / cnt), 3) if traffic else None,
@@ -615,8 +639,9 @@ def main():
     if rank != 0:
         return
     out = {
-        'metric': 'node-states/sec (N x T_steps), 1M-node grid H=256' if args.config == 'M'
-                  else 'node-states/sec (N x T_steps), config %s (parity / measurement case, not the judged line)' % args.config,
+        'metric': 'node-states/sec (N x T_steps), 1M-node grid H=256' if (args.config == 'M' and args.method == 'dopri5')
+                  else 'node-states/sec (N x T_steps), config %s (parity / measurement case, not the judged line)'
+                       % (args.config if args.config != 'M' else 'M with --method ' + args.method),
         'value': round(value, 1),
         'unit': 'node-states/s',
         'n_gpus': world,

@@ -82,6 +82,15 @@ int rhs_small_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_
                   int H, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
                   float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const float *c_dev = nullptr,
                   const RkOpt *opt = nullptr);
+// solve_small.hip: a whole fixed-grid solve (all ticks) in ONE launch for states that fit one CU; h_dt: the n_ticks step sizes in
+// the state dtype; out: n_ticks panels.  Euler also has the reverse sweep (traj / g_out: n_ticks + 1 panels, y_0 first).
+int solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method);
+int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method, const float *y0,
+                    const float *h_dt, int64_t n_ticks, float *out, hipStream_t st);
+int solve_small_bwd_supported(const ndcn_csr *A, int H, uint32_t flags, int method);
+int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags, int method,
+                        const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, float *g_y0, float *g_W,
+                        float *g_b, hipStream_t st);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 

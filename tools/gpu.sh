@@ -23,7 +23,7 @@ CMD=${1:-tests}; shift || true
 
 bench_args() {          # configuration name -> bench.py flags
   case "$1" in
-    M) echo "";; NC) echo "--no-control";; *) echo "--config $1";;
+    M) echo "";; NC) echo "--no-control";; M_euler) echo "--method euler";; M_rk4) echo "--method rk4";; *) echo "--config $1";;
   esac
 }
 
