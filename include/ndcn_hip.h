@@ -468,6 +468,27 @@ NDCN_API int ndcn_solver_stats(const ndcn_solver *s, double h_stats[6]);
 NDCN_API int64_t ndcn_solver_steplog(const ndcn_solver *s, double *h_rows, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------------
+ * A WHOLE fixed-grid solve in one launch, for states that fit one compute unit: FixedGridODESolver.integrate (solvers.py:79-99)
+ * with Euler / midpoint / RK4-3/8 steps (fixed_grid.py:7-29, rk_common.py:72-78) over ODEFunc (neural_dynamics.py:27-36) - the
+ * reference's own commands (heat_dynamics.py:20-22,33: Euler, H = 20, 400 nodes, 80-120 ticks), where a launch per step is
+ * pure latency.  One workgroup keeps the stage input in LDS and the row-local panels in registers across all steps; every tick
+ * is bit-identical to the per-step kernels.  ndcn_solver_advance_many takes this path by itself; the entry points are
+ * public for callers that own their time loop and for the reverse sweep:
+ *   h_dt      HOST array of the n_ticks step sizes, formed in the state dtype (solvers.py:81-84: t[i+1] - t[i] in fp32)
+ *   out       n_ticks panels, out[i] = y(t[i+1])
+ *   backward  (Euler; the drivers train by backprop through the solver, heat_dynamics.py:313-334): traj / g_out hold
+ *             n_ticks + 1 panels - y(t[0]) .. y(t[n_ticks]), i.e. y0 followed by the forward's `out`, and dL/dy of each -
+ *             g_y0 [n][H], g_W [H][H], g_b [H] receive the gradients (A_t: the operator's transpose as CSR).
+ * supported: H <= 64 (backward: H <= 31), a plain operator (no halo), the state (backward: 4 panels) within 160 KB of LDS and
+ * <= 576 * 20 / H rows; NDCN_EINVAL otherwise (ask ndcn_solve_small_supported first).                                      */
+NDCN_API int ndcn_solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method, int backward);
+NDCN_API int ndcn_solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method,
+                                  const float *y0, const float *h_dt, int64_t n_ticks, float *out, void *stream);
+NDCN_API int ndcn_solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *W, const float *b, int H, uint32_t flags,
+                                      int method, const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks,
+                                      float *g_y0, float *g_W, float *g_b, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement aid (bench.py `roofline`): when enabled, every kernel launch made by this library is
  * bracketed by HIP events recorded on the launch stream.  ndcn_prof_read drains them into
  * h_out[kind*4 + {0: launches, 1: total ms, 2: total algorithmic bytes, 3: total flops}] for

@@ -117,6 +117,9 @@ SIGNATURES = {
                         _P, _P, _P, ctypes.POINTER(_F), _F, _F, _P, _P, _P]),
     'ndcn_rhs_xadd_supported': (_I, [_CSR, _I, _U, _I, _I]),
     'ndcn_rhs_rk_xadd_f32': (_I, [_CSR, _P, _P, _F, _P, _P, _P, _P, _I, _U, _P, _P, ctypes.POINTER(_F), _P, _P]),
+    'ndcn_solve_small_supported': (_I, [_CSR, _I, _U, _I, _I]),
+    'ndcn_solve_small_f32': (_I, [_CSR, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_F), _L, _P, _P]),
+    'ndcn_solve_small_bwd_f32': (_I, [_CSR, _CSR, _P, _P, _I, _U, _I, _P, _P, ctypes.POINTER(_F), _L, _P, _P, _P, _P]),
     'ndcn_gather_rows_f32': (_I, [_P, _P, _L, _I, _P, _P]),
     'ndcn_rk_combine_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     'ndcn_rk_error_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),

@@ -45,6 +45,32 @@ int ndcn_abi_version(void) { return NDCN_ABI_VERSION; }
 int ndcn_debug_last_rhs_path(void) { return g_last_rhs_path; }
 const char *ndcn_last_error(void) { return g_err; }
 
+int ndcn_solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method, int backward) {
+    if (!A) return 0;
+    return backward ? solve_small_bwd_supported(A, H, flags, method) : solve_small_supported(A, H, flags, method);
+}
+
+int ndcn_solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method, const float *y0,
+                         const float *h_dt, int64_t n_ticks, float *out, void *stream) {
+    NDCN_CHECK_ARG(A && y0 && (n_ticks == 0 || (h_dt && out)) && n_ticks >= 0, "null argument");
+    NDCN_CHECK_ARG((flags & NDCN_F_NO_CONTROL) || W, "weight missing");
+    if (!(flags & NDCN_F_NO_GRAPH)) { int rc = check_csr(A, __func__); if (rc) return rc; }
+    return solve_small_f32(A, W, b, H, flags, method, y0, h_dt, n_ticks, out, ST(stream));
+}
+
+int ndcn_solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *W, const float *b, int H, uint32_t flags, int method,
+                             const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, float *g_y0, float *g_W,
+                             float *g_b, void *stream) {
+    NDCN_CHECK_ARG(A && traj && g_out && g_y0 && h_dt && n_ticks >= 1, "null argument");
+    NDCN_CHECK_ARG((flags & NDCN_F_NO_CONTROL) || (W && g_W && g_b), "weight / gradient buffers missing");
+    if (!(flags & NDCN_F_NO_GRAPH)) {
+        int rc = check_csr(A, __func__);
+        if (rc) return rc;
+        if ((rc = check_csr(A_t, __func__))) return rc;
+    }
+    return solve_small_bwd_f32(A, A_t, W, b, H, flags, method, traj, g_out, h_dt, n_ticks, g_y0, g_W, g_b, ST(stream));
+}
+
 int ndcn_device_info(int64_t h_out[6]) {
     NDCN_CHECK_ARG(h_out, "null output");
     int dev = 0;

@@ -20,6 +20,8 @@
 // accumulating  g_W += gZ^T S,  g_b += sum gZ,  a <- a + g_out[i] + A^T (gZ W)  with gZ = dt_i a (.) [K_i > 0].
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
+#include <vector>
 
 #include "kernels.h"
 
@@ -33,6 +35,33 @@ constexpr int kWaves = 16;
 constexpr int kChunk = 128;                 // ticks per launch (the step sizes ride in the kernel arguments)
 constexpr size_t kLdsMax = 160 * 1024;
 
+// Workgroup barrier for LDS hand-overs: wait for this wave's LDS operations only.  __syncthreads() also drains the vector-memory
+// counter, i.e. every barrier after a tick's output store would wait a global-memory round trip (~2 us) for nothing.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// s += sum_j val_j T[col_j * H + o] over the cnt entries from j0, one fma per entry in stored order; the index / value / row
+// fetches of B entries are issued together (two LDS round trips per B entries instead of two per entry)
+template <int B>
+__device__ __forceinline__ float gather_row(const int *ci, const float *va, const float *T, int j0, int cnt, int H, int o, float s) {
+    for (int jb = 0; __any(jb < cnt); jb += B) {
+        int c[B];
+        float v[B], x[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const bool ok = jb + u < cnt;
+            const int idx = ok ? j0 + jb + u : 0;
+            c[u] = ci[idx];
+            v[u] = va[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) x[u] = T[(jb + u < cnt ? c[u] : 0) * H + o];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+            if (jb + u < cnt) s = fmaf(v[u], x[u], s);
+    }
+    return s;
+}
+
 struct SolveArgs {
     const int *rowptr, *colidx;
     const float *val;
@@ -40,6 +69,7 @@ struct SolveArgs {
     const float *y0;                 // [n_rows][H] state at the start of this launch
     float *out;                      // [n_ticks][n_rows][H]
     int n_rows, H, nnz, n_ticks, relu, no_graph, no_control, csr_in_lds;
+    long long *dbg;                  // NDCN_SS_DEBUG=1: {shader cycles total, in evaluations, in stage updates, 100 MHz ticks total}
     float dt[kChunk];
 };
 
@@ -65,6 +95,7 @@ inline size_t lds_bytes(int64_t n_elem, int H, int64_t n_rows, int64_t nnz, bool
 }
 
 // K for the element this lane owns in pass `it` (valid lanes only), from the stage input in l.T
+template <int GB>
 __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, const int *rp, const int *ci, const float *va, int r, int q,
                                           int o, int lane, int wave, bool valid, float bias_o) {
     const int H = a.H;
@@ -74,8 +105,7 @@ __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, cons
     } else {
         int j0 = 0, cnt = 0;
         if (valid) { j0 = rp[r]; cnt = rp[r + 1] - j0; }
-        for (int j = 0; __any(j < cnt); ++j)
-            if (j < cnt) s = fmaf(va[j0 + j], l.T[ci[j0 + j] * H + o], s);
+        s = gather_row<GB>(ci, va, l.T, j0, cnt, H, o, s);
     }
     if (a.no_control) return a.relu ? relu_nan(s) : s;
     float *srow = l.srow + wave * 64;
@@ -86,6 +116,7 @@ __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, cons
     if (valid) {
         const float *sr = srow + q * H;
         const int ldw = H + 1;
+#pragma unroll 4
         for (int h = 0; h < H; ++h) k = fmaf(sr[h], l.wt[h * ldw + o], k);
         k = k + bias_o;
         if (a.relu) k = relu_nan(k);
@@ -93,25 +124,115 @@ __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, cons
     return k;
 }
 
+// The README shape on the fast path (HT = H at compile time; the plain ODEFunc: graph and control term, CSR in LDS):
+//   * the operator's entries are packed as {column * H, value bits} pairs - one 8-byte LDS read per entry, the row address is
+//     one add away;
+//   * lane o keeps row o of W (its H weights) in registers for the whole solve: the Linear is H/4 16-byte reads of the wave's S
+//     row + H fmas, no weight traffic;
+// the same fma chains in the same order as the generic path (bit-identical), ~1/3 of its instructions and LDS bytes.
+// NP passes of a wave can be evaluated together (independent chains of LDS round trips).  Measured on the README shape: no
+// gain - 16 waves share 4 SIMDs, a wave64 instruction occupies its SIMD for 4 cycles, and the ~1000 instructions a wave issues
+// per Euler step (9 passes) already keep every SIMD busy: 19 k cycles per step with one pass at a time, 23 k with three
+// (rolled, double-buffered), so the shipped kernels take NP = 1.  What is left is instruction count, not latency.
+template <int HT, int NP>
+__device__ __forceinline__ void eval_fast(const int *rp, const int2 *ent, const float *T, float *srow, const float (&wreg)[HT ? HT : 1],
+                                          const int (&r)[NP], const bool (&valid)[NP], int q, int o, int lane, float bias_o, int relu,
+                                          float (&out)[NP]) {
+    int j0[NP], cnt[NP], cmax = 0;
+    float s[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        j0[p] = 0, cnt[p] = 0, s[p] = 0.f;
+        if (valid[p]) { j0[p] = rp[r[p]]; cnt[p] = rp[r[p] + 1] - j0[p]; }
+        cmax = cnt[p] > cmax ? cnt[p] : cmax;
+    }
+    for (int jb = 0; __any(jb < cmax); jb += 4) {
+        int2 en[NP][4];
+        float x[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) en[p][u] = ent[jb + u < cnt[p] ? j0[p] + jb + u : 0];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[p][u] = T[(jb + u < cnt[p] ? en[p][u].x : 0) + o];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jb + u < cnt[p]) s[p] = fmaf(__int_as_float(en[p][u].y), x[p][u], s[p]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) srow[64 * p + lane] = s[p];
+    __builtin_amdgcn_wave_barrier();
+    float k[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) k[p] = 0.f;
+#pragma unroll
+    for (int h4 = 0; h4 < HT / 4; ++h4) {
+        float4 sv[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) sv[p] = reinterpret_cast<const float4 *>(srow + 64 * p + (valid[p] ? q : 0) * HT)[h4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            k[p] = fmaf(sv[p].x, wreg[4 * h4], k[p]);
+            k[p] = fmaf(sv[p].y, wreg[4 * h4 + 1], k[p]);
+            k[p] = fmaf(sv[p].z, wreg[4 * h4 + 2], k[p]);
+            k[p] = fmaf(sv[p].w, wreg[4 * h4 + 3], k[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const float kk = k[p] + bias_o;
+        out[p] = relu ? relu_nan(kk) : kk;
+    }
+}
+
+constexpr int kFastNp = 3;                  // passes evaluated together (srow: kFastNp x 64 floats per wave)
+
+inline size_t lds_bytes_fast(int64_t n_elem, int64_t n_rows, int64_t nnz, int64_t extra_floats = 0) {
+    return 8 * (size_t)nnz + sizeof(float) * (size_t)(n_elem + kWaves * 64 * kFastNp + extra_floats + n_rows + 1);
+}
+
 // METHOD: NDCN_M_EULER / MIDPOINT / RK4.  MAXIT: passes a wave makes over its rows (register arrays are indexed by pass)
-template <int METHOD, int MAXIT, bool CSR_LDS>
+template <int METHOD, int MAXIT, bool CSR_LDS, int HT>
 __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
     extern __shared__ float lds_raw[];
-    const int H = a.H, n_elem = a.n_rows * H;
-    const Lds l = carve(lds_raw, n_elem, H, a.n_rows, a.nnz, CSR_LDS);
+    const int H = HT ? HT : a.H, n_elem = a.n_rows * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int RPW = 64 / H;
     const int q = lane / H, o = lane - q * H;
     const bool lane_on = q < RPW;
-    // ---- stage: W^T, CSR, the initial state
-    if (!a.no_control)
-        for (int i = tid; i < H * H; i += 1024) {
-            const int oo = i / H, h = i - oo * H;
-            l.wt[h * (H + 1) + oo] = a.W[i];
+    // ---- stage: the weights (W^T in LDS, or this lane's row of W in registers), the CSR arrays, the initial state
+    Lds l;
+    int2 *f_ent = nullptr;
+    int *f_rp = nullptr;
+    float *f_srow = nullptr;
+    float wreg[HT ? HT : 1];
+    if (HT) {                                               // fast path: [entries | T | srow | rowptr]
+        f_ent = reinterpret_cast<int2 *>(lds_raw);
+        l.T = lds_raw + 2 * a.nnz;
+        f_srow = l.T + n_elem + wave * 64 * kFastNp;
+        f_rp = reinterpret_cast<int *>(l.T + n_elem + kWaves * 64 * kFastNp);
+        l.wt = l.srow = l.val = nullptr;
+        l.rowptr = l.colidx = nullptr;
+        for (int i = tid; i <= a.n_rows; i += 1024) f_rp[i] = a.rowptr[i];
+        for (int i = tid; i < a.nnz; i += 1024) f_ent[i] = make_int2(a.colidx[i] * H, __float_as_int(a.val[i]));
+#pragma unroll
+        for (int h = 0; h < (HT ? HT : 1); ++h) wreg[h] = lane_on ? a.W[o * H + h] : 0.f;
+    } else {
+        l = carve(lds_raw, n_elem, H, a.n_rows, a.nnz, CSR_LDS);
+        if (!a.no_control)
+            for (int i = tid; i < H * H; i += 1024) {
+                const int oo = i / H, h = i - oo * H;
+                l.wt[h * (H + 1) + oo] = a.W[i];
+            }
+        if (CSR_LDS) {
+            for (int i = tid; i <= a.n_rows; i += 1024) l.rowptr[i] = a.rowptr[i];
+            for (int i = tid; i < a.nnz; i += 1024) { l.colidx[i] = a.colidx[i]; l.val[i] = a.val[i]; }
         }
-    if (CSR_LDS) {
-        for (int i = tid; i <= a.n_rows; i += 1024) l.rowptr[i] = a.rowptr[i];
-        for (int i = tid; i < a.nnz; i += 1024) { l.colidx[i] = a.colidx[i]; l.val[i] = a.val[i]; }
     }
     const int *rp = CSR_LDS ? l.rowptr : a.rowptr;
     const int *ci = CSR_LDS ? l.colidx : a.colidx;
@@ -126,15 +247,32 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
         if (valid) l.T[r * H + o] = y[it];
         k1[it] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // one right-hand side over the stage input in T -> dst[it]; then T <- the next stage input
 #define NDCN_EVAL(dst)                                                                                         \
-    _Pragma("unroll") for (int it = 0; it < MAXIT; ++it) {                                                     \
-        const int r = (it * kWaves + wave) * RPW + q;                                                          \
-        if ((it * kWaves + wave) * RPW < a.n_rows)                                                             \
-            dst[it] = eval_rhs(a, l, rp, ci, va, r, q, o, lane, wave, lane_on && r < a.n_rows, bias_o);        \
+    if (HT) {                                                                                                  \
+        constexpr int NPF = 1;                                                                                 \
+        _Pragma("unroll") for (int it = 0; it < MAXIT; it += NPF) {                                            \
+            if ((it * kWaves + wave) * RPW < a.n_rows) {                                                       \
+                int rr_[NPF];                                                                                  \
+                bool vv_[NPF];                                                                                 \
+                float oo_[NPF];                                                                                \
+                _Pragma("unroll") for (int p = 0; p < NPF; ++p) {                                              \
+                    rr_[p] = ((it + p) * kWaves + wave) * RPW + q;                                             \
+                    vv_[p] = lane_on && rr_[p] < a.n_rows;                                                     \
+                }                                                                                              \
+                eval_fast<HT, NPF>(f_rp, f_ent, l.T, f_srow, wreg, rr_, vv_, q, o, lane, bias_o, a.relu, oo_); \
+                _Pragma("unroll") for (int p = 0; p < NPF; ++p) dst[it + p] = oo_[p];                          \
+            }                                                                                                  \
+        }                                                                                                      \
+    } else {                                                                                                   \
+        _Pragma("unroll") for (int it = 0; it < MAXIT; ++it) {                                                 \
+            const int r = (it * kWaves + wave) * RPW + q;                                                      \
+            if ((it * kWaves + wave) * RPW < a.n_rows)                                                         \
+                dst[it] = eval_rhs<(MAXIT > 4 ? 4 : 8)>(a, l, rp, ci, va, r, q, o, lane, wave, lane_on && r < a.n_rows, bias_o); \
+        }                                                                                                      \
     }                                                                                                          \
-    __syncthreads();
+    lds_barrier();
 #define NDCN_PUT(expr, also_out)                                                                               \
     _Pragma("unroll") for (int it = 0; it < MAXIT; ++it) {                                                     \
         const int r = (it * kWaves + wave) * RPW + q;                                                          \
@@ -144,12 +282,19 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
             if (also_out) { y[it] = v_; a.out[(size_t)tick * n_elem + r * H + o] = v_; }                       \
         }                                                                                                      \
     }                                                                                                          \
-    __syncthreads();
+    lds_barrier();
+    long long c_eval = 0, c_put = 0, c0 = 0, w0 = 0;
+    if (a.dbg) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+#define NDCN_T0 long long t_ = a.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#define NDCN_T1(acc) if (a.dbg) { const long long n_ = __builtin_readcyclecounter(); acc += n_ - t_; t_ = n_; }
     for (int tick = 0; tick < a.n_ticks; ++tick) {
         const float dt = a.dt[tick];
+        NDCN_T0
         if (METHOD == NDCN_M_EULER) {
             NDCN_EVAL(k1)
+            NDCN_T1(c_eval)
             NDCN_PUT(y[it] + dt * k1[it], true)                                              // fixed_grid.py:8 + solvers.py:92
+            NDCN_T1(c_put)
         } else if (METHOD == NDCN_M_MIDPOINT) {
             NDCN_EVAL(k1)
             NDCN_PUT(y[it] + k1[it] * dt / 2.f, false)                                       // fixed_grid.py:18
@@ -169,6 +314,14 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
             NDCN_PUT(y[it] + (k1[it] + k2[it]) * (dt / 8.f), true)                           // rk_common.py:78 + solvers.py:92
         }
     }
+    if (a.dbg && tid == 0) {
+        a.dbg[0] = (long long)__builtin_readcyclecounter() - c0;
+        a.dbg[1] = c_eval;
+        a.dbg[2] = c_put;
+        a.dbg[3] = (long long)wall_clock64() - w0;
+    }
+#undef NDCN_T0
+#undef NDCN_T1
 #undef NDCN_EVAL
 #undef NDCN_PUT
 }
@@ -185,61 +338,107 @@ struct BwdArgs {
     const float *g_out;              // [n_ticks + 1][n]: dL/dy_i (zeros where a tick carries no loss)
     float *g_y0;                     // [n]
     float *g_W, *g_b;                // [H][H], [H]  (added to what the caller zeroed: a chunked solve accumulates)
+    long long *dbg;                  // NDCN_SS_DEBUG=1: shader cycles {total, forward pieces, g_W + gS, transposed gather + update}
     const float *a_in;               // nullable [n]: the adjoint at the LAST tick of this launch, handed over by the launch that
                                      // covered the later ticks (it already holds that tick's g_out); NULL: g_out[n_ticks] itself
     int n_rows, H, nnz, n_ticks, relu, no_graph, no_control;
     float dt[kChunk];
 };
 
-// LDS: T (y_i, then gS), wt (W^T for the forward chain), srow, then  S [n] (A y_i),  Z [n] (gZ),  w (W as stored: gS = gZ W)
-template <int MAXIT>
-__global__ __launch_bounds__(1024) void solve_small_bwd_kernel(BwdArgs b) {
+// LDS: T [n] (y_i, then gS = gZ W),  S [n] (A y_i, then A^T gS),  Z [n] (dt a, then gZ),  wt (W^T, padded rows), srow, and - when
+// they fit - the CSR arrays of A (shared by the transposed gather when the operator is symmetric: normalised Laplacians are).
+// Registers: the adjoint a = dL/dy_{i+1} of the elements this thread owns (one per pass), the prefetched y_{i-1}.
+template <int MAXIT, bool CSR_LDS>
+__global__ __launch_bounds__(1024) void solve_small_bwd_kernel(BwdArgs b, int symmetric) {
     extern __shared__ float lds_raw[];
-    const int H = b.H, n_elem = b.n_rows * H;
-    float *T = lds_raw, *wt = T + n_elem, *srow_all = wt + H * (H + 1);
-    float *S = srow_all + kWaves * 64, *Z = S + n_elem, *w = Z + n_elem;
+    const int H = b.H, n_elem = b.n_rows * H, ldw = H + 1;
+    float *T = lds_raw, *S = T + n_elem, *Z = S + n_elem, *wt = Z + n_elem, *srow_all = wt + H * ldw;
+    int *l_rp = reinterpret_cast<int *>(srow_all + kWaves * 64), *l_ci = l_rp + (CSR_LDS ? b.n_rows + 1 : 0);
+    float *l_va = reinterpret_cast<float *>(l_ci + (CSR_LDS ? b.nnz : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int RPW = 64 / H;
     const int q = lane / H, o = lane - q * H;
     const bool lane_on = q < RPW;
+    // the element this thread owns in pass `it`: e0 + it * estride (valid while < n_elem on an active lane)
+    const int e0 = lane_on ? (wave * RPW + q) * H + o : n_elem, estride = kWaves * RPW * H;
     if (!b.no_control)
         for (int i = tid; i < H * H; i += 1024) {
             const int oo = i / H, h = i - oo * H;
-            wt[h * (H + 1) + oo] = b.W[i];
-            w[i] = b.W[i];
+            wt[h * ldw + oo] = b.W[i];
         }
-    const float bias_o = (!b.no_control && b.bias && lane_on) ? b.bias[o] : 0.f;
-    float adj[MAXIT];                                        // a = dL/dy_{i+1}, carried across the sweep
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        const int r = (it * kWaves + wave) * RPW + q;
-        const bool valid = lane_on && r < b.n_rows;
-        adj[it] = 0.f;
-        if (valid) adj[it] = b.a_in ? b.a_in[r * H + o] : b.g_out[(size_t)b.n_ticks * n_elem + r * H + o];
+    if (CSR_LDS) {
+        for (int i = tid; i <= b.n_rows; i += 1024) l_rp[i] = b.rowptr[i];
+        for (int i = tid; i < b.nnz; i += 1024) { l_ci[i] = b.colidx[i]; l_va[i] = b.val[i]; }
     }
-    // gradient accumulators of W: thread t < H*H owns g_W[t / H][t % H]; g_b: thread t < H
-    float gw = 0.f, gb = 0.f;
-    __syncthreads();
-    for (int i = b.n_ticks - 1; i >= 0; --i) {
-        const float dt = b.dt[i];
-        const float *yi = b.traj + (size_t)i * n_elem;
-        // ---- T <- y_i
-        for (int e = tid; e < n_elem; e += 1024) T[e] = yi[e];
-        __syncthreads();
-        // ---- forward pieces at y_i: S = A y_i, K = relu(W S + b); gZ = dt a (.) [K > 0]  (the mask of relu's output)
+    const int *rp = CSR_LDS ? l_rp : b.rowptr, *ci = CSR_LDS ? l_ci : b.colidx;
+    const float *va = CSR_LDS ? l_va : b.val;
+    const int *trp = symmetric ? rp : b.t_rowptr, *tci = symmetric ? ci : b.t_colidx;
+    const float *tva = symmetric ? va : b.t_val;
+    const float bias_o = (!b.no_control && b.bias && lane_on) ? b.bias[o] : 0.f;
+    float adj[MAXIT];
+    {
+        const float *a0 = b.a_in ? b.a_in : b.g_out + (size_t)b.n_ticks * n_elem;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            adj[it] = e < n_elem ? a0[e] : 0.f;
+        }
+    }
+    // y_i arrives through registers, requested a step ahead (MAXIT x 1024 elements cover the state: <= MAXIT passes of 1024 lanes)
+    float pre[MAXIT];
+    {
+        const float *yl = b.traj + (size_t)(b.n_ticks - 1) * n_elem;
+#pragma unroll
+        for (int u = 0; u < MAXIT; ++u) {
+            const int e = tid + 1024 * u;
+            pre[u] = e < n_elem ? yl[e] : 0.f;
+        }
+    }
+    // g_W: thread t < H*H owns entry (t / H, t % H) over the even half of the rows, thread H*H + t the other half; g_b likewise
+    const int HH = H * H;
+    const bool gw_on = !b.no_control && tid < 2 * HH, gb_on = !b.no_control && tid >= 2 * HH && tid < 2 * HH + 2 * H;
+    const int half = gw_on ? tid / HH : gb_on ? (tid - 2 * HH) / H : 0;
+    const int gw_o = gw_on ? (tid % HH) / H : gb_on ? (tid - 2 * HH) % H : 0, gw_h = gw_on ? tid % H : 0;
+    const int r_lo = half ? b.n_rows / 2 : 0, r_hi = half ? b.n_rows : b.n_rows / 2;
+    float gacc = 0.f;
+    long long c_a = 0, c_b = 0, c_c = 0, c0 = b.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    lds_barrier();
+    for (int i = b.n_ticks - 1; i >= 0; --i) {
+        const float dt = b.dt[i];
+        long long t_ = b.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        // ---- T <- y_i (prefetched), request y_{i-1};  Z <- dt a
+#pragma unroll
+        for (int u = 0; u < MAXIT; ++u) {
+            const int e = tid + 1024 * u;
+            if (e < n_elem) T[e] = pre[u];
+        }
+        if (i > 0) {
+            const float *yp = b.traj + (size_t)(i - 1) * n_elem;
+#pragma unroll
+            for (int u = 0; u < MAXIT; ++u) {
+                const int e = tid + 1024 * u;
+                if (e < n_elem) pre[u] = yp[e];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            if (e < n_elem) Z[e] = dt * adj[it];
+        }
+        lds_barrier();
+        // ---- forward pieces at y_i: S = A y_i, K = relu(W S + b); gZ = dt a (.) [K > 0]  (the mask of relu's output)
+#pragma nounroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if ((it * kWaves + wave) * RPW >= b.n_rows) break;
             const int r = (it * kWaves + wave) * RPW + q;
-            if ((it * kWaves + wave) * RPW >= b.n_rows) continue;
             const bool valid = lane_on && r < b.n_rows;
             float s = 0.f;
             if (b.no_graph) {
                 if (valid) s = T[r * H + o];
             } else {
                 int j0 = 0, cnt = 0;
-                if (valid) { j0 = b.rowptr[r]; cnt = b.rowptr[r + 1] - j0; }
-                for (int j = 0; __any(j < cnt); ++j)
-                    if (j < cnt) s = fmaf(b.val[j0 + j], T[b.colidx[j0 + j] * H + o], s);
+                if (valid) { j0 = rp[r]; cnt = rp[r + 1] - j0; }
+                s = gather_row<4>(ci, va, T, j0, cnt, H, o, s);
             }
             float k = s;
             if (!b.no_control) {
@@ -250,63 +449,86 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_kernel(BwdArgs b) {
                 k = 0.f;
                 if (valid) {
                     const float *sr = srow + q * H;
-                    for (int h = 0; h < H; ++h) k = fmaf(sr[h], wt[h * (H + 1) + o], k);
+#pragma unroll 4
+                    for (int h = 0; h < H; ++h) k = fmaf(sr[h], wt[h * ldw + o], k);
                     k = k + bias_o;
                 }
             }
             if (valid) {
-                const float gk = dt * adj[it];
                 S[r * H + o] = s;
-                Z[r * H + o] = (!b.relu || k > 0.f) ? gk : 0.f;
+                if (b.relu && !(k > 0.f)) Z[r * H + o] = 0.f;
             }
         }
-        __syncthreads();
-        // ---- g_W[oo][h] += sum_r Z[r][oo] S[r][h];  g_b[oo] += sum_r Z[r][oo];  gS = Z W  -> T (y_i is no longer needed)
-        if (!b.no_control) {
-            if (tid < H * H) {
-                const int oo = tid / H, h = tid - oo * H;
-                float acc = 0.f;
-                for (int r = 0; r < b.n_rows; ++r) acc = fmaf(Z[r * H + oo], S[r * H + h], acc);
-                gw += acc;
-            } else if (tid < H * H + H) {
-                const int oo = tid - H * H;
-                float acc = 0.f;
-                for (int r = 0; r < b.n_rows; ++r) acc += Z[r * H + oo];
-                gb += acc;
-            }
+        lds_barrier();
+        if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_a += n_ - t_; t_ = n_; }
+        // ---- g_W[oo][h] += sum_r gZ[r][oo] S[r][h];  g_b[oo] += sum_r gZ[r][oo];  gS = gZ W -> T (y_i is no longer needed)
+        if (gw_on) {
+            float acc = 0.f;
+#pragma unroll 4
+            for (int r = r_lo; r < r_hi; ++r) acc = fmaf(Z[r * H + gw_o], S[r * H + gw_h], acc);
+            gacc += acc;
+        } else if (gb_on) {
+            float acc = 0.f;
+#pragma unroll 4
+            for (int r = r_lo; r < r_hi; ++r) acc += Z[r * H + gw_o];
+            gacc += acc;
         }
+#pragma nounroll
         for (int e = tid; e < n_elem; e += 1024) {
             float gs;
             if (b.no_control) gs = Z[e];
             else {
                 const int r = e / H, h = e - r * H;
                 gs = 0.f;
-                for (int oo = 0; oo < H; ++oo) gs = fmaf(Z[r * H + oo], w[oo * H + h], gs);
+#pragma unroll 4
+                for (int oo = 0; oo < H; ++oo) gs = fmaf(Z[r * H + oo], wt[h * ldw + oo], gs);
             }
             T[e] = gs;
         }
-        __syncthreads();
-        // ---- a <- a + g_out[i] + A^T gS   (no_graph: + gS)
-#pragma unroll
+        lds_barrier();
+        if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_b += n_ - t_; t_ = n_; }
+        // ---- S <- A^T gS (each element by the thread that owns it); then a <- (a + S) + g_out[i]
+#pragma nounroll
         for (int it = 0; it < MAXIT; ++it) {
+            if ((it * kWaves + wave) * RPW >= b.n_rows) break;
             const int r = (it * kWaves + wave) * RPW + q;
-            if (!(lane_on && r < b.n_rows)) continue;
+            const bool valid = lane_on && r < b.n_rows;
             float s = 0.f;
-            if (b.no_graph) s = T[r * H + o];
-            else
-                for (int j = b.t_rowptr[r]; j < b.t_rowptr[r + 1]; ++j) s = fmaf(b.t_val[j], T[b.t_colidx[j] * H + o], s);
-            adj[it] = (adj[it] + s) + b.g_out[(size_t)i * n_elem + r * H + o];
+            if (b.no_graph) {
+                if (valid) s = T[r * H + o];
+            } else {
+                int j0 = 0, cnt = 0;
+                if (valid) { j0 = trp[r]; cnt = trp[r + 1] - j0; }
+                s = gather_row<4>(tci, tva, T, j0, cnt, H, o, s);
+            }
+            if (valid) S[r * H + o] = s;
         }
-        __syncthreads();
+        {
+            const float *gi = b.g_out + (size_t)i * n_elem;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                if (e < n_elem) adj[it] = (adj[it] + S[e]) + gi[e];
+            }
+        }
+        lds_barrier();
+        if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_c += n_ - t_; t_ = n_; }
+    }
+    if (b.dbg && tid == 0) {
+        b.dbg[0] = (long long)__builtin_readcyclecounter() - c0;
+        b.dbg[1] = c_a; b.dbg[2] = c_b; b.dbg[3] = c_c;
     }
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int r = (it * kWaves + wave) * RPW + q;
-        if (lane_on && r < b.n_rows) b.g_y0[r * H + o] = adj[it];
+        const int e = e0 + it * estride;
+        if (e < n_elem) b.g_y0[e] = adj[it];
     }
+    // the two halves of every g_W / g_b entry meet in LDS
     if (!b.no_control) {
-        if (tid < H * H) b.g_W[tid] += gw;
-        else if (tid < H * H + H) b.g_b[tid - H * H] += gb;
+        if ((gw_on || gb_on) && half) T[gw_on ? tid - HH : HH + gw_o] = gacc;
+        lds_barrier();
+        if (gw_on && !half) b.g_W[tid] += gacc + T[tid];
+        else if (gb_on && !half) b.g_b[gw_o] += gacc + T[HH + gw_o];
     }
 }
 
@@ -344,7 +566,10 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
     const bool no_graph = flags & NDCN_F_NO_GRAPH;
     const int64_t nnz = no_graph ? 0 : A->nnz;
     const bool csr = !no_graph && lds_bytes(n_elem, H, A->n_rows, nnz, true) <= kLdsMax;
-    const size_t lds = lds_bytes(n_elem, H, A->n_rows, nnz, csr);
+    static const bool fast_on = [] { const char *e = getenv("NDCN_SOLVE_SMALL_FAST"); return !(e && e[0] == '0'); }();
+    const bool fast = fast_on && (H == 16 || H == 20) && !no_graph && !(flags & NDCN_F_NO_CONTROL) &&
+                      lds_bytes_fast(n_elem, A->n_rows, nnz) <= kLdsMax;
+    const size_t lds = fast ? lds_bytes_fast(n_elem, A->n_rows, nnz) : lds_bytes(n_elem, H, A->n_rows, nnz, csr);
     const int np = passes(A->n_rows, H);
     const float *start = y0;
     for (int64_t done = 0; done < n_ticks; done += kChunk) {
@@ -356,28 +581,45 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
         a.relu = (flags & NDCN_F_RELU) ? 1 : 0; a.no_graph = no_graph ? 1 : 0; a.no_control = (flags & NDCN_F_NO_CONTROL) ? 1 : 0;
         a.csr_in_lds = csr ? 1 : 0;
         for (int i = 0; i < a.n_ticks; ++i) a.dt[i] = h_dt[done + i];
+        static const bool dbg_on = [] { const char *e = getenv("NDCN_SS_DEBUG"); return e && e[0] == '1'; }();
+        static long long *dbg_buf = nullptr;
+        if (dbg_on && !dbg_buf) NDCN_HIP(hipMalloc(&dbg_buf, 4 * sizeof(long long)));
+        a.dbg = dbg_on ? dbg_buf : nullptr;
         const double evals = (method == NDCN_M_EULER ? 1 : method == NDCN_M_MIDPOINT ? 2 : 4) * (double)a.n_ticks;
         ProfScope prof(PROF_RHS_FUSED, st, 4.0 * n_elem * (a.n_ticks + 1) + 8.0 * nnz + 4.0 * H * H,
                        evals * (2.0 * nnz * H + 2.0 * (double)A->n_rows * H * H));
-#define NDCN_GO(M_, IT_, C_)                                                                   \
+#define NDCN_GO(M_, IT_, C_, HT_)                                                              \
         do {                                                                                   \
-            auto kern = solve_small_kernel<M_, IT_, C_>;                                       \
+            auto kern = solve_small_kernel<M_, IT_, C_, HT_>;                                  \
             static bool cap_set = false;                                                       \
             if (!cap_set) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; cap_set = true; } \
             hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a);                         \
         } while (0)
-#define NDCN_GO_IT(M_, C_)                                                                     \
+#define NDCN_GO_IT(M_, C_, HT_)                                                                \
         do {                                                                                   \
-            if (np <= 4) NDCN_GO(M_, 4, C_);                                                   \
-            else NDCN_GO(M_, 12, C_);                                                          \
+            if (np <= 4) NDCN_GO(M_, 4, C_, HT_);                                              \
+            else NDCN_GO(M_, 12, C_, HT_);                                                     \
         } while (0)
-        if (method == NDCN_M_EULER) { if (csr) NDCN_GO_IT(NDCN_M_EULER, true); else NDCN_GO_IT(NDCN_M_EULER, false); }
-        else if (method == NDCN_M_MIDPOINT) { if (csr) NDCN_GO_IT(NDCN_M_MIDPOINT, true); else NDCN_GO_IT(NDCN_M_MIDPOINT, false); }
-        else if (np <= 4) { if (csr) NDCN_GO(NDCN_M_RK4, 4, true); else NDCN_GO(NDCN_M_RK4, 4, false); }
-        else { if (csr) NDCN_GO(NDCN_M_RK4, 12, true); else NDCN_GO(NDCN_M_RK4, 12, false); }
+#define NDCN_GO_M(C_, HT_)                                                                     \
+        do {                                                                                   \
+            if (method == NDCN_M_EULER) NDCN_GO_IT(NDCN_M_EULER, C_, HT_);                     \
+            else if (method == NDCN_M_MIDPOINT) NDCN_GO_IT(NDCN_M_MIDPOINT, C_, HT_);          \
+            else NDCN_GO_IT(NDCN_M_RK4, C_, HT_);                                              \
+        } while (0)
+        if (fast && H == 20) NDCN_GO_M(true, 20);
+        else if (fast) NDCN_GO_M(true, 16);
+        else if (csr) NDCN_GO_M(true, 0);
+        else NDCN_GO_M(false, 0);
+#undef NDCN_GO_M
 #undef NDCN_GO_IT
 #undef NDCN_GO
         NDCN_LAUNCH_CHECK();
+        if (dbg_on) {
+            long long h[4];
+            NDCN_HIP(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[solve_small] %d ticks: %lld shader cycles (eval %lld, update %lld), %.1f us by the 100 MHz clock -> %.0f MHz\n",
+                    a.n_ticks, h[0], h[1], h[2], h[3] / 100.0, h[3] ? 100.0 * h[0] / h[3] : 0.0);
+        }
         start = a.out + (size_t)(a.n_ticks - 1) * n_elem;
     }
     return NDCN_OK;
@@ -386,7 +628,29 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
 int solve_small_bwd_supported(const ndcn_csr *A, int H, uint32_t flags, int method) {
     if (method != NDCN_M_EULER || !solve_small_supported(A, H, flags, method)) return 0;
     const int64_t n_elem = A->n_rows * (int64_t)H;
-    return lds_bytes(n_elem, H, A->n_rows, 0, false, 2 * n_elem + H * H) <= kLdsMax && H * H + H <= 1024 ? 1 : 0;
+    return lds_bytes(n_elem, H, A->n_rows, 0, false, 2 * n_elem) <= kLdsMax && 2 * (H * H + H) <= 1024 && n_elem <= 12 * 1024 ? 1 : 0;
+}
+
+// Is the operator equal to its transpose as stored (sorted CSR: the arrays then agree element for element)?  One-off per solve:
+// three small device comparisons through a host copy (a README-sized operator is ~30 KB).
+static int csr_symmetric(const ndcn_csr *A, const ndcn_csr *At, hipStream_t st, int *out) {
+    *out = 0;
+    if (!At || A == At) { *out = A == At; return NDCN_OK; }
+    if (A->n_rows != At->n_rows || A->n_cols != At->n_cols || A->nnz != At->nnz || A->n_rows != A->n_cols) return NDCN_OK;
+    const size_t nr = (size_t)A->n_rows + 1, nz = (size_t)A->nnz;
+    std::vector<int32_t> a(nr + nz), b(nr + nz);
+    std::vector<float> va(nz), vb(nz);
+    NDCN_HIP(hipMemcpyAsync(a.data(), A->rowptr, nr * 4, hipMemcpyDeviceToHost, st));
+    NDCN_HIP(hipMemcpyAsync(b.data(), At->rowptr, nr * 4, hipMemcpyDeviceToHost, st));
+    if (nz) {
+        NDCN_HIP(hipMemcpyAsync(a.data() + nr, A->colidx, nz * 4, hipMemcpyDeviceToHost, st));
+        NDCN_HIP(hipMemcpyAsync(b.data() + nr, At->colidx, nz * 4, hipMemcpyDeviceToHost, st));
+        NDCN_HIP(hipMemcpyAsync(va.data(), A->val, nz * 4, hipMemcpyDeviceToHost, st));
+        NDCN_HIP(hipMemcpyAsync(vb.data(), At->val, nz * 4, hipMemcpyDeviceToHost, st));
+    }
+    NDCN_HIP(hipStreamSynchronize(st));
+    *out = a == b && memcmp(va.data(), vb.data(), nz * 4) == 0;
+    return NDCN_OK;
 }
 
 int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags, int method,
@@ -396,8 +660,24 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
     const bool no_graph = flags & NDCN_F_NO_GRAPH, no_control = flags & NDCN_F_NO_CONTROL;
     if (!no_graph && (!At || At->n_rows != A->n_cols || At->nnz != A->nnz)) { set_error("solve_small_bwd: the transposed operator is missing"); return NDCN_EINVAL; }
     const int64_t n_elem = A->n_rows * (int64_t)H;
-    const size_t lds = lds_bytes(n_elem, H, A->n_rows, 0, false, 2 * n_elem + H * H);
     const int np = passes(A->n_rows, H);
+    const int64_t nnz = no_graph ? 0 : A->nnz;
+    const bool csr = !no_graph && lds_bytes(n_elem, H, A->n_rows, nnz, true, 2 * n_elem) <= kLdsMax;
+    const size_t lds = lds_bytes(n_elem, H, A->n_rows, nnz, csr, 2 * n_elem);
+    // a symmetric operator (the reference's normalised Laplacian / adjacency) serves its own transposed gather from the LDS copy;
+    // the answer is remembered per (A, A_t) pair of array addresses - a training loop asks once
+    int symmetric = 0;
+    if (!no_graph) {
+        static thread_local const void *memo_a = nullptr, *memo_t = nullptr;
+        static thread_local int64_t memo_nnz = -1;
+        static thread_local int memo_sym = 0;
+        if (memo_a == A->colidx && memo_t == At->colidx && memo_nnz == A->nnz) symmetric = memo_sym;
+        else {
+            int rc = csr_symmetric(A, At, st, &symmetric);
+            if (rc) return rc;
+            memo_a = A->colidx, memo_t = At->colidx, memo_nnz = A->nnz, memo_sym = symmetric;
+        }
+    }
     if (!no_control) {
         NDCN_HIP(hipMemsetAsync(g_W, 0, sizeof(float) * H * H, st));
         NDCN_HIP(hipMemsetAsync(g_b, 0, sizeof(float) * H, st));
@@ -417,17 +697,28 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         a.n_rows = (int)A->n_rows; a.H = H; a.nnz = (int)A->nnz; a.n_ticks = (int)(hi - lo);
         a.relu = (flags & NDCN_F_RELU) ? 1 : 0; a.no_graph = no_graph ? 1 : 0; a.no_control = no_control ? 1 : 0;
         for (int i = 0; i < a.n_ticks; ++i) a.dt[i] = h_dt[lo + i];
+        static const bool dbg_on = [] { const char *e = getenv("NDCN_SS_DEBUG"); return e && e[0] == '1'; }();
+        static long long *dbg_buf = nullptr;
+        if (dbg_on && !dbg_buf) NDCN_HIP(hipMalloc(&dbg_buf, 4 * sizeof(long long)));
+        a.dbg = dbg_on ? dbg_buf : nullptr;
         ProfScope prof(PROF_RHS_FUSED, st, 4.0 * n_elem * (2.0 * a.n_ticks + 3), 3.0 * a.n_ticks * (2.0 * A->nnz * H + 2.0 * (double)A->n_rows * H * H));
-#define NDCN_GO(IT_)                                                                           \
+#define NDCN_GO(IT_, C_)                                                                       \
         do {                                                                                   \
-            auto kern = solve_small_bwd_kernel<IT_>;                                           \
+            auto kern = solve_small_bwd_kernel<IT_, C_>;                                       \
             static bool cap_set = false;                                                       \
             if (!cap_set) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; cap_set = true; } \
-            hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a);                         \
+            hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a, symmetric);              \
         } while (0)
-        if (np <= 4) NDCN_GO(4); else NDCN_GO(12);
+        if (np <= 4) { if (csr) NDCN_GO(4, true); else NDCN_GO(4, false); }
+        else { if (csr) NDCN_GO(12, true); else NDCN_GO(12, false); }
 #undef NDCN_GO
         NDCN_LAUNCH_CHECK();
+        if (dbg_on) {
+            long long h[4];
+            NDCN_HIP(hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[solve_small_bwd] %d ticks: %lld shader cycles: forward pieces %lld, g_W + gS %lld, transposed gather %lld\n",
+                    a.n_ticks, h[0], h[1], h[2], h[3]);
+        }
         first = false;
     }
     return NDCN_OK;

@@ -1139,6 +1139,36 @@ int solver_advance_many(ndcn_solver *s, const double *h_ticks, int64_t n_ticks, 
     if (overlaps_borrowed(s, out, n_ticks)) return NDCN_EINVAL;
     const size_t stride = (size_t)s->n_elem;
     int64_t i = 0;
+    // Fixed grid on a state that fits one compute unit: the whole time vector in ONE launch (solve_small.hip) - bit-identical
+    // to the per-step kernels below, without their launch latency.
+    if (s->d.method != NDCN_M_DOPRI5 && n_ticks > 0 && !s->sharded && solve_small_supported(&s->d.A, s->d.H, s->d.rhs_flags, s->d.method)) {
+        std::vector<float> dts((size_t)n_ticks);
+        float tf = s->tf;
+        for (int64_t q = 0; q < n_ticks; ++q) {            // solvers.py:81-97 with grid == t: step sizes formed in the state dtype
+            const float t1 = (float)h_ticks[q];
+            dts[(size_t)q] = t1 - tf;
+            tf = t1;
+        }
+        int rc = solve_small_f32(&s->d.A, s->d.W, s->d.b, s->d.H, s->d.rhs_flags, s->d.method, s->ycur, dts.data(), n_ticks, out, st);
+        if (rc) return rc;
+        float *last = out + (size_t)(n_ticks - 1) * stride;
+        if (s->graph_on) {                                 // replayed steps keep the state inside the solver
+            NDCN_HIP(hipMemcpyAsync(s->ycur_own, last, stride * sizeof(float), hipMemcpyDeviceToDevice, st));
+            s->ycur = s->ycur_own;
+            s->cur_is_borrowed = false;
+        } else {
+            s->ycur = last;
+            s->cur_is_borrowed = true;
+        }
+        const int per = s->d.method == NDCN_M_EULER ? 1 : s->d.method == NDCN_M_MIDPOINT ? 2 : 4;
+        s->n_rhs += per * n_ticks;
+        s->tf = tf;
+        s->t0 = n_ticks > 1 ? h_ticks[n_ticks - 2] : s->t1;
+        s->t1 = h_ticks[n_ticks - 1];
+        s->n_attempt += n_ticks;
+        s->n_accept += n_ticks;
+        return NDCN_OK;
+    }
     while (i < n_ticks) {
         if (s->d.method != NDCN_M_DOPRI5) {
             int rc = fixed_advance(s, h_ticks[i], out + i * stride, st);

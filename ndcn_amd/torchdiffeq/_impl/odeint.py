@@ -89,6 +89,10 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
     needs_grad, f0 = _needs_grad(user_func, y0, probe=lambda: func(t[0].to(y0[0].dtype), y0))
     if f0 is not None:
         func = _reuse_first_evaluation(func, y0, f0)
+    if needs_grad and method == 'euler' and _device_resident_ok(user_func, tensor_input, y0, t_user, method, options):
+        sol = _small_solve_with_grad(user_func, y0[0], t)              # one launch forward, one launch backward - or None
+        if sol is not None:
+            return sol
     if needs_grad:
         from .autograd_path import odeint_with_grad
         sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func),
@@ -108,6 +112,77 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
         sol = core.integrate_fixed(hip, func, y0, t, method, autonomous=_autonomous(user_func))
     out = tuple(torch.stack([s[i] for s in sol]) for i in range(len(y0)))
     return out[0] if tensor_input else out
+
+
+# ---------------------------------------------------------------------------------------------------
+# training on a state that fits one compute unit: the whole Euler solve and its reverse sweep, one launch each
+# ---------------------------------------------------------------------------------------------------
+
+class _SmallEulerSolve(torch.autograd.Function):
+    """FixedGridODESolver.integrate with Euler steps (solvers.py:79-99, fixed_grid.py:7-8) over ODEFunc, differentiated the
+    way the reference's drivers train - plain backpropagation through every step (heat_dynamics.py:313-334) - with
+    ndcn_solve_small_f32 / ndcn_solve_small_bwd_f32 (csrc/solve_small.hip): the forward's trajectory IS the saved state."""
+
+    @staticmethod
+    def forward(ctx, y0, W, b, csr, flags, dts):
+        lib = _lib.load()
+        n_ticks = len(dts)
+        H = y0.shape[1]
+        out = torch.empty((n_ticks + 1,) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
+        out[0].copy_(y0)
+        arr = (ctypes.c_float * n_ticks)(*dts)
+        no_control = bool(flags & _lib.F_NO_CONTROL)
+        Wd = None if no_control else W.detach().contiguous()
+        bd = None if (no_control or b is None) else b.detach().contiguous()
+        view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0.shape[0]))
+        with torch.cuda.device(y0.device):
+            _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, _lib.M_EULER, _lib.ptr(out[0]), arr,
+                                                n_ticks, _lib.ptr(out[1:]), _lib.stream_ptr()))
+        ctx.csr, ctx.flags, ctx.dts, ctx.keep = csr, flags, arr, (Wd, bd)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        lib = _lib.load()
+        Wd, bd = ctx.keep
+        H = out.shape[2]
+        g = g.contiguous()
+        g_y0 = torch.empty_like(out[0])
+        g_W = torch.empty((H, H), dtype=torch.float32, device=out.device) if Wd is not None else None
+        g_b = torch.empty((H,), dtype=torch.float32, device=out.device) if Wd is not None else None
+        csr = ctx.csr
+        view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(out.shape[1]))
+        view_t = csr.transpose().view_ref() if csr is not None else view
+        with torch.cuda.device(out.device):
+            _lib.check(lib.ndcn_solve_small_bwd_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, _lib.M_EULER, _lib.ptr(out),
+                                                    _lib.ptr(g), ctx.dts, len(ctx.dts), _lib.ptr(g_y0), _lib.ptr(g_W), _lib.ptr(g_b),
+                                                    _lib.stream_ptr()))
+        return g_y0, g_W, (g_b if bd is not None else None), None, None, None
+
+
+def _small_solve_with_grad(odefunc, y0, t):
+    """The one-launch training path when the library supports the shape (H <= 31, the state and three work panels in one
+    CU's LDS: the reference's README commands), else None - the caller falls back to the per-step autograd path."""
+    from ...csr import as_csr
+    if t.requires_grad or os.environ.get('NDCN_SOLVE_SMALL_GRAD', '1') == '0' or t.numel() < 2:
+        return None
+    lib = _lib.load()
+    H = odefunc.hidden_size
+    flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
+    csr = None
+    if not odefunc.no_graph:
+        csr = as_csr(odefunc.A)
+        if csr.device != y0.device or csr.shape[0] != y0.shape[0]:
+            return None
+    view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0.shape[0]))
+    if not lib.ndcn_solve_small_supported(view, H, flags, _lib.M_EULER, 1):
+        return None
+    core.assert_increasing(t)
+    tt = t.detach().to('cpu').to(y0.dtype)                    # solvers.py:81: the grid in the state dtype
+    dts = (tt[1:] - tt[:-1]).tolist()
+    return _SmallEulerSolve.apply(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags, dts)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -225,12 +300,55 @@ class DeviceSolver:
             pass
 
 
+def _small_operator(odefunc, y0):
+    """(csr or None, ctypes view ref, flags) of an ODEFunc for the ndcn_solve_small_* entry points, or None when the operator
+    does not live with the state."""
+    from ...csr import as_csr
+    flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
+    if odefunc.no_graph:
+        return None, ctypes.byref(_lib.empty_csr(y0.shape[0])), flags
+    csr = as_csr(odefunc.A)
+    if csr.device != y0.device or csr.shape[0] != y0.shape[0]:
+        return None
+    return csr, csr.view_ref(), flags
+
+
+def _small_solve(odefunc, y0, tt, method):
+    """ndcn_solve_small_f32 without a solver object (no workspace, no host synchronisation): the inference counterpart of
+    _SmallEulerSolve.  tt: the time grid as Python floats ALREADY rounded to the state dtype (solvers.py:81)."""
+    import numpy as np
+    op = _small_operator(odefunc, y0)
+    if op is None:
+        return None
+    csr, view, flags = op
+    lib = _lib.load()
+    H = odefunc.hidden_size
+    if not lib.ndcn_solve_small_supported(view, H, flags, _lib.METHODS[method], 0):
+        return None
+    g = np.asarray(tt, dtype=np.float32)
+    dts = (g[1:] - g[:-1]).tolist()
+    out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
+    out[0].copy_(y0)
+    no_control = bool(flags & _lib.F_NO_CONTROL)
+    W = None if no_control else _lib.require_device(odefunc.wt.weight.detach().contiguous(), 'weight')
+    b = None if (no_control or odefunc.wt.bias is None) else odefunc.wt.bias.detach().contiguous()
+    arr = (ctypes.c_float * len(dts))(*dts)
+    with torch.cuda.device(y0.device):
+        _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(W), _lib.ptr(b), H, flags, _lib.METHODS[method], _lib.ptr(out[0]), arr,
+                                            len(dts), _lib.ptr(out[1:]), _lib.stream_ptr()))
+    return out
+
+
 def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     core.assert_increasing(t)
     tt = t.detach().to('cpu', torch.float64).tolist()
     if method != 'dopri5':
         # solvers.py:81: the fixed grid is t in the state dtype
         tt = t.detach().to('cpu').to(y0.dtype).to(torch.float64).tolist()
+    if method != 'dopri5' and len(tt) > 1:
+        out = _small_solve(odefunc, y0, tt, method)       # a state that fits one compute unit: the whole grid in ONE launch
+        if out is not None:
+            return out
     # launch-bound sizes replay ONE captured hipGraph per step - a fixed-grid step, or one attempted dopri5 step - with the
     # step size in device memory (the library declines where a path has no replayable form)
     use_graph = y0.numel() <= GRAPH_MAX_ELEMS and os.environ.get('NDCN_HIPGRAPH', '1') != '0'
