@@ -190,7 +190,7 @@ __device__ __forceinline__ void eval_fast(const int *rp, const int2 *ent, const 
     }
 }
 
-constexpr int kFastNp = 3;                  // passes evaluated together (srow: kFastNp x 64 floats per wave)
+constexpr int kFastNp = 1;                  // passes evaluated together (srow: kFastNp x 64 floats per wave)
 
 inline size_t lds_bytes_fast(int64_t n_elem, int64_t n_rows, int64_t nnz, int64_t extra_floats = 0) {
     return 8 * (size_t)nnz + sizeof(float) * (size_t)(n_elem + kWaves * 64 * kFastNp + extra_floats + n_rows + 1);
@@ -532,6 +532,222 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_kernel(BwdArgs b, int sy
     }
 }
 
+// The reverse sweep on the fast path (HT = H at compile time, the plain ODEFunc, a SYMMETRIC operator - the reference's
+// normalised Laplacian / adjacency - so that one packed copy of the entries serves A and A^T):
+//   forward pieces   the forward kernel's chains (packed entries, this lane's row of W in registers)
+//   g_W              4 x 4 register blocks: thread (block, row group) keeps 16 partial sums for the WHOLE sweep and adds, per row of
+//                    its group, the outer product of two 16-byte reads (gZ[r][4a..4a+3], S[r][4b..4b+3]); the groups meet once,
+//                    at the end
+//   gS = gZ W        lane (r, o) holds column o of W in registers: H/4 16-byte reads of the row's gZ + H fmas
+//   LDS: [entries | T | S | Z | srow | rowptr]; registers: the adjoint of the owned elements, the prefetched y_{i-1}
+template <int MAXIT, int HT>
+__global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, int n_groups, int rows_per_group) {
+    extern __shared__ float lds_raw[];
+    constexpr int H = HT, RPW = 64 / HT, NB = HT / 4;        // NB x NB blocks of 4 x 4 outputs
+    const int n_elem = b.n_rows * H;
+    int2 *ent = reinterpret_cast<int2 *>(lds_raw);
+    float *T = lds_raw + 2 * b.nnz, *S = T + n_elem, *Z = S + n_elem, *Adj = Z + n_elem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *srow = Adj + n_elem + wave * 64;
+    int *rp = reinterpret_cast<int *>(Adj + n_elem + kWaves * 64);
+    const int q = lane / H, o = lane - q * H;
+    const bool lane_on = q < RPW;
+    const int e0 = lane_on ? (wave * RPW + q) * H + o : n_elem, estride = kWaves * RPW * H;
+    for (int i = tid; i <= b.n_rows; i += 1024) rp[i] = b.rowptr[i];
+    for (int i = tid; i < b.nnz; i += 1024) ent[i] = make_int2(b.colidx[i] * H, __float_as_int(b.val[i]));
+    float wreg[HT], wcol[HT];
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+        wreg[h] = lane_on ? b.W[o * H + h] : 0.f;            // row o: K[o] = sum_h S[h] W[o][h]
+        wcol[h] = lane_on ? b.W[h * H + o] : 0.f;            // column o: gS[o] = sum_oo gZ[oo] W[oo][o]
+    }
+    const float bias_o = (b.bias && lane_on) ? b.bias[o] : 0.f;
+    float pre[MAXIT];                                        // (the adjoint itself lives in LDS: with it in registers the 12-pass build spilled 40)
+    {
+        const float *a0 = b.a_in ? b.a_in : b.g_out + (size_t)b.n_ticks * n_elem;
+        const float *yl = b.traj + (size_t)(b.n_ticks - 1) * n_elem;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            if (e < n_elem) Adj[e] = a0[e];
+            pre[it] = e < n_elem ? yl[e] : 0.f;
+        }
+    }
+    // g_W blocks: thread t < NB * NB * n_groups owns block (ba, bb) = ((t % (NB NB)) / NB, t % NB) over the rows of group t / (NB NB);
+    // g_b: the NB n_groups threads behind them own 4 bias entries each over one group
+    const int n_gw = NB * NB * n_groups, n_gb = NB * n_groups;
+    const bool gw_on = tid < n_gw, gb_on = !gw_on && tid < n_gw + n_gb;
+    const int grp = gw_on ? tid / (NB * NB) : gb_on ? (tid - n_gw) / NB : 0;
+    const int ba = gw_on ? (tid % (NB * NB)) / NB : gb_on ? (tid - n_gw) % NB : 0, bb = gw_on ? tid % NB : 0;
+    const int r_lo = grp * rows_per_group, r_hi = min(b.n_rows, r_lo + rows_per_group);
+    float acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.f;
+    long long c_a = 0, c_b = 0, c_c = 0, c0 = b.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    lds_barrier();
+    for (int i = b.n_ticks - 1; i >= 0; --i) {
+        const float dt = b.dt[i];
+        long long t_ = b.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        // ---- T <- y_i (requested during the previous step's last phase, by the owners);  Z <- dt a
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            if (e < n_elem) { T[e] = pre[it]; Z[e] = dt * Adj[e]; }
+        }
+        lds_barrier();
+        // ---- forward pieces at y_i: S = A y_i, K = relu(W S + b); gZ = dt a (.) [K > 0]
+#pragma nounroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if ((it * kWaves + wave) * RPW >= b.n_rows) break;
+            const int r = (it * kWaves + wave) * RPW + q;
+            const bool valid = lane_on && r < b.n_rows;
+            int j0 = 0, cnt = 0;
+            if (valid) { j0 = rp[r]; cnt = rp[r + 1] - j0; }
+            float s = 0.f;
+            for (int jb = 0; __any(jb < cnt); jb += 4) {
+                int2 en[4];
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) en[u] = ent[jb + u < cnt ? j0 + jb + u : 0];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = T[(jb + u < cnt ? en[u].x : 0) + o];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (jb + u < cnt) s = fmaf(__int_as_float(en[u].y), x[u], s);
+            }
+            __builtin_amdgcn_wave_barrier();
+            srow[lane] = s;
+            __builtin_amdgcn_wave_barrier();
+            const float4 *sr = reinterpret_cast<const float4 *>(srow + (valid ? q : 0) * H);
+            float k = 0.f;
+#pragma unroll
+            for (int h4 = 0; h4 < NB; ++h4) {
+                const float4 sv = sr[h4];
+                k = fmaf(sv.x, wreg[4 * h4], k);
+                k = fmaf(sv.y, wreg[4 * h4 + 1], k);
+                k = fmaf(sv.z, wreg[4 * h4 + 2], k);
+                k = fmaf(sv.w, wreg[4 * h4 + 3], k);
+            }
+            k = k + bias_o;
+            if (valid) {
+                S[r * H + o] = s;
+                if (b.relu && !(k > 0.f)) Z[r * H + o] = 0.f;
+            }
+        }
+        lds_barrier();
+        if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_a += n_ - t_; t_ = n_; }
+        // ---- g_W / g_b partial sums over this thread's row group;  gS = gZ W -> T
+        if (gw_on) {
+#pragma nounroll
+            for (int r = r_lo; r < r_hi; ++r) {
+                const float4 z = reinterpret_cast<const float4 *>(Z + r * H)[ba];
+                const float4 sv = reinterpret_cast<const float4 *>(S + r * H)[bb];
+                const float zz[4] = {z.x, z.y, z.z, z.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(zz[u], ss[v], acc[u][v]);
+            }
+        } else if (gb_on) {
+#pragma nounroll
+            for (int r = r_lo; r < r_hi; ++r) {
+                const float4 z = reinterpret_cast<const float4 *>(Z + r * H)[ba];
+                acc[0][0] += z.x; acc[0][1] += z.y; acc[0][2] += z.z; acc[0][3] += z.w;
+            }
+        }
+#pragma nounroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            if ((it * kWaves + wave) * RPW >= b.n_rows) break;
+            if (e < n_elem) {
+                const float4 *zr = reinterpret_cast<const float4 *>(Z + (e - o));
+                float gs = 0.f;
+#pragma unroll
+                for (int h4 = 0; h4 < NB; ++h4) {
+                    const float4 z = zr[h4];
+                    gs = fmaf(z.x, wcol[4 * h4], gs);
+                    gs = fmaf(z.y, wcol[4 * h4 + 1], gs);
+                    gs = fmaf(z.z, wcol[4 * h4 + 2], gs);
+                    gs = fmaf(z.w, wcol[4 * h4 + 3], gs);
+                }
+                T[e] = gs;
+            }
+        }
+        lds_barrier();
+        if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_b += n_ - t_; t_ = n_; }
+        // ---- S <- A^T gS = A gS (symmetric), each element by its owner; then a <- (a + S) + g_out[i];  y_{i-1} is requested here so
+        // that its registers are live across this phase only
+        if (i > 0) {
+            const float *yp = b.traj + (size_t)(i - 1) * n_elem;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                if (e < n_elem) pre[it] = yp[e];
+            }
+        }
+#pragma nounroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if ((it * kWaves + wave) * RPW >= b.n_rows) break;
+            const int r = (it * kWaves + wave) * RPW + q;
+            const bool valid = lane_on && r < b.n_rows;
+            int j0 = 0, cnt = 0;
+            if (valid) { j0 = rp[r]; cnt = rp[r + 1] - j0; }
+            float s = 0.f;
+            for (int jb = 0; __any(jb < cnt); jb += 4) {
+                int2 en[4];
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) en[u] = ent[jb + u < cnt ? j0 + jb + u : 0];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = T[(jb + u < cnt ? en[u].x : 0) + o];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (jb + u < cnt) s = fmaf(__int_as_float(en[u].y), x[u], s);
+            }
+            if (valid) S[r * H + o] = s;
+        }
+        {
+            const float *gi = b.g_out + (size_t)i * n_elem;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                if (e < n_elem) Adj[e] = (Adj[e] + S[e]) + gi[e];
+            }
+        }
+        lds_barrier();
+        if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_c += n_ - t_; t_ = n_; }
+    }
+    if (b.dbg && tid == 0) {
+        b.dbg[0] = (long long)__builtin_readcyclecounter() - c0;
+        b.dbg[1] = c_a; b.dbg[2] = c_b; b.dbg[3] = c_c;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int e = e0 + it * estride;
+        if (e < n_elem) b.g_y0[e] = Adj[e];
+    }
+    // the row groups of every g_W / g_b entry meet in LDS: T[group][H*H + H], summed in group order (deterministic)
+    const int HH = H * H;
+    float *red = T;                                          // n_groups * (HH + H) floats <= 3 panels (checked by the host)
+    if (gw_on) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[grp * (HH + H) + (4 * ba + u) * H + 4 * bb + v] = acc[u][v];
+    } else if (gb_on) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[grp * (HH + H) + HH + 4 * ba + v] = acc[0][v];
+    }
+    lds_barrier();
+    if (tid < HH + H) {
+        float sum = 0.f;
+        for (int g = 0; g < n_groups; ++g) sum += red[g * (HH + H) + tid];
+        if (tid < HH) b.g_W[tid] += sum; else b.g_b[tid - HH] += sum;
+    }
+}
+
 int passes(int64_t n_rows, int H) {
     const int RPW = 64 / H;
     const int64_t wave_passes = (n_rows + RPW - 1) / RPW;
@@ -702,6 +918,25 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         if (dbg_on && !dbg_buf) NDCN_HIP(hipMalloc(&dbg_buf, 4 * sizeof(long long)));
         a.dbg = dbg_on ? dbg_buf : nullptr;
         ProfScope prof(PROF_RHS_FUSED, st, 4.0 * n_elem * (2.0 * a.n_ticks + 3), 3.0 * a.n_ticks * (2.0 * A->nnz * H + 2.0 * (double)A->n_rows * H * H));
+        static const bool fast_on = [] { const char *e = getenv("NDCN_SOLVE_SMALL_FAST"); return !(e && e[0] == '0'); }();
+        const bool fast_shape = fast_on && (H == 16 || H == 20) && !no_graph && !no_control && symmetric;
+        const int NBh = fast_shape ? H / 4 : 1;
+        const int n_groups = std::max(1, std::min<int>(1024 / (NBh * NBh + NBh), (int)A->n_rows));
+        const int rows_per_group = (int)((A->n_rows + n_groups - 1) / n_groups);
+        const size_t lds_fast = lds_bytes_fast(4 * n_elem, A->n_rows, nnz);
+        const bool fast = fast_shape && lds_fast <= kLdsMax && (int64_t)n_groups * (H * H + H) <= 3 * n_elem;
+        if (fast) {
+#define NDCN_FGO(IT_, HT_)                                                                     \
+            do {                                                                               \
+                auto kern = solve_small_bwd_fast_kernel<IT_, HT_>;                             \
+                static bool cap_set = false;                                                   \
+                if (!cap_set) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; cap_set = true; } \
+                hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_fast, st, a, n_groups, rows_per_group); \
+            } while (0)
+            if (H == 20) { if (np <= 4) NDCN_FGO(4, 20); else NDCN_FGO(12, 20); }
+            else { if (np <= 4) NDCN_FGO(4, 16); else NDCN_FGO(12, 16); }
+#undef NDCN_FGO
+        } else {
 #define NDCN_GO(IT_, C_)                                                                       \
         do {                                                                                   \
             auto kern = solve_small_bwd_kernel<IT_, C_>;                                       \
@@ -712,6 +947,7 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         if (np <= 4) { if (csr) NDCN_GO(4, true); else NDCN_GO(4, false); }
         else { if (csr) NDCN_GO(12, true); else NDCN_GO(12, false); }
 #undef NDCN_GO
+        }
         NDCN_LAUNCH_CHECK();
         if (dbg_on) {
             long long h[4];
