@@ -190,6 +190,13 @@ NDCN_API int ndcn_spmm_f32(const ndcn_csr *A, const float *X, const float *X_hal
 NDCN_API int ndcn_linear_f32(const float *S, const float *W, const float *b, float *Y,
                     int64_t n, int H_in, int H_out, uint32_t flags, void *stream);
 
+/* GraphConvolution.forward in the reference's own order (models.py:14-18; neural_dynamics.py:171-176): support = X W^T + b, then
+ * Y = A support  [then relu] - i.e. ndcn_linear_f32 followed by ndcn_spmm_f32 in ONE call (two launches on `stream`).
+ * X [n_cols(A), H_in], Y [n_rows(A), H_out]; work: ndcn_gcn_work_bytes() bytes of device scratch (the support panel).       */
+NDCN_API int ndcn_gcn_f32(const ndcn_csr *A, const float *X, const float *W, const float *b, float *Y, float *work,
+                          int H_in, int H_out, uint32_t flags, void *stream);
+NDCN_API int64_t ndcn_gcn_work_bytes(int64_t n_cols, int H_out);
+
 /* Backward of Y = act(S W^T + b) - the reference trains by plain autograd through every solver op
  * (heat_dynamics.py:333, dgnn.py:204; neural_dynamics.py:33,36,143-148).  gZ = g (.) [Y > 0] when the ReLU output Y is
  * given (nullable: no activation), then
@@ -243,6 +250,21 @@ NDCN_API int ndcn_dopri5_interp_bwd_f32(const float *g, const float *y0, const f
 NDCN_API int ndcn_rhs_f32(const ndcn_csr *A, const float *X, const float *X_halo, int64_t n_own,
                  const float *W, const float *b, float *Y, float *work, int H, uint32_t flags, void *stream);
 NDCN_API int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
+
+/* The right-hand side of the ADJOINT system for ODEFunc (odeint_adjoint: torchdiffeq/_impl/adjoint.py:34-59, where the reference
+ * evaluates func under enable_grad and calls torch.autograd.grad with cotangent -adj_y at EVERY evaluation of the backward
+ * solve).  With f = relu(W (A y) + b) the three vector-Jacobian products are closed forms; one call, no torch graph:
+ *   K     [n][H]  = ODEFunc(y)                              (func_eval)
+ *   vjp_y [n][H]  = -A^T ((a (.) [K > 0]) W)                (d/dt of adj_y)
+ *   vjp_W [H][H]  = -(a (.) [K > 0])^T (A y)                (d/dt of adj_params, weight part; nn.Linear's [out][in] layout)
+ *   vjp_b [H]     = -column sums of a (.) [K > 0]           (bias part)
+ * (d/dt of adj_t is zero: the reference ODEFunc ignores t, neural_dynamics.py:20-26.)  a = adj_y.  A_t: the operator's
+ * transpose as CSR.  NDCN_F_NO_GRAPH / NDCN_F_NO_CONTROL as ndcn_rhs_f32 (NO_CONTROL: vjp_W / vjp_b are not written).
+ * work: ndcn_adjoint_rhs_work_bytes() bytes, 256-byte aligned.  b nullable.                                              */
+NDCN_API int ndcn_adjoint_rhs_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *y, const float *a, const float *W,
+                                  const float *b, float *K, float *vjp_y, float *vjp_W, float *vjp_b, void *work, int H,
+                                  uint32_t flags, void *stream);
+NDCN_API int64_t ndcn_adjoint_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 
 /* ODEFunc.forward PLUS the Runge-Kutta algebra that consumes its result, in one pass over the panel
  * (H = 256: inside the fused kernel's epilogue; other widths: the same result from separate kernels).

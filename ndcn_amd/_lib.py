@@ -100,6 +100,8 @@ SIGNATURES = {
     'ndcn_csr_set_hub_scratch': (_I, [_P, _P, _P]),
     'ndcn_spmm_f32': (_I, [_CSR, _P, _P, _L, _P, _I, _F, _U, _P]),
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
+    'ndcn_gcn_f32': (_I, [_CSR, _P, _P, _P, _P, _P, _I, _I, _U, _P]),
+    'ndcn_gcn_work_bytes': (_L, [_L, _I]),
     'ndcn_linear_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'ndcn_linear_bwd_work_bytes': (_L, [_L, _I, _I]),
     'ndcn_scale_f32': (_I, [_P, _P, _F, _L, _P]),
@@ -113,6 +115,8 @@ SIGNATURES = {
     'ndcn_dopri5_interp_bwd_f32': (_I, [_P, _P, _P, ctypes.POINTER(_P), _F, _F, _P, _P, ctypes.POINTER(_P), _P, _P, _L, _P]),
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
+    'ndcn_adjoint_rhs_f32': (_I, [_CSR, _CSR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _U, _P]),
+    'ndcn_adjoint_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
                         _P, _P, _P, ctypes.POINTER(_F), _F, _F, _P, _P, _P]),
     'ndcn_rhs_xadd_supported': (_I, [_CSR, _I, _U, _I, _I]),

@@ -45,6 +45,38 @@ int ndcn_abi_version(void) { return NDCN_ABI_VERSION; }
 int ndcn_debug_last_rhs_path(void) { return g_last_rhs_path; }
 const char *ndcn_last_error(void) { return g_err; }
 
+int64_t ndcn_adjoint_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) { return adjoint_rhs_work_bytes(n_rows, H, flags); }
+
+int ndcn_adjoint_rhs_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *y, const float *a, const float *W, const float *b,
+                         float *K, float *vjp_y, float *vjp_W, float *vjp_b, void *work, int H, uint32_t flags, void *stream) {
+    NDCN_CHECK_ARG(A && y && a && K && vjp_y && work && H > 0, "null argument");
+    const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
+    if (graph) {
+        int rc = check_csr(A, __func__);
+        if (rc) return rc;
+        if ((rc = check_csr(A_t, __func__))) return rc;
+        NDCN_CHECK_ARG(A->n_rows == A->n_cols && A_t->n_rows == A->n_cols && A_t->n_cols == A->n_rows && A_t->nnz == A->nnz,
+                       "the adjoint needs a square operator and its transpose");
+    }
+    NDCN_CHECK_ARG(!ctl || (W && vjp_W && vjp_b), "weight / parameter-gradient buffers missing");
+    NDCN_CHECK_ARG(aligned16(y) && aligned16(a) && aligned16(K) && aligned16(vjp_y) && (reinterpret_cast<uintptr_t>(work) & 255) == 0,
+                   "panels must be 16-byte aligned, the scratch 256-byte aligned");
+    return adjoint_rhs_f32(A, A_t, y, a, W, b, K, vjp_y, vjp_W, vjp_b, work, H, flags, ST(stream));
+}
+
+int64_t ndcn_gcn_work_bytes(int64_t n_cols, int H_out) { return n_cols < 0 || H_out <= 0 ? 0 : (((n_cols * (int64_t)H_out * 4) + 255) & ~(int64_t)255); }
+
+int ndcn_gcn_f32(const ndcn_csr *A, const float *X, const float *W, const float *b, float *Y, float *work, int H_in, int H_out,
+                 uint32_t flags, void *stream) {
+    int rc = check_csr(A, __func__);
+    if (rc) return rc;
+    NDCN_CHECK_ARG(X && W && Y && work && H_in > 0 && H_out > 0, "null argument");
+    NDCN_CHECK_ARG(aligned16(work) && aligned16(Y), "panels must be 16-byte aligned");
+    // support = X W^T + b over the operator's COLUMN nodes (no activation), then the sparse product over it
+    if ((rc = linear_f32(X, W, b, work, A->n_cols, H_in, H_out, 0, ST(stream)))) return rc;
+    return spmm_f32(A, work, nullptr, A->n_cols, Y, H_out, 1.0f, flags & NDCN_F_RELU, ST(stream));
+}
+
 int ndcn_solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method, int backward) {
     if (!A) return 0;
     return backward ? solve_small_bwd_supported(A, H, flags, method) : solve_small_supported(A, H, flags, method);

@@ -91,6 +91,10 @@ int solve_small_bwd_supported(const ndcn_csr *A, int H, uint32_t flags, int meth
 int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags, int method,
                         const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, float *g_y0, float *g_W,
                         float *g_b, hipStream_t st);
+// adjoint.hip: func_eval and the three vector-Jacobian products of the adjoint system's right-hand side for ODEFunc
+int64_t adjoint_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
+int adjoint_rhs_f32(const ndcn_csr *A, const ndcn_csr *At, const float *y, const float *a, const float *W, const float *b, float *K,
+                    float *vjp_y, float *vjp_W, float *vjp_b, void *work, int H, uint32_t flags, hipStream_t st);
 int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp,
                          const float *b, float *Y, uint32_t flags, hipStream_t st);
 

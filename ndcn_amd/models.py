@@ -15,11 +15,10 @@ class GraphConvolution(nn.Module):
         self.fc = _HipLinear(input_size, output_size, bias=bias)
 
     def forward(self, input, propagation_adj):
-        support = self.fc(input)
-        if _needs_grad(support):
-            from .autograd_ops import spmm
-            return spmm(propagation_adj, support)
-        return hip.spmm(propagation_adj, support)
+        if not _needs_grad(input, self.fc):
+            return hip.gcn(propagation_adj, input, self.fc.weight, self.fc.bias)      # ndcn_gcn_f32: Linear -> SpMM in one call
+        from .autograd_ops import spmm
+        return spmm(propagation_adj, self.fc(input))
 
 
 class GCN(nn.Module):

@@ -168,6 +168,56 @@ class HipOps:
         return Y.view(-1) if squeeze else Y
 
     @staticmethod
+    def adjoint_rhs(A, y, a, W, b, no_graph=False, no_control=False):
+        """ndcn_adjoint_rhs_f32: (K, vjp_y, vjp_W, vjp_b) = (ODEFunc(y), -A^T((a.[K>0]) W), -(a.[K>0])^T (A y), -sum_rows a.[K>0]) -
+        the right-hand side of odeint_adjoint's augmented system (adjoint.py:34-59) without a torch graph; vjp_W / vjp_b are
+        None under no_control."""
+        y, a = _panel(y), _panel(a)
+        H = y.shape[1]
+        flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
+        lib = _lib.load()
+        if no_graph:
+            view = view_t = ctypes.byref(_lib.empty_csr(y.shape[0]))
+        else:
+            A = as_csr(A)
+            A.ensure_plans(H)
+            At = A.transpose()
+            At.ensure_plans(H)
+            view, view_t = A.view_ref(), At.view_ref()
+        K, vjp_y = torch.empty_like(y), torch.empty_like(y)
+        vW = vb = None
+        if not no_control:
+            W = _panel(W, 'weight')
+            b = _panel(b, 'bias') if b is not None else None
+            vW = torch.empty((H, H), dtype=torch.float32, device=y.device)
+            vb = torch.empty((H,), dtype=torch.float32, device=y.device)
+        work = torch.empty(int(lib.ndcn_adjoint_rhs_work_bytes(y.shape[0], H, flags)) + 256, dtype=torch.uint8, device=y.device)
+        off = (-work.data_ptr()) % 256
+        with torch.cuda.device(y.device):
+            check(lib.ndcn_adjoint_rhs_f32(view, view_t, ptr(y), ptr(a), ptr(None if no_control else W), ptr(None if no_control else b),
+                                           ptr(K), ptr(vjp_y), ptr(vW), ptr(vb), ctypes.c_void_p(work.data_ptr() + off), H, flags,
+                                           stream_ptr()))
+        return K, vjp_y, vW, vb
+
+    @staticmethod
+    def gcn(A, X, W, b=None, relu=False):
+        """A (X W^T + b) [relu]: GraphConvolution.forward of the reference (models.py:14-18) in one library call."""
+        A = as_csr(A)
+        X, W = _panel(X), _panel(W, 'weight')
+        if b is not None:
+            b = _panel(b, 'bias')
+        Ho, Hi = W.shape
+        assert X.dim() == 2 and X.shape == (A.shape[1], Hi)
+        A.ensure_plans(Ho)
+        lib = _lib.load()
+        Y = torch.empty((A.shape[0], Ho), dtype=torch.float32, device=X.device)
+        work = torch.empty(int(lib.ndcn_gcn_work_bytes(A.shape[1], Ho)), dtype=torch.uint8, device=X.device)
+        with torch.cuda.device(X.device):
+            check(lib.ndcn_gcn_f32(A.view_ref(), ptr(X), ptr(W), ptr(b), ptr(Y), ptr(work), Hi, Ho,
+                                   _lib.F_RELU if relu else 0, stream_ptr()))
+        return Y
+
+    @staticmethod
     def linear(S, W, b=None, relu=False):
         """S W^T + b [relu] over the last dimension (nn.Linear semantics; neural_dynamics.py:33,143-148)."""
         S = _panel(S)

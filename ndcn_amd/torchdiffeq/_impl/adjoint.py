@@ -31,6 +31,20 @@ class _TupleFunc(nn.Module):
         return (self.base_func(t, y[0]),)
 
 
+def _native_odefunc(func, n_state, ans):
+    """This package's ODEFunc behind the tuple wrapper, when the closed-form adjoint right-hand side applies: one N x H
+    device panel as state, the deterministic ODEFunc (dropout inactive), a square operator."""
+    import os
+    from ...neural_dynamics import ODEFunc
+    base = getattr(func, 'base_func', None)
+    if os.environ.get('NDCN_ADJOINT_NATIVE', '1') == '0' or n_state != 1 or type(base) is not ODEFunc:
+        return None
+    y = ans[0]
+    if y.dim() != 3 or y.shape[2] != base.hidden_size or not y.is_cuda or (base.training and base.dropout > 0):
+        return None
+    return base
+
+
 class _AdjointMethod(torch.autograd.Function):
 
     @staticmethod
@@ -68,6 +82,23 @@ class _AdjointMethod(torch.autograd.Function):
                 vjp_p = torch.tensor(0.).to(vjp_y[0])
             return (*[f.detach() for f in f_eval], *vjp_y, vjp_t, vjp_p)
 
+        native = _native_odefunc(func, n, ans)
+        if native is not None:
+            # HIP-native right-hand side (csrc/adjoint.hip): func_eval and the three vector-Jacobian products as closed forms
+            # of ODEFunc = relu(W (A y) + b) - no torch graph, no zeros_like, no torch reductions on the path
+            from ...ops import hip
+            f0 = native
+            zero_t = torch.zeros((), dtype=t.dtype, device=ans[0].device)
+            no_params = torch.zeros((), dtype=ans[0].dtype, device=ans[0].device)
+
+            def augmented(tt, y_aug):                                                    # noqa: F811
+                K, vjp_y, vW, vb = hip.adjoint_rhs(f0.A, y_aug[0], y_aug[1], f0.wt.weight, f0.wt.bias, f0.no_graph, f0.no_control)
+                if vW is None:                                   # no_control: `wt` sits in the parameter list, unused -> zeros
+                    vjp_p = torch.zeros_like(flat_params)
+                else:
+                    vjp_p = torch.cat([vW.view(-1), vb]) if f0.wt.bias is not None else vW.view(-1)
+                return (K, vjp_y, zero_t, vjp_p if len(f_params) else no_params)
+
         T = ans[0].shape[0]
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
@@ -79,7 +110,11 @@ class _AdjointMethod(torch.autograd.Function):
                 grad_i = tuple(g[i] for g in grad_output)
                 f_i = func(t[i], ans_i)
                 # effect of moving the measurement time                               adjoint.py:72-77
-                dLd_t = sum(torch.dot(f.reshape(-1), g.reshape(-1)).view(1) for f, g in zip(f_i, grad_i))
+                if native is not None:                           # <f, g> by the library's fixed-order reduction (fp64 partials)
+                    _, dots = hip.combine_bwd(grad_i[0].contiguous(), [f_i[0]], [1.0], [False], need_dots=True)
+                    dLd_t = torch.tensor([dots[0]], dtype=t.dtype, device=adj_y[0].device)
+                else:
+                    dLd_t = sum(torch.dot(f.reshape(-1), g.reshape(-1)).view(1) for f, g in zip(f_i, grad_i))
                 adj_time = adj_time - dLd_t
                 time_vjps.append(dLd_t)
                 if adj_params.numel() == 0:
@@ -90,7 +125,10 @@ class _AdjointMethod(torch.autograd.Function):
                 adj_y = tuple(a[1] for a in aug[n:2 * n])
                 adj_time = aug[2 * n][1]
                 adj_params = aug[2 * n + 1][1]
-                adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
+                if native is not None:
+                    adj_y = (hip.combine(adj_y[0].contiguous(), [grad_output[0][i - 1].contiguous()], [1.0]),)
+                else:
+                    adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
                 del aug0, aug
             time_vjps.append(adj_time.reshape(1))
             time_vjps = torch.cat([v.reshape(1) for v in time_vjps[::-1]])

@@ -158,6 +158,61 @@ def test_odeint_adjoint_against_reference_gradients(dev, method):
     assert out.requires_grad and out.shape == (144, 8)
 
 
+@pytest.mark.parametrize('variant', ['default', 'no_control', 'no_graph'])
+@pytest.mark.parametrize('n_side,H', [(20, 20), (12, 256), (9, 1), (30, 64)])
+def test_native_adjoint_rhs_equals_autograd_through_the_oracle(dev, variant, n_side, H):
+    """ndcn_adjoint_rhs_f32 (csrc/adjoint.hip): func_eval and the three vector-Jacobian products of the adjoint system's
+    right-hand side (adjoint.py:34-59) against torch.autograd.grad through the oracle's ODEFunc with cotangent -adj_y -
+    what the reference computes at every evaluation of its backward solve - on a NON-symmetric operator."""
+    import scipy.sparse as sp
+    from ndcn_amd import graphs, hip, CsrOperator
+    n = n_side * n_side
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(n_side)).tocsr()
+    L = (L + sp.triu(L, 1) * 0.5).tocsr()                                     # break the symmetry: A^T matters
+    L.sort_indices()
+    gen = torch.Generator().manual_seed(H + n)
+    y, a = torch.randn(n, H, generator=gen), torch.randn(n, H, generator=gen)
+    W, b = torch.randn(H, H, generator=gen) / max(1.0, H ** 0.5), torch.randn(H, generator=gen)
+    no_control, no_graph = variant == 'no_control', variant == 'no_graph'
+    A = CsrOperator.from_scipy(L, dev)
+    K, vy, vW, vb = hip.adjoint_rhs(A, y.to(dev), a.to(dev), W.to(dev), b.to(dev), no_graph=no_graph, no_control=no_control)
+    Ao = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
+    yo, Wo, bo = (v.double().requires_grad_(True) for v in (y, W, b))
+    Ko = orc.odefunc_rhs(Ao.double(), yo, Wo, bo, no_graph=no_graph, no_control=no_control)
+    gy, gW, gb = torch.autograd.grad(Ko, (yo, Wo, bo), -a.double(), allow_unused=True)
+    close = lambda got, ref: float((got.cpu().double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert close(K, Ko.detach()) and close(vy, gy)
+    if no_control:
+        assert vW is None and vb is None and gW is None
+    else:
+        assert close(vW, gW) and close(vb, gb)
+
+
+def test_odeint_adjoint_native_rhs_equals_the_autograd_rhs(dev):
+    """The backward solve of odeint_adjoint with the closed-form right-hand side (default) and with func + torch.autograd.grad
+    per evaluation (NDCN_ADJOINT_NATIVE=0): same gradients (rk4: same grid, rounding-level agreement)."""
+    import os
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('adjoint_rk4')
+    res = {}
+    for flag in ('1', '0'):
+        os.environ['NDCN_ADJOINT_NATIVE'] = flag
+        try:
+            f = ODEFunc(8, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
+            f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+            x0 = T(d['x0']).to(dev).requires_grad_(True)
+            t = T(d['t']).to(dev).requires_grad_(True)
+            y = ode.odeint_adjoint(f, x0, t, method='rk4')
+            torch.nn.functional.l1_loss(y, T(d['target']).to(dev)).backward()
+            res[flag] = [v.cpu().clone() for v in (x0.grad, f.wt.weight.grad, f.wt.bias.grad, t.grad)]
+        finally:
+            del os.environ['NDCN_ADJOINT_NATIVE']
+    for got, ref in zip(res['1'], res['0']):
+        assert rel(got, ref) < 1e-4
+
+
 @pytest.mark.parametrize('n,Hi,Ho', [(400, 20, 20), (1000, 256, 256), (777, 1, 20), (777, 20, 1), (3001, 64, 16), (130, 300, 40),
                                      (9, 256, 256), (70000, 256, 256)])
 @pytest.mark.parametrize('masked', [False, True])

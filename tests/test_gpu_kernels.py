@@ -933,6 +933,21 @@ def test_first_generation_fused_kernel_still_serves_as_fallback(dev):
     assert r.returncode == 0 and 'fallback ok' in r.stdout, r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('Hi,Ho', [(20, 20), (256, 256), (33, 7)])
+def test_gcn_entry_point_is_linear_then_spmm(dev, Hi, Ho):
+    """ndcn_gcn_f32 = GraphConvolution.forward of the reference (models.py:14-18: fc, then torch.sparse.mm) in one call: the same
+    bits as ndcn_linear_f32 followed by ndcn_spmm_f32, and the oracle's expression to rounding."""
+    from ndcn_amd import graphs, hip
+    L = graphs.normalized_adj(graphs.make_graph('power_law', 1500, seed=4))
+    A = graphs.to_device(L, dev)
+    gen = torch.Generator().manual_seed(Hi)
+    X, W, b = torch.randn(1500, Hi, generator=gen), torch.randn(Ho, Hi, generator=gen) / 4, torch.randn(Ho, generator=gen)
+    got = hip.gcn(A, X.to(dev), W.to(dev), b.to(dev))
+    assert torch.equal(got, hip.spmm(A, hip.linear(X.to(dev), W.to(dev), b.to(dev))))
+    ref = orc.gcn_layer(orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape), X, W, b)
+    assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_integration_stub_runs(dev):
     """the ~40-line ctypes stub a reference maintainer would add (examples/ndcn_hip_binding.py,
     no ndcn_amd import: ndcn_csr_create on the arrays of a torch COO operator, then ndcn_rhs_f32 on the handle's view)
