@@ -15,6 +15,9 @@
 #   sharded TAG                  multi-GPU code path on one GPU: tests + bench --sharded with the self-halo hook
 #   train                        autograd tests + training-step timing
 #   lab NAME [args]              hipcc tools/micro/NAME.hip on the box and run it
+#   locality TAG [cfg:layout ..] where the gather kernels' bytes come from (default C2:none C2:degree C3:none C3:degree C4:none M:none):
+#                                per variant TCC_HIT_sum / TCC_MISS_sum (L2 hit rate), FETCH_SIZE / WRITE_SIZE (fabric bytes,
+#                                Infinity-Cache hits included) and the kernels' average time -> gpurun_out/TAG_locality.json
 set -u
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -221,6 +224,56 @@ train)
   tail -15 gpurun_out/pytest_autograd.log | cut -c1-300
   timeout 900 python tools/bench_train.py > gpurun_out/train.log 2>&1
   cut -c1-400 gpurun_out/train.log
+  ;;
+locality)
+  R=${1:-r04}; shift || true
+  VARS=("$@"); [ ${#VARS[@]} -eq 0 ] && VARS=(C2:none C2:degree C3:none C3:degree C4:none M:none)
+  for v in "${VARS[@]}"; do
+    cfg=${v%%:*}; lay=${v##*:}
+    a=$(bench_args "$cfg"); [ "$lay" != none ] && a="$a --layout $lay"
+    for ctr in "TCC_HIT_sum TCC_MISS_sum" FETCH_SIZE WRITE_SIZE; do
+      tag=${ctr%% *}
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/loc_${R}_${cfg}_${lay}_$tag" -o p -- \
+         python "$GRAFT_REPO_ROOT/bench.py" $a --no-cpu-baseline --no-profile-pass --steps 4 --warmup 1 > /dev/null 2>&1)
+    done
+  done
+  python - "$R" "${VARS[@]}" <<'PY'
+import csv, glob, json, collections, sys, re
+tag, variants = sys.argv[1], sys.argv[2:]
+out = {'note': 'rocprofv3 --kernel-trace --pmc, one counter group per pass over `bench.py <cfg> [--layout L] --steps 4 --warmup 1` (tools/gpu.sh locality). '
+               'l2_hit_rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); fabric_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch (gfx950: FETCH_SIZE '
+               'tallies 128-byte requests at 64 B, MI355X_MICROARCH.md; Infinity-Cache hits are included); avg_us from the kernel trace of the same pass.',
+       'variants': {}}
+for v in variants:
+    cfg, lay = v.split(':')
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for grp in ('TCC_HIT_sum', 'FETCH_SIZE', 'WRITE_SIZE'):
+        base = 'gpurun_out/loc_%s_%s_%s_%s' % (tag, cfg, lay, grp)
+        for f in glob.glob(base + '/**/*counter_collection.csv', recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('ndcn::', '')
+                agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        if grp == 'TCC_HIT_sum':
+            for f in glob.glob(base + '/**/*kernel_trace.csv', recursive=True):
+                for r in csv.DictReader(open(f)):
+                    k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('ndcn::', '')
+                    dur[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    rows = {}
+    for k, c in agg.items():
+        if not re.search(r'rhs_fused|spmm_', k):
+            continue
+        m = lambda n: sum(c[n]) / len(c[n]) if c.get(n) else 0.0
+        hit, miss = m('TCC_HIT_sum'), m('TCC_MISS_sum')
+        fab = (2 * m('FETCH_SIZE') + m('WRITE_SIZE')) * 1024
+        us = sum(dur[k]) / len(dur[k]) / 1e3 if dur.get(k) else 0.0
+        rows[k] = {'launches': len(c.get('TCC_HIT_sum', [])), 'avg_us': round(us, 1), 'l2_hit_rate': round(hit / (hit + miss), 4) if hit + miss else None,
+                   'l2_requests': int(hit + miss), 'fabric_bytes': int(fab), 'fabric_GBps': round(fab / us / 1e3, 1) if us else None}
+    out['variants'][v] = rows
+    for k, r in sorted(rows.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['launches'])[:6]:
+        print('%-12s %-44s n=%3d %8.1f us  L2 hit %s  fabric %.3f GB  %s GB/s' % (v, k[:44], r['launches'], r['avg_us'], r['l2_hit_rate'], r['fabric_bytes'] / 1e9, r['fabric_GBps']))
+json.dump(out, open('gpurun_out/%s_locality.json' % tag, 'w'), indent=1)
+PY
   ;;
 lab)
   N=$1; shift
