@@ -232,16 +232,24 @@ NDCN_API int ndcn_copy_f32(float *dst, const float *src, int64_t n_elem, void *s
  *   interp    (dopri5.py:39-45, interp.py:21-65)  o = dense output at abscissa x for step size dt :  gy0, gy1, gk_0..6 ;
  *                                 d_dots[0] = <g, d o / d x>, d_dots[1] = <g, d o / d dt>                              */
 NDCN_API int64_t ndcn_rk_bwd_ws_bytes(void);
+/* Accumulating form (h_acc / acc_y0 / acc_y1, all nullable, entries nullable): a panel that feeds SEVERAL later operations - every
+ * stage derivative of a Runge-Kutta step does - receives one gradient per consumer, which autograd would add up with a pass of its
+ * own each (`add` kernels were 24 % of a dopri5 training step).  Given the gradient such a panel has ALREADY received (acc), the
+ * kernels write  gk_j = acc_j + (this operation's contribution)  in the pass they make anyway; outputs may alias their acc.
+ * combine: gy0 = acc_y0 + g is written only when acc_y0 is given (without one, g_y0 is g itself).                                */
 NDCN_API int ndcn_rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk,
-                                     double *d_dots, void *d_ws, int64_t n_elem, void *stream);
+                                     const float *const *h_acc, float *gy0, const float *acc_y0, double *d_dots, void *d_ws,
+                                     int64_t n_elem, void *stream);
 NDCN_API int ndcn_rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k,
                                    float rtol, float atol, float g_r, double inv_n, float *gy0, float *gy1,
-                                   float *const *h_gk, double *d_dots, void *d_ws, int64_t n_elem, void *stream);
+                                   float *const *h_gk, const float *acc_y0, const float *acc_y1, const float *const *h_acc,
+                                   double *d_dots, void *d_ws, int64_t n_elem, void *stream);
 NDCN_API int ndcn_rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, float atol, float coef, float *ga,
                                  float *gb, float *gy, int64_t n_elem, void *stream);
 NDCN_API int ndcn_dopri5_interp_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k /*7*/,
-                                        float dt, float x, float *gy0, float *gy1, float *const *h_gk /*7*/, double *d_dots,
-                                        void *d_ws, int64_t n_elem, void *stream);
+                                        float dt, float x, float *gy0, float *gy1, float *const *h_gk /*7*/, const float *acc_y0,
+                                        const float *acc_y1, const float *const *h_acc /*7*/, double *d_dots, void *d_ws,
+                                        int64_t n_elem, void *stream);
 
 /* The whole ODEFunc.forward in one call: Y = relu(W (A X) + b) honouring NO_GRAPH / NO_CONTROL
  * (neural_dynamics.py:20-39, dropout p = 0).  `work`: device scratch of ndcn_rhs_work_bytes() bytes, 16-byte

@@ -108,11 +108,13 @@ SIGNATURES = {
     'ndcn_relu_bwd_f32': (_I, [_P, _P, _P, _L, _P]),
     'ndcn_copy_f32': (_I, [_P, _P, _L, _P]),
     'ndcn_rk_bwd_ws_bytes': (_L, []),
-    'ndcn_rk_combine_bwd_f32': (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, ctypes.POINTER(_P), _P, _P, _L, _P]),
+    'ndcn_rk_combine_bwd_f32': (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _P, _P,
+                                _P, _P, _L, _P]),
     'ndcn_rk_error_bwd_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _F, _D, _P, _P,
-                              ctypes.POINTER(_P), _P, _P, _L, _P]),
+                              ctypes.POINTER(_P), _P, _P, ctypes.POINTER(_P), _P, _P, _L, _P]),
     'ndcn_rk_rms_bwd_f32': (_I, [_P, _P, _P, _F, _F, _F, _P, _P, _P, _L, _P]),
-    'ndcn_dopri5_interp_bwd_f32': (_I, [_P, _P, _P, ctypes.POINTER(_P), _F, _F, _P, _P, ctypes.POINTER(_P), _P, _P, _L, _P]),
+    'ndcn_dopri5_interp_bwd_f32': (_I, [_P, _P, _P, ctypes.POINTER(_P), _F, _F, _P, _P, ctypes.POINTER(_P), _P, _P, ctypes.POINTER(_P),
+                                   _P, _P, _L, _P]),
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_adjoint_rhs_f32': (_I, [_CSR, _CSR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _U, _P]),

@@ -152,17 +152,19 @@ int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const fl
 
 int64_t ndcn_rk_bwd_ws_bytes(void) { return rk_bwd_ws_bytes(); }
 
-int ndcn_rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, double *d_dots,
-                            void *d_ws, int64_t n_elem, void *stream) {
+int ndcn_rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk,
+                            const float *const *h_acc, float *gy0, const float *acc_y0, double *d_dots, void *d_ws, int64_t n_elem,
+                            void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && g && h_k && h_c && d_dots && d_ws, "bad argument");
-    return rk_combine_bwd_f32(g, h_k, h_c, n_k, h_gk, d_dots, d_ws, n_elem, ST(stream));
+    return rk_combine_bwd_f32(g, h_k, h_c, n_k, h_gk, h_acc, gy0, acc_y0, d_dots, d_ws, n_elem, ST(stream));
 }
 
 int ndcn_rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol,
-                          float atol, float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, double *d_dots,
-                          void *d_ws, int64_t n_elem, void *stream) {
+                          float atol, float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0,
+                          const float *acc_y1, const float *const *h_acc, double *d_dots, void *d_ws, int64_t n_elem, void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && y0 && y1 && h_k && h_c && d_dots && d_ws, "bad argument");
-    return rk_error_bwd_f32(y0, y1, h_k, h_c, n_k, rtol, atol, g_r, inv_n, gy0, gy1, h_gk, d_dots, d_ws, n_elem, ST(stream));
+    return rk_error_bwd_f32(y0, y1, h_k, h_c, n_k, rtol, atol, g_r, inv_n, gy0, gy1, h_gk, acc_y0, acc_y1, h_acc, d_dots, d_ws, n_elem,
+                            ST(stream));
 }
 
 int ndcn_rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, float atol, float coef, float *ga, float *gb,
@@ -172,10 +174,10 @@ int ndcn_rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rt
 }
 
 int ndcn_dopri5_interp_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k, float dt, float x,
-                               float *gy0, float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n_elem,
-                               void *stream) {
+                               float *gy0, float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1,
+                               const float *const *h_acc, double *d_dots, void *d_ws, int64_t n_elem, void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && g && y0 && y1 && h_k && d_dots && d_ws, "bad argument");
-    return rk_dense_bwd_f32(g, y0, y1, h_k, dt, x, gy0, gy1, h_gk, d_dots, d_ws, n_elem, ST(stream));
+    return rk_dense_bwd_f32(g, y0, y1, h_k, dt, x, gy0, gy1, h_gk, acc_y0, acc_y1, h_acc, d_dots, d_ws, n_elem, ST(stream));
 }
 
 int ndcn_relu_bwd_f32(float *out, const float *g, const float *y, int64_t n_elem, void *stream) {

@@ -18,12 +18,20 @@ constexpr int kBwdMaxK = 8;
 constexpr int kBwdBlocks = 1024;
 constexpr int kBwdDots = 8;
 
+// acc (nullable each): a gradient the SAME tensor already received from the operations that consumed it later; the kernel
+// writes gk = acc + (its own contribution) - the sum autograd would otherwise form with a pass of its own per consumer
+// (torch `add` kernels were 24 % of a dopri5 training step).  gk may alias acc.
 struct BwdTerms {
     const float *k[kBwdMaxK];
     float *gk[kBwdMaxK];           // nullable each
+    const float *acc[kBwdMaxK];    // nullable each
     float c[kBwdMaxK];
     int n;
 };
+
+typedef float bw_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bw_f4 ld4(const float *p, int64_t i) { return reinterpret_cast<const bw_f4 *>(p)[i]; }
+__device__ __forceinline__ void st4(float *p, int64_t i, bw_f4 v) { reinterpret_cast<bw_f4 *>(p)[i] = v; }
 
 // per-block sums of kBwdDots doubles -> partial[block][kBwdDots]
 __device__ __forceinline__ void block_store_dots(double (&d)[kBwdDots], double *__restrict__ partial) {
@@ -66,16 +74,39 @@ static int bwd_grid(int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------ combine
-__global__ __launch_bounds__(256) void combine_bwd_kernel(const float *__restrict__ g, BwdTerms t, int64_t n, double *__restrict__ partial) {
+// VEC: 16 bytes per lane (n counts float4 items then).  gy0 = acc_y0 + g when both are given (the identity branch of the sum).
+template <bool VEC>
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const float *__restrict__ g, BwdTerms t, float *gy0, const float *acc_y0,
+                                                          int64_t n, double *__restrict__ partial) {
     double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gv = g[i];
+        if (VEC) {
+            const bw_f4 gv = ld4(g, i);
+            if (gy0) st4(gy0, i, ld4(acc_y0, i) + gv);
 #pragma unroll
-        for (int j = 0; j < kBwdMaxK; ++j)
-            if (j < t.n) {
-                d[j] += (double)(gv * t.k[j][i]);
-                if (t.gk[j]) t.gk[j][i] = t.c[j] * gv;
-            }
+            for (int j = 0; j < kBwdMaxK; ++j)
+                if (j < t.n) {
+                    const bw_f4 kv = ld4(t.k[j], i);
+                    d[j] += (double)(gv.x * kv.x) + (double)(gv.y * kv.y) + (double)(gv.z * kv.z) + (double)(gv.w * kv.w);
+                    if (t.gk[j]) {
+                        bw_f4 o = t.c[j] * gv;
+                        if (t.acc[j]) o = ld4(t.acc[j], i) + o;
+                        st4(t.gk[j], i, o);
+                    }
+                }
+        } else {
+            const float gv = g[i];
+            if (gy0) gy0[i] = acc_y0[i] + gv;
+#pragma unroll
+            for (int j = 0; j < kBwdMaxK; ++j)
+                if (j < t.n) {
+                    d[j] += (double)(gv * t.k[j][i]);
+                    if (t.gk[j]) {
+                        const float o = t.c[j] * gv;
+                        t.gk[j][i] = t.acc[j] ? t.acc[j][i] + o : o;
+                    }
+                }
+        }
     }
     block_store_dots(d, partial);
 }
@@ -83,6 +114,7 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(const float *__restric
 // ------------------------------------------------------------------------------------------------ error ratio
 struct ErrBwdArgs {
     const float *y0, *y1;
+    const float *acc_y0, *acc_y1;  // nullable
     float *gy0, *gy1;              // nullable
     BwdTerms t;
     float rtol, atol, g_r, inv_n;  // inv_n = 1 / numel (global count when the mean spans ranks)
@@ -104,13 +136,22 @@ __global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n,
         for (int j = 0; j < kBwdMaxK; ++j)
             if (j < p.t.n) {
                 d[j] += (double)(s * p.t.k[j][i]);            // d r / d c_j (times g_r on the host)
-                if (p.t.gk[j]) p.t.gk[j][i] = p.g_r * (p.t.c[j] * s);
+                if (p.t.gk[j]) {
+                    const float o = p.g_r * (p.t.c[j] * s);
+                    p.t.gk[j][i] = p.t.acc[j] ? p.t.acc[j][i] + o : o;
+                }
             }
         // d r / d tol = -q s ; tol = atol + rtol max(|y0|, |y1|) ; torch.max splits the gradient evenly on ties
         const float gm = p.g_r * (-q * s) * p.rtol;
         const float w0 = m0 > m1 ? 1.f : (m0 == m1 ? 0.5f : 0.f);
-        if (p.gy0) p.gy0[i] = gm * w0 * (a0 > 0.f ? 1.f : (a0 < 0.f ? -1.f : 0.f));
-        if (p.gy1) p.gy1[i] = gm * (1.f - w0) * (a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f));
+        if (p.gy0) {
+            const float o = gm * w0 * (a0 > 0.f ? 1.f : (a0 < 0.f ? -1.f : 0.f));
+            p.gy0[i] = p.acc_y0 ? p.acc_y0[i] + o : o;
+        }
+        if (p.gy1) {
+            const float o = gm * (1.f - w0) * (a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f));
+            p.gy1[i] = p.acc_y1 ? p.acc_y1[i] + o : o;
+        }
     }
     block_store_dots(d, partial);
 }
@@ -138,6 +179,7 @@ struct DenseBwdArgs {
     const float *g, *y0, *y1;
     const float *k[7];
     float *gy0, *gy1, *gk[7];      // nullable each
+    const float *acc_y0, *acc_y1, *acc[7];   // nullable each: gradients already received (see BwdTerms)
     float cm[7];                   // dt * DPS_C_MID (fp32, as the forward)
     float cmid[7];                 // DPS_C_MID
     float dt, x;
@@ -173,11 +215,11 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p, int64_t 
         d[0] += (double)(gv * (4.f * ca * x3 + 3.f * cb * x2 + 2.f * cc * x + cd));                      // d o / d x
         d[1] += (double)(gv * (x4 * (2.f * (f1 - f0) + 16.f * sc) + x3 * (5.f * f0 - 3.f * f1 - 32.f * sc) +
                                x2 * (f1 - 4.f * f0 + 16.f * sc) + x * f0));                              // d o / d dt
-        if (p.gy0) p.gy0[i] = w_y0 * gv;
-        if (p.gy1) p.gy1[i] = w_y1 * gv;
+        if (p.gy0) p.gy0[i] = p.acc_y0 ? p.acc_y0[i] + w_y0 * gv : w_y0 * gv;
+        if (p.gy1) p.gy1[i] = p.acc_y1 ? p.acc_y1[i] + w_y1 * gv : w_y1 * gv;
 #pragma unroll
         for (int j = 0; j < 7; ++j)
-            if (p.gk[j]) p.gk[j][i] = wk[j] * gv;
+            if (p.gk[j]) p.gk[j][i] = p.acc[j] ? p.acc[j][i] + wk[j] * gv : wk[j] * gv;
     }
     block_store_dots(d, partial);
 }
@@ -185,38 +227,46 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p, int64_t 
 // ------------------------------------------------------------------------------------------------ host wrappers
 int64_t rk_bwd_ws_bytes() { return (int64_t)kBwdBlocks * kBwdDots * sizeof(double); }
 
-static int fill_bwd(BwdTerms &t, const float *const *h_k, float *const *h_gk, const float *h_c, int n_k) {
+static int fill_bwd(BwdTerms &t, const float *const *h_k, float *const *h_gk, const float *h_c, int n_k, const float *const *h_acc) {
     if (n_k < 1 || n_k > kBwdMaxK) { set_error("rk backward: 1..%d terms", kBwdMaxK); return NDCN_EINVAL; }
     t.n = n_k;
     for (int j = 0; j < kBwdMaxK; ++j) {
         t.k[j] = j < n_k ? h_k[j] : h_k[0];
         t.gk[j] = (j < n_k && h_gk) ? h_gk[j] : nullptr;
+        t.acc[j] = (j < n_k && h_acc && t.gk[j]) ? h_acc[j] : nullptr;
         t.c[j] = j < n_k ? h_c[j] : 0.f;
         if (j < n_k && !h_k[j]) { set_error("rk backward: null stage pointer"); return NDCN_EINVAL; }
     }
     return NDCN_OK;
 }
 
-int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, double *d_dots,
-                       void *d_ws, int64_t n, hipStream_t st) {
+int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, const float *const *h_acc,
+                       float *gy0, const float *acc_y0, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
     BwdTerms t;
-    int rc = fill_bwd(t, h_k, h_gk, h_c, n_k);
+    int rc = fill_bwd(t, h_k, h_gk, h_c, n_k, h_acc);
     if (rc) return rc;
-    const int grid = bwd_grid(n);
-    ProfScope prof(PROF_COMBINE, st, 4.0 * n * (2 * n_k + 1), 2.0 * n * n_k);
-    hipLaunchKernelGGL(combine_bwd_kernel, dim3(grid), dim3(256), 0, st, g, t, n, static_cast<double *>(d_ws));
+    if (!acc_y0) gy0 = nullptr;                              // without a received gradient g_y0 IS g: nothing to write
+    bool vec = n % 4 == 0 && aligned16(g) && (!gy0 || (aligned16(gy0) && aligned16(acc_y0)));
+    for (int j = 0; j < n_k; ++j) vec = vec && aligned16(t.k[j]) && (!t.gk[j] || aligned16(t.gk[j])) && (!t.acc[j] || aligned16(t.acc[j]));
+    int n_out = gy0 ? 2 : 0;
+    for (int j = 0; j < n_k; ++j) n_out += t.gk[j] ? (t.acc[j] ? 2 : 1) : 0;
+    ProfScope prof(PROF_COMBINE, st, 4.0 * n * (n_k + 1 + n_out), 2.0 * n * n_k);
+    const int grid = bwd_grid(vec ? n / 4 : n);
+    if (vec) hipLaunchKernelGGL(combine_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, g, t, gy0, acc_y0, n / 4, static_cast<double *>(d_ws));
+    else hipLaunchKernelGGL(combine_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, g, t, gy0, acc_y0, n, static_cast<double *>(d_ws));
     hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
 }
 
 int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol, float atol,
-                     float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n,
-                     hipStream_t st) {
+                     float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1,
+                     const float *const *h_acc, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
     ErrBwdArgs p;
-    int rc = fill_bwd(p.t, h_k, h_gk, h_c, n_k);
+    int rc = fill_bwd(p.t, h_k, h_gk, h_c, n_k, h_acc);
     if (rc) return rc;
     p.y0 = y0; p.y1 = y1; p.gy0 = gy0; p.gy1 = gy1; p.rtol = rtol; p.atol = atol; p.g_r = g_r; p.inv_n = (float)inv_n;
+    p.acc_y0 = gy0 ? acc_y0 : nullptr; p.acc_y1 = gy1 ? acc_y1 : nullptr;
     const int grid = bwd_grid(n);
     ProfScope prof(PROF_ERROR, st, 4.0 * n * (2 * n_k + 4), 2.0 * n * (3 * n_k + 12));
     hipLaunchKernelGGL(error_bwd_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
@@ -239,13 +289,16 @@ static const double kCMidBwd[7] = {
 };
 
 int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k, float dt, float x, float *gy0,
-                     float *gy1, float *const *h_gk, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
+                     float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1, const float *const *h_acc,
+                     double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
     DenseBwdArgs p;
     p.g = g; p.y0 = y0; p.y1 = y1; p.gy0 = gy0; p.gy1 = gy1; p.dt = dt; p.x = x;
+    p.acc_y0 = gy0 ? acc_y0 : nullptr; p.acc_y1 = gy1 ? acc_y1 : nullptr;
     for (int j = 0; j < 7; ++j) {
         if (!h_k[j]) { set_error("dense backward: null stage pointer"); return NDCN_EINVAL; }
         p.k[j] = h_k[j];
         p.gk[j] = h_gk ? h_gk[j] : nullptr;
+        p.acc[j] = (p.gk[j] && h_acc) ? h_acc[j] : nullptr;
         p.cmid[j] = (float)kCMidBwd[j];
         p.cm[j] = dt * (float)kCMidBwd[j];
     }

@@ -137,6 +137,15 @@ def _grad_ptrs(like, needs):
     return outs, (_P * len(needs))(*[None if o is None else o.data_ptr() for o in outs])
 
 
+def _acc_ptrs(accs, n):
+    """nullable array of the gradients the terms have ALREADY received (accumulating VJPs, include/ndcn_hip.h); the tensors
+    are kept alive by the caller for the duration of the launch (stream-ordered free of the caching allocator)."""
+    if accs is None or all(a is None for a in accs):
+        return None
+    assert len(accs) == n
+    return (_P * n)(*[None if a is None else _panel(a, 'received gradient').data_ptr() for a in accs])
+
+
 class HipOps:
     """Panel operations on fp32 CUDA tensors, each ONE kernel launch through the C-ABI."""
 
@@ -471,32 +480,40 @@ class HipOps:
 
     # ---------------------------------------------------------------- VJPs of the dopri5 panel operations
     @staticmethod
-    def combine_bwd(g, ks, cs, need_k, need_dots=True):
-        """VJP of combine: ([c_j g or None], [<g, k_j>] as host floats or None)."""
+    def combine_bwd(g, ks, cs, need_k, need_dots=True, accs=None, acc_y0=None):
+        """VJP of combine: ([c_j g or None], [<g, k_j>] as host floats or None).  accs / acc_y0: gradients the terms / y0 have
+        already received - the outputs become acc_j + c_j g (and a third result acc_y0 + g is returned when acc_y0 is given)."""
         g = _panel(g)
         ks = [_panel(k) for k in ks]
         arr_k, arr_c, n = _terms(ks, cs)
         gk, arr_g = _grad_ptrs(g, need_k)
+        arr_a = _acc_ptrs(accs, n)
+        gy0 = torch.empty_like(g) if acc_y0 is not None else None
         d = _BwdDots.get(g.device)
         with _REDUCE_LOCK, torch.cuda.device(g.device):
-            check(_lib.load().ndcn_rk_combine_bwd_f32(ptr(g), arr_k, arr_c, n, arr_g, ptr(d.out), ptr(d.ws), g.numel(),
-                                                      stream_ptr()))
-            return gk, (d.fetch()[:n] if need_dots else None)
+            check(_lib.load().ndcn_rk_combine_bwd_f32(ptr(g), arr_k, arr_c, n, arr_g, arr_a, ptr(gy0),
+                                                      ptr(_panel(acc_y0)) if acc_y0 is not None else None, ptr(d.out), ptr(d.ws),
+                                                      g.numel(), stream_ptr()))
+            dots = d.fetch()[:n] if need_dots else None
+        return (gk, dots) if acc_y0 is None else (gk, dots, gy0)
 
     @staticmethod
-    def error_bwd(y0, y1, ks, cs, rtol, atol, g_r, need_y0, need_y1, need_k, need_dots=True):
+    def error_bwd(y0, y1, ks, cs, rtol, atol, g_r, need_y0, need_y1, need_k, need_dots=True, accs=None, acc_y0=None, acc_y1=None):
         """VJP of the error ratio mean(((sum c_j k_j) / tol)^2) for upstream gradient g_r:
-        (gy0, gy1, [gk_j], [d ratio / d c_j] (NOT yet multiplied by g_r) as host floats)."""
+        (gy0, gy1, [gk_j], [d ratio / d c_j] (NOT yet multiplied by g_r) as host floats); accs / acc_y0 / acc_y1 as combine_bwd."""
         y0, y1 = _panel(y0), _panel(y1)
         ks = [_panel(k) for k in ks]
         arr_k, arr_c, n = _terms(ks, cs)
         gk, arr_g = _grad_ptrs(y0, need_k)
+        arr_a = _acc_ptrs(accs, n)
         gy0 = torch.empty_like(y0) if need_y0 else None
         gy1 = torch.empty_like(y0) if need_y1 else None
         d = _BwdDots.get(y0.device)
         with _REDUCE_LOCK, torch.cuda.device(y0.device):
             check(_lib.load().ndcn_rk_error_bwd_f32(ptr(y0), ptr(y1), arr_k, arr_c, n, float(rtol), float(atol), float(g_r),
-                                                    1.0 / y0.numel(), ptr(gy0), ptr(gy1), arr_g, ptr(d.out), ptr(d.ws),
+                                                    1.0 / y0.numel(), ptr(gy0), ptr(gy1), arr_g,
+                                                    ptr(_panel(acc_y0)) if acc_y0 is not None else None,
+                                                    ptr(_panel(acc_y1)) if acc_y1 is not None else None, arr_a, ptr(d.out), ptr(d.ws),
                                                     y0.numel(), stream_ptr()))
             return gy0, gy1, gk, (d.fetch()[:n] if need_dots else None)
 
@@ -514,19 +531,23 @@ class HipOps:
         return ga, gb, gy
 
     @staticmethod
-    def interp_bwd(g, y0, y1, ks, dt, x, need_y0, need_y1, need_k, need_dots=True):
-        """VJP of the dopri5 dense output at abscissa x: (gy0, gy1, [gk_j], <g, do/dx>, <g, do/ddt>)."""
+    def interp_bwd(g, y0, y1, ks, dt, x, need_y0, need_y1, need_k, need_dots=True, accs=None, acc_y0=None, acc_y1=None):
+        """VJP of the dopri5 dense output at abscissa x: (gy0, gy1, [gk_j], <g, do/dx>, <g, do/ddt>); accs / acc_y0 / acc_y1 as
+        combine_bwd."""
         g, y0, y1 = _panel(g), _panel(y0), _panel(y1)
         ks = [_panel(k) for k in ks]
         assert len(ks) == 7
         arr_k = (_P * 7)(*[k.data_ptr() for k in ks])
         gk, arr_g = _grad_ptrs(g, need_k)
+        arr_a = _acc_ptrs(accs, 7)
         gy0 = torch.empty_like(g) if need_y0 else None
         gy1 = torch.empty_like(g) if need_y1 else None
         d = _BwdDots.get(g.device)
         with _REDUCE_LOCK, torch.cuda.device(g.device):
             check(_lib.load().ndcn_dopri5_interp_bwd_f32(ptr(g), ptr(y0), ptr(y1), arr_k, float(dt), float(x), ptr(gy0),
-                                                         ptr(gy1), arr_g, ptr(d.out), ptr(d.ws), g.numel(), stream_ptr()))
+                                                         ptr(gy1), arr_g, ptr(_panel(acc_y0)) if acc_y0 is not None else None,
+                                                         ptr(_panel(acc_y1)) if acc_y1 is not None else None, arr_a, ptr(d.out),
+                                                         ptr(d.ws), g.numel(), stream_ptr()))
             dots = d.fetch() if need_dots else (0.0, 0.0)
         return gy0, gy1, gk, dots[0], dots[1]
 

@@ -300,6 +300,131 @@ def _dense_output(y0, y1, ks, dts, x, cache):
     return _HipValue.apply(hip_fn, torch_fn, y0, y1, *ks, dts, x)
 
 
+# ---- "carry" forms of the three panel operations ---------------------------------------------------------------------
+# Every stage derivative of a Runge-Kutta step feeds SEVERAL later operations (the following stage sums, the error estimate,
+# the dense output), and so does the step's initial state.  Autograd adds the gradients such a tensor receives with one
+# elementwise pass per consumer: 258 `add` launches = 24 % of the kernel time of a dopri5 training step on the 100k-node grid
+# (rocprofv3, tools/prof_train.py).  The carry forms hand their panel operands on as extra OUTPUTS (aliases), and the solver
+# below threads them from operation to operation, so that every panel has ONE consumer; the gradient a panel has received
+# from the later operations then arrives as the gradient of the carried output, and the VJP kernel adds its own contribution
+# in the pass it makes anyway (the `acc` operands of csrc/rk_bwd.hip).  Same values, same graph semantics - the sums are
+# formed in a different order than autograd's, to fp32 rounding.  NDCN_GRAD_CARRY=0 restores the fan-out forms (A/B test).
+
+def _carry():
+    return _analytic() and os.environ.get('NDCN_GRAD_CARRY', '1') != '0'
+
+
+class _StageCarryFn(torch.autograd.Function):
+    """(u, y0', k_1', ..) = (y0 + sum_j c_j k_j, y0, k_1, ..)"""
+
+    @staticmethod
+    def forward(ctx, n, y0, *rest):
+        ks, cs = rest[:n], rest[n:]
+        idx, kk, cc = _active(ks, cs)
+        ctx.n, ctx.idx, ctx.cc = n, idx, cc
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*kk, *cs)
+        u = hip.combine(y0, kk, cc) if kk else y0.clone()
+        return (u, y0) + tuple(ks)
+
+    @staticmethod
+    def backward(ctx, g, g_y0c, *g_kc):
+        n, idx, cc = ctx.n, ctx.idx, ctx.cc
+        saved = ctx.saved_tensors
+        kk, cs = saved[:len(idx)], saved[len(idx):]
+        needs = ctx.needs_input_grad
+        need_y0, need_k, need_c = needs[1], needs[2:2 + n], needs[2 + n:]
+        gk_all = [g_kc[j] if need_k[j] else None for j in range(n)]
+        gc_all = [None] * n
+        g_y0 = g_y0c if need_y0 else None
+        if g is not None:
+            g = g.contiguous()
+            want_dots = any(need_c[j] for j in idx)
+            acc_y0 = g_y0c if (need_y0 and g_y0c is not None) else None
+            if idx and (any(need_k[j] for j in idx) or want_dots or acc_y0 is not None):
+                res = hip.combine_bwd(g, kk, cc, [need_k[j] for j in idx], need_dots=want_dots,
+                                      accs=[g_kc[j] if need_k[j] else None for j in idx], acc_y0=acc_y0)
+                gk, dots = res[0], res[1]
+                for q, j in enumerate(idx):
+                    if need_k[j]:
+                        gk_all[j] = gk[q]
+                    if need_c[j]:
+                        gc_all[j] = _scalar_like(cs[j], dots[q])
+                if need_y0:
+                    g_y0 = res[2] if acc_y0 is not None else g
+            elif need_y0:
+                g_y0 = g if g_y0c is None else hip.combine(g_y0c.contiguous(), [g], [f32(1)])
+        return (None, g_y0) + tuple(gk_all) + tuple(gc_all)
+
+
+class _ErrorCarryFn(torch.autograd.Function):
+    """(ratio, y0', y1', k_1', ..)"""
+
+    @staticmethod
+    def forward(ctx, n, rtol, atol, bad_out, y0, y1, *rest):
+        ks, cs = rest[:n], rest[n:]
+        idx, kk, cc = _active(ks, cs)
+        s, bad = hip.error(y0, y1, kk, cc, rtol, atol)
+        bad_out.append(bad)
+        ctx.n, ctx.idx, ctx.cc, ctx.tol = n, idx, cc, (rtol, atol)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(y0, y1, *kk, *cs)
+        return (torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1) + tuple(ks)
+
+    @staticmethod
+    def backward(ctx, g, g_y0c, g_y1c, *g_kc):
+        n, idx, cc = ctx.n, ctx.idx, ctx.cc
+        saved = ctx.saved_tensors
+        y0, y1 = saved[:2]
+        kk, cs = saved[2:2 + len(idx)], saved[2 + len(idx):]
+        needs = ctx.needs_input_grad
+        need_k, need_c = needs[6:6 + n], needs[6 + n:]
+        gk_all = [g_kc[j] if need_k[j] else None for j in range(n)]
+        gc_all = [None] * n
+        gy0, gy1 = (g_y0c if needs[4] else None), (g_y1c if needs[5] else None)
+        if g is not None:
+            g_r = float(g)
+            gy0, gy1, gk, dots = hip.error_bwd(y0, y1, kk, cc, ctx.tol[0], ctx.tol[1], g_r, needs[4], needs[5],
+                                               [need_k[j] for j in idx], need_dots=any(need_c[j] for j in idx),
+                                               accs=[g_kc[j] if need_k[j] else None for j in idx],
+                                               acc_y0=g_y0c if needs[4] else None, acc_y1=g_y1c if needs[5] else None)
+            for q, j in enumerate(idx):
+                if need_k[j]:
+                    gk_all[j] = gk[q]
+                if need_c[j]:
+                    gc_all[j] = _scalar_like(cs[j], g_r * dots[q])
+        return (None, None, None, None, gy0, gy1) + tuple(gk_all) + tuple(gc_all)
+
+
+class _DenseCarryFn(torch.autograd.Function):
+    """(dense output, y0', y1', k_1', .., k_7')"""
+
+    @staticmethod
+    def forward(ctx, cache, a0, a1, *rest):
+        kk, dt_, x_ = rest[:7], rest[7], rest[8]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(a0, a1, *rest)
+        return (_dense_value(cache, a0, a1, kk, dt_, x_), a0, a1) + tuple(kk)
+
+    @staticmethod
+    def backward(ctx, g, g_a0c, g_a1c, *g_kc):
+        saved = ctx.saved_tensors
+        a0, a1, kk, dt_, x_ = saved[0], saved[1], saved[2:9], saved[9], saved[10]
+        needs = ctx.needs_input_grad
+        need_k = list(needs[3:10])
+        gk = [g_kc[j] if need_k[j] else None for j in range(7)]
+        gy0, gy1 = (g_a0c if needs[1] else None), (g_a1c if needs[2] else None)
+        g_dt = g_x = None
+        if g is not None:
+            gy0, gy1, gk, d_x, d_dt = hip.interp_bwd(g.contiguous(), a0, a1, list(kk), f32(float(dt_)), f32(float(x_)), needs[1], needs[2],
+                                                     need_k, need_dots=needs[10] or needs[11],
+                                                     accs=[g_kc[j] if need_k[j] else None for j in range(7)],
+                                                     acc_y0=g_a0c if needs[1] else None, acc_y1=g_a1c if needs[2] else None)
+            g_dt = _scalar_like(dt_, d_dt) if needs[10] else None
+            g_x = _scalar_like(x_, d_x) if needs[11] else None
+        return (None, gy0, gy1) + tuple(gk) + (g_dt, g_x)
+
+
 # ---- the solver, scalar chain in torch exactly as the reference keeps it -----------------------------------------
 
 def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
@@ -340,6 +465,7 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         dt = torch.tensor(0.01, dtype=torch.float64)
         bad.append(0)
     pending_bad = bad[0] if bad else 0
+    carry = _carry()
     y_cur = y0
     t_lo = t_hi = tt[0]
     stage = None
@@ -355,17 +481,35 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             t0s, dts = t0.to(dtype), dt.to(dtype)                      # rk_common.py:45-46
             k = [[f] for f in f_cur]
             yi = y_cur
+            yc = list(y_cur)                                           # carry mode: the step's y0 as handed on from op to op
             for a_i, b_i in zip(core.DP_ALPHA, core.DP_BETA):
                 ti = t0s + a_i * dts
-                yi = tuple(_combine(y_, k_, [dts * b for b in b_i]) for y_, k_ in zip(y_cur, k))
+                if carry:
+                    us = []
+                    for s_, (y_, k_) in enumerate(zip(yc, k)):
+                        outs_ = _StageCarryFn.apply(len(k_), y_, *k_, *[dts * b for b in b_i])
+                        us.append(outs_[0])
+                        yc[s_], k[s_] = outs_[1], list(outs_[2:])
+                    yi = tuple(us)
+                else:
+                    yi = tuple(_combine(y_, k_, [dts * b for b in b_i]) for y_, k_ in zip(y_cur, k))
                 for k_, f_ in zip(k, func(targ(ti.item()), yi)):
                     k_.append(f_)
                 nfe += 1
             y1 = yi
-            f1 = tuple(k_[-1] for k_ in k)
             bads = []
-            ratios = [_error_ratio(a_, b_, k_, [dts * c for c in core.DP_C_ERR], rt_, at_, bads)
-                      for a_, b_, k_, rt_, at_ in zip(y_cur, y1, k, rtols, atols)]
+            if carry:
+                ratios, y1c = [], []
+                for s_, (a_, b_, k_, rt_, at_) in enumerate(zip(yc, y1, k, rtols, atols)):
+                    outs_ = _ErrorCarryFn.apply(len(k_), rt_, at_, bads, a_, b_, *k_, *[dts * c for c in core.DP_C_ERR])
+                    ratios.append(outs_[0])
+                    yc[s_], k[s_] = outs_[1], list(outs_[3:])
+                    y1c.append(outs_[2])
+                y1 = tuple(y1c)
+            else:
+                ratios = [_error_ratio(a_, b_, k_, [dts * c for c in core.DP_C_ERR], rt_, at_, bads)
+                          for a_, b_, k_, rt_, at_ in zip(y_cur, y1, k, rtols, atols)]
+            f1 = tuple(k_[-1] for k_ in k)
             accept = bool((torch.stack([r.detach() for r in ratios]) <= 1).all())      # dopri5.py:109
             worst = max(ratios)
             # misc.py:160-170
@@ -381,12 +525,14 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             if step_log is not None:
                 step_log.append((t0.item(), dt.item(), 1.0 if accept else 0.0, worst.item(), dt_next.item()))
             if accept:
-                stage = (y_cur, y1, k, dts, {})
+                stage = (tuple(yc) if carry else y_cur, y1, k, dts, {})
                 y_cur, f_cur = y1, f1
                 t_lo, t_hi = t0, t0 + dt
                 pending_bad = sum(bads)
             else:
                 t_lo = t_hi = t0
+                if carry:                                              # the retry reads what the rejected attempt handed on
+                    y_cur, f_cur = tuple(yc), tuple(k_[0] for k_ in k)
             dt = dt_next
             n_steps += 1
         # interp.py:51-65
@@ -396,8 +542,18 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         x = ((at - a0) / (a1 - a0)).to(dtype)
         s_y0, s_y1, s_k, s_dts, caches = stage
         outs = []
-        for j, (p0, p1, kk) in enumerate(zip(s_y0, s_y1, s_k)):
-            outs.append(_dense_output(p0, p1, kk, s_dts, x, caches.setdefault(j, {})))
+        if carry:
+            n_y0, n_y1, n_k = [], [], []
+            for j, (p0, p1, kk) in enumerate(zip(s_y0, s_y1, s_k)):
+                o_ = _DenseCarryFn.apply(caches.setdefault(j, {}), p0, p1, *kk, s_dts, x)
+                outs.append(o_[0])
+                n_y0.append(o_[1]); n_y1.append(o_[2]); n_k.append(list(o_[3:]))
+            # the next tick (or the next step, whose y0 / k1 are this step's y1 / k7) continues from the handed-on tensors
+            stage = (tuple(n_y0), tuple(n_y1), n_k, s_dts, caches)
+            y_cur, f_cur = tuple(n_y1), tuple(k_[-1] for k_ in n_k)
+        else:
+            for j, (p0, p1, kk) in enumerate(zip(s_y0, s_y1, s_k)):
+                outs.append(_dense_output(p0, p1, kk, s_dts, x, caches.setdefault(j, {})))
         sol.append(tuple(outs))
     if step_log is not None:
         step_log.append(('nfe', nfe))

@@ -158,6 +158,42 @@ def test_odeint_adjoint_against_reference_gradients(dev, method):
     assert out.requires_grad and out.shape == (144, 8)
 
 
+@pytest.mark.parametrize('rtol,atol', [(1e-2, 1e-3), (1e-5, 1e-7)])
+def test_dopri5_backprop_carry_form_equals_fan_out_form(dev, rtol, atol):
+    """The carry forms of the panel operations (every panel has one consumer; the VJP kernels add the gradient it already
+    received: autograd_path._StageCarryFn / _ErrorCarryFn / _DenseCarryFn, csrc/rk_bwd.hip `acc`) against the fan-out forms
+    (autograd adds per consumer, NDCN_GRAD_CARRY=0): same trajectory bit for bit, same step log, gradients wrt y0, W and b
+    equal to summation-order rounding - with rejected steps, several ticks inside one step and ticks spanning several steps."""
+    import os
+    from ndcn_amd import CsrOperator
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('fixed_rk4_equal')
+    res = {}
+    for flag in ('1', '0'):
+        os.environ['NDCN_GRAD_CARRY'] = flag
+        try:
+            torch.manual_seed(5)
+            f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
+            f.load_state_dict({'wt.weight': T(d['W']), 'wt.bias': T(d['b'])})
+            x0 = T(d['x0']).to(dev).requires_grad_(True)
+            t = torch.tensor([0., 0.01, 0.02, 0.9, 1.0, 2.5], device=dev)
+            log = []
+            y = ode.odeint(f, x0, t, rtol=rtol, atol=atol, method='dopri5', step_log=log)
+            w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+            (y * w).sum().backward()
+            res[flag] = (y.detach().cpu(), log, [v.cpu().clone() for v in (x0.grad, f.wt.weight.grad, f.wt.bias.grad)])
+        finally:
+            del os.environ['NDCN_GRAD_CARRY']
+    assert torch.equal(res['1'][0], res['0'][0]) and res['1'][1] == res['0'][1]
+    if rtol < 1e-3:
+        assert any(r[2] == 0.0 for r in res['1'][1] if r[0] != 'nfe')           # rejected attempts are part of the case
+    # (a two-step solve agrees to 2e-7; through 14 attempts the controller's scalar chain - dt depends on the error ratios of
+    # all earlier steps - amplifies the different summation order to ~1e-5, measured: tools/micro/carry_ab.py)
+    for got, ref in zip(res['1'][2], res['0'][2]):
+        assert rel(got, ref) < 2e-4, rel(got, ref)
+
+
 @pytest.mark.parametrize('variant', ['default', 'no_control', 'no_graph'])
 @pytest.mark.parametrize('n_side,H', [(20, 20), (12, 256), (9, 1), (30, 64)])
 def test_native_adjoint_rhs_equals_autograd_through_the_oracle(dev, variant, n_side, H):
