@@ -47,7 +47,9 @@ class _Rhs(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W, b, A, no_graph, no_control):
-        Y = hip.rhs(A, X.detach(), W.detach(), None if b is None else b.detach(), no_graph=no_graph, no_control=no_control)
+        # (W itself, not a detached alias: the packed-weight cache of ops.rhs is keyed on the tensor object and its version
+        # counter - every evaluation of a solve then reuses the packed image instead of rebuilding it: two launches per RHS)
+        Y = hip.rhs(A, X.detach(), W, None if b is None else b.detach(), no_graph=no_graph, no_control=no_control)
         ctx.A, ctx.no_graph, ctx.no_control, ctx.has_b = A, no_graph, no_control, b is not None
         ctx.save_for_backward(X, W, Y)
         return Y

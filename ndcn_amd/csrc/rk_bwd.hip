@@ -120,37 +120,78 @@ struct ErrBwdArgs {
     float rtol, atol, g_r, inv_n;  // inv_n = 1 / numel (global count when the mean spans ranks)
 };
 
+// one element of the error-ratio VJP; outputs through references (accumulators applied by the caller)
+__device__ __forceinline__ void error_bwd_elem(const ErrBwdArgs &p, const float (&kv)[kBwdMaxK], float a0, float a1, double (&d)[kBwdDots],
+                                               float (&gk)[kBwdMaxK], float &o0, float &o1) {
+    float e = p.t.c[0] * kv[0];
+#pragma unroll
+    for (int j = 1; j < kBwdMaxK; ++j)
+        if (j < p.t.n) e = e + p.t.c[j] * kv[j];
+    const float m0 = fabsf(a0), m1 = fabsf(a1);
+    const float tol = p.atol + p.rtol * max_nan(m0, m1);
+    const float q = e / tol;
+    const float s = 2.f * q * p.inv_n / tol;             // d r / d e
+#pragma unroll
+    for (int j = 0; j < kBwdMaxK; ++j)
+        if (j < p.t.n) {
+            d[j] += (double)(s * kv[j]);                  // d r / d c_j (times g_r on the host)
+            gk[j] = p.g_r * (p.t.c[j] * s);
+        }
+    // d r / d tol = -q s ; tol = atol + rtol max(|y0|, |y1|) ; torch.max splits the gradient evenly on ties
+    const float gm = p.g_r * (-q * s) * p.rtol;
+    const float w0 = m0 > m1 ? 1.f : (m0 == m1 ? 0.5f : 0.f);
+    o0 = gm * w0 * (a0 > 0.f ? 1.f : (a0 < 0.f ? -1.f : 0.f));
+    o1 = gm * (1.f - w0) * (a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f));
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n, double *__restrict__ partial) {
     double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int W = VEC ? 4 : 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float e = p.t.c[0] * p.t.k[0][i];
+        float kv[W][kBwdMaxK], a0[W], a1[W], gk[W][kBwdMaxK], o0[W], o1[W];
+        if (VEC) {
+            const bw_f4 v0 = ld4(p.y0, i), v1 = ld4(p.y1, i);
+            a0[0] = v0.x; a0[W > 1 ? 1 : 0] = v0.y; a0[W > 1 ? 2 : 0] = v0.z; a0[W > 1 ? 3 : 0] = v0.w;
+            a1[0] = v1.x; a1[W > 1 ? 1 : 0] = v1.y; a1[W > 1 ? 2 : 0] = v1.z; a1[W > 1 ? 3 : 0] = v1.w;
 #pragma unroll
-        for (int j = 1; j < kBwdMaxK; ++j)
-            if (j < p.t.n) e = e + p.t.c[j] * p.t.k[j][i];
-        const float a0 = p.y0[i], a1 = p.y1[i];
-        const float m0 = fabsf(a0), m1 = fabsf(a1);
-        const float tol = p.atol + p.rtol * max_nan(m0, m1);
-        const float q = e / tol;
-        const float s = 2.f * q * p.inv_n / tol;             // d r / d e
-#pragma unroll
-        for (int j = 0; j < kBwdMaxK; ++j)
-            if (j < p.t.n) {
-                d[j] += (double)(s * p.t.k[j][i]);            // d r / d c_j (times g_r on the host)
-                if (p.t.gk[j]) {
-                    const float o = p.g_r * (p.t.c[j] * s);
-                    p.t.gk[j][i] = p.t.acc[j] ? p.t.acc[j][i] + o : o;
+            for (int j = 0; j < kBwdMaxK; ++j)
+                if (j < p.t.n) {
+                    const bw_f4 k4 = ld4(p.t.k[j], i);
+                    kv[0][j] = k4.x; kv[W > 1 ? 1 : 0][j] = k4.y; kv[W > 1 ? 2 : 0][j] = k4.z; kv[W > 1 ? 3 : 0][j] = k4.w;
                 }
-            }
-        // d r / d tol = -q s ; tol = atol + rtol max(|y0|, |y1|) ; torch.max splits the gradient evenly on ties
-        const float gm = p.g_r * (-q * s) * p.rtol;
-        const float w0 = m0 > m1 ? 1.f : (m0 == m1 ? 0.5f : 0.f);
-        if (p.gy0) {
-            const float o = gm * w0 * (a0 > 0.f ? 1.f : (a0 < 0.f ? -1.f : 0.f));
-            p.gy0[i] = p.acc_y0 ? p.acc_y0[i] + o : o;
+        } else {
+            a0[0] = p.y0[i]; a1[0] = p.y1[i];
+#pragma unroll
+            for (int j = 0; j < kBwdMaxK; ++j)
+                if (j < p.t.n) kv[0][j] = p.t.k[j][i];
         }
-        if (p.gy1) {
-            const float o = gm * (1.f - w0) * (a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f));
-            p.gy1[i] = p.acc_y1 ? p.acc_y1[i] + o : o;
+#pragma unroll
+        for (int u = 0; u < W; ++u) error_bwd_elem(p, kv[u], a0[u], a1[u], d, gk[u], o0[u], o1[u]);
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < kBwdMaxK; ++j)
+                if (j < p.t.n && p.t.gk[j]) {
+                    bw_f4 o = {gk[0][j], gk[W > 1 ? 1 : 0][j], gk[W > 1 ? 2 : 0][j], gk[W > 1 ? 3 : 0][j]};
+                    if (p.t.acc[j]) o = ld4(p.t.acc[j], i) + o;
+                    st4(p.t.gk[j], i, o);
+                }
+            if (p.gy0) {
+                bw_f4 o = {o0[0], o0[W > 1 ? 1 : 0], o0[W > 1 ? 2 : 0], o0[W > 1 ? 3 : 0]};
+                if (p.acc_y0) o = ld4(p.acc_y0, i) + o;
+                st4(p.gy0, i, o);
+            }
+            if (p.gy1) {
+                bw_f4 o = {o1[0], o1[W > 1 ? 1 : 0], o1[W > 1 ? 2 : 0], o1[W > 1 ? 3 : 0]};
+                if (p.acc_y1) o = ld4(p.acc_y1, i) + o;
+                st4(p.gy1, i, o);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kBwdMaxK; ++j)
+                if (j < p.t.n && p.t.gk[j]) p.t.gk[j][i] = p.t.acc[j] ? p.t.acc[j][i] + gk[0][j] : gk[0][j];
+            if (p.gy0) p.gy0[i] = p.acc_y0 ? p.acc_y0[i] + o0[0] : o0[0];
+            if (p.gy1) p.gy1[i] = p.acc_y1 ? p.acc_y1[i] + o1[0] : o1[0];
         }
     }
     block_store_dots(d, partial);
@@ -267,9 +308,13 @@ int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, 
     if (rc) return rc;
     p.y0 = y0; p.y1 = y1; p.gy0 = gy0; p.gy1 = gy1; p.rtol = rtol; p.atol = atol; p.g_r = g_r; p.inv_n = (float)inv_n;
     p.acc_y0 = gy0 ? acc_y0 : nullptr; p.acc_y1 = gy1 ? acc_y1 : nullptr;
-    const int grid = bwd_grid(n);
+    bool vec = n % 4 == 0 && aligned16(y0) && aligned16(y1) && (!gy0 || aligned16(gy0)) && (!gy1 || aligned16(gy1)) &&
+               (!p.acc_y0 || aligned16(p.acc_y0)) && (!p.acc_y1 || aligned16(p.acc_y1));
+    for (int j = 0; j < n_k; ++j) vec = vec && aligned16(p.t.k[j]) && (!p.t.gk[j] || aligned16(p.t.gk[j])) && (!p.t.acc[j] || aligned16(p.t.acc[j]));
+    const int grid = bwd_grid(vec ? n / 4 : n);
     ProfScope prof(PROF_ERROR, st, 4.0 * n * (2 * n_k + 4), 2.0 * n * (3 * n_k + 12));
-    hipLaunchKernelGGL(error_bwd_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
+    if (vec) hipLaunchKernelGGL(error_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, p, n / 4, static_cast<double *>(d_ws));
+    else hipLaunchKernelGGL(error_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
     hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
