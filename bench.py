@@ -122,6 +122,9 @@ class SingleGpuRunner:
         self.x0, self.T, self.method = x0, T, method
         self.ticks = [float(v) for v in (ticks if ticks is not None else [0.0, T])]
         self.out = torch.empty_like(x0)
+        # fixed grid: odeint() gives every tick a panel of its own (the Euler update then rides in the RHS epilogue: the
+        # step's result is written where the next step reads it); two panels in turn reproduce that without holding 99 GB
+        self.out2 = torch.empty_like(x0) if method != 'dopri5' else None
         self.solver.begin(x0, self.ticks[0], borrow=True)      # as odeint() hands the initial state over
         self.pos = 1                                     # next tick to reach
         self.solve_steps = 0                             # attempted steps of one whole solve (known after the first)
@@ -141,7 +144,8 @@ class SingleGpuRunner:
                 reached_end = True
             else:
                 before = self.solver.stats()['steps']
-                reached = self.solver.advance(self.ticks[self.pos], self.out, step_budget=k - done)
+                dst = self.out if (self.out2 is None or self.pos % 2) else self.out2
+                reached = self.solver.advance(self.ticks[self.pos], dst, step_budget=k - done)
                 done += int(self.solver.stats()['steps'] - before)
                 reached_end = False
                 if reached:
