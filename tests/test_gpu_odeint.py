@@ -103,11 +103,11 @@ def test_adams_golden(dev, name, as_module):
     nfe = dict([log.pop()])['nfe']
     ref, got = d['steplog'], np.array(log)
     check_traj(y.cpu().numpy(), d['traj'], l1=1e-5, mx=2e-4)
-    if name != 'adams_tight':                               # (rtol 1e-5: a 1-ulp difference of an error ratio near 1 may flip a decision)
-        assert got.shape[0] == ref.shape[0] and nfe == int(d['nfe'])
-        assert np.array_equal(got[:, 2:4], ref[:, 2:4])
-    else:
-        assert abs(nfe - int(d['nfe'])) <= 0.15 * int(d['nfe'])
+    # every fixture, adams_tight (rtol 1e-5: 52 attempts, 105 evaluations) included: the error ratios are formed in ATen's
+    # float32 order on reference-sized panels (rk.hip), so orders and accept / reject decisions are the reference's
+    # (tools/micro/adams_tight_probe.py prints the first diverging attempt should that ever change)
+    assert got.shape[0] == ref.shape[0] and nfe == int(d['nfe'])
+    assert np.array_equal(got[:, 2:4], ref[:, 2:4])
 
 
 @pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4', 'dopri5'])
@@ -942,4 +942,7 @@ def test_dgnn_cora_accuracy_parity(dev):
     accs = dgnn.main(['--dataset', 'cora', '--model', 'differential_gcn', '--iter', '2', '--dropout', '0', '--hidden', '256',
                       '--T', '1.2', '--time_tick', '16', '--epochs', '100', '--weight_decay', '0.024', '--no_control',
                       '--method', 'dopri5', '--alpha', '0', '--seed', '0'], data=data, quiet=True)
-    assert 0.80 <= accs.mean() <= 0.86, accs
+    # measured on MI355X (this command, two runs each): seed 0 -> 81.9 / 83.4 %, seed 1 -> 84.5 / 83.8 %, seed 2 -> 83.9 / 83.5 %:
+    # mean 83.5 % over the six runs, inside README.md:67-73's span (83.18 +/- 0.76, min 82.6, max 84.5) and above the oracle's
+    # 81.6 % under torch 2.10
+    assert accs.shape == (2,) and 0.81 <= accs.min() and accs.max() <= 0.85 and 0.82 <= accs.mean() <= 0.84, accs
