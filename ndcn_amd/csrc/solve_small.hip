@@ -69,6 +69,7 @@ struct SolveArgs {
     const float *y0;                 // [n_rows][H] state at the start of this launch
     float *out;                      // [n_ticks][n_rows][H]
     int n_rows, H, nnz, n_ticks, relu, no_graph, no_control, csr_in_lds;
+    int width;                       // fast path: entries per ELL row (the operator's longest row)
     long long *dbg;                  // NDCN_SS_DEBUG=1: {shader cycles total, in evaluations, in stage updates, 100 MHz ticks total}
     float dt[kChunk];
 };
@@ -130,38 +131,29 @@ __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, cons
 //   * lane o keeps row o of W (its H weights) in registers for the whole solve: the Linear is H/4 16-byte reads of the wave's S
 //     row + H fmas, no weight traffic;
 // the same fma chains in the same order as the generic path (bit-identical), ~1/3 of its instructions and LDS bytes.
-// NP passes of a wave can be evaluated together (independent chains of LDS round trips).  Measured on the README shape: no
-// gain - 16 waves share 4 SIMDs, a wave64 instruction occupies its SIMD for 4 cycles, and the ~1000 instructions a wave issues
-// per Euler step (9 passes) already keep every SIMD busy: 19 k cycles per step with one pass at a time, 23 k with three
-// (rolled, double-buffered), so the shipped kernels take NP = 1.  What is left is instruction count, not latency.
+// The fast path keeps the operator in ELL form in LDS: every row padded to `width` (the longest row, <= 16) entries
+// {column * H, value bits}, the padding {offset of an all-zero row, 0.0f}.  A row's gather is then `width` times {one 8-byte LDS read
+// at a constant offset, one add, one 4-byte LDS read, one fma} - no row extents, no predicates, no loop over rounds: a third of
+// the CSR form's instructions, and the solve is bound by instruction issue (one CU: 64 lanes per cycle).  The padding adds
+// 0.0f * 0.0f to a sum that started at +0.0f: the bits of every sum are those of the CSR chain.
+// (NP passes of a wave could be evaluated together - independent chains of LDS round trips - but measured, that buys nothing: 16
+// waves share 4 SIMDs and the ~1000 instructions a wave issues per Euler step already keep every SIMD busy: 19 k cycles per step
+// with one pass at a time, 23 k with three in a rolled double-buffered form.  What is left is instruction count, not latency.)
 template <int HT, int NP>
-__device__ __forceinline__ void eval_fast(const int *rp, const int2 *ent, const float *T, float *srow, const float (&wreg)[HT ? HT : 1],
+__device__ __forceinline__ void eval_fast(const int2 *ell, int width, const float *T, float *srow, const float (&wreg)[HT ? HT : 1],
                                           const int (&r)[NP], const bool (&valid)[NP], int q, int o, int lane, float bias_o, int relu,
                                           float (&out)[NP]) {
-    int j0[NP], cnt[NP], cmax = 0;
     float s[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        j0[p] = 0, cnt[p] = 0, s[p] = 0.f;
-        if (valid[p]) { j0[p] = rp[r[p]]; cnt[p] = rp[r[p] + 1] - j0[p]; }
-        cmax = cnt[p] > cmax ? cnt[p] : cmax;
-    }
-    for (int jb = 0; __any(jb < cmax); jb += 4) {
-        int2 en[NP][4];
-        float x[NP][4];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) en[p][u] = ent[jb + u < cnt[p] ? j0[p] + jb + u : 0];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x[p][u] = T[(jb + u < cnt[p] ? en[p][u].x : 0) + o];
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (jb + u < cnt[p]) s[p] = fmaf(__int_as_float(en[p][u].y), x[p][u], s[p]);
+        const int2 *row = ell + (valid[p] ? r[p] : 0) * width;
+        float acc = 0.f;
+#pragma unroll 3
+        for (int j = 0; j < width; ++j) {
+            const int2 en = row[j];
+            acc = fmaf(__int_as_float(en.y), T[en.x + o], acc);
+        }
+        s[p] = acc;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -190,10 +182,21 @@ __device__ __forceinline__ void eval_fast(const int *rp, const int2 *ent, const 
     }
 }
 
+// ELL image of a CSR in LDS (one thread per row); zero_off: offset (in floats, relative to the gather's panel) of H zeros
+__device__ __forceinline__ void build_ell(int2 *ell, int width, int n_rows, int H, const int *rowptr, const int *colidx, const float *val,
+                                          int zero_off, int tid) {
+    for (int r = tid; r < n_rows; r += 1024) {
+        const int j0 = rowptr[r], cnt = rowptr[r + 1] - j0;
+        for (int j = 0; j < width; ++j)
+            ell[r * width + j] = j < cnt ? make_int2(colidx[j0 + j] * H, __float_as_int(val[j0 + j])) : make_int2(zero_off, 0);
+    }
+}
+
 constexpr int kFastNp = 1;                  // passes evaluated together (srow: kFastNp x 64 floats per wave)
 
-inline size_t lds_bytes_fast(int64_t n_elem, int64_t n_rows, int64_t nnz, int64_t extra_floats = 0) {
-    return 8 * (size_t)nnz + sizeof(float) * (size_t)(n_elem + kWaves * 64 * kFastNp + extra_floats + n_rows + 1);
+// [ELL entries | panels (n_elem + extra) | srow | zero row]
+inline size_t lds_bytes_fast(int64_t n_elem, int64_t n_rows, int64_t width, int H, int64_t extra_floats = 0) {
+    return 8 * (size_t)(n_rows * width) + sizeof(float) * (size_t)(n_elem + extra_floats + kWaves * 64 * kFastNp + H);
 }
 
 // METHOD: NDCN_M_EULER / MIDPOINT / RK4.  MAXIT: passes a wave makes over its rows (register arrays are indexed by pass)
@@ -208,18 +211,17 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
     // ---- stage: the weights (W^T in LDS, or this lane's row of W in registers), the CSR arrays, the initial state
     Lds l;
     int2 *f_ent = nullptr;
-    int *f_rp = nullptr;
     float *f_srow = nullptr;
     float wreg[HT ? HT : 1];
     if (HT) {                                               // fast path: [entries | T | srow | rowptr]
         f_ent = reinterpret_cast<int2 *>(lds_raw);
-        l.T = lds_raw + 2 * a.nnz;
+        l.T = lds_raw + 2 * a.n_rows * a.width;
         f_srow = l.T + n_elem + wave * 64 * kFastNp;
-        f_rp = reinterpret_cast<int *>(l.T + n_elem + kWaves * 64 * kFastNp);
+        float *zrow = l.T + n_elem + kWaves * 64 * kFastNp;
         l.wt = l.srow = l.val = nullptr;
         l.rowptr = l.colidx = nullptr;
-        for (int i = tid; i <= a.n_rows; i += 1024) f_rp[i] = a.rowptr[i];
-        for (int i = tid; i < a.nnz; i += 1024) f_ent[i] = make_int2(a.colidx[i] * H, __float_as_int(a.val[i]));
+        for (int i = tid; i < H; i += 1024) zrow[i] = 0.f;
+        build_ell(f_ent, a.width, a.n_rows, H, a.rowptr, a.colidx, a.val, (int)(zrow - l.T), tid);
 #pragma unroll
         for (int h = 0; h < (HT ? HT : 1); ++h) wreg[h] = lane_on ? a.W[o * H + h] : 0.f;
     } else {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
                     rr_[p] = ((it + p) * kWaves + wave) * RPW + q;                                             \
                     vv_[p] = lane_on && rr_[p] < a.n_rows;                                                     \
                 }                                                                                              \
-                eval_fast<HT, NPF>(f_rp, f_ent, l.T, f_srow, wreg, rr_, vv_, q, o, lane, bias_o, a.relu, oo_); \
+                eval_fast<HT, NPF>(f_ent, a.width, l.T, f_srow, wreg, rr_, vv_, q, o, lane, bias_o, a.relu, oo_);      \
                 _Pragma("unroll") for (int p = 0; p < NPF; ++p) dst[it + p] = oo_[p];                          \
             }                                                                                                  \
         }                                                                                                      \
@@ -342,6 +344,7 @@ struct BwdArgs {
     const float *a_in;               // nullable [n]: the adjoint at the LAST tick of this launch, handed over by the launch that
                                      // covered the later ticks (it already holds that tick's g_out); NULL: g_out[n_ticks] itself
     int n_rows, H, nnz, n_ticks, relu, no_graph, no_control;
+    int width;                       // fast path: entries per ELL row
     float dt[kChunk];
 };
 
@@ -545,16 +548,17 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
     extern __shared__ float lds_raw[];
     constexpr int H = HT, RPW = 64 / HT, NB = HT / 4;        // NB x NB blocks of 4 x 4 outputs
     const int n_elem = b.n_rows * H;
-    int2 *ent = reinterpret_cast<int2 *>(lds_raw);
-    float *T = lds_raw + 2 * b.nnz, *S = T + n_elem, *Z = S + n_elem, *Adj = Z + n_elem;
+    int2 *ell = reinterpret_cast<int2 *>(lds_raw);
+    const int width = b.width;
+    float *T = lds_raw + 2 * b.n_rows * width, *S = T + n_elem, *Z = S + n_elem, *Adj = Z + n_elem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *srow = Adj + n_elem + wave * 64;
-    int *rp = reinterpret_cast<int *>(Adj + n_elem + kWaves * 64);
+    float *zrow = Adj + n_elem + kWaves * 64;
     const int q = lane / H, o = lane - q * H;
     const bool lane_on = q < RPW;
     const int e0 = lane_on ? (wave * RPW + q) * H + o : n_elem, estride = kWaves * RPW * H;
-    for (int i = tid; i <= b.n_rows; i += 1024) rp[i] = b.rowptr[i];
-    for (int i = tid; i < b.nnz; i += 1024) ent[i] = make_int2(b.colidx[i] * H, __float_as_int(b.val[i]));
+    for (int i = tid; i < H; i += 1024) zrow[i] = 0.f;
+    build_ell(ell, width, b.n_rows, H, b.rowptr, b.colidx, b.val, (int)(zrow - T), tid);
     float wreg[HT], wcol[HT];
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
@@ -603,19 +607,14 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
             if ((it * kWaves + wave) * RPW >= b.n_rows) break;
             const int r = (it * kWaves + wave) * RPW + q;
             const bool valid = lane_on && r < b.n_rows;
-            int j0 = 0, cnt = 0;
-            if (valid) { j0 = rp[r]; cnt = rp[r + 1] - j0; }
             float s = 0.f;
-            for (int jb = 0; __any(jb < cnt); jb += 4) {
-                int2 en[4];
-                float x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) en[u] = ent[jb + u < cnt ? j0 + jb + u : 0];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = T[(jb + u < cnt ? en[u].x : 0) + o];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (jb + u < cnt) s = fmaf(__int_as_float(en[u].y), x[u], s);
+            {
+                const int2 *row = ell + (valid ? r : 0) * width;
+#pragma unroll 3
+                for (int j = 0; j < width; ++j) {
+                    const int2 en = row[j];
+                    s = fmaf(__int_as_float(en.y), T[en.x + o], s);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             srow[lane] = s;
@@ -692,19 +691,14 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
             if ((it * kWaves + wave) * RPW >= b.n_rows) break;
             const int r = (it * kWaves + wave) * RPW + q;
             const bool valid = lane_on && r < b.n_rows;
-            int j0 = 0, cnt = 0;
-            if (valid) { j0 = rp[r]; cnt = rp[r + 1] - j0; }
             float s = 0.f;
-            for (int jb = 0; __any(jb < cnt); jb += 4) {
-                int2 en[4];
-                float x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) en[u] = ent[jb + u < cnt ? j0 + jb + u : 0];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = T[(jb + u < cnt ? en[u].x : 0) + o];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (jb + u < cnt) s = fmaf(__int_as_float(en[u].y), x[u], s);
+            {
+                const int2 *row = ell + (valid ? r : 0) * width;
+#pragma unroll 3
+                for (int j = 0; j < width; ++j) {
+                    const int2 en = row[j];
+                    s = fmaf(__int_as_float(en.y), T[en.x + o], s);
+                }
             }
             if (valid) S[r * H + o] = s;
         }
@@ -775,6 +769,23 @@ int solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method) 
     return passes(A->n_rows, H) <= 12 ? 1 : 0;
 }
 
+// The longest row of a README-sized operator (a few hundred rows): one small device-to-host copy of rowptr, remembered per
+// (rowptr address, nnz) - a solve loop asks once.
+static int ell_width(const ndcn_csr *A, hipStream_t st, int *out) {
+    static thread_local const void *memo_p = nullptr;
+    static thread_local int64_t memo_nnz = -1, memo_rows = -1;
+    static thread_local int memo_w = 0;
+    if (memo_p == A->rowptr && memo_nnz == A->nnz && memo_rows == A->n_rows) { *out = memo_w; return NDCN_OK; }
+    std::vector<int32_t> rp((size_t)A->n_rows + 1);
+    NDCN_HIP(hipMemcpyAsync(rp.data(), A->rowptr, rp.size() * 4, hipMemcpyDeviceToHost, st));
+    NDCN_HIP(hipStreamSynchronize(st));
+    int w = 0;
+    for (int64_t r = 0; r < A->n_rows; ++r) w = std::max(w, rp[(size_t)r + 1] - rp[(size_t)r]);
+    memo_p = A->rowptr, memo_nnz = A->nnz, memo_rows = A->n_rows, memo_w = w;
+    *out = w;
+    return NDCN_OK;
+}
+
 int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method, const float *y0,
                     const float *h_dt, int64_t n_ticks, float *out, hipStream_t st) {
     if (!solve_small_supported(A, H, flags, method)) { set_error("solve_small: unsupported shape"); return NDCN_EINVAL; }
@@ -783,9 +794,14 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
     const int64_t nnz = no_graph ? 0 : A->nnz;
     const bool csr = !no_graph && lds_bytes(n_elem, H, A->n_rows, nnz, true) <= kLdsMax;
     static const bool fast_on = [] { const char *e = getenv("NDCN_SOLVE_SMALL_FAST"); return !(e && e[0] == '0'); }();
-    const bool fast = fast_on && (H == 16 || H == 20) && !no_graph && !(flags & NDCN_F_NO_CONTROL) &&
-                      lds_bytes_fast(n_elem, A->n_rows, nnz) <= kLdsMax;
-    const size_t lds = fast ? lds_bytes_fast(n_elem, A->n_rows, nnz) : lds_bytes(n_elem, H, A->n_rows, nnz, csr);
+    int width = 0;
+    bool fast = fast_on && (H == 16 || H == 20) && !no_graph && !(flags & NDCN_F_NO_CONTROL);
+    if (fast) {
+        int rc = ell_width(A, st, &width);
+        if (rc) return rc;
+        fast = width >= 1 && width <= 16 && lds_bytes_fast(n_elem, A->n_rows, width, H) <= kLdsMax;
+    }
+    const size_t lds = fast ? lds_bytes_fast(n_elem, A->n_rows, width, H) : lds_bytes(n_elem, H, A->n_rows, nnz, csr);
     const int np = passes(A->n_rows, H);
     const float *start = y0;
     for (int64_t done = 0; done < n_ticks; done += kChunk) {
@@ -796,6 +812,7 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
         a.n_ticks = (int)std::min<int64_t>(kChunk, n_ticks - done);
         a.relu = (flags & NDCN_F_RELU) ? 1 : 0; a.no_graph = no_graph ? 1 : 0; a.no_control = (flags & NDCN_F_NO_CONTROL) ? 1 : 0;
         a.csr_in_lds = csr ? 1 : 0;
+        a.width = width;
         for (int i = 0; i < a.n_ticks; ++i) a.dt[i] = h_dt[done + i];
         static const bool dbg_on = [] { const char *e = getenv("NDCN_SS_DEBUG"); return e && e[0] == '1'; }();
         static long long *dbg_buf = nullptr;
@@ -923,8 +940,11 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         const int NBh = fast_shape ? H / 4 : 1;
         const int n_groups = std::max(1, std::min<int>(1024 / (NBh * NBh + NBh), (int)A->n_rows));
         const int rows_per_group = (int)((A->n_rows + n_groups - 1) / n_groups);
-        const size_t lds_fast = lds_bytes_fast(4 * n_elem, A->n_rows, nnz);
-        const bool fast = fast_shape && lds_fast <= kLdsMax && (int64_t)n_groups * (H * H + H) <= 3 * n_elem;
+        int width = 0;
+        if (fast_shape) { int rcw = ell_width(A, st, &width); if (rcw) return rcw; }
+        const size_t lds_fast = lds_bytes_fast(4 * n_elem, A->n_rows, width, H);
+        const bool fast = fast_shape && width >= 1 && width <= 16 && lds_fast <= kLdsMax && (int64_t)n_groups * (H * H + H) <= 3 * n_elem;
+        a.width = width;
         if (fast) {
 #define NDCN_FGO(IT_, HT_)                                                                     \
             do {                                                                               \
