@@ -251,6 +251,19 @@ NDCN_API int ndcn_dopri5_interp_bwd_f32(const float *g, const float *y0, const f
                                         const float *acc_y1, const float *const *h_acc /*7*/, double *d_dots, void *d_ws,
                                         int64_t n_elem, void *stream);
 
+/* n_t <= 7 ticks of ONE accepted step in one pass: the forward (fit + evaluate, as ndcn_dopri5_interp_direct_f32 per tick - the same
+ * bits) and its VJP (as ndcn_dopri5_interp_bwd_f32 summed over the ticks; d_dots[t] = <g_t, d o / d x_t>, d_dots[7] = sum_t <g_t,
+ * d o / d dt>).  The drivers sample 16-120 ticks over a handful of steps (heat_dynamics.py:35,123; dgnn.py:173-182): the step's
+ * panels are read once per launch instead of once per tick.  h_out / h_g: HOST arrays of n_t device panels; h_xpow: n_t x 5.       */
+NDCN_API int ndcn_dopri5_interp_direct_multi_f32(const float *y0, const float *y1, const float *const *h_k /*7*/,
+                                                 const float *h_cmid /*7*/, float dt, const float *h_xpow, float *const *h_out,
+                                                 int n_t, int64_t n_elem, void *stream);
+NDCN_API int ndcn_dopri5_interp_bwd_multi_f32(const float *const *h_g, int n_t, const float *y0, const float *y1,
+                                              const float *const *h_k /*7*/, float dt, const float *h_x, float *gy0, float *gy1,
+                                              float *const *h_gk /*7*/, const float *acc_y0, const float *acc_y1,
+                                              const float *const *h_acc /*7*/, double *d_dots, void *d_ws, int64_t n_elem,
+                                              void *stream);
+
 /* The whole ODEFunc.forward in one call: Y = relu(W (A X) + b) honouring NO_GRAPH / NO_CONTROL
  * (neural_dynamics.py:20-39, dropout p = 0).  `work`: device scratch of ndcn_rhs_work_bytes() bytes, 16-byte
  * aligned (H = 256: the fused SpMM->LDS->MFMA kernel keeps its packed weights there; other widths: the

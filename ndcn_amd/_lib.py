@@ -115,6 +115,10 @@ SIGNATURES = {
     'ndcn_rk_rms_bwd_f32': (_I, [_P, _P, _P, _F, _F, _F, _P, _P, _P, _L, _P]),
     'ndcn_dopri5_interp_bwd_f32': (_I, [_P, _P, _P, ctypes.POINTER(_P), _F, _F, _P, _P, ctypes.POINTER(_P), _P, _P, ctypes.POINTER(_P),
                                    _P, _P, _L, _P]),
+    'ndcn_dopri5_interp_direct_multi_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _F, ctypes.POINTER(_F), ctypes.POINTER(_P),
+                                            _I, _L, _P]),
+    'ndcn_dopri5_interp_bwd_multi_f32': (_I, [ctypes.POINTER(_P), _I, _P, _P, ctypes.POINTER(_P), _F, ctypes.POINTER(_F), _P, _P,
+                                         ctypes.POINTER(_P), _P, _P, ctypes.POINTER(_P), _P, _P, _L, _P]),
     'ndcn_rhs_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _P]),
     'ndcn_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_adjoint_rhs_f32': (_I, [_CSR, _CSR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _U, _P]),

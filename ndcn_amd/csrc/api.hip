@@ -180,6 +180,20 @@ int ndcn_dopri5_interp_bwd_f32(const float *g, const float *y0, const float *y1,
     return rk_dense_bwd_f32(g, y0, y1, h_k, dt, x, gy0, gy1, h_gk, acc_y0, acc_y1, h_acc, d_dots, d_ws, n_elem, ST(stream));
 }
 
+int ndcn_dopri5_interp_direct_multi_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
+                                        const float *h_xpow, float *const *h_out, int n_t, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && y0 && y1 && h_k && h_cmid && h_xpow && h_out, "bad argument");
+    return interp_direct_multi_f32(y0, y1, h_k, h_cmid, dt, h_xpow, h_out, n_t, n_elem, ST(stream));
+}
+
+int ndcn_dopri5_interp_bwd_multi_f32(const float *const *h_g, int n_t, const float *y0, const float *y1, const float *const *h_k, float dt,
+                                     const float *h_x, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0,
+                                     const float *acc_y1, const float *const *h_acc, double *d_dots, void *d_ws, int64_t n_elem,
+                                     void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && h_g && y0 && y1 && h_k && h_x && d_dots && d_ws, "bad argument");
+    return rk_dense_bwd_multi_f32(h_g, n_t, y0, y1, h_k, dt, h_x, gy0, gy1, h_gk, acc_y0, acc_y1, h_acc, d_dots, d_ws, n_elem, ST(stream));
+}
+
 int ndcn_relu_bwd_f32(float *out, const float *g, const float *y, int64_t n_elem, void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && (n_elem == 0 || (out && g && y)), "bad argument");
     return relu_bwd_f32(out, g, y, n_elem, ST(stream));

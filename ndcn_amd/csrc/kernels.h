@@ -116,6 +116,9 @@ int rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, f
 int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const float *const *h_k, float dt, float x, float *gy0,
                      float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1, const float *const *h_acc,
                      double *d_dots, void *d_ws, int64_t n, hipStream_t st);
+int rk_dense_bwd_multi_f32(const float *const *h_g, int nt, const float *y0, const float *y1, const float *const *h_k, float dt,
+                           const float *h_x, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1,
+                           const float *const *h_acc, double *d_dots, void *d_ws, int64_t n, hipStream_t st);
 void prof_pause(bool on);
 extern thread_local int g_last_rhs_path;     // ndcn_debug_last_rhs_path     // no launch timing while a stream is being captured
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,

@@ -265,6 +265,67 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdArgs p, int64_t 
     block_store_dots(d, partial);
 }
 
+// Several ticks of ONE accepted step in one pass (the drivers sample 16-120 ticks over a handful of steps: heat_dynamics.py:35,123;
+// dgnn.py:173-182): the step's nine panels and their received gradients are read once instead of once per tick.
+//   gk_j = acc_j + sum_t wk_j(x_t) g_t,  gy0 / gy1 likewise;  dots: d[t] = <g_t, d o / d x_t> (t < nt <= 7), d[7] = sum_t <g_t, d o / d dt>
+constexpr int kDenseMulti = 7;
+struct DenseMultiArgs {
+    const float *g[kDenseMulti];
+    const float *y0, *y1;
+    const float *k[7];
+    float *gy0, *gy1, *gk[7];
+    const float *acc_y0, *acc_y1, *acc[7];
+    float cm[7], cmid[7];
+    float dt, x[kDenseMulti];
+    int nt;
+};
+
+__global__ __launch_bounds__(256) void dense_bwd_multi_kernel(DenseMultiArgs p, int64_t n, double *__restrict__ partial) {
+    double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float dt = p.dt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float y0 = p.y0[i], y1 = p.y1[i];
+        float kv[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) kv[j] = p.k[j][i];
+        float sm = 0.f, sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { sm += p.cm[j] * kv[j]; sc += p.cmid[j] * kv[j]; }
+        const float ym = y0 + sm, f0 = kv[0], f1 = kv[6];
+        const float ca = 2.f * dt * (f1 - f0) - 8.f * y0 - 8.f * y1 + 16.f * ym;
+        const float cb = dt * (5.f * f0 - 3.f * f1) + 18.f * y0 + 14.f * y1 - 32.f * ym;
+        const float cc = dt * (f1 - 4.f * f0) - 11.f * y0 - 5.f * y1 + 16.f * ym;
+        const float cd = dt * f0;
+        float o_y0 = 0.f, o_y1 = 0.f, o_k[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < kDenseMulti; ++t)
+            if (t < p.nt) {
+                const float x = p.x[t], x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+                const float w_ym = 16.f * x4 - 32.f * x3 + 16.f * x2;
+                const float w_y0 = (-8.f * x4 + 18.f * x3 - 11.f * x2 + 1.f) + w_ym;
+                const float w_y1 = -8.f * x4 + 14.f * x3 - 5.f * x2;
+                const float w_f0 = dt * (-2.f * x4 + 5.f * x3 - 4.f * x2 + x);
+                const float w_f1 = dt * (2.f * x4 - 3.f * x3 + x2);
+                const float gv = p.g[t][i];
+                d[t] += (double)(gv * (4.f * ca * x3 + 3.f * cb * x2 + 2.f * cc * x + cd));
+                d[7] += (double)(gv * (x4 * (2.f * (f1 - f0) + 16.f * sc) + x3 * (5.f * f0 - 3.f * f1 - 32.f * sc) +
+                                       x2 * (f1 - 4.f * f0 + 16.f * sc) + x * f0));
+                o_y0 += w_y0 * gv;
+                o_y1 += w_y1 * gv;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) o_k[j] += (w_ym * p.cm[j]) * gv;
+                o_k[0] += w_f0 * gv;
+                o_k[6] += w_f1 * gv;
+            }
+        if (p.gy0) p.gy0[i] = p.acc_y0 ? p.acc_y0[i] + o_y0 : o_y0;
+        if (p.gy1) p.gy1[i] = p.acc_y1 ? p.acc_y1[i] + o_y1 : o_y1;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (p.gk[j]) p.gk[j][i] = p.acc[j] ? p.acc[j][i] + o_k[j] : o_k[j];
+    }
+    block_store_dots(d, partial);
+}
+
 // ------------------------------------------------------------------------------------------------ host wrappers
 int64_t rk_bwd_ws_bytes() { return (int64_t)kBwdBlocks * kBwdDots * sizeof(double); }
 
@@ -350,6 +411,34 @@ int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const flo
     const int grid = bwd_grid(n);
     ProfScope prof(PROF_EVAL, st, 4.0 * n * 19, 2.0 * n * 60);
     hipLaunchKernelGGL(dense_bwd_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
+int rk_dense_bwd_multi_f32(const float *const *h_g, int nt, const float *y0, const float *y1, const float *const *h_k, float dt,
+                           const float *h_x, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1,
+                           const float *const *h_acc, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
+    if (nt < 1 || nt > kDenseMulti) { set_error("dense backward: 1..%d ticks per launch", kDenseMulti); return NDCN_EINVAL; }
+    DenseMultiArgs p;
+    p.nt = nt; p.y0 = y0; p.y1 = y1; p.gy0 = gy0; p.gy1 = gy1; p.dt = dt;
+    p.acc_y0 = gy0 ? acc_y0 : nullptr; p.acc_y1 = gy1 ? acc_y1 : nullptr;
+    for (int t = 0; t < kDenseMulti; ++t) {
+        p.g[t] = h_g[t < nt ? t : 0];
+        p.x[t] = t < nt ? h_x[t] : 0.f;
+        if (t < nt && !h_g[t]) { set_error("dense backward: null gradient panel"); return NDCN_EINVAL; }
+    }
+    for (int j = 0; j < 7; ++j) {
+        if (!h_k[j]) { set_error("dense backward: null stage pointer"); return NDCN_EINVAL; }
+        p.k[j] = h_k[j];
+        p.gk[j] = h_gk ? h_gk[j] : nullptr;
+        p.acc[j] = (p.gk[j] && h_acc) ? h_acc[j] : nullptr;
+        p.cmid[j] = (float)kCMidBwd[j];
+        p.cm[j] = dt * (float)kCMidBwd[j];
+    }
+    const int grid = bwd_grid(n);
+    ProfScope prof(PROF_EVAL, st, 4.0 * n * (27 + nt), 2.0 * n * (30 + 30 * nt));
+    hipLaunchKernelGGL(dense_bwd_multi_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
     hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;

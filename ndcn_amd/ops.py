@@ -552,6 +552,46 @@ class HipOps:
         return gy0, gy1, gk, dots[0], dots[1]
 
     @staticmethod
+    def interp_direct_multi(y0, y1, ks, cmid, dt, xpows):
+        """len(xpows) <= 8 ticks of one step in one pass: [dense output at each tick] - per tick the arithmetic of interp_direct."""
+        y0, y1 = _panel(y0), _panel(y1)
+        ks = [_panel(k) for k in ks]
+        nt = len(xpows)
+        assert len(ks) == 7 and 1 <= nt <= 8
+        outs = [torch.empty_like(y0) for _ in range(nt)]
+        arr_k, arr_c, _ = _terms(ks, cmid)
+        xp = (_F * (5 * nt))(*[float(v) for row in xpows for v in row])
+        arr_o = (_P * nt)(*[o.data_ptr() for o in outs])
+        with torch.cuda.device(y0.device):
+            check(_lib.load().ndcn_dopri5_interp_direct_multi_f32(ptr(y0), ptr(y1), arr_k, arr_c, float(dt), xp, arr_o, nt, y0.numel(),
+                                                                  stream_ptr()))
+        return outs
+
+    @staticmethod
+    def interp_bwd_multi(gs, y0, y1, ks, dt, xs, need_y0, need_y1, need_k, accs=None, acc_y0=None, acc_y1=None):
+        """VJP of len(gs) <= 7 dense outputs of ONE step: (gy0, gy1, [gk_j], [<g_t, do/dx_t>], sum_t <g_t, do/ddt>)."""
+        gs = [_panel(g) for g in gs]
+        y0, y1 = _panel(y0), _panel(y1)
+        ks = [_panel(k) for k in ks]
+        nt = len(gs)
+        assert len(ks) == 7 and 1 <= nt <= 7 and len(xs) == nt
+        arr_k = (_P * 7)(*[k.data_ptr() for k in ks])
+        arr_gs = (_P * nt)(*[g.data_ptr() for g in gs])
+        arr_x = (_F * nt)(*[float(v) for v in xs])
+        gk, arr_g = _grad_ptrs(y0, need_k)
+        arr_a = _acc_ptrs(accs, 7)
+        gy0 = torch.empty_like(y0) if need_y0 else None
+        gy1 = torch.empty_like(y0) if need_y1 else None
+        d = _BwdDots.get(y0.device)
+        with _REDUCE_LOCK, torch.cuda.device(y0.device):
+            check(_lib.load().ndcn_dopri5_interp_bwd_multi_f32(arr_gs, nt, ptr(y0), ptr(y1), arr_k, float(dt), arr_x, ptr(gy0), ptr(gy1), arr_g,
+                                                               ptr(_panel(acc_y0)) if acc_y0 is not None else None,
+                                                               ptr(_panel(acc_y1)) if acc_y1 is not None else None, arr_a, ptr(d.out),
+                                                               ptr(d.ws), y0.numel(), stream_ptr()))
+            dots = d.fetch()
+        return gy0, gy1, gk, list(dots[:nt]), dots[7]
+
+    @staticmethod
     def interp_fit(y0, y1, ks, cmid, dt):
         y0, y1 = _panel(y0), _panel(y1)
         ks = [_panel(k) for k in ks]

@@ -425,6 +425,51 @@ class _DenseCarryFn(torch.autograd.Function):
         return (None, gy0, gy1) + tuple(gk) + (g_dt, g_x)
 
 
+class _DenseMultiCarryFn(torch.autograd.Function):
+    """(o_1, .., o_nt, y0', y1', k_1', .., k_7'): nt <= 7 ticks of ONE accepted step in one pass (forward: fit + evaluate per
+    tick, the bits of the single-tick form; backward: the step's nine panels and their received gradients are read once)."""
+
+    @staticmethod
+    def forward(ctx, nt, a0, a1, *rest):
+        kk, dt_, xs = rest[:7], rest[7], rest[8:8 + nt]
+        ctx.nt = nt
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(a0, a1, *rest)
+        dt32 = f32(float(dt_))
+        cmid = [f32(dt32 * f32(c)) for c in core.DP_C_MID]
+        xpows = []
+        for x_ in xs:
+            xv = f32(float(x_))
+            x2 = f32(xv * xv)
+            x3 = f32(x2 * xv)
+            xpows.append((f32(x3 * xv), x3, x2, xv, f32(1)))
+        outs = hip.interp_direct_multi(a0, a1, list(kk), cmid, dt32, xpows)
+        return tuple(outs) + (a0, a1) + tuple(kk)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        nt = ctx.nt
+        saved = ctx.saved_tensors
+        a0, a1, kk, dt_, xs = saved[0], saved[1], saved[2:9], saved[9], saved[10:10 + nt]
+        g_out, g_a0c, g_a1c, g_kc = gs[:nt], gs[nt], gs[nt + 1], gs[nt + 2:nt + 9]
+        needs = ctx.needs_input_grad
+        need_k = list(needs[3:10])
+        gk = [g_kc[j] if need_k[j] else None for j in range(7)]
+        gy0, gy1 = (g_a0c if needs[1] else None), (g_a1c if needs[2] else None)
+        g_dt, g_x = None, [None] * nt
+        live = [t for t in range(nt) if g_out[t] is not None]
+        if live:
+            gy0, gy1, gk, dxs, d_dt = hip.interp_bwd_multi([g_out[t].contiguous() for t in live], a0, a1, list(kk), f32(float(dt_)),
+                                                           [f32(float(xs[t])) for t in live], needs[1], needs[2], need_k,
+                                                           accs=[g_kc[j] if need_k[j] else None for j in range(7)],
+                                                           acc_y0=g_a0c if needs[1] else None, acc_y1=g_a1c if needs[2] else None)
+            g_dt = _scalar_like(dt_, d_dt) if needs[10] else None
+            for q, t in enumerate(live):
+                if needs[11 + t]:
+                    g_x[t] = _scalar_like(xs[t], dxs[q])
+        return (None, gy0, gy1) + tuple(gk) + (g_dt,) + tuple(g_x)
+
+
 # ---- the solver, scalar chain in torch exactly as the reference keeps it -----------------------------------------
 
 def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
@@ -466,11 +511,14 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         bad.append(0)
     pending_bad = bad[0] if bad else 0
     carry = _carry()
+    multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     y_cur = y0
     t_lo = t_hi = tt[0]
     stage = None
     sol = [y0]
-    for i in range(1, len(tt)):
+    i = 0
+    while i + 1 < len(tt):
+        i += 1
         nxt = tt[i]
         n_steps = 0
         while nxt.item() > t_hi.item():
@@ -542,7 +590,29 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         x = ((at - a0) / (a1 - a0)).to(dtype)
         s_y0, s_y1, s_k, s_dts, caches = stage
         outs = []
-        if carry:
+        if carry and multi_tick:
+            # every tick this accepted step covers (<= 7 per operation) in ONE pass over the step's panels
+            xs = [x]
+            while i + 1 < len(tt) and len(xs) < 7 and not (tt[i + 1].item() > t_hi.item()):
+                i += 1
+                at = tt[i].to(dtype)
+                assert (a0.item() <= at.item()) and (at.item() <= a1.item()), \
+                    'invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}'.format(a0, at, a1)
+                xs.append(((at - a0) / (a1 - a0)).to(dtype))
+            nt_ = len(xs)
+            per_tick = [[] for _ in range(nt_)]
+            n_y0, n_y1, n_k = [], [], []
+            for j, (p0, p1, kk) in enumerate(zip(s_y0, s_y1, s_k)):
+                o_ = _DenseMultiCarryFn.apply(nt_, p0, p1, *kk, s_dts, *xs)
+                for q in range(nt_):
+                    per_tick[q].append(o_[q])
+                n_y0.append(o_[nt_]); n_y1.append(o_[nt_ + 1]); n_k.append(list(o_[nt_ + 2:]))
+            stage = (tuple(n_y0), tuple(n_y1), n_k, s_dts, caches)
+            y_cur, f_cur = tuple(n_y1), tuple(k_[-1] for k_ in n_k)
+            for q in range(nt_ - 1):
+                sol.append(tuple(per_tick[q]))
+            outs = per_tick[-1]
+        elif carry:
             n_y0, n_y1, n_k = [], [], []
             for j, (p0, p1, kk) in enumerate(zip(s_y0, s_y1, s_k)):
                 o_ = _DenseCarryFn.apply(caches.setdefault(j, {}), p0, p1, *kk, s_dts, x)
