@@ -108,6 +108,11 @@ typedef struct ndcn_csr {
     const float   *lt_val;          /* [lt_nnz] */
     float         *hub_Sseg;        /* [hub_nseg][hub_H] */
     float         *hub_S;           /* [hub_n][hub_H] */
+    /* Facts about the arrays that some entry points need and would otherwise read back from the device at every call
+     * (ndcn_solve_small_*: the ELL width; its reverse sweep: whether A^T = A).  0 = not known: the library finds out, with one
+     * small device-to-host copy per call.  ndcn_csr_create fills max_row_len; the Python binding fills both once per operator. */
+    int32_t        max_row_len;     /* the longest row, or 0 */
+    int32_t        symmetric;       /* 1: the stored arrays equal those of the transpose; 2: they do not; 0: unknown */
 } ndcn_csr;
 
 /* ------------------------------------------------------------------------------------------------

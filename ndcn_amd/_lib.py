@@ -43,7 +43,8 @@ class CsrView(ctypes.Structure):
                 ('hub_seg_rowptr', ctypes.c_void_p), ('hub_colidx', ctypes.c_void_p), ('hub_val', ctypes.c_void_p),
                 ('hub_cmb_rowptr', ctypes.c_void_p), ('hub_cmb_colidx', ctypes.c_void_p), ('hub_cmb_val', ctypes.c_void_p),
                 ('lt_rowptr', ctypes.c_void_p), ('lt_colidx', ctypes.c_void_p), ('lt_val', ctypes.c_void_p),
-                ('hub_Sseg', ctypes.c_void_p), ('hub_S', ctypes.c_void_p)]
+                ('hub_Sseg', ctypes.c_void_p), ('hub_S', ctypes.c_void_p),
+                ('max_row_len', ctypes.c_int32), ('symmetric', ctypes.c_int32)]
 
 
 class CsrHints(ctypes.Structure):

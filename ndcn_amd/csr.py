@@ -228,7 +228,27 @@ class CsrOperator:
                                           self.rowptr.data_ptr(), self.colidx.data_ptr() if self.nnz else None,
                                           self.val.data_ptr() if self.nnz else None,
                                           self.row_order.data_ptr() if self.row_order is not None else None, None)
+            width, sym = self.facts()
+            if width:
+                self._view.max_row_len, self._view.symmetric = width, sym
         return self._view
+
+    def facts(self):
+        """(longest row, 1 if the stored arrays equal the transpose's else 2): ndcn_csr::max_row_len / symmetric, found once per
+        operator object (its arrays are never mutated) - only for operators small enough for the one-launch solves that ask."""
+        f = getattr(self, '_facts', None)
+        if f is None:
+            if self.nnz == 0 or self.shape[0] * 1 > (1 << 16):
+                f = (0, 0)
+            else:
+                width = int((self.rowptr[1:] - self.rowptr[:-1]).max())
+                sym = 2
+                if self.shape[0] == self.shape[1]:
+                    t = self.transpose()
+                    sym = 1 if (torch.equal(t.rowptr, self.rowptr) and torch.equal(t.colidx, self.colidx) and torch.equal(t.val, self.val)) else 2
+                f = (width, sym)
+            self._facts = f
+        return f
 
     def view_ref(self):
         return ctypes.byref(self.view())
@@ -242,6 +262,7 @@ class CsrOperator:
             rows = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device),
                                            (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64))
             self._t = CsrOperator.from_coo(self.colidx.to(torch.int64), rows, self.val, (self.shape[1], self.shape[0]))
+            self._t._t = self                                  # (the transpose of the transpose)
         return self._t
 
     def to_scipy(self):

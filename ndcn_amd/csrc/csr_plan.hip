@@ -422,6 +422,14 @@ __global__ __launch_bounds__(256) void light_fill_kernel(int64_t n, int64_t n_co
 
 __global__ void set_i32_kernel(int32_t *p, int32_t v) { *p = v; }
 
+__global__ __launch_bounds__(256) void max_row_len_kernel(int64_t n, const int32_t *__restrict__ rowptr, int *out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int d = r < n ? rowptr[r + 1] - rowptr[r] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_down(d, off, 64));
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, d);
+}
+
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = the total (int32: every sum here is bounded by nnz < 2^31)
 int exclusive_scan(ndcn_csr_handle *h, const int32_t *in, int32_t *out, int64_t n, int32_t *h_total, hipStream_t st) {
     if (n == 0) {
@@ -560,6 +568,19 @@ int csr_create(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream
     h->H = H;
     h->n_halo = hi.n_halo > 0 ? hi.n_halo : 0;
     A.row_order = hi.row_order;
+    if (A.n_rows > 0 && A.nnz > 0) {                        // the longest row (ndcn_csr::max_row_len)
+        int *d_max;
+        int rc0 = dev_alloc(h, &d_max, 1);
+        if (rc0) return rc0;
+        NDCN_HIP(hipMemsetAsync(d_max, 0, sizeof(int), st));
+        hipLaunchKernelGGL(max_row_len_kernel, dim3((unsigned)((A.n_rows + 255) / 256)), dim3(256), 0, st, A.n_rows, A.rowptr, d_max);
+        NDCN_LAUNCH_CHECK();
+        int got = 0;
+        NDCN_HIP(hipMemcpyAsync(&got, d_max, sizeof(int), hipMemcpyDeviceToHost, st));
+        NDCN_HIP(hipStreamSynchronize(st));
+        dev_release(h, d_max);
+        A.max_row_len = got;
+    }
     if (H != 256) return NDCN_OK;                       // the plans serve the H = 256 kernels
     int rc;
     // ---- long-row plan

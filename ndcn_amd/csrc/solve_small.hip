@@ -769,19 +769,16 @@ int solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method) 
     return passes(A->n_rows, H) <= 12 ? 1 : 0;
 }
 
-// The longest row of a README-sized operator (a few hundred rows): one small device-to-host copy of rowptr, remembered per
-// (rowptr address, nnz) - a solve loop asks once.
+// The longest row: what the operator's view says (ndcn_csr::max_row_len, filled by ndcn_csr_create / the Python binding once per
+// operator), else one small device-to-host copy of rowptr per call.  (Nothing is remembered per pointer: an address says
+// nothing about what the arrays behind it hold now.)
 static int ell_width(const ndcn_csr *A, hipStream_t st, int *out) {
-    static thread_local const void *memo_p = nullptr;
-    static thread_local int64_t memo_nnz = -1, memo_rows = -1;
-    static thread_local int memo_w = 0;
-    if (memo_p == A->rowptr && memo_nnz == A->nnz && memo_rows == A->n_rows) { *out = memo_w; return NDCN_OK; }
+    if (A->max_row_len > 0) { *out = A->max_row_len; return NDCN_OK; }
     std::vector<int32_t> rp((size_t)A->n_rows + 1);
     NDCN_HIP(hipMemcpyAsync(rp.data(), A->rowptr, rp.size() * 4, hipMemcpyDeviceToHost, st));
     NDCN_HIP(hipStreamSynchronize(st));
     int w = 0;
     for (int64_t r = 0; r < A->n_rows; ++r) w = std::max(w, rp[(size_t)r + 1] - rp[(size_t)r]);
-    memo_p = A->rowptr, memo_nnz = A->nnz, memo_rows = A->n_rows, memo_w = w;
     *out = w;
     return NDCN_OK;
 }
@@ -864,8 +861,8 @@ int solve_small_bwd_supported(const ndcn_csr *A, int H, uint32_t flags, int meth
     return lds_bytes(n_elem, H, A->n_rows, 0, false, 2 * n_elem) <= kLdsMax && 2 * (H * H + H) <= 1024 && n_elem <= 12 * 1024 ? 1 : 0;
 }
 
-// Is the operator equal to its transpose as stored (sorted CSR: the arrays then agree element for element)?  One-off per solve:
-// three small device comparisons through a host copy (a README-sized operator is ~30 KB).
+// Is the operator equal to its transpose as stored (sorted CSR: the arrays then agree element for element)?  Three small
+// device arrays compared through a host copy (a README-sized operator is ~30 KB); callers that know say so in the view.
 static int csr_symmetric(const ndcn_csr *A, const ndcn_csr *At, hipStream_t st, int *out) {
     *out = 0;
     if (!At || A == At) { *out = A == At; return NDCN_OK; }
@@ -897,18 +894,14 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
     const int64_t nnz = no_graph ? 0 : A->nnz;
     const bool csr = !no_graph && lds_bytes(n_elem, H, A->n_rows, nnz, true, 2 * n_elem) <= kLdsMax;
     const size_t lds = lds_bytes(n_elem, H, A->n_rows, nnz, csr, 2 * n_elem);
-    // a symmetric operator (the reference's normalised Laplacian / adjacency) serves its own transposed gather from the LDS copy;
-    // the answer is remembered per (A, A_t) pair of array addresses - a training loop asks once
+    // a symmetric operator (the reference's normalised Laplacian / adjacency) serves its own transposed gather from the LDS copy:
+    // the view says so (ndcn_csr::symmetric), else the arrays are compared through a host copy, per call
     int symmetric = 0;
     if (!no_graph) {
-        static thread_local const void *memo_a = nullptr, *memo_t = nullptr;
-        static thread_local int64_t memo_nnz = -1;
-        static thread_local int memo_sym = 0;
-        if (memo_a == A->colidx && memo_t == At->colidx && memo_nnz == A->nnz) symmetric = memo_sym;
-        else {
+        if (A->symmetric == 1 || A == At) symmetric = 1;
+        else if (A->symmetric == 0) {
             int rc = csr_symmetric(A, At, st, &symmetric);
             if (rc) return rc;
-            memo_a = A->colidx, memo_t = At->colidx, memo_nnz = A->nnz, memo_sym = symmetric;
         }
     }
     if (!no_control) {
