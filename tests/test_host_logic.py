@@ -143,3 +143,24 @@ def test_step_size_controller_matches_reference_formula():
         assert abs(got - want) <= 1e-12 * abs(want), (dt, ratio, got, want)
     assert core.optimal_step_size(0.5, np.float32(0)) == 5.0
     assert np.isnan(core.optimal_step_size(0.5, np.float32('nan')))
+
+
+def test_bench_cpu_legs_on_a_tiny_sample(monkeypatch):
+    """bench.py's CPU legs (oracle only, no device): the at-scale point - one timed right-hand side and one one-step solve,
+    extrapolated - and the fixed-grid sample of `--method euler`, at sizes that take milliseconds."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    monkeypatch.setitem(bench.AT_SCALE_NODES, 'M', 12 * 12)
+    monkeypatch.setitem(bench.AT_SCALE_NODES, 'C2', 300)
+    r = bench.cpu_at_scale('M', 8, 5.0, .01, .001)
+    assert r['nodes'] == 144 and r['steps_in_it'] == 1 and r['rhs_evals_in_it'] == 8 and r['value_extrapolated'] > 0
+    r2 = bench.cpu_at_scale('C2', 8, 5.0, .01, .001)
+    assert r2['rhs_evals_in_it'] == 4 and r2['steps_in_it'] == 1                      # one RK4 step
+    assert bench.cpu_at_scale('C5', 8, 5.0, .01, .001) is None                         # C5's CPU leg already runs the full size
+    monkeypatch.setitem(bench.CPU_SAMPLE, 'M', 8 * 8)
+    monkeypatch.setattr(bench, 'FIXED_GRID_METHOD', 'euler')
+    base, parity = bench.cpu_baseline('M', 8, 5.0, .01, .001, threads=2, runs=5, dev=None, at_scale=False)
+    assert parity is None and base['kind'] == 'port' and base['value'] > 0 and 'euler' in base['sample'] and 'at_scale' not in base
