@@ -347,7 +347,8 @@ NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_
  * dt and rounded to fp32, as misc.py:25 `(scale * x)` does.  Terms are added left to right, products and
  * sums rounded separately (no FMA), exactly like `sum([...])` over tensors.
  */
-/* out = y0 + sum_j c_j k_j          rk_common.py:51 via misc.py:22-25 ; dopri5.py:42 (y_mid)          */
+/* out = y0 + sum_j c_j k_j          rk_common.py:51 via misc.py:22-25 ; dopri5.py:42 (y_mid).  y0 == NULL: sum_j c_j k_j alone
+ * (the gradient combinations of a reverse sweep).                                                      */
 NDCN_API int ndcn_rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k,
                         int64_t n_elem, void *stream);
 

@@ -294,7 +294,7 @@ int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int 
 int ndcn_rk_combine_f32(float *out, const float *y0, const float *const *h_k, const float *h_c, int n_k, int64_t n_elem,
                         void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && h_k && h_c, "bad argument");
-    NDCN_CHECK_ARG(n_elem == 0 || (out && y0), "null panel");
+    NDCN_CHECK_ARG(n_elem == 0 || out, "null panel");       // y0 == NULL: the plain linear combination sum_j c_j k_j
     return rk_combine_f32(out, y0, h_k, h_c, n_k, n_elem, ST(stream));
 }
 

@@ -456,6 +456,17 @@ class HipOps:
         return out
 
     @staticmethod
+    def lincomb(ks, cs, y0=None):
+        """[y0 +] sum_j cs[j] * ks[j] in one pass (ndcn_rk_combine_f32 with or without the unit-coefficient term)."""
+        ks = [_panel(k) for k in ks]
+        out = torch.empty_like(ks[0])
+        arr_k, arr_c, n = _terms(ks, cs)
+        with torch.cuda.device(out.device):
+            check(_lib.load().ndcn_rk_combine_f32(ptr(out), ptr(_panel(y0)) if y0 is not None else None, arr_k, arr_c, n, out.numel(),
+                                                  stream_ptr()))
+        return out
+
+    @staticmethod
     def error(y0, y1, ks, cs, rtol, atol):
         """(sum of squared error ratios, non-finite count of y1) as host floats; one 16-byte read-back."""
         y0, y1 = _panel(y0), _panel(y1)

@@ -173,3 +173,46 @@ def test_readme_training_step_runs_on_two_launches(dev, capsys):
     first = float(lines[0].split('Train Loss ')[1].split('(')[0])
     last = float(lines[-1].split('Train Loss ')[1].split('(')[0])
     assert last < first
+
+
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('variant', ['default', 'no_control', 'no_graph'])
+@pytest.mark.parametrize('shape', [(45, 20), (30, 256), (12, 33)])
+def test_fixed_grid_training_through_fused_launches_equals_the_per_op_autograd_path(dev, method, variant, shape):
+    """Fixed-grid solves too large for one compute unit (or not Euler) train through `_FixedGridSolve`: the solver's fused
+    launches forward, a closed-form reverse sweep backward (stages re-formed per step, SpMM / masked Linear backward / SpMM with
+    A^T, the step size folded in).  Against the per-operation autograd path (NDCN_FIXED_GRID_GRAD=0: one autograd node per
+    kernel): the same trajectory bit for bit, gradients wrt y0, W, b to summation-order rounding; H = 256 runs rhs_fused3 with
+    its RK4 / COMBINE epilogues under grad."""
+    from ndcn_amd import torchdiffeq as ode
+    S, H = shape
+    f, L, x0 = _case(dev, S, H, no_control=variant == 'no_control', no_graph=variant == 'no_graph', seed=11)
+    t = torch.sort(torch.rand(9, generator=torch.Generator().manual_seed(6)) * 1.5).values
+    t[0] = 0.0
+    wts = torch.randn(9, x0.shape[0], H, generator=torch.Generator().manual_seed(7))
+
+    def run(flags):
+        os.environ.update(flags)
+        try:
+            f.zero_grad()
+            y0 = x0.to(dev).requires_grad_(True)
+            y = ode.odeint(f, y0, t.to(dev), method=method)
+            (y * wts.to(dev)).sum().backward()
+            return (y.detach().cpu(), y0.grad.cpu(), None if f.wt.weight.grad is None else f.wt.weight.grad.cpu().clone(),
+                    None if f.wt.bias.grad is None else f.wt.bias.grad.cpu().clone())
+        finally:
+            for k in flags:
+                del os.environ[k]
+    ya, gya, gWa, gba = run({'NDCN_SOLVE_SMALL_GRAD': '0'})                          # (keep the one-launch path out of the way)
+    yb, gyb, gWb, gbb = run({'NDCN_SOLVE_SMALL_GRAD': '0', 'NDCN_FIXED_GRID_GRAD': '0'})
+    assert torch.equal(ya, yb)
+
+    def close(a, b, what):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (what, float((a - b).abs().max()), scale)
+    close(gya, gyb, 'g_y0')
+    if variant != 'no_control':
+        close(gWa, gWb, 'g_W')
+        close(gba, gbb, 'g_b')
+    else:
+        assert gWa is None or float(gWa.abs().max()) == 0.0
