@@ -5,6 +5,7 @@ The reference keeps its operator `A` as a dense torch matrix or a torch sparse C
 column-ascending rows; this module converts once and caches the result next to the tensor it came from.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -133,7 +134,9 @@ class CsrOperator:
         return h
 
     def _release(self):
-        if getattr(self, '_handle', None):
+        # (only in the process that created the handle: a fork()ed child - multiprocessing's Manager server, a DataLoader worker -
+        # inherits this object, and its garbage collector must not call into a HIP context that does not exist there)
+        if getattr(self, '_handle', None) and getattr(self, '_handle_pid', None) == os.getpid():
             try:
                 _lib.load().ndcn_csr_destroy(self._handle)
             except Exception:
@@ -163,7 +166,7 @@ class CsrOperator:
             _lib.check(lib.ndcn_csr_create(self.shape[0], self.shape[1], self.nnz, self.rowptr.data_ptr(),
                                            self.colidx.data_ptr() if self.nnz else None, self.val.data_ptr() if self.nnz else None,
                                            int(H), ctypes.byref(hints), _lib.stream_ptr(), ctypes.byref(handle)))
-        self._handle = handle
+        self._handle, self._handle_pid = handle, os.getpid()
         info = (ctypes.c_int64 * 16)()
         _lib.check(lib.ndcn_csr_info(handle, info))
         (r_rows, r_cap, r_kib, r_groups, staged_nnz, staged_cols, stride, n_order, hub_n, hub_nseg, hub_thr, hub_nnz, lt_nnz,

@@ -426,6 +426,7 @@ class DeviceShard:
         from . import _lib
         self.plan = plan
         self.lib = lib = _lib.load()
+        self._pid = os.getpid()
         self.n_global_rows = int(n_global_rows)
         dev = plan.device
         # communicator: rank 0 draws the id, everybody learns it over the caller's process group.  Every rank reaches the
@@ -488,12 +489,13 @@ class DeviceShard:
         return ctypes.pointer(v)
 
     def close(self):
-        if self.halo:
+        mine = getattr(self, '_pid', None) == os.getpid()     # (never from a fork()ed copy of this object)
+        if self.halo and mine:
             self.lib.ndcn_halo_plan_destroy(self.halo)
-            self.halo = None
-        if self.comm:
+        self.halo = None
+        if self.comm and mine:
             self.lib.ndcn_comm_destroy(self.comm)
-            self.comm = None
+        self.comm = None
 
     def __del__(self):
         try:

@@ -375,6 +375,7 @@ class DeviceSolver:
         nbytes = int(self.lib.ndcn_solver_workspace_bytes(ctypes.byref(self.desc)))
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.handle = ctypes.c_void_p()
+        self._pid = os.getpid()
         with torch.cuda.device(dev):
             _lib.check(self.lib.ndcn_solver_create(ctypes.byref(self.desc), _lib.ptr(self.workspace), nbytes,
                                                    ctypes.byref(self.handle)))
@@ -416,9 +417,9 @@ class DeviceSolver:
         return [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
 
     def close(self):
-        if self.handle:
+        if self.handle and self._pid == os.getpid():          # (never from a fork()ed copy of this object)
             self.lib.ndcn_solver_destroy(self.handle)
-            self.handle = ctypes.c_void_p()
+        self.handle = ctypes.c_void_p()
 
     def __del__(self):
         try:
