@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void patch_expand_kernel(int64_t n_slots, cons
     out[s] = ok ? (int32_t)(node - row_base) : -1;
 }
 
-// The stride of a 2-D lattice stencil in row-major node order from its offset set, or 0 (csr.py: detect_stencil_order).
+// The stride of a 2-D lattice stencil in row-major node order from its offset set, or 0 (restated in tests/_plan_reference.py: detect_stencil_order).
 int64_t stencil_stride(std::vector<long long> off) {
     if (off.empty() || off.size() > 25) return 0;
     // the smallest large |offset| is S - b_max with b_max <= 2 (a boundary band of a shard may see only the lattice row
@@ -214,7 +214,7 @@ int detect_stencil(ndcn_csr_handle *h, int64_t row_base, int64_t n_own, bool hin
     return NDCN_OK;
 }
 
-// Walk order of the fused RHS kernel's 64-row tiles on a lattice of stride S (csr.py: lattice_tile_order): 32 consecutive
+// Walk order of the fused RHS kernel's 64-row tiles on a lattice of stride S (tests/_plan_reference.py: lattice_tile_order): 32 consecutive
 // positions - what an XCD runs concurrently - form a block of 32 lattice rows x 64 columns.
 int lattice_tile_order(ndcn_csr_handle *h, int64_t S, hipStream_t st) {
     const int64_t n = h->v.n_rows, block_rows = 32, n_chunks = 8;

@@ -619,7 +619,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     ndcn_csr light;
     const ndcn_csr *A_full = A;
     // With a halo panel the plan still applies when the caller laid the hubs' rows out right BEHIND the halo rows (one
-    // allocation: [halo | hub_S], what ndcn_amd/csr.py + sharding.py do for node-range shards of power-law graphs): the
+    // allocation: [halo | hub_S], what ndcn_csr_create's n_halo hint + sharding.py do for node-range shards of power-law graphs): the
     // kernel's second panel is then [halo | hubs], and the light operator's hub columns n_cols + h index into it as they are.
     const int64_t n_halo = Xh ? A->n_cols - n_own : 0;
     const bool hub_behind_halo = Xh && A->hub_S == Xh + n_halo * (int64_t)kH2;

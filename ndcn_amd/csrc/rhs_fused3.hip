@@ -1,6 +1,6 @@
 // The whole ODEFunc  K = relu(W (A X) + b)  (neural_dynamics.py:27-36) plus the Runge-Kutta algebra that consumes K
 // (rk_common.py:45-60,72-78; misc.py:22-25,146-157), H = 256, for operators that carry the 16-row group-record plan
-// (ndcn_csr::rec, csr.py:build_rec_plan): the gather side of spmm_rec.hip feeding the split-fp16 MFMA product of split16.h,
+// (ndcn_csr::rec, built by ndcn_csr_create: csr_plan.hip): the gather side of spmm_rec.hip feeding the split-fp16 MFMA product of split16.h,
 // one persistent workgroup per CU.
 //
 // Why (profiles/r02g_fused_timing.txt): rhs_fused2's gather waves fetch every neighbour row through the vector-memory

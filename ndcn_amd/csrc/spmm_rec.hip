@@ -8,7 +8,7 @@
 // byte a group of rows needs arrives by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) at addresses that
 // are known without loading streamed index data first, several groups ahead of its use:
 //
-//   plan (ndcn_csr::rec, built once per operator by ndcn_amd/csr.py:build_rec_plan): rows are cut into groups of R
+//   plan (ndcn_csr::rec, built once per operator by ndcn_csr_create: csr_plan.hip): rows are cut into groups of R
 //   (consecutive in the operator's walk order); group g owns one fixed-size RECORD of RECW KiB
 //       words [0, CAP)            the DISTINCT columns the group's rows reference (its "union"), padded by repetition
 //       words [CAP, CAP + 2R)     per row {row id | -1, cnt | ofs << 16}   (cnt = 0xffff: group does not fit, see below)
@@ -26,7 +26,7 @@
 //
 // Groups whose union exceeds CAP, whose entries exceed the record, or that hold a row longer than 64 entries are
 // flagged by the plan; their rows are gathered directly from the CSR arrays by the compute waves (rare by
-// construction: the plan is only attached when it covers the operator, csr.py:ensure_plans).
+// construction: the plan is only attached when it covers the operator, csr_plan.hip: csr_create).
 //
 // Measured (spmm_lab, bit-exact): 8 consecutive lattice rows per group 0.467 ms = 4.55 TB/s algorithmic = 0.57 of
 // the 8 TB/s peak; 4 x 4 lattice patches (16 rows, union 36) 0.407 ms = 5.22 TB/s = 0.65 - faster than the runtime's

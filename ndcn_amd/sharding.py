@@ -136,7 +136,7 @@ class HaloPlan:
             if not halo:
                 sub = sub[:, :n]                                    # interior rows reference own columns only
             op = CsrOperator.from_scipy(sub, device)
-            op.lattice_hint = (lo_, n)                              # where the row block sits in the shard (csr.py: detect_stencil_order)
+            op.lattice_hint = (lo_, n)                              # where the row block sits in the shard (ndcn_csr_hints::lattice_row_base / lattice_n_own)
             out.append((lo_, hi_, op, halo))
         return out
 
