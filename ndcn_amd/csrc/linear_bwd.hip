@@ -277,6 +277,29 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float *__restrict_
     out[e] = s;
 }
 
+// g_W and g_b in ONE launch (a training step makes ~30 Linear backwards: one small launch less each)
+__global__ __launch_bounds__(256) void chunk_sum2_kernel(const float *__restrict__ part_w, float *__restrict__ out_w, int n_w,
+                                                         const float *__restrict__ part_b, float *__restrict__ out_b, int n_b,
+                                                         int n_chunks) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    const float *part = part_w;
+    float *out = out_w;
+    int n_elem = n_w;
+    if (e >= n_w) { e -= n_w; part = part_b; out = out_b; n_elem = n_b; }
+    if (e >= n_elem) return;
+    float s = 0.f;
+    int c = 0;
+    for (; c + 8 <= n_chunks; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * n_elem + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < n_chunks; ++c) s += part[(size_t)c * n_elem + e];
+    out[e] = s;
+}
+
 // ---------------------------------------------------------------------------------------------------- gS
 // gS[n, Hi] = gZ[n, Ho] W[Ho, Hi]: the forward kernel's tiling (64 rows x BN columns per workgroup, k chunks of 32
 // through padded LDS) with the mask applied while the A tile is staged and W staged transposed.
@@ -529,8 +552,11 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
 #undef NDCN_GW
         }
         NDCN_LAUNCH_CHECK();
-        if (gW) hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho * Hi + 255) / 256)), dim3(256), 0, st, part_w, gW, Ho * Hi, (int)used);
-        if (gb) hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho + 255) / 256)), dim3(256), 0, st, part_b, gb, Ho, (int)used);
+        if (gW && gb)
+            hipLaunchKernelGGL(chunk_sum2_kernel, dim3((unsigned)((Ho * Hi + Ho + 255) / 256)), dim3(256), 0, st, part_w, gW, Ho * Hi, part_b, gb,
+                               Ho, (int)used);
+        else if (gW) hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho * Hi + 255) / 256)), dim3(256), 0, st, part_w, gW, Ho * Hi, (int)used);
+        else hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho + 255) / 256)), dim3(256), 0, st, part_b, gb, Ho, (int)used);
         NDCN_LAUNCH_CHECK();
     }
     return NDCN_OK;
