@@ -50,7 +50,7 @@ def in_family(kind, kernel_name):
         return bool(m) and m.group(2).split(',')[-1].strip() != '0'
     if kind == 'spmm':
         m = re.search(r'spmm_(rec|wide)_kernel<([^>]*)>', kernel_name)
-        return 'spmm_csr' in kernel_name or (bool(m) and m.group(2).split(',')[-1].strip() == '0')
+        return 'spmm_csr' in kernel_name or 'spmm_sweep' in kernel_name or (bool(m) and m.group(2).split(',')[-1].strip() == '0')
     return {'combine': 'combine_kernel', 'linear': 'linear_', 'error': 'rk_error'}.get(kind, kind) in kernel_name
 
 
@@ -76,6 +76,12 @@ def pmc_traffic(kind, cfg):
             biggest = max(biggest, v['hbm_bytes_per_launch'])
     if not den:
         return None, None
+    if kind == 'rhs_fused':
+        # operators with the column-sweep plan evaluate the right-hand side in TWO launches (spmm_sweep_kernel: S = A X, then the
+        # fused kernel on the identity operator over S; one ProfScope spans both): the evaluation's traffic is the sum
+        sweep = [v['hbm_bytes_per_launch'] for name, v in d.items() if 'spmm_sweep_kernel' in name]
+        if sweep:
+            num += sweep[0] * den
     # the standalone SpMM of an operator with a long-row plan is one main launch + small hub-segment launches of the same
     # kernel family: its traffic is the main launch's, not the launch-weighted mean (which read 1.10 x for C3 in round 3
     # where the main launch moves 4.9 x)
@@ -455,7 +461,10 @@ def main():
             spmm_line = {'avg_ms': round(ms, 4), 'alg_bytes': byt, 'GBps': round(byt / ms / 1e6, 1),
                          'frac_of_hbm_peak': round(byt / ms / 1e6 / HBM_PEAK_GBS, 4),
                          'plan': None if A_op.rec is None else 'group-record %d rows / %d columns' % (A_op.rec['rows'], A_op.rec['cap']),
-                         'long_row_plan': None if getattr(A_op, 'hub', None) is None else '%d hub rows' % A_op.hub['n']}
+                         'long_row_plan': None if getattr(A_op, 'hub', None) is None else '%d hub rows' % A_op.hub['n'],
+                         'sweep_plan': None if getattr(A_op, 'sweep', None) is None else
+                         'column sweep: %d pass(es), %d rows per wave, blocks of %d columns, window %d' % (
+                             A_op.sweep['passes'], A_op.sweep['rows_per_wave'], 1 << A_op.sweep['logb'], A_op.sweep['window'])}
             cfg_spmm = 'NC' if (args.config == 'M' and args.no_control) else args.config
             tr, src = pmc_traffic('spmm', cfg_spmm)
             if tr:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 11
+#define NDCN_ABI_VERSION 12
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -113,6 +113,32 @@ typedef struct ndcn_csr {
      * small device-to-host copy per call.  ndcn_csr_create fills max_row_len; the Python binding fills both once per operator. */
     int32_t        max_row_len;     /* the longest row, or 0 */
     int32_t        symmetric;       /* 1: the stored arrays equal those of the transpose; 2: they do not; 0: unknown */
+    /* Optional column-sweep plan (sweep_ent = NULL when absent), built by ndcn_csr_create for H = 256 operators WITHOUT
+     * locality whose rows are long relative to their count (a 10^5-node G(n,p) graph of mean degree 40: heat_dynamics.py:89 at
+     * BASELINE config 2).  A row gather fetches nnz rows of X through the fabric (L2 hit rate 6 %); the sweep keeps the partial
+     * sums of ALL rows in registers and lets every XCD walk the columns of X in ascending order, so that the rows of X an XCD
+     * needs at one time form a window of its 4 MiB L2: 8 * n_cols rows cross the fabric per pass instead of nnz
+     * (ndcn_amd/csrc/spmm_sweep.hip).  Layout: the rows are cut into sweep_passes passes of <= 100 352 rows; a pass gives each of
+     * its 8 x 256 waves a "slab" of sweep_rpw consecutive rows (8 XCD chunks of ceil(rows / 8) rows, 256 slabs per chunk);
+     *   sweep_slab [passes * 2048][2]  {first entry (a multiple of 8), entries} of the slab in sweep_ent
+     *   sweep_ent  pairs of 32-bit words {row within the slab << 24 | column, fp32 value bits}: the slab's entries merged over
+     *              its rows and sorted by column - per row still in ascending column order, i.e. the fma chain of a sequential
+     *              CSR loop: results are bit-identical to it - padded to groups of 8 with {49 << 24, 0}
+     *   sweep_prog [passes][8][256]    one word per wave: (launch tag << 16) | column block it fetches from - waves of an XCD
+     *              keep within sweep_window blocks of 2^sweep_logb columns of each other (a locality hint with a bounded wait,
+     *              never needed for correctness)
+     *   sweep_S    [n_rows][256] scratch for S = A X in front of the Linear (ndcn_rhs_f32 / ndcn_rhs_rk_f32: the fused kernel
+     *              then runs on the identity operator sweep_eye_* over S) - owned by the operator, like hub_S: one launch
+     *              stream at a time.  Used when no halo panel is passed.                                                   */
+    int32_t         sweep_passes, sweep_rpw, sweep_logb, sweep_window;
+    int64_t         sweep_rows_per_pass;
+    const uint32_t *sweep_ent;
+    const int32_t  *sweep_slab;
+    uint32_t       *sweep_prog;
+    float          *sweep_S;
+    const int32_t  *sweep_eye_rowptr;  /* [n_rows + 1] = 0 .. n_rows */
+    const int32_t  *sweep_eye_colidx;  /* [n_rows] = 0 .. n_rows - 1 */
+    const float    *sweep_eye_val;     /* [n_rows] ones */
 } ndcn_csr;
 
 /* ------------------------------------------------------------------------------------------------
@@ -157,6 +183,8 @@ typedef struct ndcn_csr_hints {
 #define NDCN_PLAN_NO_HUB            8u   /* no long-row plan                                                          */
 #define NDCN_PLAN_EXTERNAL_SCRATCH 16u   /* the caller provides the long-row plan's scratch (ndcn_csr_set_hub_scratch) */
 #define NDCN_PLAN_ORDER_ONLY       32u   /* lattice detection and walk orders only, no records                        */
+#define NDCN_PLAN_NO_SWEEP         64u   /* no column-sweep plan                                                      */
+#define NDCN_PLAN_FORCE_SWEEP     128u   /* build the column-sweep plan whatever the fetch arithmetic says (tests)     */
 NDCN_API int ndcn_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colidx,
                              const float *val, int H, const ndcn_csr_hints *hints, void *stream, ndcn_csr_handle **out);
 NDCN_API int ndcn_csr_destroy(ndcn_csr_handle *h);
@@ -172,6 +200,11 @@ NDCN_API const int32_t *ndcn_csr_group_order(const ndcn_csr_handle *h);
 NDCN_API float *ndcn_csr_halo_panel(const ndcn_csr_handle *h);
 /* NDCN_PLAN_EXTERNAL_SCRATCH: Sseg [hub_nseg][H] and halo_S [n_halo + hub_n][H], 16-byte aligned, owned by the caller     */
 NDCN_API int ndcn_csr_set_hub_scratch(ndcn_csr_handle *h, float *Sseg, float *halo_S);
+/* column-sweep plan: h_out = {passes, rows per wave, log2 of the column block, window in blocks, padded entries, rows per pass,
+ * 1 if the scratch panel is set, 0} (all zero without the plan); under NDCN_PLAN_EXTERNAL_SCRATCH the caller provides the
+ * [n_rows][256] scratch panel (16-byte aligned) before the first right-hand side                                            */
+NDCN_API int ndcn_csr_sweep_info(const ndcn_csr_handle *h, int64_t h_out[8]);
+NDCN_API int ndcn_csr_set_sweep_scratch(ndcn_csr_handle *h, float *S);
 
 NDCN_API int         ndcn_abi_version(void);
 NDCN_API const char *ndcn_last_error(void);            /* thread-local, valid until the next failing call */
@@ -553,6 +586,7 @@ NDCN_API int ndcn_prof_kinds(void);
 #define NDCN_PATH_FUSED3 2
 #define NDCN_PATH_HUB    4
 #define NDCN_PATH_HALO   8
+#define NDCN_PATH_SWEEP 16
 NDCN_API int ndcn_debug_last_rhs_path(void);
 
 #ifdef __cplusplus

@@ -11,8 +11,8 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 11
-PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO = 1, 2, 4, 8
+ABI_VERSION = 12
+PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO, PATH_SWEEP = 1, 2, 4, 8, 16
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
@@ -44,7 +44,12 @@ class CsrView(ctypes.Structure):
                 ('hub_cmb_rowptr', ctypes.c_void_p), ('hub_cmb_colidx', ctypes.c_void_p), ('hub_cmb_val', ctypes.c_void_p),
                 ('lt_rowptr', ctypes.c_void_p), ('lt_colidx', ctypes.c_void_p), ('lt_val', ctypes.c_void_p),
                 ('hub_Sseg', ctypes.c_void_p), ('hub_S', ctypes.c_void_p),
-                ('max_row_len', ctypes.c_int32), ('symmetric', ctypes.c_int32)]
+                ('max_row_len', ctypes.c_int32), ('symmetric', ctypes.c_int32),
+                ('sweep_passes', ctypes.c_int32), ('sweep_rpw', ctypes.c_int32), ('sweep_logb', ctypes.c_int32),
+                ('sweep_window', ctypes.c_int32), ('sweep_rows_per_pass', ctypes.c_int64),
+                ('sweep_ent', ctypes.c_void_p), ('sweep_slab', ctypes.c_void_p), ('sweep_prog', ctypes.c_void_p),
+                ('sweep_S', ctypes.c_void_p), ('sweep_eye_rowptr', ctypes.c_void_p), ('sweep_eye_colidx', ctypes.c_void_p),
+                ('sweep_eye_val', ctypes.c_void_p)]
 
 
 class CsrHints(ctypes.Structure):
@@ -56,6 +61,7 @@ class CsrHints(ctypes.Structure):
 
 
 PLAN_NO_REC, PLAN_NO_STENCIL, PLAN_NO_TILE_ORDER, PLAN_NO_HUB, PLAN_EXTERNAL_SCRATCH, PLAN_ORDER_ONLY = 1, 2, 4, 8, 16, 32
+PLAN_NO_SWEEP, PLAN_FORCE_SWEEP = 64, 128
 
 
 def empty_csr(n_rows):
@@ -99,6 +105,8 @@ SIGNATURES = {
     'ndcn_csr_group_order': (_P, [_P]),
     'ndcn_csr_halo_panel': (_P, [_P]),
     'ndcn_csr_set_hub_scratch': (_I, [_P, _P, _P]),
+    'ndcn_csr_sweep_info': (_I, [_P, ctypes.POINTER(_L)]),
+    'ndcn_csr_set_sweep_scratch': (_I, [_P, _P]),
     'ndcn_spmm_f32': (_I, [_CSR, _P, _P, _L, _P, _I, _F, _U, _P]),
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
     'ndcn_gcn_f32': (_I, [_CSR, _P, _P, _P, _P, _P, _I, _I, _U, _P]),

@@ -32,6 +32,7 @@ class CsrOperator:
         self.tile_order = False      # the fused kernel walks its tiles in a lattice order
         self.stencil_stride = 0      # lattice stride the library detected (0: none)
         self.hub = None              # what the long-row plan is + its scratch panels, or None
+        self.sweep = None            # what the column-sweep plan is + its scratch panel, or None
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -154,6 +155,8 @@ class CsrOperator:
           .rec  {'rows', 'cap', 'kib', 'groups', 'staged', 'loads_per_row'} or None
           .hub  {'n', 'nseg', 'H', 'nnz', 'lt_nnz', 'threshold', 'Sseg', 'halo_S', 'S'} or None (the scratch panels are
                 torch tensors: a shard's exchange receives into the head of 'halo_S')
+          .sweep {'passes', 'rows_per_wave', 'logb', 'window', 'entries', 'rows_per_pass', 'S'} or None: the column-sweep
+                plan of operators without locality (struct ndcn_csr: sweep_*; csrc/spmm_sweep.hip)
           .group_order / .stencil_stride / .tile_order (bool) of a detected lattice."""
         if self.device.type != 'cuda':
             raise _lib.NdcnHipError(_lib.EINVAL, 'operator plans are built on the device; this operator lives on %s' % self.device)
@@ -193,6 +196,14 @@ class CsrOperator:
             _lib.check(lib.ndcn_csr_set_hub_scratch(handle, Sseg.data_ptr(), halo_S.data_ptr()))
             self.hub = {'n': hub_n, 'nseg': hub_nseg, 'H': int(H), 'nnz': hub_nnz, 'lt_nnz': lt_nnz, 'threshold': hub_thr,
                         'Sseg': Sseg, 'halo_S': halo_S, 'S': halo_S[n_halo:]}
+        self.sweep = None
+        sw = (ctypes.c_int64 * 8)()
+        _lib.check(lib.ndcn_csr_sweep_info(handle, sw))
+        if int(sw[0]):
+            S = torch.empty(self.shape[0], H, dtype=torch.float32, device=self.device)
+            _lib.check(lib.ndcn_csr_set_sweep_scratch(handle, S.data_ptr()))
+            self.sweep = {'passes': int(sw[0]), 'rows_per_wave': int(sw[1]), 'logb': int(sw[2]), 'window': int(sw[3]),
+                          'entries': int(sw[4]), 'rows_per_pass': int(sw[5]), 'S': S}
         return self
 
     def build_rec_plan(self, rows_per_group=8, cap=32, kib=1):

@@ -15,6 +15,9 @@
 //   long-row plan       degree histogram -> threshold; exclusive scans (hipcub) over the hub flags and the light
 //                       operator's row lengths; one pass copies the hub rows' entries into their compact CSR over
 //                       <= 256-entry segments and the light rows into the operator the fused kernel runs on
+//   column-sweep plan   (operators without locality whose partial sums fit the register files: spmm_sweep.hip) the rows cut
+//                       into slabs of <= 49 consecutive rows, one per wave; every entry packed as {row in slab << 24 | column,
+//                       value}; a segmented radix sort (hipcub) by column inside each slab; slabs padded to groups of 8
 //
 // The decisions (which record shape, which threshold, whether a plan pays) are the ones ndcn_amd/csr.py took in Python
 // up to ABI 10; tests/_plan_reference.py keeps that restatement and tests/test_gpu_plans.py compares bit for bit.
@@ -41,6 +44,7 @@ struct ndcn_csr_handle {
     int64_t n_halo = 0;
     float *halo_S = nullptr;            // [n_halo + hub_n][H]: the kernels' second panel ([halo | hub rows])
     int H = 0;
+    int64_t sweep_entries = 0;          // padded entries of the column-sweep plan
 };
 
 namespace ndcn {
@@ -532,6 +536,153 @@ int build_hub_plan(ndcn_csr_handle *h, int H, int thr, bool external_scratch, hi
     return NDCN_OK;
 }
 
+
+// ---- column-sweep plan (struct ndcn_csr: sweep_*; the kernel: spmm_sweep.hip) ---------------------------------------------------
+// Geometry, shared with spmm_sweep_f32: pass p holds rows [p R, min(n, (p + 1) R)), R = sweep_rows_per_pass; its np rows are cut
+// into 8 XCD chunks of ceil(np / 8) rows, every chunk into 256 slabs of ceil(chunk / 256) <= 49 consecutive rows.
+constexpr int kSweepRows = 49, kSweepSlots = 256, kSweepSlabs = kXcds * kSweepSlots;
+
+struct SweepGeom { int64_t n, rpp; };
+__device__ __host__ inline void sweep_slab_rows(const SweepGeom g, int64_t s, int64_t *row0, int64_t *row1) {
+    const int64_t p = s / kSweepSlabs, x = (s % kSweepSlabs) / kSweepSlots, sl = s % kSweepSlots;
+    const int64_t base = p * g.rpp, end = (p + 1) * g.rpp < g.n ? (p + 1) * g.rpp : g.n, np = end - base;
+    const int64_t per_xcd = (np + kXcds - 1) / kXcds, rpw = (per_xcd + kSweepSlots - 1) / kSweepSlots;
+    const int64_t xend = base + (x + 1) * per_xcd < end ? base + (x + 1) * per_xcd : end;
+    int64_t r0 = base + x * per_xcd + sl * rpw, r1 = r0 + rpw;
+    if (r0 > xend) r0 = xend;
+    if (r1 > xend) r1 = xend;
+    *row0 = r0, *row1 = r1;
+}
+
+// per slab: where its entries start in the CSR arrays (its rows are consecutive), how many there are, the count padded to 8
+__global__ __launch_bounds__(256) void sweep_slab_kernel(int64_t nslab, SweepGeom g, const int32_t *__restrict__ rowptr, int32_t *seg_off,
+                                                         int32_t *cnt_pad) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nslab) return;
+    if (s == nslab) { seg_off[s] = rowptr[g.n]; return; }
+    int64_t r0, r1;
+    sweep_slab_rows(g, s, &r0, &r1);
+    seg_off[s] = rowptr[r0];
+    cnt_pad[s] = (rowptr[r1] - rowptr[r0] + 7) & ~7;
+}
+
+// per entry: {row within its slab << 24 | column, value bits} as ONE 64-bit word (low word first in memory)
+__global__ __launch_bounds__(256) void sweep_pack_kernel(SweepGeom g, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                         const float *__restrict__ val, unsigned long long *packed) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= g.n) return;
+    const int64_t p = r / g.rpp, base = p * g.rpp, end = (p + 1) * g.rpp < g.n ? (p + 1) * g.rpp : g.n, np = end - base;
+    const int64_t per_xcd = (np + kXcds - 1) / kXcds, rpw = (per_xcd + kSweepSlots - 1) / kSweepSlots;
+    const unsigned local = (unsigned)(((r - base) % per_xcd) % rpw);
+    for (int32_t j = rowptr[r]; j < rowptr[r + 1]; ++j)
+        packed[j] = ((unsigned long long)__float_as_uint(val[j]) << 32) | (unsigned long long)(local << 24 | (unsigned)colidx[j]);
+}
+
+__global__ __launch_bounds__(256) void sweep_pad_kernel(int64_t n_words, unsigned long long *ent) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) ent[i] = (unsigned long long)((unsigned)kSweepRows << 24);      // 0 * X[0] into the dummy row
+}
+
+// one workgroup per slab: its sorted entries into its padded place, and the slab's table row
+__global__ __launch_bounds__(256) void sweep_place_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ pad_start,
+                                                          const unsigned long long *__restrict__ sorted, unsigned long long *ent,
+                                                          int32_t *slab) {
+    const int64_t s = blockIdx.x;
+    const int32_t src = seg_off[s], cnt = seg_off[s + 1] - src, dst = pad_start[s];
+    for (int32_t i = threadIdx.x; i < cnt; i += blockDim.x) ent[dst + i] = sorted[src + i];
+    if (threadIdx.x == 0) { slab[2 * s] = dst; slab[2 * s + 1] = cnt; }
+}
+
+__global__ __launch_bounds__(256) void sweep_eye_kernel(int64_t n, int32_t *rowptr, int32_t *colidx, float *val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) rowptr[i] = (int32_t)i;
+    if (i < n) { colidx[i] = (int32_t)i; val[i] = 1.0f; }
+}
+
+// Worth it when the sweep moves clearly fewer rows of X through the fabric than the gather: 8 XCDs x n_cols rows per pass
+// against nnz (measured on the 10^5-node G(n,p) graph of mean degree 40: 0.8 M against 4.0 M rows, 0.20 against 0.56 ms).
+// And only when the panel is larger than what an XCD's L2 holds anyway (8 192 rows of 1 KiB = 2 x 4 MiB).
+bool sweep_pays(const ndcn_csr &A, int passes) {
+    return A.n_cols >= 8192 && (double)A.nnz >= 2.0 * (double)passes * kXcds * (double)A.n_cols;
+}
+
+int build_sweep_plan(ndcn_csr_handle *h, bool external_scratch, hipStream_t st) {
+    ndcn_csr &A = h->v;
+    const int64_t n = A.n_rows, cap = (int64_t)kSweepSlabs * kSweepRows;        // 100 352 rows per pass
+    const int passes = (int)((n + cap - 1) / cap);
+    const int64_t rpp = (n + passes - 1) / passes, nslab = (int64_t)passes * kSweepSlabs;
+    const SweepGeom g{n, rpp};
+    int rc;
+    int32_t *seg_off, *cnt_pad, *pad_start, *slab;
+    unsigned long long *packed, *sorted, *ent;
+    int32_t *keys_out;
+    if ((rc = dev_alloc(h, &seg_off, (size_t)nslab + 1)) || (rc = dev_alloc(h, &cnt_pad, (size_t)nslab)) ||
+        (rc = dev_alloc(h, &pad_start, (size_t)nslab + 1)) || (rc = dev_alloc(h, &slab, (size_t)nslab * 2)) ||
+        (rc = dev_alloc(h, &packed, (size_t)A.nnz)) || (rc = dev_alloc(h, &sorted, (size_t)A.nnz)) || (rc = dev_alloc(h, &keys_out, (size_t)A.nnz)))
+        return rc;
+    hipLaunchKernelGGL(sweep_slab_kernel, dim3((unsigned)((nslab + 256) / 256)), dim3(256), 0, st, nslab, g, A.rowptr, seg_off, cnt_pad);
+    NDCN_LAUNCH_CHECK();
+    int32_t total = 0;
+    if ((rc = exclusive_scan(h, cnt_pad, pad_start, nslab, &total, st))) return rc;
+    hipLaunchKernelGGL(sweep_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, A.rowptr, A.colidx, A.val, packed);
+    NDCN_LAUNCH_CHECK();
+    // the slab's entries by column (ties - two rows of a slab referencing one column - fold into different accumulators)
+    int end_bit = 1;
+    while (end_bit < 31 && (1ll << end_bit) < A.n_cols) ++end_bit;
+    size_t bytes = 0;
+    NDCN_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, reinterpret_cast<const uint32_t *>(A.colidx),
+                                                        reinterpret_cast<uint32_t *>(keys_out), packed, sorted, (int)A.nnz, (int)nslab, seg_off,
+                                                        seg_off + 1, 0, end_bit, st));
+    char *tmp;
+    if ((rc = dev_alloc(h, &tmp, bytes ? bytes : 16))) return rc;
+    NDCN_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(tmp, bytes, reinterpret_cast<const uint32_t *>(A.colidx), reinterpret_cast<uint32_t *>(keys_out),
+                                                        packed, sorted, (int)A.nnz, (int)nslab, seg_off, seg_off + 1, 0, end_bit, st));
+    const int64_t n_words = (int64_t)total + 32;                 // + 4 groups: the kernel prefetches two groups past a slab's end
+    if ((rc = dev_alloc(h, &ent, (size_t)n_words))) return rc;
+    hipLaunchKernelGGL(sweep_pad_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, n_words, ent);
+    NDCN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sweep_place_kernel, dim3((unsigned)nslab), dim3(256), 0, st, seg_off, pad_start, sorted, ent, slab);
+    NDCN_LAUNCH_CHECK();
+    uint32_t *prog;
+    int32_t *eye_rowptr, *eye_colidx;
+    float *eye_val;
+    if ((rc = dev_alloc(h, &prog, (size_t)nslab)) || (rc = dev_alloc(h, &eye_rowptr, (size_t)n + 1)) || (rc = dev_alloc(h, &eye_colidx, (size_t)n)) ||
+        (rc = dev_alloc(h, &eye_val, (size_t)n)))
+        return rc;
+    NDCN_HIP(hipMemsetAsync(prog, 0, (size_t)nslab * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(sweep_eye_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, n, eye_rowptr, eye_colidx, eye_val);
+    NDCN_LAUNCH_CHECK();
+    NDCN_HIP(hipStreamSynchronize(st));
+    dev_release(h, seg_off);
+    dev_release(h, cnt_pad);
+    dev_release(h, pad_start);
+    dev_release(h, packed);
+    dev_release(h, sorted);
+    dev_release(h, keys_out);
+    dev_release(h, tmp);
+    const int64_t per_xcd = (rpp + kXcds - 1) / kXcds;
+    A.sweep_passes = passes;
+    A.sweep_rpw = (int32_t)((per_xcd + kSweepSlots - 1) / kSweepSlots);
+    A.sweep_rows_per_pass = rpp;
+    // column blocks of 1024 rows of X (1 MiB) and a window of 3: every wave of an XCD within the last 3 MiB of its 4 MiB L2
+    // (tools/micro/sweep_lab.hip: 0.200 ms; 2048 x 2: 0.196; 512 x 6: 0.227; no synchronisation: 0.341)
+    A.sweep_logb = 10;
+    A.sweep_window = 3;
+    A.sweep_ent = reinterpret_cast<const uint32_t *>(ent);
+    A.sweep_slab = slab;
+    A.sweep_prog = prog;
+    A.sweep_eye_rowptr = eye_rowptr;
+    A.sweep_eye_colidx = eye_colidx;
+    A.sweep_eye_val = eye_val;
+    h->sweep_entries = total;
+    if (!external_scratch) {
+        float *S;
+        if ((rc = dev_alloc(h, &S, (size_t)n * 256))) return rc;
+        A.sweep_S = S;
+    }
+    return NDCN_OK;
+}
+
 int choose_hub_threshold(ndcn_csr_handle *h, int forced, int *thr_out, hipStream_t st) {
     // Rows longer than the threshold leave the fused kernel.  Worth it only when such rows are the exception (measured,
     // 10^6 nodes: Barabasi-Albert m = 5 36.8 -> 24.5 ms/step at threshold 32; G(n,p) with mean degree 41, where 32 moves
@@ -560,7 +711,7 @@ int choose_hub_threshold(ndcn_csr_handle *h, int forced, int *thr_out, hipStream
     return NDCN_OK;
 }
 
-int csr_create(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream_t st) {
+int csr_create_plans(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream_t st) {
     ndcn_csr &A = h->v;
     ndcn_csr_hints none;
     memset(&none, 0, sizeof(none));
@@ -644,6 +795,21 @@ int csr_create(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream
     return NDCN_OK;
 }
 
+int csr_create(ndcn_csr_handle *h, int H, const ndcn_csr_hints *hints, hipStream_t st) {
+    int rc = csr_create_plans(h, H, hints, st);
+    if (rc) return rc;
+    // ---- column-sweep plan: whole operators without a group-record plan whose rows are long relative to their count
+    ndcn_csr &A = h->v;
+    const uint32_t flags = hints ? hints->flags : 0;
+    const bool whole = !hints || (hints->lattice_n_own == 0 && hints->n_halo == 0);
+    if (H != 256 || A.nnz == 0 || A.n_rows == 0 || !whole || A.rec || (flags & (NDCN_PLAN_NO_SWEEP | NDCN_PLAN_ORDER_ONLY)) || env_off("NDCN_SWEEP_PLAN"))
+        return NDCN_OK;
+    if (A.n_cols * (int64_t)1024 >= (1ll << 32) || A.n_cols >= (1 << 24)) return NDCN_OK;
+    const int passes = (int)((A.n_rows + (int64_t)kSweepSlabs * kSweepRows - 1) / ((int64_t)kSweepSlabs * kSweepRows));
+    if (!(flags & NDCN_PLAN_FORCE_SWEEP) && !(passes <= 4 && sweep_pays(A, passes))) return NDCN_OK;
+    return build_sweep_plan(h, flags & NDCN_PLAN_EXTERNAL_SCRATCH, st);
+}
+
 }  // namespace
 }  // namespace ndcn
 
@@ -696,6 +862,23 @@ int ndcn_csr_set_hub_scratch(ndcn_csr_handle *h, float *Sseg, float *halo_S) {
     h->v.hub_Sseg = Sseg;
     h->halo_S = halo_S;
     h->v.hub_S = halo_S + h->n_halo * (int64_t)h->v.hub_H;
+    return NDCN_OK;
+}
+
+int ndcn_csr_sweep_info(const ndcn_csr_handle *h, int64_t o[8]) {
+    NDCN_CHECK_ARG(h && o, "null argument");
+    const ndcn_csr &A = h->v;
+    const int64_t v[8] = {A.sweep_ent ? A.sweep_passes : 0, A.sweep_ent ? A.sweep_rpw : 0, A.sweep_ent ? A.sweep_logb : 0,
+                          A.sweep_ent ? A.sweep_window : 0, h->sweep_entries, A.sweep_ent ? A.sweep_rows_per_pass : 0, A.sweep_S ? 1 : 0, 0};
+    memcpy(o, v, sizeof(v));
+    return NDCN_OK;
+}
+
+int ndcn_csr_set_sweep_scratch(ndcn_csr_handle *h, float *S) {
+    NDCN_CHECK_ARG(h, "null handle");
+    if (!h->v.sweep_ent) return NDCN_OK;
+    NDCN_CHECK_ARG(S && aligned16(S), "the sweep scratch must be a 16-byte aligned device buffer of n_rows x 256 floats");
+    h->v.sweep_S = S;
     return NDCN_OK;
 }
 

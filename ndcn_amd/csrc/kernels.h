@@ -60,6 +60,9 @@ int rhs_fused3_variant(int mode, int n_prev);
 int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
                    uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,
                    float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st, const RkOpt *opt = nullptr);
+// spmm_sweep.hip: Y = A X through the column-sweep plan (H = 256, no halo panel, alpha = 1, no activation)
+int spmm_sweep_supported(const ndcn_csr *A, int H);
+int spmm_sweep_f32(const ndcn_csr *A, const float *X, float *Y, hipStream_t st);
 int spmm_rec_supported(const ndcn_csr *A, int H);
 int spmm_rec_variant(int mode, int n_prev);
 int64_t spmm_rec_partials_bytes();
@@ -119,7 +122,7 @@ int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const flo
 int rk_dense_bwd_multi_f32(const float *const *h_g, int nt, const float *y0, const float *y1, const float *const *h_k, float dt,
                            const float *h_x, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1,
                            const float *const *h_acc, double *d_dots, void *d_ws, int64_t n, hipStream_t st);
-void prof_pause(bool on);
+bool prof_pause(bool on);     // returns the previous state
 extern thread_local int g_last_rhs_path;     // ndcn_debug_last_rhs_path     // no launch timing while a stream is being captured
 int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol, int64_t n, double *d_out,
                      void *d_ws, hipStream_t st);

@@ -44,7 +44,11 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(g_prof.recs[slot].b, st);
 }
 
-void prof_pause(bool on) { g_prof.paused = on; }
+bool prof_pause(bool on) {       // returns the previous state (nested users restore it)
+    const bool was = g_prof.paused;
+    g_prof.paused = on;
+    return was;
+}
 
 }  // namespace ndcn
 

@@ -614,6 +614,29 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
                    const RkOpt *opt) {
     const int n_rows = (int)A->n_rows;
     if (n_rows == 0) return NDCN_OK;
+    // Column-sweep plan (struct ndcn_csr; spmm_sweep.hip): S = A X by the sweep into the operator's scratch panel, then this
+    // kernel on the IDENTITY operator over S - the Linear, the ReLU and the RK epilogue as on any operator (row i folds
+    // fma(1, S[i], 0) = S[i]).  One profiled unit: the two launches are one evaluation of the right-hand side.
+    if (!Xh && A->sweep_S && !(opt && opt->xadd) && spmm_sweep_supported(A, kH2) && aligned16(X)) {
+        const double P = 4.0 * kH2 * (double)A->n_rows;
+        double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * kH2 * (double)(A->n_rows + A->n_cols) + 4.0 * kH2 * kH2;
+        if (mode != MODE_PLAIN) bytes += P * (n_prev + 2 + ((mode == MODE_COMBINE && opt && opt->y_aux && opt->c_aux) ? 1 : 0));
+        ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * kH2 + 2.0 * (double)A->n_rows * kH2 * kH2);
+        const bool was_paused = prof_pause(true);
+        int rc = spmm_sweep_f32(A, X, A->sweep_S, st);
+        if (!rc) {
+            ndcn_csr eye = {};
+            eye.n_rows = eye.n_cols = eye.nnz = A->n_rows;
+            eye.rowptr = A->sweep_eye_rowptr; eye.colidx = A->sweep_eye_colidx; eye.val = A->sweep_eye_val;
+            RkOpt o = opt ? *opt : RkOpt{};
+            if (!o.y1) o.y1 = X;                          // ERROR mode: the state whose record is formed is the evaluation's input
+            rc = rhs_fused2_f32(&eye, A->sweep_S, nullptr, A->n_rows, Wp, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
+                                d_out, d_ws, st, &o);
+            g_last_rhs_path |= NDCN_PATH_SWEEP;
+        }
+        prof_pause(was_paused);
+        return rc;
+    }
     // Long-row plan: the hub rows' (A X) rows are formed ahead by two small SpMMs (segments, then their sums) and the
     // kernel runs on the "light" operator that reads them as its second panel (include/ndcn_hip.h, struct ndcn_csr).
     ndcn_csr light;

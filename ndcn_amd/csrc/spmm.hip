@@ -445,6 +445,8 @@ int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, 
     // kernels - the tail of the launch.  As in the fused right-hand side: the hubs' rows are formed ahead by two small SpMMs
     // (<= 256-entry segments, then their sums in order) and the launch proper runs on the light operator, which reads each
     // hub's finished row as ONE entry of a second panel.
+    // Column-sweep plan (struct ndcn_csr; spmm_sweep.hip): operators without locality whose partial sums fit the register files
+    if (vec && !Xh && alpha == 1.f && !(flags & NDCN_F_RELU) && spmm_sweep_supported(A, H)) return spmm_sweep_f32(A, X, Y, st);
     static const int use_hub = env_int("NDCN_SPMM_HUB", 1);
     if (use_hub && vec && !Xh && A->hub_n > 0 && A->hub_H == H && A->hub_S && A->hub_Sseg && A->lt_rowptr) {
         ndcn_csr seg = {};

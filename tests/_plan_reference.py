@@ -292,3 +292,43 @@ class PlanReference:
         self._view = None
         return self
 
+
+
+def sweep_plan_reference(rowptr, colidx, val, shape):
+    """Column-sweep plan (include/ndcn_hip.h, struct ndcn_csr: sweep_*; csrc/csr_plan.hip: build_sweep_plan) restated in numpy:
+    passes of <= 100 352 rows, 8 XCD chunks per pass, 256 slabs of consecutive rows per chunk; per slab the entries merged over
+    its rows, stably sorted by column, packed as {row in slab << 24 | column, value bits} and padded to groups of 8 with
+    {49 << 24, 0}.  Returns dict(passes, rows_per_pass, rpw, slab [n_slabs, 2] int32, ent [n_entries + 32, 2] uint32)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colidx = np.asarray(colidx, dtype=np.int64)
+    bits = np.asarray(val, dtype=np.float32).view(np.uint32)
+    n = int(shape[0])
+    cap = 8 * 256 * 49
+    passes = (n + cap - 1) // cap
+    rpp = (n + passes - 1) // passes
+    slab, ent = [], []
+    pos = 0
+    for p in range(passes):
+        base, end = p * rpp, min(n, (p + 1) * rpp)
+        per_xcd = (end - base + 7) // 8
+        rpw = (per_xcd + 255) // 256
+        for x in range(8):
+            xend = min(end, base + (x + 1) * per_xcd)
+            for sl in range(256):
+                r0 = min(xend, base + x * per_xcd + sl * rpw)
+                r1 = min(xend, r0 + rpw)
+                lo, hi = rowptr[r0], rowptr[r1]
+                rows = np.repeat(np.arange(r0, r1), np.diff(rowptr[r0:r1 + 1])) - r0
+                order = np.argsort(colidx[lo:hi], kind='stable')
+                key = (rows[order].astype(np.uint32) << np.uint32(24)) | colidx[lo:hi][order].astype(np.uint32)
+                cnt = int(hi - lo)
+                pad = (-cnt) % 8
+                ent.append(np.stack([key, bits[lo:hi][order]], 1))
+                if pad:
+                    ent.append(np.tile(np.array([[49 << 24, 0]], dtype=np.uint32), (pad, 1)))
+                slab.append((pos, cnt))
+                pos += cnt + pad
+    ent.append(np.tile(np.array([[49 << 24, 0]], dtype=np.uint32), (32, 1)))
+    per_xcd0 = (rpp + 7) // 8
+    return {'passes': passes, 'rows_per_pass': rpp, 'rpw': (per_xcd0 + 255) // 256, 'entries': pos,
+            'slab': np.asarray(slab, dtype=np.int32).reshape(-1, 2), 'ent': np.concatenate(ent).astype(np.uint32)}
