@@ -306,6 +306,121 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm_kernel(const float *__re
           V10(22), V10(23), "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "s16", "s17", "s18", "s19", S10(2), S10(3), S10(4), S10(5), S10(6), S10(7));
 }
 
+
+// ---- second generation: 16 fetches in flight per wave through an LDS ring (global_load_lds_dwordx4: no register data path),
+// entries read 64 at a time by ONE vector load (lane i = entry i) and handed to the scalar unit by v_readlane with immediate
+// lane numbers - the chunk loop is generated (tools/gen_sweep_asm.py -> tools/micro/sweep_v2_body.inc)
+#undef PUBLISH
+#undef BEHIND
+#define PUBLISH                                              \
+    "v_mov_b32 v217, s67\n"                                  \
+    "s_mov_b64 s[74:75], exec\n"                             \
+    "s_mov_b64 exec, 1\n"                                    \
+    "global_store_dword v216, v217, %[prog]\n"               \
+    "s_mov_b64 exec, s[74:75]\n"
+#define BEHIND                                               \
+    "v_min_u32 v220, v220, v221\n"                           \
+    "v_min_u32 v222, v222, v223\n"                           \
+    "v_min_u32 v220, v220, v222\n"                           \
+    "v_cmp_gt_u32 vcc, s70, v220\n"                          \
+    "s_cmp_eq_u64 vcc, 0\n"
+#include "sweep_v2_body.inc"
+
+template <int LOGB, int S>
+__global__ __launch_bounds__(WAVES * 64) void sweep_asm2_kernel(const float *__restrict__ X, const unsigned *__restrict__ ent,
+                                                                const int *__restrict__ slab_ptr, float *__restrict__ Y, int n_rows,
+                                                                int rows_per_xcd, unsigned *prog_all, unsigned etag, int nblk) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * WAVES + wv;
+    const int slab = xcd * SLOTS + slot;
+    const int e0 = __builtin_amdgcn_readfirstlane(slab_ptr[2 * slab]), cnt = __builtin_amdgcn_readfirstlane(slab_ptr[2 * slab + 1]);
+    const int nchunk = (cnt + 63) >> 6;
+    const unsigned *p = ent + (size_t)e0 * 2;                 // e0 is a multiple of 64
+    unsigned *prog = prog_all + xcd * SLOTS;
+    const int row0 = xcd * rows_per_xcd + slot * RW;
+    const int row_end = min(n_rows, (xcd + 1) * rows_per_xcd);
+    const int nvalid = __builtin_amdgcn_readfirstlane(max(0, min(RW, row_end - row0)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const unsigned long long xb_ = (unsigned long long)X, yb_ = (unsigned long long)(Y + (size_t)(nvalid > 0 ? row0 : 0) * 256);
+    const u4 rsy = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)yb_), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(yb_ >> 32) & 0xffffu)),
+                    (unsigned)nvalid * 1024u, 0x00020000u};
+    const int voff = lane * 16, v8 = lane * 8;
+    const int wm1 = S - 1, window = S, logb = LOGB;
+    asm volatile(
+        "s_mov_b64 s[24:25], %[ent]\n"
+        "s_mov_b32 s64, %[nchunk]\n"
+        "s_mov_b32 s65, 0\n"
+        "s_mov_b32 s76, 0\n"
+        "s_mov_b32 s77, 0\n"
+        "s_mov_b32 s22, %[ldsbase]\n"
+        "v_add_u32 v214, s22, %[voff]\n"
+        "v_mov_b32 v215, %[v8]\n"
+        "v_mov_b32 v216, %[slot4]\n"
+        "s_mov_b32 s67, %[etag]\n"
+        PUBLISH
+        "s_mov_b32 s68, 0\n"
+        "L_zero_%=:\n"
+        "s_set_gpr_idx_on s68, gpr_idx(DST)\n"
+        "v_mov_b32 v0, 0\n"
+        "s_set_gpr_idx_off\n"
+        "s_add_u32 s68, s68, 1\n"
+        "s_cmp_lt_u32 s68, 200\n"
+        "s_cbranch_scc1 L_zero_%=\n"
+        "s_cmp_eq_u32 s64, 0\n"
+        "s_cbranch_scc1 L_tail_%=\n"
+        "global_load_dwordx2 v[208:209], v215, s[24:25]\n"
+        "global_load_dwordx2 v[210:211], v215, s[24:25] offset:512\n"
+        "global_load_dwordx2 v[212:213], v215, s[24:25] offset:1024\n"
+        "s_waitcnt vmcnt(0)\n"
+        SWEEP_PROLOGUE
+        "s_waitcnt vmcnt(15)\n"
+        "ds_read_b128 v[200:203], v214\n"
+        "L_loop_%=:\n"
+        SWEEP_CHUNK
+        "v_mov_b32 v208, v210\n"
+        "v_mov_b32 v209, v211\n"
+        "v_mov_b32 v210, v212\n"
+        "v_mov_b32 v211, v213\n"
+        "s_add_u32 s24, s24, 512\n"
+        "s_addc_u32 s25, s25, 0\n"
+        "global_load_dwordx2 v[212:213], v215, s[24:25] offset:1024\n"
+        "s_sub_u32 s64, s64, 1\n"
+        "s_cmp_lg_u32 s64, 0\n"
+        "s_cbranch_scc1 L_loop_%=\n"
+        "L_tail_%=:\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        "s_or_b32 s67, %[nblk], %[etag]\n"
+        PUBLISH
+        "s_mov_b32 s68, 0\n"
+        "s_mov_b32 s69, 0\n"
+        "s_mov_b32 s64, %[nvalid]\n"
+        "s_cmp_eq_u32 s64, 0\n"
+        "s_cbranch_scc1 L_done_%=\n"
+        "L_st_%=:\n"
+        "s_set_gpr_idx_on s68, gpr_idx(SRC0)\n"
+        "v_mov_b32 v200, v0\n"
+        "v_mov_b32 v201, v1\n"
+        "v_mov_b32 v202, v2\n"
+        "v_mov_b32 v203, v3\n"
+        "s_set_gpr_idx_off\n"
+        "buffer_store_dwordx4 v[200:203], %[voff], %[rsy], s69 offen nt\n"
+        "s_add_u32 s68, s68, 4\n"
+        "s_add_u32 s69, s69, 0x400\n"
+        "s_sub_u32 s64, s64, 1\n"
+        "s_cmp_lg_u32 s64, 0\n"
+        "s_cbranch_scc1 L_st_%=\n"
+        "L_done_%=:\n"
+        "s_waitcnt vmcnt(0)\n"
+        :
+        : [voff] "v"(voff), [v8] "v"(v8), [rsy] "s"(rsy), [ent] "s"(p), [nchunk] "s"(nchunk), [prog] "s"(prog), [etag] "s"(etag), [nblk] "s"(nblk),
+          [slot4] "s"(slot * 4), [nvalid] "s"(nvalid), [logb] "s"(logb), [window] "s"(window), [wm1] "s"(wm1), [xlo] "s"((unsigned)xb_),
+          [xhi] "s"((unsigned)(xb_ >> 32)), [ldsbase] "s"(wv * 16384)
+        : "memory", "vcc", "scc", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", V10(1), V10(2), V10(3), V10(4), V10(5), V10(6),
+          V10(7), V10(8), V10(9), V10(10), V10(11), V10(12), V10(13), V10(14), V10(15), V10(16), V10(17), V10(18), V10(19), V10(20), V10(21),
+          "v220", "v221", "v222", "v223", "s16", "s17", "s18", "s19", S10(2), S10(3), S10(4), S10(5), S10(6), S10(7));
+}
+
 struct Dev {
     float *X, *Y, *Yref, *val;
     int *rowptr, *col, *slab_ptr;
@@ -363,6 +478,34 @@ static double run_asm(Dev &d, int reps) {
     CK(hipEventSynchronize(e1));
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+template <int LOGB, int S>
+static double run_asm2(Dev &d, int reps) {
+    const int nblk = (d.n + (1 << LOGB) - 1) >> LOGB;
+    const int rows_per_xcd = (d.n + 7) / 8;
+    CK(hipMemset(d.done, 0, 8 * d.nblk_max * 4));
+    d.epoch = 0;
+    static bool attr = false;
+    CK(hipFuncSetAttribute((const void *)sweep_asm2_kernel<LOGB, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto launch = [&]() {
+        ++d.epoch;
+        hipLaunchKernelGGL((sweep_asm2_kernel<LOGB, S>), dim3(256), dim3(WAVES * 64), 128 * 1024, 0, d.X, (const unsigned *)d.ent, d.slab_ptr, d.Y, d.n,
+                           rows_per_xcd, d.done, d.epoch << 16, nblk);
+    };
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipDeviceSynchronize());
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(e1);
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    (void)attr;
     return ms / reps;
 }
 
@@ -431,9 +574,9 @@ int main(int argc, char **argv) {
             slab_ptr[2 * (x * SLOTS + sl)] = (int)(ent.size() / 2);
             slab_ptr[2 * (x * SLOTS + sl) + 1] = (int)tmp.size();
             for (const E &e : tmp) { ent.push_back(e.r << 24 | e.c); unsigned u; memcpy(&u, &e.v, 4); ent.push_back(u); }
-            while ((ent.size() / 2) % 8) { ent.push_back(49u << 24); ent.push_back(0); }   // padding: 0 * X[0] into the dummy row
+            while ((ent.size() / 2) % 64) { ent.push_back(49u << 24); ent.push_back(0); }   // padding: 0 * X[0] into the dummy row
         }
-    for (int i = 0; i < 64; ++i) ent.push_back(0);             // the prefetch reads two groups past the end
+    for (int i = 0; i < 2 * 256; ++i) ent.push_back(0);             // the prefetch reads two groups past the end
     Dev d;
     d.n = n;
     d.nblk_max = (n >> 8) + 2;
@@ -472,6 +615,21 @@ int main(int argc, char **argv) {
     t = run_asm<LOGB, 8>(d, 10); printf(" %7.3f ms", t);                                                                 \
     t = run_asm<LOGB, 60000>(d, 10); printf(" %7.3f ms\n", t);
     ROW(8) ROW(9) ROW(10) ROW(11)
+    printf("second generation (LDS ring, 16 fetches in flight):\n");
+    printf("  %-26s %10s %10s %10s %10s %10s %10s\n", "columns per block", "S = 2", "S = 3", "S = 4", "S = 6", "S = 8", "no sync");
+#define ROW2(LOGB)                                                                                                       \
+    printf("  %-26d", 1 << LOGB);                                                                                        \
+    t = run_asm2<LOGB, 2>(d, 10); printf(" %7.3f ms", t);                                                                \
+    t = run_asm2<LOGB, 3>(d, 10); printf(" %7.3f ms", t);                                                                \
+    t = run_asm2<LOGB, 4>(d, 10); printf(" %7.3f ms", t);                                                                \
+    t = run_asm2<LOGB, 6>(d, 10); printf(" %7.3f ms", t);                                                                \
+    t = run_asm2<LOGB, 8>(d, 10); printf(" %7.3f ms", t);                                                                \
+    t = run_asm2<LOGB, 60000>(d, 10); printf(" %7.3f ms\n", t);
+    ROW2(9) ROW2(10) ROW2(11)
+    run_asm2<10, 3>(d, 1);
+    check(d, "asm2 sweep<1024, 3>");
+    run_asm2<11, 2>(d, 1);
+    check(d, "asm2 sweep<2048, 2>");
     printf("memory side only, compiler-generated, no sync (every entry folded into ONE accumulator; results meaningless):");
     t = run_sweep<11, 1000, true>(d, 10); printf(" %7.3f ms\n", t);
     run_asm<10, 2>(d, 1);
