@@ -128,8 +128,9 @@ typedef struct ndcn_csr {
      *              keep within sweep_window blocks of 2^sweep_logb columns of each other (a locality hint with a bounded wait,
      *              never needed for correctness)
      *   sweep_S    [n_rows][256] scratch for S = A X in front of the Linear (ndcn_rhs_f32 / ndcn_rhs_rk_f32: the fused kernel
-     *              then runs on the identity operator sweep_eye_* over S) - owned by the operator, like hub_S: one launch
-     *              stream at a time.  Used when no halo panel is passed.                                                   */
+     *              then runs on the identity operator sweep_eye_* over S, whose 16-row group records stage S by LDS-DMA:
+     *              rhs_fused3) - owned by the operator, like hub_S: one launch stream at a time.  Used when no halo panel is
+     *              passed.                                                                                                 */
     int32_t         sweep_passes, sweep_rpw, sweep_logb, sweep_window;
     int64_t         sweep_rows_per_pass;
     const uint32_t *sweep_ent;
@@ -139,6 +140,8 @@ typedef struct ndcn_csr {
     const int32_t  *sweep_eye_rowptr;  /* [n_rows + 1] = 0 .. n_rows */
     const int32_t  *sweep_eye_colidx;  /* [n_rows] = 0 .. n_rows - 1 */
     const float    *sweep_eye_val;     /* [n_rows] ones */
+    const int32_t  *sweep_eye_rec;     /* the identity operator's group-record plan {16, 40, 2}: the dense stage runs rhs_fused3 */
+    int32_t         sweep_eye_groups;
 } ndcn_csr;
 
 /* ------------------------------------------------------------------------------------------------

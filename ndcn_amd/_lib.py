@@ -49,7 +49,7 @@ class CsrView(ctypes.Structure):
                 ('sweep_window', ctypes.c_int32), ('sweep_rows_per_pass', ctypes.c_int64),
                 ('sweep_ent', ctypes.c_void_p), ('sweep_slab', ctypes.c_void_p), ('sweep_prog', ctypes.c_void_p),
                 ('sweep_S', ctypes.c_void_p), ('sweep_eye_rowptr', ctypes.c_void_p), ('sweep_eye_colidx', ctypes.c_void_p),
-                ('sweep_eye_val', ctypes.c_void_p)]
+                ('sweep_eye_val', ctypes.c_void_p), ('sweep_eye_rec', ctypes.c_void_p), ('sweep_eye_groups', ctypes.c_int32)]
 
 
 class CsrHints(ctypes.Structure):

@@ -653,6 +653,20 @@ int build_sweep_plan(ndcn_csr_handle *h, bool external_scratch, hipStream_t st) 
     hipLaunchKernelGGL(sweep_eye_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, n, eye_rowptr, eye_colidx, eye_val);
     NDCN_LAUNCH_CHECK();
     NDCN_HIP(hipStreamSynchronize(st));
+    // the identity operator's 16-row group records: the dense stage of the right-hand side runs rhs_fused3 over S
+    {
+        ndcn_csr_handle eye;
+        memset(&eye.v, 0, sizeof(eye.v));
+        eye.v.n_rows = eye.v.n_cols = eye.v.nnz = n;
+        eye.v.rowptr = eye_rowptr, eye.v.colidx = eye_colidx, eye.v.val = eye_val;
+        RecPlan rp;
+        rc = build_rec(&eye, nullptr, n, kShapes[1], &rp, st);
+        for (void *q : eye.owned) h->owned.push_back(q);
+        eye.owned.clear();
+        if (rc) return rc;
+        A.sweep_eye_rec = rp.rec;
+        A.sweep_eye_groups = (int32_t)rp.groups;
+    }
     dev_release(h, seg_off);
     dev_release(h, cnt_pad);
     dev_release(h, pad_start);

@@ -628,6 +628,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
             ndcn_csr eye = {};
             eye.n_rows = eye.n_cols = eye.nnz = A->n_rows;
             eye.rowptr = A->sweep_eye_rowptr; eye.colidx = A->sweep_eye_colidx; eye.val = A->sweep_eye_val;
+            if (A->sweep_eye_rec) { eye.rec = A->sweep_eye_rec; eye.rec_groups = A->sweep_eye_groups; eye.rec_rows = 16; eye.rec_cap = 40; eye.rec_kib = 2; }
             RkOpt o = opt ? *opt : RkOpt{};
             if (!o.y1) o.y1 = X;                          // ERROR mode: the state whose record is formed is the evaluation's input
             rc = rhs_fused2_f32(&eye, A->sweep_S, nullptr, A->n_rows, Wp, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,

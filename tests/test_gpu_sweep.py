@@ -155,7 +155,7 @@ def test_sweep_rhs_equals_the_one_launch_fused_kernel(dev, name):
     cs = [np.float32(c) for c in (0.11, -0.07, 0.23, 0.05, -0.31, 0.19)]
     lib = _lib.load()
     K = hip.rhs(A, X, W, b)
-    assert lib.ndcn_debug_last_rhs_path() == _lib.PATH_FUSED2 | _lib.PATH_SWEEP
+    assert lib.ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3 | _lib.PATH_SWEEP
     Kr = hip.rhs(R, X, W, b)
     assert lib.ndcn_debug_last_rhs_path() == _lib.PATH_FUSED2
     assert torch.equal(K, Kr)
@@ -238,7 +238,7 @@ def test_sweep_at_the_size_of_config_2(dev):
     assert torch.equal(_bits(S), _bits(hip.spmm(R, X)))
     W, b = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev), ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
     K = hip.rhs(A, X, W, b)
-    assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED2 | _lib.PATH_SWEEP
+    assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3 | _lib.PATH_SWEEP
     rows = np.random.RandomState(0).choice(n, 64, replace=False)
     Xd = X.cpu().double().numpy()
     Sd = m[rows].astype(np.float64) @ Xd
