@@ -34,8 +34,7 @@
 
 namespace ndcn {
 
-namespace {
-
+// (not in an anonymous namespace: rocprofv3 summaries key on the kernel name up to its first parenthesis)
 constexpr int kSweepRows = 49;       // rows per wave (196 accumulator registers); row 49 = the dummy the padding entries add to
 constexpr int kSweepWaves = 8;       // waves per workgroup = per CU (256 VGPRs each)
 constexpr int kSweepSlots = 256;     // waves per XCD
@@ -221,9 +220,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void spmm_sweep_kernel(SweepArgs 
           S10(4), S10(5), S10(6), S10(7));
 }
 
-std::atomic<uint32_t> g_sweep_launches{0};
-
-}  // namespace
+static std::atomic<uint32_t> g_sweep_launches{0};
 
 int spmm_sweep_supported(const ndcn_csr *A, int H) {
     static const int enabled = [] { const char *e = getenv("NDCN_SWEEP"); return e ? atoi(e) : 1; }();
