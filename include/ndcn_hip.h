@@ -249,7 +249,10 @@ NDCN_API int64_t ndcn_gcn_work_bytes(int64_t n_cols, int H_out);
  * H_in = H_out = 256 also gS: given scratch, the product runs on the fp16 matrix cores from two-piece splits of both
  * operands - fp32-grade, as the forward kernels - and the planes of W^T are packed there; without it, the fp32 MFMA).   */
 NDCN_API int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW,
-                                 float *gb, void *work, int64_t n, int H_in, int H_out, void *stream);
+                                 float *gb, void *work, int64_t n, int H_in, int H_out, uint32_t flags, void *stream);
+/* flags: NDCN_F_PACKED (H_in = H_out = 256, gS) - `work` still holds the planes of W^T that an earlier call with the same W and
+ * the same n packed there (its tail; the head is this call's scratch): the backward of a solve evaluates the right-hand side's
+ * VJP dozens of times between two weight updates.                                                                          */
 NDCN_API int64_t ndcn_linear_bwd_work_bytes(int64_t n, int H_in, int H_out);
 /* out = w * x: the VJP of one term of the Runge-Kutta linear combinations (rk_common.py:51,75-78; interp.py:21-35). */
 NDCN_API int ndcn_scale_f32(float *out, const float *x, float w, int64_t n_elem, void *stream);

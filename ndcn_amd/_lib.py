@@ -111,7 +111,7 @@ SIGNATURES = {
     'ndcn_linear_f32': (_I, [_P, _P, _P, _P, _L, _I, _I, _U, _P]),
     'ndcn_gcn_f32': (_I, [_CSR, _P, _P, _P, _P, _P, _I, _I, _U, _P]),
     'ndcn_gcn_work_bytes': (_L, [_L, _I]),
-    'ndcn_linear_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'ndcn_linear_bwd_f32': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _U, _P]),
     'ndcn_linear_bwd_work_bytes': (_L, [_L, _I, _I]),
     'ndcn_scale_f32': (_I, [_P, _P, _F, _L, _P]),
     'ndcn_relu_bwd_f32': (_I, [_P, _P, _P, _L, _P]),

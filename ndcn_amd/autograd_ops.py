@@ -66,7 +66,8 @@ class _Rhs(torch.autograd.Function):
             S = None
             if need_w:
                 S = X.detach() if ctx.no_graph else hip.spmm(ctx.A, X.detach())
-            gS, gW, gb = hip.linear_bwd(g, W.detach(), S=S, Y=Y, need_gS=ctx.needs_input_grad[0], need_gW=need_w, need_gb=need_b)
+            # (W itself, not a detached alias: linear_bwd keeps the packed planes of W^T per weight tensor object and version)
+            gS, gW, gb = hip.linear_bwd(g, W, S=S, Y=Y, need_gS=ctx.needs_input_grad[0], need_gW=need_w, need_gb=need_b)
         else:
             gS = hip.relu_bwd(g, Y) if ctx.needs_input_grad[0] else None
         gX = None

@@ -142,12 +142,12 @@ int64_t ndcn_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) { return rhs_
 int64_t ndcn_linear_bwd_work_bytes(int64_t n, int H_in, int H_out) { return linear_bwd_work_bytes(n, H_in, H_out); }
 
 int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb,
-                        void *work, int64_t n, int H_in, int H_out, void *stream) {
+                        void *work, int64_t n, int H_in, int H_out, uint32_t flags, void *stream) {
     NDCN_CHECK_ARG(n >= 0 && H_in > 0 && H_out > 0, "bad shape");
     NDCN_CHECK_ARG(n == 0 || g, "null gradient");
     NDCN_CHECK_ARG(!gS || W, "gS needs the weight");
     NDCN_CHECK_ARG(gS != g, "gS must not alias g");
-    return linear_bwd_f32(g, Y, S, W, gS, gW, gb, work, n, H_in, H_out, ST(stream));
+    return linear_bwd_f32(g, Y, S, W, gS, gW, gb, work, n, H_in, H_out, ST(stream), flags);
 }
 
 int64_t ndcn_rk_bwd_ws_bytes(void) { return rk_bwd_ws_bytes(); }

@@ -493,7 +493,7 @@ int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho) {
 }
 
 int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb, void *work,
-                   int64_t n, int Hi, int Ho, hipStream_t st) {
+                   int64_t n, int Hi, int Ho, hipStream_t st, uint32_t flags) {
     if (n == 0) {
         if (gW) NDCN_HIP(hipMemsetAsync(gW, 0, (size_t)Ho * Hi * sizeof(float), st));
         if (gb) NDCN_HIP(hipMemsetAsync(gb, 0, (size_t)Ho * sizeof(float), st));
@@ -509,7 +509,7 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
         } else if (split_on && Hi == 256 && Ho == 256 && work && a16) {
             // (a caller without scratch - gS only, older bindings - keeps the fp32 MFMA kernel below)
             void *Wq = static_cast<char *>(work) + wgrad_work_bytes(n, Hi, Ho);
-            int rcp = pack_weight_256_t16(W, Wq, st);
+            int rcp = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256_t16(W, Wq, st);
             if (rcp) return rcp;
             hipLaunchKernelGGL(linear_gs_256_split_kernel, dim3((unsigned)((n + kGsRows - 1) / kGsRows)), dim3(256), 0, st, g, Y, Wq, gS, n);
         } else {

@@ -120,9 +120,11 @@ struct ErrBwdArgs {
     float rtol, atol, g_r, inv_n;  // inv_n = 1 / numel (global count when the mean spans ranks)
 };
 
-// one element of the error-ratio VJP; outputs through references (accumulators applied by the caller)
-__device__ __forceinline__ void error_bwd_elem(const ErrBwdArgs &p, const float (&kv)[kBwdMaxK], float a0, float a1, double (&d)[kBwdDots],
-                                               float (&gk)[kBwdMaxK], float &o0, float &o1) {
+// one element of the error-ratio VJP: s = d r / d e (the stage gradients are g_r c_j s, formed where they are stored: keeping
+// them per component cost 32 registers of a 250-register kernel that ran at ONE wave per SIMD, 1.65 TB/s), the two state
+// gradients through references (accumulators applied by the caller)
+__device__ __forceinline__ float error_bwd_elem(const ErrBwdArgs &p, const float (&kv)[kBwdMaxK], float a0, float a1, double (&d)[kBwdDots],
+                                                float &o0, float &o1) {
     float e = p.t.c[0] * kv[0];
 #pragma unroll
     for (int j = 1; j < kBwdMaxK; ++j)
@@ -133,23 +135,22 @@ __device__ __forceinline__ void error_bwd_elem(const ErrBwdArgs &p, const float 
     const float s = 2.f * q * p.inv_n / tol;             // d r / d e
 #pragma unroll
     for (int j = 0; j < kBwdMaxK; ++j)
-        if (j < p.t.n) {
-            d[j] += (double)(s * kv[j]);                  // d r / d c_j (times g_r on the host)
-            gk[j] = p.g_r * (p.t.c[j] * s);
-        }
+        if (j < p.t.n) d[j] += (double)(s * kv[j]);       // d r / d c_j (times g_r on the host)
     // d r / d tol = -q s ; tol = atol + rtol max(|y0|, |y1|) ; torch.max splits the gradient evenly on ties
     const float gm = p.g_r * (-q * s) * p.rtol;
     const float w0 = m0 > m1 ? 1.f : (m0 == m1 ? 0.5f : 0.f);
     o0 = gm * w0 * (a0 > 0.f ? 1.f : (a0 < 0.f ? -1.f : 0.f));
     o1 = gm * (1.f - w0) * (a1 > 0.f ? 1.f : (a1 < 0.f ? -1.f : 0.f));
+    return s;
 }
 
+// (waves_per_eu: with launch_bounds alone the scheduler hoists every load and takes 250 + 98 registers - one wave per SIMD)
 template <bool VEC>
-__global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n, double *__restrict__ partial) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void error_bwd_kernel(ErrBwdArgs p, int64_t n, double *__restrict__ partial) {
     double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int W = VEC ? 4 : 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float kv[W][kBwdMaxK], a0[W], a1[W], gk[W][kBwdMaxK], o0[W], o1[W];
+        float kv[W][kBwdMaxK], a0[W], a1[W], sv[W], o0[W], o1[W];
         if (VEC) {
             const bw_f4 v0 = ld4(p.y0, i), v1 = ld4(p.y1, i);
             a0[0] = v0.x; a0[W > 1 ? 1 : 0] = v0.y; a0[W > 1 ? 2 : 0] = v0.z; a0[W > 1 ? 3 : 0] = v0.w;
@@ -167,12 +168,13 @@ __global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n,
                 if (j < p.t.n) kv[0][j] = p.t.k[j][i];
         }
 #pragma unroll
-        for (int u = 0; u < W; ++u) error_bwd_elem(p, kv[u], a0[u], a1[u], d, gk[u], o0[u], o1[u]);
+        for (int u = 0; u < W; ++u) sv[u] = error_bwd_elem(p, kv[u], a0[u], a1[u], d, o0[u], o1[u]);
         if (VEC) {
 #pragma unroll
             for (int j = 0; j < kBwdMaxK; ++j)
                 if (j < p.t.n && p.t.gk[j]) {
-                    bw_f4 o = {gk[0][j], gk[W > 1 ? 1 : 0][j], gk[W > 1 ? 2 : 0][j], gk[W > 1 ? 3 : 0][j]};
+                    const float cj = p.t.c[j];
+                    bw_f4 o = {p.g_r * (cj * sv[0]), p.g_r * (cj * sv[W > 1 ? 1 : 0]), p.g_r * (cj * sv[W > 1 ? 2 : 0]), p.g_r * (cj * sv[W > 1 ? 3 : 0])};
                     if (p.t.acc[j]) o = ld4(p.t.acc[j], i) + o;
                     st4(p.t.gk[j], i, o);
                 }
@@ -189,7 +191,10 @@ __global__ __launch_bounds__(256) void error_bwd_kernel(ErrBwdArgs p, int64_t n,
         } else {
 #pragma unroll
             for (int j = 0; j < kBwdMaxK; ++j)
-                if (j < p.t.n && p.t.gk[j]) p.t.gk[j][i] = p.t.acc[j] ? p.t.acc[j][i] + gk[0][j] : gk[0][j];
+                if (j < p.t.n && p.t.gk[j]) {
+                    const float o = p.g_r * (p.t.c[j] * sv[0]);
+                    p.t.gk[j][i] = p.t.acc[j] ? p.t.acc[j][i] + o : o;
+                }
             if (p.gy0) p.gy0[i] = p.acc_y0 ? p.acc_y0[i] + o0[0] : o0[0];
             if (p.gy1) p.gy1[i] = p.acc_y1 ? p.acc_y1[i] + o1[0] : o1[0];
         }

@@ -314,6 +314,35 @@ def _carry():
     return _analytic() and os.environ.get('NDCN_GRAD_CARRY', '1') != '0'
 
 
+# ---- deferred scalar gradients -----------------------------------------------------------------------------------------
+# The VJP kernels reduce the gradients of their SCALAR inputs (dt * beta, the error coefficients, the interpolation abscissa) on
+# the device; reading each of them back where it is produced stops the host ~35 times per training step with nothing queued
+# behind (17 % idle GPU on the 100k-node case).  In carry mode the kernels' sums come back as DEFERRED host tensors (ops.
+# _BwdDots.lazy: a pinned slot an asynchronous copy fills, plus an event) and every scalar input of a carry op passes through
+# `_Await` - an identity whose backward waits for that event before anything reads the value.  The `_Await` nodes take host
+# tensors, so autograd runs them on the thread that called backward(), while the panel nodes run on the device's worker thread:
+# the wait blocks the scalar chain only, the worker keeps queueing panel launches.  NDCN_GRAD_LAZY=0: eager reads.
+
+def _lazy():
+    return os.environ.get('NDCN_GRAD_LAZY', '1') != '0'
+
+
+class _Await(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from ...ops import _BwdDots
+        return _BwdDots.await_lazy(g)
+
+
+def _grad_scalar(ref, v):
+    """gradient of a scalar input: a deferred 0-d tensor as it is (float32, like every coefficient), a float through torch.tensor"""
+    return v if torch.is_tensor(v) else torch.tensor(v, dtype=ref.dtype, device=ref.device)
+
+
 class _StageCarryFn(torch.autograd.Function):
     """(u, y0', k_1', ..) = (y0 + sum_j c_j k_j, y0, k_1, ..)"""
 
@@ -322,6 +351,7 @@ class _StageCarryFn(torch.autograd.Function):
         ks, cs = rest[:n], rest[n:]
         idx, kk, cc = _active(ks, cs)
         ctx.n, ctx.idx, ctx.cc = n, idx, cc
+        ctx.lazy = _lazy()                       # (the solver below routes every coefficient of a carry op through _Await)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*kk, *cs)
         u = hip.combine(y0, kk, cc) if kk else y0.clone()
@@ -343,13 +373,13 @@ class _StageCarryFn(torch.autograd.Function):
             acc_y0 = g_y0c if (need_y0 and g_y0c is not None) else None
             if idx and (any(need_k[j] for j in idx) or want_dots or acc_y0 is not None):
                 res = hip.combine_bwd(g, kk, cc, [need_k[j] for j in idx], need_dots=want_dots,
-                                      accs=[g_kc[j] if need_k[j] else None for j in idx], acc_y0=acc_y0)
+                                      accs=[g_kc[j] if need_k[j] else None for j in idx], acc_y0=acc_y0, lazy=ctx.lazy)
                 gk, dots = res[0], res[1]
                 for q, j in enumerate(idx):
                     if need_k[j]:
                         gk_all[j] = gk[q]
                     if need_c[j]:
-                        gc_all[j] = _scalar_like(cs[j], dots[q])
+                        gc_all[j] = _grad_scalar(cs[j], dots[q])
                 if need_y0:
                     g_y0 = res[2] if acc_y0 is not None else g
             elif need_y0:
@@ -367,6 +397,7 @@ class _ErrorCarryFn(torch.autograd.Function):
         s, bad = hip.error(y0, y1, kk, cc, rtol, atol)
         bad_out.append(bad)
         ctx.n, ctx.idx, ctx.cc, ctx.tol = n, idx, cc, (rtol, atol)
+        ctx.lazy = _lazy()
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(y0, y1, *kk, *cs)
         return (torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1) + tuple(ks)
@@ -387,12 +418,12 @@ class _ErrorCarryFn(torch.autograd.Function):
             gy0, gy1, gk, dots = hip.error_bwd(y0, y1, kk, cc, ctx.tol[0], ctx.tol[1], g_r, needs[4], needs[5],
                                                [need_k[j] for j in idx], need_dots=any(need_c[j] for j in idx),
                                                accs=[g_kc[j] if need_k[j] else None for j in idx],
-                                               acc_y0=g_y0c if needs[4] else None, acc_y1=g_y1c if needs[5] else None)
+                                               acc_y0=g_y0c if needs[4] else None, acc_y1=g_y1c if needs[5] else None, lazy=ctx.lazy)
             for q, j in enumerate(idx):
                 if need_k[j]:
                     gk_all[j] = gk[q]
                 if need_c[j]:
-                    gc_all[j] = _scalar_like(cs[j], g_r * dots[q])
+                    gc_all[j] = dots[q] if ctx.lazy else _scalar_like(cs[j], g_r * dots[q])      # (lazy: g_r is folded in on the device)
         return (None, None, None, None, gy0, gy1) + tuple(gk_all) + tuple(gc_all)
 
 
@@ -433,6 +464,7 @@ class _DenseMultiCarryFn(torch.autograd.Function):
     def forward(ctx, nt, a0, a1, *rest):
         kk, dt_, xs = rest[:7], rest[7], rest[8:8 + nt]
         ctx.nt = nt
+        ctx.lazy = _lazy()
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(a0, a1, *rest)
         dt32 = f32(float(dt_))
@@ -462,11 +494,11 @@ class _DenseMultiCarryFn(torch.autograd.Function):
             gy0, gy1, gk, dxs, d_dt = hip.interp_bwd_multi([g_out[t].contiguous() for t in live], a0, a1, list(kk), f32(float(dt_)),
                                                            [f32(float(xs[t])) for t in live], needs[1], needs[2], need_k,
                                                            accs=[g_kc[j] if need_k[j] else None for j in range(7)],
-                                                           acc_y0=g_a0c if needs[1] else None, acc_y1=g_a1c if needs[2] else None)
-            g_dt = _scalar_like(dt_, d_dt) if needs[10] else None
+                                                           acc_y0=g_a0c if needs[1] else None, acc_y1=g_a1c if needs[2] else None, lazy=ctx.lazy)
+            g_dt = _grad_scalar(dt_, d_dt) if needs[10] else None
             for q, t in enumerate(live):
                 if needs[11 + t]:
-                    g_x[t] = _scalar_like(xs[t], dxs[q])
+                    g_x[t] = _grad_scalar(xs[t], dxs[q])
         return (None, gy0, gy1) + tuple(gk) + (g_dt,) + tuple(g_x)
 
 
@@ -511,6 +543,7 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         bad.append(0)
     pending_bad = bad[0] if bad else 0
     carry = _carry()
+    lazy = carry and _lazy()
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     y_cur = y0
     t_lo = t_hi = tt[0]
@@ -530,12 +563,16 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             k = [[f] for f in f_cur]
             yi = y_cur
             yc = list(y_cur)                                           # carry mode: the step's y0 as handed on from op to op
+            # (one coefficient tensor per consuming operation; created where they are used, i.e. behind queued GPU work - not
+            # in front of the step's first launch, where 50 tiny host operations would sit between the accept decision's
+            # read-back and the next kernel)
+            coef = (lambda v: _Await.apply(v)) if lazy else (lambda v: v)
             for a_i, b_i in zip(core.DP_ALPHA, core.DP_BETA):
                 ti = t0s + a_i * dts
                 if carry:
                     us = []
                     for s_, (y_, k_) in enumerate(zip(yc, k)):
-                        outs_ = _StageCarryFn.apply(len(k_), y_, *k_, *[dts * b for b in b_i])
+                        outs_ = _StageCarryFn.apply(len(k_), y_, *k_, *[coef(dts * b) for b in b_i])
                         us.append(outs_[0])
                         yc[s_], k[s_] = outs_[1], list(outs_[2:])
                     yi = tuple(us)
@@ -549,7 +586,7 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             if carry:
                 ratios, y1c = [], []
                 for s_, (a_, b_, k_, rt_, at_) in enumerate(zip(yc, y1, k, rtols, atols)):
-                    outs_ = _ErrorCarryFn.apply(len(k_), rt_, at_, bads, a_, b_, *k_, *[dts * c for c in core.DP_C_ERR])
+                    outs_ = _ErrorCarryFn.apply(len(k_), rt_, at_, bads, a_, b_, *k_, *[coef(dts * c) for c in core.DP_C_ERR])
                     ratios.append(outs_[0])
                     yc[s_], k[s_] = outs_[1], list(outs_[3:])
                     y1c.append(outs_[2])
@@ -603,7 +640,7 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             per_tick = [[] for _ in range(nt_)]
             n_y0, n_y1, n_k = [], [], []
             for j, (p0, p1, kk) in enumerate(zip(s_y0, s_y1, s_k)):
-                o_ = _DenseMultiCarryFn.apply(nt_, p0, p1, *kk, s_dts, *xs)
+                o_ = _DenseMultiCarryFn.apply(nt_, p0, p1, *kk, *([_Await.apply(s_dts)] + [_Await.apply(x_) for x_ in xs] if lazy else [s_dts] + xs))
                 for q in range(nt_):
                     per_tick[q].append(o_[q])
                 n_y0.append(o_[nt_]); n_y1.append(o_[nt_ + 1]); n_k.append(list(o_[nt_ + 2:]))

@@ -289,6 +289,16 @@ def test_linear_backward_kernels(dev, n, Hi, Ho, masked):
     if masked:
         assert torch.equal(hip.relu_bwd(g, Y), g * (Y > 0))
     assert torch.equal(hip.scale(g, -0.37), g * np.float32(-0.37))
+    if Hi == 256 and Ho == 256:
+        # the planes of W^T are packed once per weight tensor version (ops._PackedWeights, NDCN_F_PACKED): an in-place update
+        # of W must be seen, and a different weight at the same shape must not hit
+        with torch.no_grad():
+            W.mul_(-0.5)
+        gS3 = hip.linear_bwd(g, W, S=S, Y=Y)[0]
+        assert float((gS3.double() - gZ @ W.double()).abs().max()) < 2e-5 * Ho ** 0.5
+        assert torch.equal(gS3, hip.linear_bwd(g, W, S=S, Y=Y)[0])
+        W2 = (W * 3).contiguous()
+        assert float((hip.linear_bwd(g, W2, S=S, Y=Y)[0].double() - gZ @ W2.double()).abs().max()) < 2e-5 * Ho ** 0.5 * 3
 
 
 @pytest.mark.parametrize('n,H', [(400, 20), (100003, 7)])
