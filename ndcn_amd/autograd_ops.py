@@ -57,23 +57,28 @@ class _Rhs(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, W, Y = ctx.saved_tensors
-        g = g.contiguous()
-        gW = gb = None
-        if not ctx.no_control:
-            # ReLU mask fused into the operand loads of the two GEMMs; g_W = gZ^T S split over row chunks, g_b with it
-            need_w = ctx.needs_input_grad[1]
-            need_b = ctx.has_b and ctx.needs_input_grad[2]
-            S = None
-            if need_w:
-                S = X.detach() if ctx.no_graph else hip.spmm(ctx.A, X.detach())
-            # (W itself, not a detached alias: linear_bwd keeps the packed planes of W^T per weight tensor object and version)
-            gS, gW, gb = hip.linear_bwd(g, W, S=S, Y=Y, need_gS=ctx.needs_input_grad[0], need_gW=need_w, need_gb=need_b)
-        else:
-            gS = hip.relu_bwd(g, Y) if ctx.needs_input_grad[0] else None
-        gX = None
-        if ctx.needs_input_grad[0]:
-            gX = gS if ctx.no_graph else hip.spmm(ctx.A.transpose(), gS.contiguous())
+        gX, gW, gb = rhs_vjp(ctx.A, ctx.no_graph, ctx.no_control, X, W, Y, g.contiguous(), ctx.needs_input_grad[0],
+                             ctx.needs_input_grad[1], ctx.has_b and ctx.needs_input_grad[2])
         return gX, gW, gb, None, None, None
+
+
+def rhs_vjp(A, no_graph, no_control, X, W, Y, g, need_x, need_w, need_b):
+    """(g_X, g_W, g_b) of Y = relu(W (A X) + b) for the upstream gradient g - the closed form every differentiable wrapper of the
+    right-hand side shares: ReLU mask fused into the operand loads of the two GEMMs, g_W = gZ^T S split over row chunks (S = A X
+    recomputed instead of stored), g_b with it, g_X = A^T g_S through the SpMM on the transposed CSR."""
+    gW = gb = None
+    if not no_control:
+        S = None
+        if need_w:
+            S = X.detach() if no_graph else hip.spmm(A, X.detach())
+        # (W itself, not a detached alias: linear_bwd keeps the packed planes of W^T per weight tensor object and version)
+        gS, gW, gb = hip.linear_bwd(g, W, S=S, Y=Y, need_gS=need_x, need_gW=need_w, need_gb=need_b)
+    else:
+        gS = hip.relu_bwd(g, Y) if need_x else None
+    gX = None
+    if need_x:
+        gX = gS if no_graph else hip.spmm(A.transpose(), gS.contiguous())
+    return gX, gW, gb
 
 
 def spmm(A, x):

@@ -25,9 +25,9 @@ from . import core
 f32 = np.float32
 
 
-def odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=False, step_log=None):
+def odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=False, step_log=None, odefunc=None):
     if method == 'dopri5':
-        return integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=autonomous, step_log=step_log, **options)
+        return integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=autonomous, step_log=step_log, odefunc=odefunc, **options)
     if method == 'adams':
         # gradients flow through every panel operation of the accepted steps; the step sizes and orders the controller
         # chose are constants of the graph (the reference's autograd also follows dt through the error ratios - a
@@ -387,6 +387,62 @@ class _StageCarryFn(torch.autograd.Function):
         return (None, g_y0) + tuple(gk_all) + tuple(gc_all)
 
 
+class _RhsStageCarryFn(torch.autograd.Function):
+    """(K, u', y0', k_1', ..) = (relu(W (A u) + b), y0 + sum_j c_j k_j + c_new K, y0, k_1, ..): one evaluation of ODEFunc and the
+    NEXT stage input in ONE launch (ndcn_rhs_rk_f32, mode combine - the launch of the inference solver), i.e. `_Rhs` followed by
+    `_StageCarryFn` as one node: the forward saves the combine launch (5 of a dopri5 step's 6), the backward runs the same two
+    VJPs - the combine's first (its gradient for K joins what K's later consumers sent), then the right-hand side's."""
+
+    @staticmethod
+    def forward(ctx, n, op, u, W, b, y0, *rest):
+        ks, cs = rest[:n], rest[n:]                                   # n earlier stages, n + 1 coefficients (the new K last)
+        A, no_graph, no_control = op
+        idx, kk, cc = _active(ks, cs[:n])
+        c_new = f32(float(cs[n]))
+        K, u_next = hip.rhs_rk(A, u, W, b, 'combine', y0, kk, cc + [c_new], no_graph=no_graph, no_control=no_control)
+        ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b = n, idx, cc + [c_new], op, b is not None
+        ctx.lazy = _lazy()
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(u, W, K, *kk, *cs)
+        return (K, u_next, y0) + tuple(ks)
+
+    @staticmethod
+    def backward(ctx, g_K, g_u, g_y0c, *g_kc):
+        from ...autograd_ops import rhs_vjp
+        n, idx, cc = ctx.n, ctx.idx, ctx.cc
+        saved = ctx.saved_tensors
+        u, W, K = saved[:3]
+        kk, cs = saved[3:3 + len(idx)], saved[3 + len(idx):]
+        needs = ctx.needs_input_grad                                  # (n, op, u, W, b, y0, k.., c..)
+        need_u, need_w, need_b, need_y0 = needs[2], needs[3], ctx.has_b and needs[4], needs[5]
+        need_k, need_c = needs[6:6 + n], needs[6 + n:]
+        gk_all = [g_kc[j] if need_k[j] else None for j in range(n)]
+        gc_all = [None] * (n + 1)
+        g_y0 = g_y0c if need_y0 else None
+        if g_u is not None:
+            g_u = g_u.contiguous()
+            acc_y0 = g_y0c if (need_y0 and g_y0c is not None) else None
+            want_dots = any(need_c[j] for j in idx) or need_c[n]
+            res = hip.combine_bwd(g_u, list(kk) + [K], cc, [need_k[j] for j in idx] + [True], need_dots=want_dots,
+                                  accs=[g_kc[j] if need_k[j] else None for j in idx] + [g_K], acc_y0=acc_y0, lazy=ctx.lazy)
+            gk, dots = res[0], res[1]
+            for q, j in enumerate(idx):
+                if need_k[j]:
+                    gk_all[j] = gk[q]
+                if need_c[j]:
+                    gc_all[j] = _grad_scalar(cs[j], dots[q])
+            if need_c[n]:
+                gc_all[n] = _grad_scalar(cs[n], dots[len(idx)])
+            g_K = gk[len(idx)]
+            if need_y0:
+                g_y0 = res[2] if acc_y0 is not None else g_u
+        gu_in = gW = gb = None
+        if g_K is not None:
+            A, no_graph, no_control = ctx.op
+            gu_in, gW, gb = rhs_vjp(A, no_graph, no_control, u, W, K, g_K.contiguous(), need_u, need_w, need_b)
+        return (None, None, gu_in, gW, gb, g_y0) + tuple(gk_all) + tuple(gc_all)
+
+
 class _ErrorCarryFn(torch.autograd.Function):
     """(ratio, y0', y1', k_1', ..)"""
 
@@ -522,7 +578,7 @@ def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
     return torch.min(100 * h0, h1)
 
 
-def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=None, **options):
+def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=None, odefunc=None, **options):
     core.assert_increasing(t)
     dtype = y0[0].dtype
     targ = core.TimeArg(y0[0], autonomous)
@@ -544,6 +600,12 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
     pending_bad = bad[0] if bad else 0
     carry = _carry()
     lazy = carry and _lazy()
+    # a plain ODEFunc on one state tensor (odeint checked): its evaluations carry the next stage input in their epilogue
+    fused = None
+    if carry and odefunc is not None and len(y0) == 1 and os.environ.get('NDCN_GRAD_FUSED_STAGE', '1') != '0':
+        from ...csr import as_csr
+        fused = ((None if odefunc.no_graph else as_csr(odefunc.A), bool(odefunc.no_graph), bool(odefunc.no_control)),
+                 odefunc.wt.weight, odefunc.wt.bias)
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     y_cur = y0
     t_lo = t_hi = tt[0]
@@ -567,7 +629,22 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             # in front of the step's first launch, where 50 tiny host operations would sit between the accept decision's
             # read-back and the next kernel)
             coef = (lambda v: _Await.apply(v)) if lazy else (lambda v: v)
-            for a_i, b_i in zip(core.DP_ALPHA, core.DP_BETA):
+            if fused is not None:
+                # stage input 1 by a combine launch; evaluations 2 .. 6 form the next stage input themselves; evaluation 7 (at
+                # y1, the next step's k1) is the plain right-hand side
+                op_, W_, b_ = fused
+                outs_ = _StageCarryFn.apply(1, yc[0], k[0][0], coef(dts * core.DP_BETA[0][0]))
+                u_, yc[0], k[0] = outs_[0], outs_[1], list(outs_[2:])
+                for st_ in range(6):
+                    if st_ < 5:
+                        outs_ = _RhsStageCarryFn.apply(len(k[0]), op_, u_, W_, b_, yc[0], *k[0],
+                                                       *[coef(dts * bb) for bb in core.DP_BETA[st_ + 1]])
+                        u_, yc[0], k[0] = outs_[1], outs_[2], list(outs_[3:]) + [outs_[0]]
+                    else:
+                        yi = (u_,)
+                        k[0].append(func(targ((t0s + core.DP_ALPHA[5] * dts).item()), yi)[0])
+                    nfe += 1
+            for a_i, b_i in (() if fused is not None else zip(core.DP_ALPHA, core.DP_BETA)):
                 ti = t0s + a_i * dts
                 if carry:
                     us = []

@@ -97,8 +97,10 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
             return sol
     if needs_grad:
         from .autograd_path import odeint_with_grad
+        plain = method == 'dopri5' and _device_resident_ok(user_func, tensor_input, y0, t_user, method, options) and \
+            _small_operator(user_func, y0[0]) is not None
         sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func),
-                               step_log=step_log)
+                               step_log=step_log, odefunc=user_func if plain else None)
     elif _device_resident_ok(user_func, tensor_input, y0, t_user, method, options):
         return _device_resident(user_func, y0[0], t, rtol, atol, method, options, step_log)
     elif method == 'dopri5':

@@ -176,7 +176,10 @@ def test_dopri5_backprop_carry_forms_against_fan_out_form_and_oracle(dev, ticks,
     t = torch.tensor(ticks)
     w = torch.randn(len(ticks), *d['x0'].shape, generator=torch.Generator().manual_seed(3))
     res = {}
-    for name, env in (('multi', {}), ('single', {'NDCN_GRAD_MULTI_TICK': '0'}), ('fanout', {'NDCN_GRAD_CARRY': '0'})):
+    # (default = carry + multi-tick + the next stage input formed in the evaluations' epilogues (_RhsStageCarryFn) + deferred scalar
+    # gradients (_Await); 'unfused' / 'eager' switch the last two off one at a time)
+    for name, env in (('multi', {}), ('single', {'NDCN_GRAD_MULTI_TICK': '0'}), ('unfused', {'NDCN_GRAD_FUSED_STAGE': '0'}),
+                      ('eager', {'NDCN_GRAD_LAZY': '0'}), ('fanout', {'NDCN_GRAD_CARRY': '0'})):
         os.environ.update(env)
         try:
             f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev)).to(dev)
@@ -189,10 +192,13 @@ def test_dopri5_backprop_carry_forms_against_fan_out_form_and_oracle(dev, ticks,
         finally:
             for k in env:
                 del os.environ[k]
-    for name in ('multi', 'single'):
+    forms = ('multi', 'single', 'unfused', 'eager')
+    for name in forms:
         assert torch.equal(res[name][0], res['fanout'][0]) and res[name][1] == res['fanout'][1]
+    for got, ref in zip(res['eager'][2], res['multi'][2]):
+        assert torch.equal(got, ref)                       # deferred read-back: the same bits, later
     if rtol > 1e-4:
-        for name in ('multi', 'single'):
+        for name in forms:
             for got, ref in zip(res[name][2], res['fanout'][2]):
                 assert rel(got, ref) < 2e-4, (name, rel(got, ref))
         return
@@ -203,7 +209,7 @@ def test_dopri5_backprop_carry_forms_against_fan_out_form_and_oracle(dev, ticks,
     (yo * w).sum().backward()
     for q, ref in enumerate((xo.grad, Wo.grad, bo.grad)):
         base = rel(res['fanout'][2][q], ref)
-        for name in ('multi', 'single'):
+        for name in forms:
             # (chaotic: the figures move by tens of per cent of themselves between runs of the SAME form on different boxes; a
             # wrong VJP shows as a relative error of order one)
             assert rel(res[name][2][q], ref) <= 3.0 * base + 2e-2, (name, q, rel(res[name][2][q], ref), base)
