@@ -327,6 +327,9 @@ def _lazy():
     return os.environ.get('NDCN_GRAD_LAZY', '1') != '0'
 
 
+_LAZY_NOW = [False]          # set by the solver loop for the solve it runs: do the carry ops of this solve defer their scalars?
+
+
 class _Await(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -351,7 +354,7 @@ class _StageCarryFn(torch.autograd.Function):
         ks, cs = rest[:n], rest[n:]
         idx, kk, cc = _active(ks, cs)
         ctx.n, ctx.idx, ctx.cc = n, idx, cc
-        ctx.lazy = _lazy()                       # (the solver below routes every coefficient of a carry op through _Await)
+        ctx.lazy = _LAZY_NOW[0]                  # (the solver below routes every coefficient of a carry op through _Await)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*kk, *cs)
         u = hip.combine(y0, kk, cc) if kk else y0.clone()
@@ -401,7 +404,7 @@ class _RhsStageCarryFn(torch.autograd.Function):
         c_new = f32(float(cs[n]))
         K, u_next = hip.rhs_rk(A, u, W, b, 'combine', y0, kk, cc + [c_new], no_graph=no_graph, no_control=no_control)
         ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b = n, idx, cc + [c_new], op, b is not None
-        ctx.lazy = _lazy()
+        ctx.lazy = _LAZY_NOW[0]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(u, W, K, *kk, *cs)
         return (K, u_next, y0) + tuple(ks)
@@ -453,7 +456,7 @@ class _ErrorCarryFn(torch.autograd.Function):
         s, bad = hip.error(y0, y1, kk, cc, rtol, atol)
         bad_out.append(bad)
         ctx.n, ctx.idx, ctx.cc, ctx.tol = n, idx, cc, (rtol, atol)
-        ctx.lazy = _lazy()
+        ctx.lazy = _LAZY_NOW[0]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(y0, y1, *kk, *cs)
         return (torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1) + tuple(ks)
@@ -520,7 +523,7 @@ class _DenseMultiCarryFn(torch.autograd.Function):
     def forward(ctx, nt, a0, a1, *rest):
         kk, dt_, xs = rest[:7], rest[7], rest[8:8 + nt]
         ctx.nt = nt
-        ctx.lazy = _lazy()
+        ctx.lazy = _LAZY_NOW[0]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(a0, a1, *rest)
         dt32 = f32(float(dt_))
@@ -599,13 +602,16 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         bad.append(0)
     pending_bad = bad[0] if bad else 0
     carry = _carry()
-    lazy = carry and _lazy()
+    # deferred scalar gradients pay where a read-back stalls real GPU work; on the reference's own sizes (400 x 20) the extra
+    # autograd node per coefficient costs more than the stall (README-sized dopri5 step 11 -> 19 ms, tools/micro/train_ab.py)
+    lazy = carry and _lazy() and y0[0].numel() >= int(os.environ.get('NDCN_GRAD_LAZY_MIN', 1 << 20))
     # a plain ODEFunc on one state tensor (odeint checked): its evaluations carry the next stage input in their epilogue
     fused = None
     if carry and odefunc is not None and len(y0) == 1 and os.environ.get('NDCN_GRAD_FUSED_STAGE', '1') != '0':
         from ...csr import as_csr
         fused = ((None if odefunc.no_graph else as_csr(odefunc.A), bool(odefunc.no_graph), bool(odefunc.no_control)),
                  odefunc.wt.weight, odefunc.wt.bias)
+    _LAZY_NOW[0] = lazy
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     y_cur = y0
     t_lo = t_hi = tt[0]

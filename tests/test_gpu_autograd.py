@@ -178,7 +178,8 @@ def test_dopri5_backprop_carry_forms_against_fan_out_form_and_oracle(dev, ticks,
     res = {}
     # (default = carry + multi-tick + the next stage input formed in the evaluations' epilogues (_RhsStageCarryFn) + deferred scalar
     # gradients (_Await); 'unfused' / 'eager' switch the last two off one at a time)
-    for name, env in (('multi', {}), ('single', {'NDCN_GRAD_MULTI_TICK': '0'}), ('unfused', {'NDCN_GRAD_FUSED_STAGE': '0'}),
+    for name, env in (('multi', {'NDCN_GRAD_LAZY_MIN': '0'}), ('single', {'NDCN_GRAD_MULTI_TICK': '0', 'NDCN_GRAD_LAZY_MIN': '0'}),
+                      ('unfused', {'NDCN_GRAD_FUSED_STAGE': '0', 'NDCN_GRAD_LAZY_MIN': '0'}),
                       ('eager', {'NDCN_GRAD_LAZY': '0'}), ('fanout', {'NDCN_GRAD_CARRY': '0'})):
         os.environ.update(env)
         try:
