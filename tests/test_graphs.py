@@ -148,6 +148,50 @@ def test_group_record_plan_reconstructs_the_operator():
     assert CsrOperator.from_scipy(five).detect_stencil_order() is not None    # 5-point stencil, stride 50
 
 
+@pytest.mark.parametrize('shape,avg', [((3000, 3000), 12), ((700, 5000), 9), ((100352 + 5, 600), 2)])
+def test_column_sweep_plan_restatement_reconstructs_the_operator(shape, avg):
+    """tests/_plan_reference.py: sweep_plan_reference - what tests/test_gpu_sweep.py compares the library's column-sweep plan with -
+    decodes back to the operator: every entry once, in its slab, the slab's stream sorted by column (ties in row order), rows in
+    ascending column order, padding to groups of 8 with the dummy row, the table pointing at group-aligned starts."""
+    from _plan_reference import sweep_plan_reference
+    rng = np.random.RandomState(shape[0])
+    deg = rng.poisson(avg, size=shape[0])
+    deg[:3] = 0
+    rows = np.repeat(np.arange(shape[0]), deg)
+    m = sp.csr_matrix((rng.randn(rows.size).astype(np.float32), (rows, rng.randint(0, shape[1], size=rows.size))), shape=shape)
+    m.sum_duplicates()
+    m.sort_indices()
+    ref = sweep_plan_reference(m.indptr, m.indices, m.data, m.shape)
+    n = shape[0]
+    assert ref['passes'] == (n + 100351) // 100352 and ref['slab'].shape == (ref['passes'] * 2048, 2)
+    assert ref['rpw'] <= 49 and ref['ent'].shape == (ref['entries'] + 32, 2)
+    assert (ref['slab'][:, 0] % 8 == 0).all() and int(ref['slab'][:, 1].sum()) == m.nnz
+    rr, cc, vv = [], [], []
+    used = np.zeros(ref['entries'] + 32, bool)
+    for s_, (start, cnt) in enumerate(ref['slab']):
+        e = ref['ent'][start:start + cnt]
+        used[start:start + cnt] = True
+        if not cnt:
+            continue
+        col = (e[:, 0] & 0xffffff).astype(np.int64)
+        loc = (e[:, 0] >> 24).astype(np.int64)
+        assert (np.diff(col) >= 0).all() and loc.max() < ref['rpw']
+        tie = np.diff(col) == 0
+        assert (np.diff(loc)[tie] > 0).all()                              # equal columns: in row order (a stable sort)
+        p_, x_, sl_ = s_ // 2048, (s_ % 2048) // 256, s_ % 256
+        base = p_ * ref['rows_per_pass']
+        end = min(n, base + ref['rows_per_pass'])
+        per_xcd = (end - base + 7) // 8
+        rpw = (per_xcd + 255) // 256
+        rr.append(base + x_ * per_xcd + sl_ * rpw + loc)
+        cc.append(col)
+        vv.append(e[:, 1].copy().view(np.float32))
+    assert (ref['ent'][~used] == np.array([49 << 24, 0], dtype=np.uint32)).all()      # padding: 0 * X[0] into the dummy row
+    back = sp.csr_matrix((np.concatenate(vv), (np.concatenate(rr), np.concatenate(cc))), shape=shape)
+    back.sort_indices()
+    assert np.array_equal(back.indptr, m.indptr) and np.array_equal(back.indices, m.indices) and np.array_equal(back.data, m.data)
+
+
 def test_planetoid_loader_against_reference_steps():
     """ndcn_amd/planetoid.py vs the fixture assembled from the reference's data files (tools/gen_golden.py G8).
     Needs the reference's data directory; skipped where it is absent (GPU box)."""
