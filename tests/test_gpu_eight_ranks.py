@@ -107,7 +107,9 @@ def test_eight_shards_on_one_device_equal_the_unsharded_solver(case):
         for name, arr in (('indptr', L.indptr), ('indices', L.indices), ('data', L.data), ('bounds', np.asarray(bounds)),
                           ('W', f.wt.weight.detach().numpy()), ('b', f.wt.bias.detach().numpy())):
             np.save(os.path.join(shm, name + '.npy'), arr)
-        ret = mp.Manager().dict()
+        # (a SPAWNED manager: a fork()ed server inherits this process's garbage - tensors, events, handles of a HIP context it does
+        # not have - and its garbage collector then runs their destructors)
+        ret = mp.get_context('spawn').Manager().dict()
         port = 29300 + os.getpid() % 300 + (0 if case == 'grid' else 301)
         mp.spawn(_worker, args=(WORLD, port, case, shm, ret), nprocs=WORLD, join=True)
         assert len(ret) == WORLD

@@ -612,7 +612,9 @@ def test_two_rank_sharded_hip_path_equals_device_solver(dev, case):
     from ndcn_amd.neural_dynamics import ODEFunc
     from ndcn_amd.torchdiffeq import odeint
     world, port = 2, 29900 + os.getpid() % 90 + {'grid': 0, 'small_world': 1, 'power_law': 2}[case]
-    ret = mp.Manager().dict()
+    # (a SPAWNED manager: a fork()ed server inherits this process's garbage - tensors, events, handles of a HIP context it does
+    # not have - and its garbage collector then runs their destructors)
+    ret = mp.get_context('spawn').Manager().dict()
     mp.spawn(_two_rank_worker, args=(world, port, case, ret), nprocs=world, join=True)
     assert len(ret) == world and ret[0]['halo'] > 0 and ret[1]['halo'] > 0
     if case == 'power_law':                                    # the long-row plan was active on the shards, beside their halo panels
