@@ -124,7 +124,8 @@ typedef struct ndcn_csr {
      *   sweep_ent  pairs of 32-bit words {row within the slab << 24 | column, fp32 value bits}: the slab's entries merged over
      *              its rows and sorted by column - per row still in ascending column order, i.e. the fma chain of a sequential
      *              CSR loop: results are bit-identical to it - padded to groups of 8 with {49 << 24, 0}
-     *   sweep_prog [passes][8][256]    one word per wave: (launch tag << 16) | column block it fetches from - waves of an XCD
+     *   sweep_prog [passes][8][256] + [passes]   one word per wave: (launch tag << 16) | column block it fetches from, then one
+     *              launch counter per pass (the tag's source: kept on the device so that a hipGraph replay advances it) - waves of an XCD
      *              keep within sweep_window blocks of 2^sweep_logb columns of each other (a locality hint with a bounded wait,
      *              never needed for correctness)
      *   sweep_S    [n_rows][256] scratch for S = A X in front of the Linear (ndcn_rhs_f32 / ndcn_rhs_rk_f32: the fused kernel

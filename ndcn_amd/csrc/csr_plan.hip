@@ -646,10 +646,10 @@ int build_sweep_plan(ndcn_csr_handle *h, bool external_scratch, hipStream_t st) 
     uint32_t *prog;
     int32_t *eye_rowptr, *eye_colidx;
     float *eye_val;
-    if ((rc = dev_alloc(h, &prog, (size_t)nslab)) || (rc = dev_alloc(h, &eye_rowptr, (size_t)n + 1)) || (rc = dev_alloc(h, &eye_colidx, (size_t)n)) ||
+    if ((rc = dev_alloc(h, &prog, (size_t)nslab + passes)) || (rc = dev_alloc(h, &eye_rowptr, (size_t)n + 1)) || (rc = dev_alloc(h, &eye_colidx, (size_t)n)) ||
         (rc = dev_alloc(h, &eye_val, (size_t)n)))
         return rc;
-    NDCN_HIP(hipMemsetAsync(prog, 0, (size_t)nslab * sizeof(uint32_t), st));
+    NDCN_HIP(hipMemsetAsync(prog, 0, ((size_t)nslab + passes) * sizeof(uint32_t), st));     // progress words + one launch counter per pass
     hipLaunchKernelGGL(sweep_eye_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, n, eye_rowptr, eye_colidx, eye_val);
     NDCN_LAUNCH_CHECK();
     NDCN_HIP(hipStreamSynchronize(st));

@@ -28,8 +28,6 @@
 //
 // Measured (MI355X, tools/micro/sweep_lab.hip, profiles/r04i_sweep_lab.txt): 0.195-0.200 ms against 0.559 ms for the row
 // gather on the same operator (blocks of 1024-2048 columns, window 2-3), 0.34 ms without the synchronisation.
-#include <atomic>
-
 #include "kernels.h"
 
 namespace ndcn {
@@ -51,7 +49,7 @@ struct SweepArgs {
     unsigned x_bytes;
     int row_base, row_end;      // the pass's rows
     int rows_per_xcd, rpw;
-    unsigned etag;
+    uint32_t *epoch;            // this pass's launch counter (device memory: a hipGraph replay must see a new tag too)
     int nblk, logb, window;
 };
 
@@ -108,6 +106,10 @@ __global__ __launch_bounds__(kSweepWaves * 64) void spmm_sweep_kernel(SweepArgs 
                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(yb >> 32) & 0xffffu)), (unsigned)nvalid * 1024u, 0x00020000u};
     const int voff = lane * 16;
     const int wm1 = a.window - 1;
+    // the tag distinguishes this launch's progress words from what earlier launches left in the line (16 bits: a wrap-around
+    // after 65 536 launches can at worst make one launch run unsynchronised); wave 0 of workgroup 0 advances the counter when it
+    // is done - a workgroup that starts later than that tags with the next launch's value and merely loses the hint
+    const unsigned etag = ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) << 16;
     asm volatile(
         "s_mov_b64 s[72:73], %[ent]\n"
         "s_mov_b32 s64, %[ngrp]\n"
@@ -212,15 +214,15 @@ __global__ __launch_bounds__(kSweepWaves * 64) void spmm_sweep_kernel(SweepArgs 
         "L_done_%=:\n"
         "s_waitcnt vmcnt(0)\n"
         :
-        : [voff] "v"(voff), [rsx] "s"(rsx), [rsy] "s"(rsy), [ent] "s"(p), [ngrp] "s"(ngrp), [prog] "s"(prog), [etag] "s"(a.etag),
+        : [voff] "v"(voff), [rsx] "s"(rsx), [rsy] "s"(rsy), [ent] "s"(p), [ngrp] "s"(ngrp), [prog] "s"(prog), [etag] "s"(etag),
           [nblk] "s"(a.nblk), [slot4] "s"(slot * 4), [nvalid] "s"(nvalid), [logb] "s"(a.logb), [window] "s"(a.window), [wm1] "s"(wm1)
         : "memory", "vcc", "scc", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", V10(1), V10(2), V10(3), V10(4), V10(5), V10(6),
           V10(7), V10(8), V10(9), V10(10), V10(11), V10(12), V10(13), V10(14), V10(15), V10(16), V10(17), V10(18), V10(19), V10(20), V10(21),
           V10(22), V10(23), "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "s16", "s17", "s18", "s19", S10(2), S10(3),
           S10(4), S10(5), S10(6), S10(7));
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(a.epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-static std::atomic<uint32_t> g_sweep_launches{0};
 
 int spmm_sweep_supported(const ndcn_csr *A, int H) {
     static const int enabled = [] { const char *e = getenv("NDCN_SWEEP"); return e ? atoi(e) : 1; }();
@@ -248,9 +250,7 @@ int spmm_sweep_f32(const ndcn_csr *A, const float *X, float *Y, hipStream_t st) 
         const int np = a.row_end - a.row_base;
         a.rows_per_xcd = (np + kXcds - 1) / kXcds;
         a.rpw = (a.rows_per_xcd + kSweepSlots - 1) / kSweepSlots;
-        // the tag distinguishes this launch's progress words from what earlier launches left in the line (16 bits: a
-        // wrap-around after 65 536 launches can at worst make one launch run unsynchronised)
-        a.etag = (g_sweep_launches.fetch_add(1, std::memory_order_relaxed) & 0xffffu) << 16;
+        a.epoch = A->sweep_prog + (size_t)A->sweep_passes * kXcds * kSweepSlots + p;
         a.logb = logb;
         a.nblk = (int)((A->n_cols + (1ll << logb) - 1) >> logb);
         a.window = window;
