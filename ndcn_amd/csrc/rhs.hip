@@ -18,6 +18,15 @@ __global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict_
     }
 }
 
+// y = relu(y) in place, 16 bytes per lane (n4 float4 items; the panels of the H = 256 kernels are 16-byte aligned multiples of 4)
+__global__ __launch_bounds__(256) void relu_inplace4_kernel(float4 *y, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = y[i];
+    v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
+    y[i] = v;
+}
+
 int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) {
     const bool graph = !(flags & NDCN_F_NO_GRAPH), ctl = !(flags & NDCN_F_NO_CONTROL);
     if (!(graph && ctl)) return 0;
@@ -53,7 +62,18 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
         if (rc) return rc;
         return linear_f32(work, W, b, Y, n, H, H, act, st);
     }
-    if (graph) return spmm_f32(A, X, Xh, n_own, Y, H, 1.f, act, st);          // no_control: relu(A x)
+    if (graph) {                                                                // no_control: relu(A x)
+        // operators with a column-sweep plan: S = A X by the sweep straight into Y, the ReLU as a streaming pass in place
+        if (act && !Xh && H == 256 && spmm_sweep_supported(A, H) && aligned16(X) && aligned16(Y)) {
+            int rc = spmm_sweep_f32(A, X, Y, st);
+            if (rc) return rc;
+            const int64_t total = n * (int64_t)H;
+            hipLaunchKernelGGL(relu_inplace4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4 *>(Y), total / 4);
+            NDCN_LAUNCH_CHECK();
+            return NDCN_OK;
+        }
+        return spmm_f32(A, X, Xh, n_own, Y, H, 1.f, act, st);
+    }
     if (ctl) return linear_f32(X, W, b, Y, n, H, H, act, st);                   // no_graph: relu(W x + b)
     const int64_t total = n * (int64_t)H;                                       // neither: relu(x)
     if (total == 0) return NDCN_OK;
@@ -85,7 +105,8 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
         aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))
         return spmm_rec_f32(A, X, Xh, n_own, K, 1.f, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st,
                             nullptr, opt);
-    if (graph_only && spmm_wide_rk_supported(A, H) && aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))     // any other graph
+    const bool swept = graph_only && !Xh && H == 256 && spmm_sweep_supported(A, H) && aligned16(X) && aligned16(K);
+    if (!swept && graph_only && spmm_wide_rk_supported(A, H) && aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))     // any other graph
         return spmm_wide_rk_f32(A, X, Xh, n_own, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st,
                                 nullptr, opt);
     // composition with the same term order: K first, then the algebra over {kprev..., K}

@@ -181,8 +181,54 @@ def test_sweep_rhs_equals_the_one_launch_fused_kernel(dev, name):
         assert b1 == b2 == (0.0 if Xin is X else 1.0)
         if Xin is X:
             assert torch.equal(K1, K2) and abs(s1 - s2) <= 1e-12 * abs(s1)
-    # no_control / no_graph right-hand sides of the same module do not involve the dense product: the SpMM path above
+    # no_control (relu(A X), dgnn's right-hand side): the sweep, then the ReLU / the stage algebra as streaming passes - against the
+    # row gather with the algebra in its epilogue (same S bits, same op order per element)
     assert torch.equal(hip.rhs(A, X, W, b, no_control=True), hip.rhs(R, X, W, b, no_control=True))
+    Xn = X.clone()
+    Xn[5, 9] = float('nan')
+    assert torch.equal(_bits(hip.rhs(A, Xn, W, b, no_control=True)), _bits(hip.rhs(R, Xn, W, b, no_control=True)))
+    for npv in (0, 3, 5):
+        c = cs[:npv] + [cs[5]]
+        K1, y1 = hip.rhs_rk(A, X, W, b, 'combine', y0, ks[:npv], c, no_control=True)
+        K2, y2 = hip.rhs_rk(R, X, W, b, 'combine', y0, ks[:npv], c, no_control=True)
+        assert torch.equal(K1, K2) and torch.equal(y1, y2), npv
+    for st in range(4):
+        K1, y1 = hip.rhs_rk(A, X, W, b, 'rk4', y0, ks[:st], [np.float32(0.37)], no_control=True)
+        K2, y2 = hip.rhs_rk(R, X, W, b, 'rk4', y0, ks[:st], [np.float32(0.37)], no_control=True)
+        assert torch.equal(K1, K2) and torch.equal(y1, y2), st
+    K1, (s1, b1) = hip.rhs_rk(A, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3, no_control=True)
+    K2, (s2, b2) = hip.rhs_rk(R, X, W, b, 'error', y0, ks, cs, rtol=1e-2, atol=1e-3, no_control=True)
+    assert torch.equal(K1, K2) and b1 == b2 == 0.0 and abs(s1 - s2) <= 1e-12 * abs(s1)
+
+
+def test_training_through_a_swept_operator(dev):
+    """loss.backward() through dopri5 and rk4 on an operator with the column-sweep plan: the forward evaluations, the S = A X the
+    weight gradient re-forms and g_X = A^T g_S (the transposed operator gets a plan of its own) all run the sweep - gradients
+    against the plan-free operator."""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    n, H = 9000, 256
+    m = _rand(n, n, 40, 6)
+    op = graphs.normalized_laplacian(sp.csr_matrix(abs(m) + abs(m).T))
+    t = torch.linspace(0., 1., 3).to(dev)
+    x0 = torch.rand(n, H, generator=torch.Generator().manual_seed(2)).to(dev)
+    w = torch.randn(3, n, H, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for name, mk in (('swept', lambda: graphs.to_device(op, dev)), ('plain', lambda: _plain(op, dev))):
+        for method, kw in (('dopri5', dict(rtol=1e-2, atol=1e-3)), ('rk4', {})):
+            torch.manual_seed(0)
+            A = mk()
+            f = ODEFunc(H, A).to(dev)
+            x = x0.clone().requires_grad_(True)
+            y = ode.odeint(f, x, t, method=method, **kw)
+            (y * w).sum().backward()
+            if name == 'swept':
+                assert A.sweep is not None and A.transpose().sweep is not None
+            res[name, method] = (y.detach(), x.grad, f.wt.weight.grad, f.wt.bias.grad)
+    for method in ('dopri5', 'rk4'):
+        for got, ref in zip(res['swept', method], res['plain', method]):
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, method
 
 
 def test_sweep_is_taken_where_the_fetch_arithmetic_says_it_pays(dev):
