@@ -162,10 +162,10 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_kernel(const float *__restri
     "global_store_dword v232, v233, %[prog]\n"               \
     "s_mov_b64 exec, s[74:75]\n"
 #define BEHIND                  /* vcc = lanes holding a wave whose progress is below the threshold s70 */ \
-    "v_min_u32 v244, v244, v245\n"                           \
-    "v_min_u32 v246, v246, v247\n"                           \
-    "v_min_u32 v244, v244, v246\n"                           \
-    "v_cmp_gt_u32 vcc, s70, v244\n"                          \
+    "v_min_u32 v234, v234, v235\n"                           \
+    "v_min_u32 v236, v236, v237\n"                           \
+    "v_min_u32 v234, v234, v236\n"                           \
+    "v_cmp_gt_u32 vcc, s70, v234\n"                          \
     "s_cmp_eq_u64 vcc, 0\n"
 
 template <int LOGB, int S>
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm_kernel(const float *__re
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
         xcc_dbg[blockIdx.x] = (int)id;
+        reinterpret_cast<unsigned long long *>(xcc_dbg + 256)[blockIdx.x] = wall_clock64();
     }
     asm volatile(
         "s_mov_b64 s[72:73], %[ent]\n"
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm_kernel(const float *__re
         "L_slow_%=:\n"
         "s_mov_b32 s71, 0\n"
         "L_spin_%=:\n"
-        "global_load_dwordx4 v[244:247], %[voff], %[prog] sc1\n"
+        "global_load_dwordx4 v[234:237], %[voff], %[prog] sc1\n"
         "s_waitcnt vmcnt(0)\n"
         BEHIND
         "s_cbranch_scc1 L_prefetch_%=\n"
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm_kernel(const float *__re
         "s_cbranch_scc1 L_spin_%=\n"
         "s_mov_b32 s77, 1\n"
         "L_prefetch_%=:\n"
-        "global_load_dwordx4 v[244:247], %[voff], %[prog] sc1\n"
+        "global_load_dwordx4 v[234:237], %[voff], %[prog] sc1\n"
         "s_mov_b32 s76, 1\n"
         "L_nocross_%=:\n"
         FOLD(16, 17, 200, 201, 202, 203) ISSUE(32, 200, 203)
@@ -285,12 +286,12 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm_kernel(const float *__re
         "s_cbranch_scc1 L_done_%=\n"
         "L_st_%=:\n"
         "s_set_gpr_idx_on s68, gpr_idx(SRC0)\n"
-        "v_mov_b32 v236, v0\n"
-        "v_mov_b32 v237, v1\n"
-        "v_mov_b32 v238, v2\n"
-        "v_mov_b32 v239, v3\n"
+        "v_mov_b32 v200, v0\n"
+        "v_mov_b32 v201, v1\n"
+        "v_mov_b32 v202, v2\n"
+        "v_mov_b32 v203, v3\n"
         "s_set_gpr_idx_off\n"
-        "buffer_store_dwordx4 v[236:239], %[voff], %[rsy], s69 offen nt\n"
+        "buffer_store_dwordx4 v[200:203], %[voff], %[rsy], s69 offen nt\n"
         "s_add_u32 s68, s68, 4\n"
         "s_add_u32 s69, s69, 0x400\n"
         "s_sub_u32 s64, s64, 1\n"
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm_kernel(const float *__re
           [nvalid] "s"(nvalid), [logb] "n"(LOGB), [S] "n"(S)
         : "memory", "vcc", "scc", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", V10(1), V10(2), V10(3), V10(4), V10(5), V10(6),
           V10(7), V10(8), V10(9), V10(10), V10(11), V10(12), V10(13), V10(14), V10(15), V10(16), V10(17), V10(18), V10(19), V10(20), V10(21),
-          V10(22), V10(23), "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "s16", "s17", "s18", "s19", S10(2), S10(3), S10(4), S10(5), S10(6), S10(7));
+          V10(22), "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "s16", "s17", "s18", "s19", S10(2), S10(3), S10(4), S10(5), S10(6), S10(7));
 }
 
 
@@ -421,6 +422,58 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm2_kernel(const float *__r
           "v220", "v221", "v222", "v223", "s16", "s17", "s18", "s19", S10(2), S10(3), S10(4), S10(5), S10(6), S10(7));
 }
 
+
+// ---- companion prefetcher (experiment; outcome NEGATIVE as built, profiles/r04i_sweep_lab.txt): with 32 workgroups polling the
+// progress line once per block the prefetcher sustains one block per 4.4 us where the sweep passes one per 2 us - it trails the
+// sweep instead of leading it (its workgroups finish 230 us AFTER the sweep, timestamps below), re-reads what the sweep already
+// fetched and, queued stream-ordered behind its predecessors, competes with the NEXT launch: 0.35-0.73 ms per sweep instead of 0.20.
+// What a working version needs: the poll of block b + 1 in flight while block b's lines are requested (no sleep), or one poll per
+// several blocks of 512 rows; and a guard against the backlog.  The ceiling it would approach: 0.142 ms (all-hits run, fold = 2048).
+// ---- companion prefetcher (experiment): the all-hits ceiling of the sweep is 0.142 ms (fold = 2048), the sweep itself takes
+// 0.200: a fifth of its fetches are the FIRST touch of a row of X in the XCD and wait for the fabric, and vector memory returns in
+// order.  A second kernel on its own stream - 4 workgroups of 4 waves per XCD, 16 registers, so that its waves fit beside the
+// sweep's 2 x 248 on a SIMD - walks X in row order `ahead` blocks in front of the slowest wave of its XCD (it reads the same
+// progress line) and touches every 128-byte line once: the sweep's own fetches then hit.
+__global__ __launch_bounds__(256) void sweep_prefetch_kernel(const float *__restrict__ X, int n_rows, const unsigned *prog_all, unsigned etag,
+                                                             int nblk, int logb, int ahead, unsigned *sink) {
+    if (sink && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(sink)[2 * blockIdx.x] = wall_clock64();
+    const int lane = threadIdx.x & 63;
+    const int xcd = blockIdx.x & 7, part = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), parts = (gridDim.x >> 3) * 4;
+    const unsigned *prog = prog_all + xcd * SLOTS;
+    const unsigned rows_per_blk = 1u << logb;
+    for (int b = 0; b < nblk; ++b) {
+        if (b > ahead) {
+            const unsigned thr = etag | (unsigned)(b - ahead);
+            int tries = 0;
+            for (;;) {
+                unsigned m = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m = min(m, __hip_atomic_load(prog + lane * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((m >> 16) > (etag >> 16) && __all(1)) {}                     // (a later launch's tags count as "ahead")
+                if (!__any(m < thr)) break;
+                if (++tries > 4000) {                                             // the sweep is not running beside us: give up
+                    if (sink && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(sink)[2 * blockIdx.x + 1] = wall_clock64() | (1ull << 63);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        const long row0 = (long)b << logb;
+        const long rows = min((long)rows_per_blk, (long)n_rows - row0);
+        const long lines = rows * 8;                                              // 128-byte lines of the block
+        const char *base = reinterpret_cast<const char *>(X) + row0 * 1024;
+        for (long l0 = (long)part * 64; l0 < lines; l0 += (long)parts * 64) {
+            const long l = l0 + lane;
+            if (l < lines) {
+                unsigned tmp;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(base + l * 128) : "memory");   // never waited for
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sink && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(sink)[2 * blockIdx.x + 1] = wall_clock64();
+}
+
 struct Dev {
     float *X, *Y, *Yref, *val;
     int *rowptr, *col, *slab_ptr;
@@ -428,6 +481,7 @@ struct Dev {
     unsigned *done;
     int n, nblk_max;
     int *xcc;
+    unsigned long long *ts;
     unsigned epoch = 0;
 };
 
@@ -476,6 +530,39 @@ static double run_asm(Dev &d, int reps) {
     for (int i = 0; i < reps; ++i) launch();
     hipEventRecord(e1);
     CK(hipEventSynchronize(e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+template <int LOGB, int S>
+static double run_asm_pf(Dev &d, int reps, int ahead, int pf_groups) {
+    const int nblk = (d.n + (1 << LOGB) - 1) >> LOGB;
+    const int rows_per_xcd = (d.n + 7) / 8;
+    CK(hipMemset(d.done, 0, 8 * d.nblk_max * 4));
+    d.epoch = 0;
+    static hipStream_t s1 = nullptr, s2 = nullptr;
+    if (!s1) { CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); }
+    hipEvent_t e0, e1, go;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventCreateWithFlags(&go, hipEventDisableTiming);
+    auto launch = [&]() {
+        ++d.epoch;
+        hipEventRecord(go, s1);                                  // the prefetcher of launch i starts when launch i - 1 has finished
+        hipStreamWaitEvent(s2, go, 0);
+        hipLaunchKernelGGL(sweep_prefetch_kernel, dim3(8 * pf_groups), dim3(256), 0, s2, d.X, d.n, d.done, d.epoch << 16, nblk, LOGB, ahead,
+                           (unsigned *)d.ts);
+        hipLaunchKernelGGL((sweep_asm_kernel<LOGB, S>), dim3(256), dim3(WAVES * 64), 0, s1, d.X, d.ent, d.slab_ptr, d.Y, d.n, rows_per_xcd, d.done,
+                           d.epoch << 16, nblk, d.xcc);
+    };
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipDeviceSynchronize());
+    hipEventRecord(e0, s1);
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(e1, s1);
+    CK(hipEventSynchronize(e1));
+    CK(hipDeviceSynchronize());
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     return ms / reps;
@@ -539,6 +626,9 @@ static bool check(Dev &d, const char *what) {
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 100000;
     const double deg = argc > 2 ? atof(argv[2]) : 40.0;
+    // fold > 0: the sweep FETCHES row (column % fold) - every fetch an L2 hit once `fold` rows are resident: the ceiling of the
+    // L2 -> CU path for this access pattern (results then differ from the row gather, which is the point of the exercise)
+    const int fold = argc > 3 ? atoi(argv[3]) : 0;
     if ((n + 7) / 8 > SLOTS * RW) { printf("n too large for one pass\n"); return 1; }
     // G(n, p) by geometric skips, rows ascending, columns ascending
     std::vector<int> rowptr(n + 1, 0), col;
@@ -573,7 +663,7 @@ int main(int argc, char **argv) {
             std::stable_sort(tmp.begin(), tmp.end(), [](const E &a, const E &b) { return a.c < b.c; });
             slab_ptr[2 * (x * SLOTS + sl)] = (int)(ent.size() / 2);
             slab_ptr[2 * (x * SLOTS + sl) + 1] = (int)tmp.size();
-            for (const E &e : tmp) { ent.push_back(e.r << 24 | e.c); unsigned u; memcpy(&u, &e.v, 4); ent.push_back(u); }
+            for (const E &e : tmp) { ent.push_back(e.r << 24 | (fold > 0 ? e.c % (unsigned)fold : e.c)); unsigned u; memcpy(&u, &e.v, 4); ent.push_back(u); }
             while ((ent.size() / 2) % 64) { ent.push_back(49u << 24); ent.push_back(0); }   // padding: 0 * X[0] into the dummy row
         }
     for (int i = 0; i < 2 * 256; ++i) ent.push_back(0);             // the prefetch reads two groups past the end
@@ -584,7 +674,7 @@ int main(int argc, char **argv) {
     for (auto &v : hX) v = (float)(rnd() - 0.5);
     CK(hipMalloc(&d.X, hX.size() * 4)); CK(hipMalloc(&d.Y, hX.size() * 4)); CK(hipMalloc(&d.Yref, hX.size() * 4));
     CK(hipMalloc(&d.val, nnz * 4)); CK(hipMalloc(&d.col, nnz * 4)); CK(hipMalloc(&d.rowptr, (n + 1) * 4));
-    CK(hipMalloc(&d.slab_ptr, slab_ptr.size() * 4)); CK(hipMalloc(&d.ent, ent.size() * 4)); CK(hipMalloc(&d.done, 8 * d.nblk_max * 4)); CK(hipMalloc(&d.xcc, 256 * 4));
+    CK(hipMalloc(&d.slab_ptr, slab_ptr.size() * 4)); CK(hipMalloc(&d.ent, ent.size() * 4)); CK(hipMalloc(&d.done, 8 * d.nblk_max * 4)); CK(hipMalloc(&d.xcc, 256 * 4 + 256 * 8)); CK(hipMalloc(&d.ts, (256 + 128) * 8)); CK(hipMemset(d.ts, 0, (256 + 128) * 8));
     CK(hipMemcpy(d.X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d.val, val.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d.col, col.data(), nnz * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d.rowptr, rowptr.data(), (n + 1) * 4, hipMemcpyHostToDevice));
@@ -615,6 +705,33 @@ int main(int argc, char **argv) {
     t = run_asm<LOGB, 8>(d, 10); printf(" %7.3f ms", t);                                                                 \
     t = run_asm<LOGB, 60000>(d, 10); printf(" %7.3f ms\n", t);
     ROW(8) ROW(9) ROW(10) ROW(11)
+    // (argv[4] = 1: the companion-prefetcher experiment - slow to run: its workgroups spin with bounded waits)
+    if (argc > 4 && atoi(argv[4]) == 1) {
+    printf("with the companion prefetcher on a second stream (blocks ahead of the slowest wave x workgroups per XCD):\n");
+    for (int ahead : {2, 3, 4})
+        for (int grp : {2, 4, 8}) {
+            const double a = run_asm_pf<10, 3>(d, 10, ahead, grp), b2 = run_asm_pf<10, 2>(d, 10, ahead, grp), c2 = run_asm_pf<11, 2>(d, 10, ahead, grp);
+            printf("  ahead %d, %d x 4 waves per XCD:  <1024, 3> %7.3f ms   <1024, 2> %7.3f ms   <2048, 2> %7.3f ms\n", ahead, grp, a, b2, c2);
+        }
+    run_asm_pf<10, 3>(d, 1, 3, 4);
+    CK(hipDeviceSynchronize());
+    check(d, "asm sweep<1024, 3> + prefetcher");
+    {
+        std::vector<unsigned long long> ts(64), sw(256);
+        CK(hipMemcpy(ts.data(), d.ts, 64 * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(sw.data(), reinterpret_cast<char *>(d.xcc) + 256 * 4, 256 * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < 32; ++i) t0 = std::min(t0, ts[2 * i]);
+        unsigned long long smin = ~0ull, smax = 0;
+        for (int i = 0; i < 256; ++i) { smin = std::min(smin, sw[i]); smax = std::max(smax, sw[i]); }
+        printf("  wall clock (100 MHz ticks) relative to the first prefetch workgroup: sweep workgroups start %+lld .. %+lld;", (long long)(smin - t0), (long long)(smax - t0));
+        printf(" prefetch workgroups 0..3 end at");
+        for (int i = 0; i < 4; ++i) printf(" %+lld%s", (long long)((ts[2 * i + 1] & ~(1ull << 63)) - t0), (ts[2 * i + 1] >> 63) ? "(gave up)" : "");
+        int late = 0;
+        for (int i = 0; i < 256; ++i) late += (sw[i] - smin) > 1000;
+        printf("; %d sweep workgroups started > 10 us after the first\n", late);
+    }
+    }
     printf("second generation (LDS ring, 16 fetches in flight):\n");
     printf("  %-26s %10s %10s %10s %10s %10s %10s\n", "columns per block", "S = 2", "S = 3", "S = 4", "S = 6", "S = 8", "no sync");
 #define ROW2(LOGB)                                                                                                       \
