@@ -170,7 +170,7 @@ class SingleGpuRunner:
 
 
 # bounded CPU samples per configuration: {nodes, ticks} such that 2 warm-ups + 5 timed solves stay within ~10-30 s of CPU work
-CPU_SAMPLE = {'M': 128 * 128, 'NC': 128 * 128, 'C2': 8000, 'C3': 16000, 'C4': 16000, 'C5': 0}
+CPU_SAMPLE = {'M': 128 * 128, 'NC': 128 * 128, 'C2': 10000, 'C3': 16000, 'C4': 16000, 'C5': 0}   # (C2: >= 8192 nodes, so that the parity block's HIP solve takes the column sweep like the full configuration)
 
 
 FIXED_GRID_METHOD = None         # set by main(): config M with --method euler / rk4
@@ -266,11 +266,15 @@ def gpu_parity(f_or, x0, tt, method, rtol, atol, ref, ref_log, dev):
     with torch.no_grad():
         y = ode.odeint(g, x0.to(dev), tt.to(dev), rtol=rtol, atol=atol, method=method, step_log=log if method == 'dopri5' else None)
     err = (y.cpu() - ref).abs()
+    from ndcn_amd import _lib
+    bits = int(_lib.load().ndcn_debug_last_rhs_path())
+    path = '+'.join(n_ for b_, n_ in ((_lib.PATH_FUSED2, 'fused2'), (_lib.PATH_FUSED3, 'fused3'), (_lib.PATH_HUB, 'long-row plan'),
+                                      (_lib.PATH_HALO, 'halo'), (_lib.PATH_SWEEP, 'column sweep')) if bits & b_) or 'composed / narrow'
     mine = [bool(r[2]) for r in log if r[0] != 'nfe']
     theirs = [bool(r[2]) for r in ref_log if r[0] != 'nfe']
     return {'l1': float(err.mean()), 'max_abs': float(err.max()), 'ref_max_abs': float(ref.abs().max()),
             'steps_equal': (mine == theirs) if method == 'dopri5' else None,
-            'attempts': len(mine) if method == 'dopri5' else len(tt) - 1, 'l1_bound': 1e-4}
+            'attempts': len(mine) if method == 'dopri5' else len(tt) - 1, 'l1_bound': 1e-4, 'rhs_kernels': path}
 
 
 def cpu_baseline(cfg, H, T, rtol, atol, threads, runs=5, nodes=0, dev=None, at_scale=True):

@@ -158,16 +158,20 @@ class _BwdDots:
         ev = torch.cuda.Event()
         ev.record()
         outs = [dst[i] for i in range(m)]
-        for o in outs:
-            cls._pending[o.data_ptr()] = ev
+        rec = (ev, [o.data_ptr() for o in outs])
+        for p in rec[1]:
+            cls._pending[p] = rec          # (a slot the ring hands out again replaces the stale record of its previous use)
         return outs
 
     @classmethod
     def await_lazy(cls, t):
         if t is not None and cls._pending:
-            ev = cls._pending.pop(t.data_ptr(), None)
-            if ev is not None:
-                ev.synchronize()
+            rec = cls._pending.get(t.data_ptr())
+            if rec is not None:
+                rec[0].synchronize()
+                for p in rec[1]:           # one copy filled all the slots of this read-back: none of them needs the event again
+                    if cls._pending.get(p) is rec:
+                        del cls._pending[p]
         return t
 
 
