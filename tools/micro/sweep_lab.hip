@@ -423,12 +423,13 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm2_kernel(const float *__r
 }
 
 
-// ---- companion prefetcher (experiment; outcome NEGATIVE as built, profiles/r04i_sweep_lab.txt): with 32 workgroups polling the
-// progress line once per block the prefetcher sustains one block per 4.4 us where the sweep passes one per 2 us - it trails the
-// sweep instead of leading it (its workgroups finish 230 us AFTER the sweep, timestamps below), re-reads what the sweep already
-// fetched and, queued stream-ordered behind its predecessors, competes with the NEXT launch: 0.35-0.73 ms per sweep instead of 0.20.
-// What a working version needs: the poll of block b + 1 in flight while block b's lines are requested (no sleep), or one poll per
-// several blocks of 512 rows; and a guard against the backlog.  The ceiling it would approach: 0.142 ms (all-hits run, fold = 2048).
+// ---- companion prefetcher (experiment; outcome NEGATIVE, profiles/r04i_sweep_lab.txt).  First form (every wave polls the progress
+// line once per block): the poll sits behind the wave's own outstanding requests - in-order return makes every block cost a full
+// drain, 4.4 us per block against the sweep's 2: the prefetcher TRAILS the sweep and its backlog competes with the next launch
+// (0.35-0.73 ms).  Second form (below: a pacer wave that only polls and publishes through LDS, request waves that never wait):
+// it keeps up - its workgroups end with the sweep - and the sweep takes 0.214-0.229 ms, i.e. nothing is gained over 0.197-0.204
+// without it: the first-touch waits the all-hits run (0.142 ms) removes are not what a prefetcher removes - the lines still
+// have to cross the fabric into the XCD's L2 at the same time as the hits are served.
 // ---- companion prefetcher (experiment): the all-hits ceiling of the sweep is 0.142 ms (fold = 2048), the sweep itself takes
 // 0.200: a fifth of its fetches are the FIRST touch of a row of X in the XCD and wait for the fabric, and vector memory returns in
 // order.  A second kernel on its own stream - 4 workgroups of 4 waves per XCD, 16 registers, so that its waves fit beside the
@@ -436,41 +437,61 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_asm2_kernel(const float *__r
 // progress line) and touches every 128-byte line once: the sweep's own fetches then hit.
 __global__ __launch_bounds__(256) void sweep_prefetch_kernel(const float *__restrict__ X, int n_rows, const unsigned *prog_all, unsigned etag,
                                                              int nblk, int logb, int ahead, unsigned *sink) {
+    // second form: wave 0 of the workgroup is the PACER - it does nothing but poll the XCD's progress line and publish
+    // {slowest wave's block, done} in LDS; waves 1..3 request lines and never wait on vector memory (the first form's poll sat
+    // behind the wave's own outstanding requests: in-order return made every block cost a full drain)
+    __shared__ volatile int s_lag, s_done;
     if (sink && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(sink)[2 * blockIdx.x] = wall_clock64();
-    const int lane = threadIdx.x & 63;
-    const int xcd = blockIdx.x & 7, part = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), parts = (gridDim.x >> 3) * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3, groups = gridDim.x >> 3;
     const unsigned *prog = prog_all + xcd * SLOTS;
-    const unsigned rows_per_blk = 1u << logb;
-    for (int b = 0; b < nblk; ++b) {
-        if (b > ahead) {
-            const unsigned thr = etag | (unsigned)(b - ahead);
-            int tries = 0;
-            for (;;) {
-                unsigned m = 0xffffffffu;
+    if (threadIdx.x == 0) { s_lag = 0; s_done = 0; }
+    __syncthreads();
+    if (wave == 0) {
+        int idle = 0, last = -1;
+        for (;;) {
+            unsigned m = 0xffffffffu;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) m = min(m, __hip_atomic_load(prog + lane * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if ((m >> 16) > (etag >> 16) && __all(1)) {}                     // (a later launch's tags count as "ahead")
-                if (!__any(m < thr)) break;
-                if (++tries > 4000) {                                             // the sweep is not running beside us: give up
-                    if (sink && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(sink)[2 * blockIdx.x + 1] = wall_clock64() | (1ull << 63);
-                    return;
+            for (int q = 0; q < 4; ++q) {
+                const unsigned w = __hip_atomic_load(prog + lane * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = w >> 16, mine = etag >> 16;
+                const unsigned blk = tag == mine ? (w & 0xffffu) : (((tag - mine) & 0xffffu) < 0x8000u ? (unsigned)nblk : 0u);   // older tag: not started
+                m = min(m, blk);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o, 64));
+            if (lane == 0) s_lag = (int)m;
+            if ((int)m >= nblk) break;
+            idle = ((int)m == last) ? idle + 1 : 0;
+            last = (int)m;
+            if (idle > 3000) break;                                   // nothing moves: the sweep is not running beside us
+        }
+        if (lane == 0) s_done = 1;
+    } else {
+        const int part = grp * 3 + (wave - 1), parts = groups * 3;
+        int b = 0;
+        while (b < nblk) {
+            const int lag = s_lag;
+            if (s_done) break;
+            if (b < lag) b = lag;                                     // everybody is past these rows already
+            if (b > lag + ahead) { __builtin_amdgcn_s_sleep(2); continue; }
+            if (b >= nblk) break;
+            const long row0 = (long)b << logb;
+            const long rows = min(1l << logb, (long)n_rows - row0);
+            const long lines = rows * 8;                              // 128-byte lines of the block
+            const char *base = reinterpret_cast<const char *>(X) + row0 * 1024;
+            for (long l0 = (long)part * 64; l0 < lines; l0 += (long)parts * 64) {
+                const long l = l0 + lane;
+                if (l < lines) {
+                    unsigned tmp;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(base + l * 128) : "memory");   // never waited for
                 }
-                __builtin_amdgcn_s_sleep(8);
             }
+            ++b;
         }
-        const long row0 = (long)b << logb;
-        const long rows = min((long)rows_per_blk, (long)n_rows - row0);
-        const long lines = rows * 8;                                              // 128-byte lines of the block
-        const char *base = reinterpret_cast<const char *>(X) + row0 * 1024;
-        for (long l0 = (long)part * 64; l0 < lines; l0 += (long)parts * 64) {
-            const long l = l0 + lane;
-            if (l < lines) {
-                unsigned tmp;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(base + l * 128) : "memory");   // never waited for
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (sink && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(sink)[2 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -708,8 +729,8 @@ int main(int argc, char **argv) {
     // (argv[4] = 1: the companion-prefetcher experiment - slow to run: its workgroups spin with bounded waits)
     if (argc > 4 && atoi(argv[4]) == 1) {
     printf("with the companion prefetcher on a second stream (blocks ahead of the slowest wave x workgroups per XCD):\n");
-    for (int ahead : {2, 3, 4})
-        for (int grp : {2, 4, 8}) {
+    for (int ahead : {1, 2, 3})
+        for (int grp : {2, 4}) {
             const double a = run_asm_pf<10, 3>(d, 10, ahead, grp), b2 = run_asm_pf<10, 2>(d, 10, ahead, grp), c2 = run_asm_pf<11, 2>(d, 10, ahead, grp);
             printf("  ahead %d, %d x 4 waves per XCD:  <1024, 3> %7.3f ms   <1024, 2> %7.3f ms   <2048, 2> %7.3f ms\n", ahead, grp, a, b2, c2);
         }
