@@ -446,6 +446,63 @@ class _RhsStageCarryFn(torch.autograd.Function):
         return (None, None, gu_in, gW, gb, g_y0) + tuple(gk_all) + tuple(gc_all)
 
 
+class _RhsErrorCarryFn(torch.autograd.Function):
+    """(K, ratio, y0', y1', k_1', ..) = (relu(W (A y1) + b), mean((sum_j c_j k_j + c_new K)^2 / tol^2), y0, y1, k_1, ..): the LAST
+    evaluation of a dopri5 step with the error record in its epilogue (ndcn_rhs_rk_f32, mode error - the inference solver's
+    launch), i.e. `_Rhs` followed by `_ErrorCarryFn` as one node.  Used where the inference path fuses the record too: panels
+    beyond the ATen-order reductions' range (rk.hip: NDCN_ATEN_NORM_MAX), so both paths take identical accept / reject decisions."""
+
+    @staticmethod
+    def forward(ctx, n, op, rtol, atol, bad_out, W, b, y0, y1, *rest):
+        ks, cs = rest[:n], rest[n:]                                   # n earlier stages, n + 1 coefficients (the new K last)
+        A, no_graph, no_control = op
+        idx, kk, cc = _active(ks, cs[:n])
+        c_new = f32(float(cs[n]))
+        K, (s, bad) = hip.rhs_rk(A, y1, W, b, 'error', y0, kk, cc + [c_new], rtol=rtol, atol=atol, no_graph=no_graph, no_control=no_control)
+        bad_out.append(bad)
+        ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b, ctx.tol = n, idx, cc + [c_new], op, b is not None, (rtol, atol)
+        ctx.lazy = _LAZY_NOW[0]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(y0, y1, W, K, *kk, *cs)
+        return (K, torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1) + tuple(ks)
+
+    @staticmethod
+    def backward(ctx, g_K, g, g_y0c, g_y1c, *g_kc):
+        from ...autograd_ops import rhs_vjp
+        n, idx, cc = ctx.n, ctx.idx, ctx.cc
+        saved = ctx.saved_tensors
+        y0, y1, W, K = saved[:4]
+        kk, cs = saved[4:4 + len(idx)], saved[4 + len(idx):]
+        needs = ctx.needs_input_grad                                  # (n, op, rtol, atol, bad_out, W, b, y0, y1, k.., c..)
+        need_w, need_b, need_y0, need_y1 = needs[5], ctx.has_b and needs[6], needs[7], needs[8]
+        need_k, need_c = needs[9:9 + n], needs[9 + n:]
+        gk_all = [g_kc[j] if need_k[j] else None for j in range(n)]
+        gc_all = [None] * (n + 1)
+        gy0, gy1 = (g_y0c if need_y0 else None), (g_y1c if need_y1 else None)
+        if g is not None:
+            g_r = float(g)
+            want_dots = any(need_c[j] for j in idx) or need_c[n]
+            gy0, gy1, gk, dots = hip.error_bwd(y0, y1, list(kk) + [K], cc, ctx.tol[0], ctx.tol[1], g_r, need_y0, need_y1,
+                                               [need_k[j] for j in idx] + [True], need_dots=want_dots,
+                                               accs=[g_kc[j] if need_k[j] else None for j in idx] + [g_K],
+                                               acc_y0=g_y0c if need_y0 else None, acc_y1=g_y1c if need_y1 else None, lazy=ctx.lazy)
+            for q, j in enumerate(idx):
+                if need_k[j]:
+                    gk_all[j] = gk[q]
+                if need_c[j]:
+                    gc_all[j] = dots[q] if ctx.lazy else _scalar_like(cs[j], g_r * dots[q])
+            if need_c[n]:
+                gc_all[n] = dots[len(idx)] if ctx.lazy else _scalar_like(cs[n], g_r * dots[len(idx)])
+            g_K = gk[len(idx)]
+        gW = gb = None
+        if g_K is not None:
+            A, no_graph, no_control = ctx.op
+            gx, gW, gb = rhs_vjp(A, no_graph, no_control, y1, W, K, g_K.contiguous(), need_y1, need_w, need_b)
+            if need_y1 and gx is not None:
+                gy1 = gx if gy1 is None else hip.combine(gy1.contiguous(), [gx], [f32(1)])      # y1 is the evaluation's input AND the record's state
+        return (None, None, None, None, None, gW, gb, gy0, gy1) + tuple(gk_all) + tuple(gc_all)
+
+
 class _ErrorCarryFn(torch.autograd.Function):
     """(ratio, y0', y1', k_1', ..)"""
 
@@ -611,6 +668,10 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         from ...csr import as_csr
         fused = ((None if odefunc.no_graph else as_csr(odefunc.A), bool(odefunc.no_graph), bool(odefunc.no_control)),
                  odefunc.wt.weight, odefunc.wt.bias)
+    # the error record rides in the last evaluation's epilogue where the inference solver puts it there too (rk.hip: panels beyond
+    # the range of the ATen-order reductions), so that both paths see the same ratio
+    fuse_err = fused is not None and y0[0].numel() > int(os.environ.get('NDCN_ATEN_NORM_MAX', 1 << 18)) and \
+        os.environ.get('NDCN_GRAD_FUSED_ERROR', '1') != '0'
     _LAZY_NOW[0] = lazy
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     y_cur = y0
@@ -635,6 +696,7 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             # in front of the step's first launch, where 50 tiny host operations would sit between the accept decision's
             # read-back and the next kernel)
             coef = (lambda v: _Await.apply(v)) if lazy else (lambda v: v)
+            fused_bads, fused_ratio = [], None
             if fused is not None:
                 # stage input 1 by a combine launch; evaluations 2 .. 6 form the next stage input themselves; evaluation 7 (at
                 # y1, the next step's k1) is the plain right-hand side
@@ -646,6 +708,11 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
                         outs_ = _RhsStageCarryFn.apply(len(k[0]), op_, u_, W_, b_, yc[0], *k[0],
                                                        *[coef(dts * bb) for bb in core.DP_BETA[st_ + 1]])
                         u_, yc[0], k[0] = outs_[1], outs_[2], list(outs_[3:]) + [outs_[0]]
+                    elif fuse_err:
+                        yi = (u_,)                                    # evaluation 7 with the error record in its epilogue
+                        outs_ = _RhsErrorCarryFn.apply(len(k[0]), op_, rtols[0], atols[0], fused_bads, W_, b_, yc[0], u_, *k[0],
+                                                       *[coef(dts * c) for c in core.DP_C_ERR])
+                        fused_ratio, yc[0], yi, k[0] = outs_[1], outs_[2], (outs_[3],), list(outs_[4:]) + [outs_[0]]
                     else:
                         yi = (u_,)
                         k[0].append(func(targ((t0s + core.DP_ALPHA[5] * dts).item()), yi)[0])
@@ -666,7 +733,9 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
                 nfe += 1
             y1 = yi
             bads = []
-            if carry:
+            if fused is not None and fuse_err:
+                ratios, bads = [fused_ratio], fused_bads
+            elif carry:
                 ratios, y1c = [], []
                 for s_, (a_, b_, k_, rt_, at_) in enumerate(zip(yc, y1, k, rtols, atols)):
                     outs_ = _ErrorCarryFn.apply(len(k_), rt_, at_, bads, a_, b_, *k_, *[coef(dts * c) for c in core.DP_C_ERR])

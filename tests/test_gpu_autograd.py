@@ -218,6 +218,43 @@ def test_dopri5_backprop_carry_forms_against_fan_out_form_and_oracle(dev, ticks,
             assert rel(res[name][2][q], ref) <= 3.0 * base + 2e-2, (name, q, rel(res[name][2][q], ref), base)
 
 
+@pytest.mark.parametrize('no_control', [False, True])
+def test_dopri5_training_with_the_error_record_in_the_last_evaluation(dev, no_control):
+    """Panels beyond the ATen-order reductions' range (> 2^18 elements: where the inference solver fuses the error record into the
+    last evaluation too): _RhsErrorCarryFn - evaluation 7 and the record as one node - against the separate forms
+    (NDCN_GRAD_FUSED_ERROR=0: _Rhs + _ErrorCarryFn; NDCN_GRAD_FUSED_STAGE=0: no fused nodes at all): same accept / reject
+    sequence, trajectories and gradients equal to rounding (the record's fp64 sum is partitioned differently)."""
+    import os
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    side, H = 36, 256                                                  # 1296 x 256 = 331 776 elements
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    t = torch.tensor([0., 0.4, 0.9, 1.5]).to(dev)
+    w = torch.randn(4, side * side, H, generator=torch.Generator().manual_seed(1)).to(dev)
+    res = {}
+    for name, env in (('fused', {}), ('separate_error', {'NDCN_GRAD_FUSED_ERROR': '0'}), ('separate', {'NDCN_GRAD_FUSED_STAGE': '0'})):
+        os.environ.update(env)
+        try:
+            torch.manual_seed(0)
+            f = ODEFunc(H, graphs.to_device(op, dev), no_control=no_control).to(dev)
+            x0 = torch.rand(side * side, H, generator=torch.Generator().manual_seed(2)).to(dev).requires_grad_(True)
+            log = []
+            y = ode.odeint(f, x0, t, rtol=1e-3, atol=1e-4, method='dopri5', step_log=log)
+            (y * w).sum().backward()
+            grads = [x0.grad] + ([] if no_control else [f.wt.weight.grad, f.wt.bias.grad])
+            res[name] = (y.detach(), [r[2] for r in log if r[0] != 'nfe'], [g.clone() for g in grads])
+        finally:
+            for k in env:
+                del os.environ[k]
+    assert len(res['fused'][1]) >= 3
+    for name in ('separate_error', 'separate'):
+        assert res[name][1] == res['fused'][1]
+        assert float((res[name][0] - res['fused'][0]).abs().max()) <= 1e-5 * float(res['fused'][0].abs().max())
+        for got, ref in zip(res[name][2], res['fused'][2]):
+            assert rel(got, ref) < 2e-3, (name, rel(got, ref))
+
+
 @pytest.mark.parametrize('variant', ['default', 'no_control', 'no_graph'])
 @pytest.mark.parametrize('n_side,H', [(20, 20), (12, 256), (9, 1), (30, 64)])
 def test_native_adjoint_rhs_equals_autograd_through_the_oracle(dev, variant, n_side, H):

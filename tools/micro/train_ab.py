@@ -16,7 +16,7 @@ out['c1'] = bench_train.one_case('c1', 20, 20, 80, 'dopri5', dev, 0)['gpu_ms_per
 out['100k'] = bench_train.one_case('100k', 316, 256, 10, 'dopri5', dev, 0)['gpu_ms_per_adam_step']
 print('RESULT', json.dumps(out))
 """ % (ROOT, ROOT)
-VARIANTS = [('default', {}), ('eager scalars', {'NDCN_GRAD_LAZY': '0'}), ('unfused stages', {'NDCN_GRAD_FUSED_STAGE': '0'}),
+VARIANTS = [('default', {}), ('separate error', {'NDCN_GRAD_FUSED_ERROR': '0'}), ('eager scalars', {'NDCN_GRAD_LAZY': '0'}), ('unfused stages', {'NDCN_GRAD_FUSED_STAGE': '0'}),
             ('both off', {'NDCN_GRAD_LAZY': '0', 'NDCN_GRAD_FUSED_STAGE': '0'}), ('default again', {})]
 for name, env in VARIANTS:
     e = dict(os.environ)
