@@ -947,4 +947,7 @@ def test_dgnn_cora_accuracy_parity(dev):
     # measured on MI355X (this command, two runs each): seed 0 -> 81.9 / 83.4 %, seed 1 -> 84.5 / 83.8 %, seed 2 -> 83.9 / 83.5 %:
     # mean 83.5 % over the six runs, inside README.md:67-73's span (83.18 +/- 0.76, min 82.6, max 84.5) and above the oracle's
     # 81.6 % under torch 2.10
-    assert accs.shape == (2,) and 0.81 <= accs.min() and accs.max() <= 0.85 and 0.82 <= accs.mean() <= 0.84, accs
+    # round 4, 32 more runs of this command (tools/micro/cora_ab.py, with and without the error record in the last evaluation's
+    # epilogue: indistinguishable): mean 83.3 %, min 81.8, max 84.5, standard deviation 0.8 - a two-run mean below 81.5 % or above
+    # 85 % would be a 3-sigma event
+    assert accs.shape == (2,) and 0.805 <= accs.min() and accs.max() <= 0.855 and 0.815 <= accs.mean() <= 0.85, accs
