@@ -600,10 +600,13 @@ __global__ __launch_bounds__(256) void sweep_eye_kernel(int64_t n, int32_t *rowp
 }
 
 // Worth it when the sweep moves clearly fewer rows of X through the fabric than the gather: 8 XCDs x n_cols rows per pass
-// against nnz (measured on the 10^5-node G(n,p) graph of mean degree 40: 0.8 M against 4.0 M rows, 0.20 against 0.56 ms).
-// And only when the panel is larger than what an XCD's L2 holds anyway (8 192 rows of 1 KiB = 2 x 4 MiB).
+// against nnz.  Measured on G(n,p) graphs of mean degree 40 (tools/micro/sweep_sizes.py, profiles/r04i_sweep_sizes.txt):
+// sweep = 3.8e-8 ms per entry + 7.8e-8 ms per row an XCD pulls in, row gather = 1.44e-7 ms per entry - break-even at
+// nnz = 0.73 x (8 passes n_cols); n = 10^5: 0.22 against 0.58 ms, 3 x 10^5 (3 passes): 1.06 against 1.78, 5 x 10^5: 2.19 against 2.94.
+// The right-hand side pays one more write and read of S for the sweep, so the plan is taken from 1.5 x upwards, and only
+// when the panel is larger than what an XCD's L2 holds anyway (8 192 rows of 1 KiB = 2 x 4 MiB).
 bool sweep_pays(const ndcn_csr &A, int passes) {
-    return A.n_cols >= 8192 && (double)A.nnz >= 2.0 * (double)passes * kXcds * (double)A.n_cols;
+    return A.n_cols >= 8192 && (double)A.nnz >= 1.5 * (double)passes * kXcds * (double)A.n_cols;
 }
 
 int build_sweep_plan(ndcn_csr_handle *h, bool external_scratch, hipStream_t st) {

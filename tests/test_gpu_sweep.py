@@ -232,7 +232,7 @@ def test_training_through_a_swept_operator(dev):
 
 
 def test_sweep_is_taken_where_the_fetch_arithmetic_says_it_pays(dev):
-    """ndcn_csr_create's own decision (include/ndcn_hip.h): n_cols >= 8192 and nnz >= 2 * passes * 8 * n_cols, no group-record
+    """ndcn_csr_create's own decision (include/ndcn_hip.h): n_cols >= 8192 and nnz >= 1.5 * passes * 8 * n_cols, no group-record
     plan, a whole operator - and odeint on such an operator runs its solver through the sweep."""
     from ndcn_amd import CsrOperator, graphs, _lib
     from ndcn_amd import torchdiffeq as ode
