@@ -155,7 +155,10 @@ constexpr int kF3EpiKernargOffset = (int)((sizeof(F3Args) + 7) / 8 * 8);       /
 // formed where it is needed instead of by a kernel of its own (3 panels): every wave fetches the Xadd rows of the union rows
 // it stages, a step ahead like them, and adds them into its LDS rows - one product, one sum per element, the roundings of
 // combine_kernel - before the barrier that hands the group to the fold.  One more gather (1.07 panels) instead of 3 panels.
-template <bool HALO, int MODE, int NP, bool XADD = false>
+// NT: the epilogue's stores carry the non-temporal hint - right for panels far beyond the 256 MiB Infinity Cache (the metric's 1 GB
+// panels: 8.35 against 8.58 ms per step without it), wrong for panels that live in it and are read right back by the next launch
+// (BASELINE config 2, 102 MB: 1.323 against 1.290 ms per RK4 step); the launcher decides by the panel's size
+template <bool HALO, int MODE, int NP, bool XADD = false, bool NT = true>
 __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
     static_assert(!(XADD && HALO), "the halo rows of Xadd are not exchanged");
     (void)epi_by_kernarg_only;
@@ -425,7 +428,8 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
     };
     auto stp = [&](float *base /*uniform*/, int voff, f32x4 v) {
         // (s_nop: the data registers of a 16-byte store must not be written in the next wait state)
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+        if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
     };
     // RK epilogue of one K row (as rhs_fused2.hip: epi_finish)
     auto epilogue = [&](int row, f32x4 kn, const Panels &p) {
@@ -633,9 +637,9 @@ int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n
     return ((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) ? 1 : 0;
 }
 
-template <bool HALO, int MODE, int NP, bool XADD = false>
+template <bool HALO, int MODE, int NP, bool XADD = false, bool NT = true>
 static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st) {
-    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XADD>;
+    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XADD, NT>;
     static bool attr_set = false;
     if (!attr_set) {
         NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
@@ -687,7 +691,13 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (a.Xadd) bytes += P;                                          // the second gather
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
     int rc = NDCN_OK;
-#define NDCN_F3(HALO_, MODE_, NP_) rc = launch_f3<HALO_, MODE_, NP_>(a, e, grid, st)
+    // panels that fit the Infinity Cache with room for the next launch's (<= 128 MiB): plain stores (operators without a halo panel)
+    const bool cached = !Xh && (int64_t)A->n_rows * 1024 <= (128ll << 20);
+#define NDCN_F3(HALO_, MODE_, NP_)                                                        \
+    do {                                                                                  \
+        if (!HALO_ && cached) rc = launch_f3<false, MODE_, NP_, false, false>(a, e, grid, st); \
+        else rc = launch_f3<HALO_, MODE_, NP_>(a, e, grid, st);                           \
+    } while (0)
 #define NDCN_F3_DISPATCH(HALO_)                                       \
     do {                                                              \
         if (mode == F3_PLAIN) NDCN_F3(HALO_, F3_PLAIN, 0);            \
