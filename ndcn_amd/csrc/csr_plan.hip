@@ -681,10 +681,11 @@ int build_sweep_plan(ndcn_csr_handle *h, bool external_scratch, hipStream_t st) 
     A.sweep_passes = passes;
     A.sweep_rpw = (int32_t)((per_xcd + kSweepSlots - 1) / kSweepSlots);
     A.sweep_rows_per_pass = rpp;
-    // column blocks of 1024 rows of X (1 MiB) and a window of 3: every wave of an XCD within the last 3 MiB of its 4 MiB L2
-    // (tools/micro/sweep_lab.hip: 0.200 ms; 2048 x 2: 0.196; 512 x 6: 0.227; no synchronisation: 0.341)
-    A.sweep_logb = 10;
-    A.sweep_window = 3;
+    // column blocks of 2048 rows of X (2 MiB) and a window of 2: every wave of an XCD within two blocks of the slowest
+    // (tools/micro/sweep_lab.hip: 0.196 ms; 1024 x 3: 0.200; 512 x 6: 0.227; no synchronisation: 0.341 - and on BASELINE config 2's RK4
+    // step, alternating runs in one box: 1.258 ms against 1.279 for 1024 x 3, 1.262 for 1024 x 4, 1.38 for 1024 x 2)
+    A.sweep_logb = 11;
+    A.sweep_window = 2;
     A.sweep_ent = reinterpret_cast<const uint32_t *>(ent);
     A.sweep_slab = slab;
     A.sweep_prog = prog;
