@@ -30,8 +30,9 @@ struct BwdTerms {
 };
 
 typedef float bw_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bw_f4 ld4(const float *p, int64_t i) { return reinterpret_cast<const bw_f4 *>(p)[i]; }
-__device__ __forceinline__ void st4(float *p, int64_t i, bw_f4 v) { reinterpret_cast<bw_f4 *>(p)[i] = v; }
+// (non-temporal: a backward pass streams dozens of panels once each - 100k-node Adam step 33.6 -> 32.5 ms in alternating runs)
+__device__ __forceinline__ bw_f4 ld4(const float *p, int64_t i) { return __builtin_nontemporal_load(reinterpret_cast<const bw_f4 *>(p) + i); }
+__device__ __forceinline__ void st4(float *p, int64_t i, bw_f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<bw_f4 *>(p) + i); }
 
 // per-block sums of kBwdDots doubles -> partial[block][kBwdDots]
 __device__ __forceinline__ void block_store_dots(double (&d)[kBwdDots], double *__restrict__ partial) {
