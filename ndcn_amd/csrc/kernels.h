@@ -41,7 +41,7 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
                hipStream_t st, const RkOpt *opt = nullptr);
 int rhs_fused_supported(int H, uint32_t flags);
 int pack_weight_256(const float *W, float *Wp, hipStream_t st);
-int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st);   // planes of W^T + scales: kS16Bytes + 8 bytes
+int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st);   // planes of W^T + per-row unscale factors: kS16Bytes + kS16TailBytes
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);
 int rhs_fused2_variant(int mode, int n_prev);
 int64_t rhs_fused2_partials_bytes();

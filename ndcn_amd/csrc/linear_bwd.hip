@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
     __shared__ float s_sc[kGsRows], s_un[kGsRows];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * kGsRows;
-    const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Wq) + kS16Bytes)[1];
+    const float *w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Wq) + kS16Bytes);     // [256]: per output column
     // eight rows' requests fly together, unconditionally (rows past n re-read row n - 1 and are zeroed afterwards)
 #pragma unroll
     for (int i0 = 0; i0 < 16; i0 += 8) {
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
             s16_scale_bits(s16_wave_umax(s16_row_max_bits(v)), sb, ub);
             if (lane == 0) {
                 s_sc[r] = __builtin_bit_cast(float, sb);
-                s_un[r] = __builtin_bit_cast(float, ub) * w_unscale;
+                s_un[r] = __builtin_bit_cast(float, ub);
             }
         }
     }
@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
                 for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, ks + kRingQ, pl);
         }
     }
-    // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31], multiplied back by 1 / (row scale * weight scale)
+    // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31], multiplied back by 1 / (column n's weight-row scale), then 1 / (row scale)
+    const float wu[2] = {w_unscale[64 * wave + (lane & 31)], w_unscale[64 * wave + 32 + (lane & 31)]};
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
             if (gr >= n) continue;
             const float un = s_un[m];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) gS[gr * 256 + 64 * wave + 32 * jj + (lane & 31)] = acc[mt][jj][r] * un;
+            for (int jj = 0; jj < 2; ++jj) gS[gr * 256 + 64 * wave + 32 * jj + (lane & 31)] = (acc[mt][jj][r] * wu[jj]) * un;
         }
 }
 
@@ -489,7 +490,7 @@ static int64_t wgrad_work_bytes(int64_t n, int Hi, int Ho) {
 
 // partial gW / gb blocks, then (Hi = Ho = 256) the packed fp16 planes of W^T for the gS product
 int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho) {
-    return wgrad_work_bytes(n, Hi, Ho) + ((Hi == 256 && Ho == 256) ? (int64_t)kS16Bytes + 256 : 0);
+    return wgrad_work_bytes(n, Hi, Ho) + ((Hi == 256 && Ho == 256) ? (int64_t)kS16Bytes + kS16TailBytes : 0);
 }
 
 int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb, void *work,

@@ -203,47 +203,43 @@ int rhs_fused_supported(int H, uint32_t flags) {
     return H == kH ? 1 : 0;
 }
 
-// packed fp32 weights (256 KiB) followed by the split fp16 weights (two planes, 256 KiB, + their scale pair; sized for three)
+// packed fp32 weights (256 KiB) followed by the split fp16 weights (two planes, 256 KiB, + 256 unscale factors; sized for three planes)
 int64_t rhs_fused_work_bytes(int H) { return (int64_t)H * H * sizeof(float) + (int64_t)H * H * 3 * 2; }
 
-// Split weights for the fp16 consumers (split16.h): one global power-of-two scale that brings max |W| into [0.5, 1), then
-// every scaled weight as two fp16 pieces (round to nearest, then the exact remainder rounded to nearest), MFMA 32x32x16
-// B-operand order:  Wh[(((j * 16 + s) * 2 + p) * 64 + lane) * 8 + e] = piece p of W[32 j + (lane & 31)][16 s + 8 (lane >> 5) + e];
-// behind the planes: float {scale, 1 / scale}.
-// max |W| over the 256 x 256 weights as a bit pattern, by every thread of a 256-thread block (each block of the pack kernel
-// forms it for itself: 256 KiB out of L2, cheaper than a launch of its own in front)
-__device__ __forceinline__ unsigned weight_max_bits_256(const float *__restrict__ W) {
-    __shared__ unsigned smax[256];
-    unsigned m = 0;
-    for (int i = threadIdx.x; i < kH * kH / 4; i += 256) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(W)[i];
-        const unsigned b = s16_row_max_bits(v);
-        m = b > m ? b : m;
-    }
-    smax[threadIdx.x] = m;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (threadIdx.x < w) smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + w] ? smax[threadIdx.x] : smax[threadIdx.x + w];
-        __syncthreads();
-    }
-    return smax[0];
-}
-
-// TRANSPOSED: the planes of W^T (the B operand of gS = gZ W, linear_bwd.hip)
+// Split weights for the fp16 consumers (split16.h): every row n of the B operand (W[n][:]; TRANSPOSED: W[:][n]) gets a power-of-two
+// scale of its own that brings its largest magnitude into [2^14, 2^15), then every scaled weight becomes two fp16 pieces (round to
+// nearest, then the exact remainder rounded to nearest), MFMA 32x32x16 B-operand order:
+//   Wh[(((j * 16 + s) * 2 + p) * 64 + lane) * 8 + e] = piece p of B[32 j + (lane & 31)][16 s + 8 (lane >> 5) + e];
+// behind the planes: float unscale[256] = 1 / scale of row n (the consumers multiply output column n back by it).
+// A block packs four k-steps of ONE n-tile j: it needs the maxima of rows 32 j .. 32 j + 31 only (8 threads per row, 32 values each).
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ Wh,
                                                                   float *__restrict__ tail) {
-    unsigned sb, ub;
-    s16_scale_bits(weight_max_bits_256(W), sb, ub);
-    const float sc = __builtin_bit_cast(float, sb);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        tail[0] = sc;
-        tail[1] = __builtin_bit_cast(float, ub);
-    }
+    __shared__ float s_scale[32];
     const int idx = blockIdx.x * 256 + threadIdx.x;            // one (j, s, lane): 8 * 16 * 64 = 8192
-    if (idx >= 8 * 16 * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, j = idx >> 10;
+    {
+        const int r = threadIdx.x >> 3, part = threadIdx.x & 7, n = 32 * j + r;
+        unsigned m = 0;
+        for (int k = 32 * part; k < 32 * part + 32; ++k) {
+            const unsigned b = __builtin_bit_cast(unsigned, TRANSPOSED ? W[k * kH + n] : W[n * kH + k]) & 0x7fffffffu;
+            m = b > m ? b : m;
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+            m = o > m ? o : m;
+        }
+        if (part == 0) {
+            unsigned sb, ub;
+            s16_scale_bits(m, sb, ub);
+            s_scale[r] = __builtin_bit_cast(float, sb);
+            if ((blockIdx.x & 3) == 0) tail[n] = __builtin_bit_cast(float, ub);
+        }
+    }
+    __syncthreads();
     const int row = 32 * j + (lane & 31), col = 16 * s + 8 * (lane >> 5);
+    const float sc = s_scale[lane & 31];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float w = (TRANSPOSED ? W[(col + e) * kH + row] : W[row * kH + col + e]) * sc;
@@ -262,7 +258,7 @@ int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
     return NDCN_OK;
 }
 
-// Wq <- the fp16 planes of W^T + {scale, 1 / scale} (kS16Bytes + 8 bytes)
+// Wq <- the fp16 planes of W^T + the 256 per-row unscale factors (kS16Bytes + kS16TailBytes)
 int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st) {
     float *tail = reinterpret_cast<float *>(static_cast<char *>(Wq) + kS16Bytes);
     hipLaunchKernelGGL(pack_weight_256_f16_kernel<true>, dim3(32), dim3(256), 0, st, W, static_cast<_Float16 *>(Wq), tail);

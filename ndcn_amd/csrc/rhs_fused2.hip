@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     __shared__ __attribute__((aligned(16))) float s_tile[2 * kTileFloats2];
     // per S-tile row: the power-of-two scale of the fp16 split (split16.h) and 1 / (row scale * weight scale)
     __shared__ __attribute__((aligned(16))) float s_sc[2 * kTile2], s_un[2 * kTile2];
-    const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Wq) + kS16Bytes)[1];
+    const float *w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Wq) + kS16Bytes);   // [256]: per output column
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
                 if (lane == 0) {
                     const int slot = (buf == s_tile ? 0 : kTile2) + lr;
                     s_sc[slot] = __builtin_bit_cast(float, sb);
-                    s_un[slot] = __builtin_bit_cast(float, ub) * w_unscale;
+                    s_un[slot] = __builtin_bit_cast(float, ub);
                 }
             }
         }
@@ -462,8 +462,16 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     };
 #endif
     auto dump_tile = [&](float *dst, int tb) {
-        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; with the split product row m is multiplied back by
-        // 1 / (row scale * weight scale) (16 rows per lane and m-tile: four 16-byte LDS reads)
+        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; with the split product column n is multiplied back by
+        // 1 / (its weight row's scale), then row m by 1 / (row scale) (16 rows per lane and m-tile: four 16-byte LDS reads)
+#if NDCN_SPLIT
+        // (a pass of its own: one more live register inside the loop below costs the kernel its third wave per SIMD)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float wu = w_unscale[64 * wave + 32 * n + (lane & 31)];
+            if (n == 0) { acc00 *= wu; acc10 *= wu; } else { acc01 *= wu; acc11 *= wu; }
+        }
+#endif
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 un[4];
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float o = (mt == 0 ? (n == 0 ? acc00[r] : acc01[r]) : (n == 0 ? acc10[r] : acc11[r])) * un[r >> 2][r & 3] + bv;
+                    float o = ((mt == 0 ? (n == 0 ? acc00[r] : acc01[r]) : (n == 0 ? acc10[r] : acc11[r]))) * un[r >> 2][r & 3] + bv;
                     if (a.relu) o = relu_nan(o);
                     dst[m * kLd2 + col] = o;
                 }

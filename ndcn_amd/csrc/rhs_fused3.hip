@@ -83,8 +83,9 @@ constexpr unsigned kF3OffS = kF3OffRec + kF3NRec * kF3RecW * 1024;
 constexpr unsigned kF3OffRow = kF3OffS + 2 * kF3Tile * kF3Ld * 4;
 constexpr unsigned kF3OffSync = kF3OffRow + 2 * kF3Tile * 4;
 constexpr unsigned kF3OffBias = kF3OffSync + 16;
-constexpr unsigned kF3OffUnscale = kF3OffBias + 256 * 4;      // per S-tile row: 1 / (row scale * weight scale) of the fp16 split (split16.h)
-constexpr unsigned kF3Lds = kF3OffUnscale + 2 * kF3Tile * 4;
+constexpr unsigned kF3OffUnscale = kF3OffBias + 256 * 4;      // per S-tile row: 1 / (row scale) of the fp16 split (split16.h)
+constexpr unsigned kF3OffWun = kF3OffUnscale + 2 * kF3Tile * 4;   // per output column: 1 / (scale of the column's weight row)
+constexpr unsigned kF3Lds = kF3OffWun + 256 * 4;
 
 // workgroup barrier: this wave's LDS traffic has been performed first, and hipcc moves no memory access across it
 __device__ __forceinline__ void f3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
     int *s_rowid = reinterpret_cast<int *>(lds) + kF3OffRow / 4;
     unsigned *s_sync = reinterpret_cast<unsigned *>(lds) + kF3OffSync / 4;
     float *s_bias = lds + kF3OffBias / 4;          // a fetch issued from inside the MFMA loop queues behind the producers' requests
-    float *s_unscale = lds + kF3OffUnscale / 4;     // per S-tile row: 1 / (row scale * weight scale) of the fp16 split
+    float *s_unscale = lds + kF3OffUnscale / 4;     // per S-tile row: 1 / (row scale) of the fp16 split
+    float *s_wun = lds + kF3OffWun / 4;             // per output column: 1 / (weight-row scale)
 
     // groups of this workgroup: XCD x owns a contiguous chunk, its workgroups take the chunk's groups round-robin
     const int xcd = blockIdx.x % kXcds, wg = blockIdx.x / kXcds, wpx = gridDim.x / kXcds;
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
             }
         };
         auto dump_tile = [&](float *dst, int tb) {
-            // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; row m is multiplied back by 1 / (row scale * weight scale)
+            // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]; multiplied back by 1 / (weight-row scale of column n), then by
+            // 1 / (scale of S row m) - both exact; in this order no intermediate leaves the fp32 range for any row the scale clamps
             int ln = lane;
             asm volatile("" : "+v"(ln));
 #pragma unroll
@@ -291,11 +294,11 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
 #pragma unroll
                 for (int jj = 0; jj < kNT; ++jj) {
                     const int col = 32 * (kNT * mw + jj) + (ln & 31);
-                    const float bv = s_bias[col];
+                    const float bv = s_bias[col], wu = s_wun[col];
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int m = rr + 8 * q + 4 * (ln >> 5);
-                        float o = acc[jj][4 * q + rr] * unp[rr] + bv;
+                        float o = (acc[jj][4 * q + rr] * wu) * unp[rr] + bv;
                         if (a.relu) o = relu_nan(o);
                         dst[m * kF3Ld + col] = o;
                     }
@@ -364,8 +367,8 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
     if (lane < 2 * kF3Tile / kF3WP) s_rowid[pw * (2 * kF3Tile / kF3WP) + lane] = -1;     // 64 slots
     if (pw == 0 && lane == 0) *s_sync = 0u;
     if (pw < 4) s_bias[64 * pw + lane] = a.bias ? a.bias[64 * pw + lane] : 0.f;
-    // 1 / (global weight scale), written behind the packed planes by pack_weight_256 (split16.h)
-    const float w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Wq) + kS16Bytes)[1];
+    // 1 / (scale of weight row n), written behind the packed planes by pack_weight_256 (split16.h)
+    if (pw < 4) s_wun[64 * pw + lane] = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.Wq) + kS16Bytes)[64 * pw + lane];
 
     auto dma_rec = [&](int it) {
         if (pw < kF3RecW && it < my) {
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
                 char *hrow = reinterpret_cast<char *>(s_tiles + sl * kF3Ld) + 8 * lane;
                 *reinterpret_cast<u32x2_s16 *>(hrow) = h0;
                 *reinterpret_cast<u32x2_s16 *>(hrow + 512) = h1;
-                if (lane == 0) s_unscale[sl] = __builtin_bit_cast(float, ub) * w_unscale;
+                if (lane == 0) s_unscale[sl] = __builtin_bit_cast(float, ub);
             }
             s_rowid[sl] = row;
             // the panels of this slot in the NEXT step (its K rows were staged 3 steps ago)

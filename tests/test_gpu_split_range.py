@@ -1,0 +1,184 @@
+"""The H = 256 dense product of the fused right-hand sides (two fp16 pieces per operand, split16.h) on operands that LEAVE the
+well-conditioned regime: one dominant weight, one dominant output row, log-normal / log-uniform weights, an S row with one channel
+2^12 above the rest against small weights, a reference-style checkpoint through load_state_dict.  The reference's Linear is a plain
+fp32 nn.Linear (neural_dynamics.py:33): a drop-in that loads its state_dicts must not lose bits because of ONE outlier.
+
+Bound asserted per output (the one _sampled_rhs_check of test_gpu_odeint.py states):  |got - fp64| <= 2e-6 * sum of the magnitudes
+that enter the output; plus trajectory L1 < 1e-4 against the oracle over a dopri5 solve with identical accept / reject decisions.
+Every kernel that consumes the split planes is driven: rhs_fused3 (lattice plan), rhs_fused2 (no plan), the column sweep's dense
+stage (rhs_fused3 on the identity operator), linear_gs_256_split (the VJP's gS = gZ W)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ndcn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def _default_init(seed=0):
+    torch.manual_seed(seed)
+    lin = torch.nn.Linear(H, H)
+    return lin.weight.detach().clone(), lin.bias.detach().clone()
+
+
+def _weights(kind):
+    """(W, b, X column scale): the operand families of the round-4 review"""
+    W, b = _default_init()
+    g = torch.Generator().manual_seed(11)
+    xs = None
+    if kind == 'default':
+        pass
+    elif kind.startswith('one_weight_2^'):
+        W[17, 33] *= 2.0 ** int(kind.split('^')[1])
+    elif kind.startswith('one_row_2^'):
+        W[17, :] *= 2.0 ** int(kind.split('^')[1])
+    elif kind == 'lognormal':
+        W = torch.exp(torch.randn(H, H, generator=g) * np.log(10.0)) * 1e-3 * torch.sign(torch.rand(H, H, generator=g) - 0.5)
+    elif kind == 'loguniform_6_decades':
+        W = 10.0 ** (torch.rand(H, H, generator=g) * 6 - 6) * torch.sign(torch.rand(H, H, generator=g) - 0.5)
+    elif kind == 'channel_2^12_small_weights':                      # S channel 5 is 2^12 above the rest, its weights 2^-12 below
+        xs = torch.ones(H)
+        xs[5] = 2.0 ** 12
+        W[:, 5] *= 2.0 ** -12
+    elif kind == 'channel_2^12':
+        xs = torch.ones(H)
+        xs[5] = 2.0 ** 12
+    else:
+        raise KeyError(kind)
+    return W.contiguous(), b, xs
+
+
+KINDS = ['default', 'one_weight_2^8', 'one_weight_2^12', 'one_weight_2^16', 'one_row_2^12', 'lognormal', 'loguniform_6_decades',
+         'channel_2^12_small_weights', 'channel_2^12']
+
+
+def _operator(which, dev):
+    from ndcn_amd import graphs
+    if which == 'fused3':
+        L = graphs.normalized_laplacian(graphs.grid_8_neighbor(48))
+    elif which == 'fused2':
+        L = graphs.normalized_laplacian(graphs.make_graph('power_law', 3000, seed=3))
+    else:                                                            # the column sweep: G(n,p), n_cols >= 8192
+        L = graphs.normalized_laplacian(graphs.make_graph('random', 9000, seed=1))
+    return L, graphs.to_device(L, dev)
+
+
+def _want_path(which):
+    from ndcn_amd import _lib
+    return {'fused3': _lib.PATH_FUSED3, 'fused2': _lib.PATH_FUSED2, 'sweep': _lib.PATH_FUSED3 | _lib.PATH_SWEEP}[which]
+
+
+def _rhs_bound_check(L, A, W, b, X, dev, want_path):
+    from ndcn_amd import hip, _lib
+    got = hip.rhs(A, X.to(dev), W.to(dev), b.to(dev)).cpu().double().numpy()
+    path = int(_lib.load().ndcn_debug_last_rhs_path())
+    assert path & ~(_lib.PATH_HUB) == want_path, path
+    Xh = X.numpy()
+    S = orc.spmm_f64(L.indptr, L.indices, L.data, Xh)
+    Wd, bd = W.double().numpy(), b.double().numpy()
+    ref = np.maximum(S @ Wd.T + bd, 0)
+    absS = orc.spmm_f64(L.indptr, L.indices, np.abs(L.data), np.abs(Xh))
+    mag = absS @ np.abs(Wd).T + np.abs(bd)
+    ratio = float((np.abs(got - ref) / (mag + 1e-300)).max())
+    assert (np.abs(got - ref) <= 2e-6 * mag + 1e-30).all(), ratio
+    return ratio
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('which', ['fused3', 'fused2', 'sweep'])
+def test_rhs_h256_outlier_operands_within_the_fp32_grade_bound(dev, which, kind):
+    L, A = _operator(which, dev)
+    W, b, xs = _weights(kind)
+    X = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(5))
+    if xs is not None:
+        X = (X * xs).contiguous()
+    _rhs_bound_check(L, A, W, b, X, dev, _want_path(which))
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_linear_gs_256_split_outlier_operands(dev, kind):
+    """gS = (g * [Y > 0]) W on the planes of W^T (linear_bwd.hip): per output |err| <= 2e-6 sum_o |gZ_o| |W_oi|."""
+    from ndcn_amd import hip
+    W, b, xs = _weights(kind)
+    n = 1000
+    gen = torch.Generator().manual_seed(6)
+    g = torch.randn(n, H, generator=gen)
+    if xs is not None:
+        g = (g * xs).contiguous()                                   # a dominant gradient channel against a small weight ROW of W^T
+        if kind == 'channel_2^12_small_weights':
+            W, b, _ = _weights('default')
+            W[5, :] *= 2.0 ** -12
+    Y = torch.rand(n, H, generator=gen) - 0.3
+    gS, _, _ = hip.linear_bwd(g.to(dev), W.to(dev), S=None, Y=Y.to(dev), need_gS=True, need_gW=False, need_gb=False)
+    gZ = (g * (Y > 0)).double().numpy()
+    ref = gZ @ W.double().numpy()
+    mag = np.abs(gZ) @ np.abs(W.double().numpy())
+    got = gS.cpu().double().numpy()
+    assert (np.abs(got - ref) <= 2e-6 * mag + 1e-30).all(), float((np.abs(got - ref) / (mag + 1e-300)).max())
+
+
+@pytest.mark.parametrize('kind', ['one_weight_2^8', 'one_weight_2^12', 'lognormal', 'channel_2^12_small_weights'])
+@pytest.mark.parametrize('which', ['fused3', 'fused2'])
+def test_dopri5_trajectory_with_outlier_checkpoint_matches_the_oracle(dev, which, kind):
+    """A reference-style checkpoint (state_dict keys of neural_dynamics.py:16: wt.weight / wt.bias) with outlier weights, loaded
+    through load_state_dict, solved with dopri5: trajectory L1 < 1e-4 of its scale and the oracle's accept / reject sequence."""
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    L, A = _operator(which, dev)
+    W, b, xs = _weights(kind)
+    # keep the dynamics tame: the outlier stays an outlier, the spectral size of W stays O(1)
+    W = W / max(1.0, float(torch.linalg.matrix_norm(W, 2)))
+    f = ODEFunc(H, A).to(dev).eval()
+    f.load_state_dict({'wt.weight': W, 'wt.bias': b})
+    x0 = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(8))
+    if xs is not None:
+        x0 = (x0 * xs).contiguous()
+    t = torch.tensor([0., 0.5, 1.0])
+    log, lo = [], []
+    with torch.no_grad():
+        y = ode.odeint(f, x0.to(dev), t.to(dev), rtol=.01, atol=.001, method='dopri5', step_log=log)
+    fo = orc.OracleODEFunc(orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape), W, b)
+    ref = orc.odeint(fo, x0, t, rtol=.01, atol=.001, method='dopri5', step_log=lo)
+    assert [r[2] for r in log[:-1]] == [r[2] for r in lo]
+    err = (y.cpu() - ref).abs().double()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float(err.mean()) < 1e-4 * scale, float(err.mean()) / scale
+    # the oracle's own fp32 chain is no closer to fp64 than 1e-6 of the magnitudes per evaluation: a max-abs bound at 1e-3 of scale
+    assert float(err.max()) < 1e-3 * scale, float(err.max()) / scale
+
+
+def test_weight_row_scales_are_powers_of_two_per_output_row(dev):
+    """The pack kernel's tail: one unscale factor per output row, a power of two with max |W[n]| / unscale in [2^14, 2^15)."""
+    from ndcn_amd import _lib
+    from ndcn_amd.ops import ptr, stream_ptr
+    lib = _lib.load()
+    W, b, _ = _weights('one_row_2^12')
+    W[40, :] = 0.0                                                   # an all-zero row keeps a finite scale
+    Wd = W.to(dev)
+    wbytes = int(lib.ndcn_rhs_work_bytes(64, H, _lib.F_RELU))
+    assert wbytes >= H * H * 4 + 2 * H * H * 2 + H * 4
+    work = torch.zeros(wbytes, dtype=torch.uint8, device=dev)
+    from ndcn_amd import graphs, hip
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(16))
+    A = graphs.to_device(L, dev)
+    A.ensure_plans(H)
+    X = torch.rand(256, H, device=dev)
+    Y = torch.empty_like(X)
+    with torch.cuda.device(dev):
+        rc = lib.ndcn_rhs_f32(A.view_ref(), ptr(X), None, 256, ptr(Wd), ptr(b.to(dev)), ptr(Y), ptr(work), H, _lib.F_RELU, stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    tail = work[H * H * 4 + 2 * H * H * 2:][:H * 4].view(torch.float32).cpu().numpy().astype(np.float64)
+    mant, _ = np.frexp(tail)
+    assert (mant == 0.5).all()                                       # exact powers of two
+    scaled = W.abs().max(dim=1).values.double().numpy() / tail
+    nz = scaled > 0
+    assert nz.sum() == H - 1 and (scaled[nz] >= 2.0 ** 14).all() and (scaled[nz] < 2.0 ** 15).all()
