@@ -82,17 +82,25 @@ class _PackedWeights:
     scratch at every call (two small launches in front of the big one).  A solver calls them thousands of times with
     the same weights: the scratch is kept per weight TENSOR OBJECT (weak reference: a new tensor that happens to reuse the
     address or the id of a dead one never hits), version counter (in-place updates - optimizers, load_state_dict - move
-    it) and stream; later calls pass NDCN_F_PACKED.
+    it), stream and EPOCH; later calls pass NDCN_F_PACKED.
 
-    What the key cannot see: writes that bypass the tensor's version counter - `W.data.copy_()`, `dist.broadcast(W.data)`,
-    raw-pointer writes through the C ABI.  After such a write call `ndcn_amd.ops.invalidate_packed_weights()` (or run with
-    NDCN_PACK_CACHE=0, which re-packs at every call: two small launches, ~10 us)."""
+    Epoch (round 5): `W.data.add_()`, `W.data.copy_()`, `dist.broadcast(W.data)` and raw-pointer writes bypass the version
+    counter - hand-written SGD / EMA / clipping code does exactly that between two solves.  Every `odeint` / `odeint_adjoint`
+    call therefore starts a new epoch (`new_epoch`): the first use of a weight inside it re-packs (two small launches, ~10 us
+    per solve), the thousands that follow hit.  What is left to the caller: such a write BETWEEN two direct `hip.rhs` calls
+    outside any solve (or in the middle of one - which no autograd graph survives either): call
+    `ndcn_amd.ops.invalidate_packed_weights()` after it, or run with NDCN_PACK_CACHE=0 (re-pack at every call)."""
     _cache = {}
+    _epoch = 0
     enabled = os.environ.get('NDCN_PACK_CACHE', '1') != '0'
 
     @classmethod
     def invalidate(cls):
         cls._cache.clear()
+
+    @classmethod
+    def new_epoch(cls):
+        cls._epoch += 1
 
     @classmethod
     def get(cls, W, nbytes, tag='fwd'):
@@ -101,13 +109,16 @@ class _PackedWeights:
         key = (id(W), torch.cuda.current_stream(W.device).cuda_stream, nbytes, tag)
         hit = cls._cache.get(key)
         if hit is not None and hit[0]() is W and hit[1] == W._version and hit[2] == W.data_ptr():
-            return hit[3], _lib.F_PACKED
+            if hit[4] == cls._epoch:
+                return hit[3], _lib.F_PACKED
+            cls._cache[key] = hit[:4] + (cls._epoch,)             # same buffer, packed again by this call (stream-ordered)
+            return hit[3], 0
         if len(cls._cache) >= 8:
             dead = [k for k, v in cls._cache.items() if v[0]() is None]
             for k in dead or [next(iter(cls._cache))]:
                 cls._cache.pop(k)
         work = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
-        cls._cache[key] = (weakref.ref(W), W._version, W.data_ptr(), work)
+        cls._cache[key] = (weakref.ref(W), W._version, W.data_ptr(), work, cls._epoch)
         return work, 0
 
 
@@ -749,6 +760,12 @@ class HipOps:
 
 
 hip = HipOps()
+
+
+def new_solve_epoch():
+    """Called at the top of every odeint / odeint_adjoint: packed weight images of earlier solves are re-validated by re-packing
+    (see _PackedWeights)."""
+    _PackedWeights.new_epoch()
 
 
 def invalidate_packed_weights():

@@ -15,7 +15,7 @@ import os
 import torch
 
 from ... import _lib
-from ...ops import hip
+from ...ops import hip, new_solve_epoch
 from . import core
 
 SOLVERS = {m: m for m in core.METHODS}      # the in-scope subset of odeint.py:8-17
@@ -72,6 +72,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
     user_func = func
     t_user = t
     tensor_input, func, y0, t = core.check_inputs(func, y0, t)
+    new_solve_epoch()                            # weights written through `.data` since the last solve are packed afresh
 
     if options is None:
         options = {}

@@ -1083,6 +1083,44 @@ def test_packed_weight_cache_follows_weight_updates(dev):
         assert float((k3 - torch.relu(hip.spmm(A, X) @ W.t())).abs().max()) < 2e-4 and not torch.equal(k3, k2)
 
 
+def test_packed_weight_cache_sees_data_writes_between_solves(dev):
+    """Round-4 advisor: `p.data.add_()` (hand-written SGD, EMA, clipping) does not move the version counter, and the training path
+    hands the live Parameter to the cache.  Every odeint call opens a new epoch of the cache: the solve after such a write - forward
+    values AND gradients - equals a fresh module holding the same numbers."""
+    from ndcn_amd import CsrOperator, graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    H = 256
+    A = CsrOperator.from_scipy(graphs.normalized_laplacian(graphs.grid_8_neighbor(24)), dev)
+    torch.manual_seed(3)
+    f = ODEFunc(H, A).to(dev)
+    x0 = torch.rand(576, H, device=dev)
+    t = torch.tensor([0., 0.3, 0.6], device=dev)
+
+    def solve(func, grad):
+        if not grad:
+            with torch.no_grad():
+                return ode.odeint(lambda tt, y: func(tt, y), x0, t, method='rk4'), None     # python-stepped path: hip.rhs per stage
+        for p in func.parameters():
+            p.grad = None
+        y = ode.odeint(func, x0, t, rtol=1e-3, atol=1e-4, method='dopri5')
+        y[-1].square().sum().backward()
+        return y.detach(), [p.grad.clone() for p in func.parameters()]
+
+    for grad in (False, True):
+        solve(f, grad)                                               # packs W (and, with grad, the planes of W^T)
+        with torch.no_grad():
+            f.wt.weight.data.mul_(0.5)                               # bypasses the version counter
+            f.wt.weight.data[7, 9] += 0.25
+        got, gg = solve(f, grad)
+        fresh = ODEFunc(H, A).to(dev)
+        fresh.load_state_dict(f.state_dict())
+        want, gw = solve(fresh, grad)
+        assert torch.equal(got, want), grad
+        if grad:
+            assert all(torch.equal(a, b) for a, b in zip(gg, gw))
+
+
 def test_packed_weight_cache_is_not_fooled_by_address_reuse(dev):
     """A NEW weight tensor that lands on the address of a freed one (same shape: the caching allocator hands the block
     out again) must not hit the packed image of the old one."""
