@@ -502,7 +502,7 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
     }
     const bool small = Hi < 16 || Ho < 16;
     if (gS) {
-        ProfScope prof(PROF_LINEAR, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * Hi * Ho, 2.0 * n * (double)Hi * Ho);
+        ProfScope prof(PROF_LINEAR_GS, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * Hi * Ho, 2.0 * n * (double)Hi * Ho);
         static const bool split_on = [] { const char *e = getenv("NDCN_GS_SPLIT"); return !(e && e[0] == '0'); }();
         const bool a16 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(gS) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
         if (small) {
@@ -529,7 +529,7 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
         const int64_t used = (n + rpc - 1) / rpc;
         float *part_w = static_cast<float *>(work);
         float *part_b = part_w + (size_t)used * Ho * Hi;
-        ProfScope prof(PROF_LINEAR, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * (used + 1) * (double)Hi * Ho, 2.0 * n * (double)Hi * Ho);
+        ProfScope prof(PROF_LINEAR_WGRAD, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * (used + 1) * (double)Hi * Ho, 2.0 * n * (double)Hi * Ho);
         static const bool wsplit_on = [] { const char *e = getenv("NDCN_GW_SPLIT"); return !(e && e[0] == '0'); }();
         if (small) {
             hipLaunchKernelGGL(linear_wgrad_small_kernel, dim3((unsigned)used), dim3(256), 0, st, g, Y, S, part_w, gb ? part_b : nullptr, n, Hi, Ho, rpc);

@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float *__restrict__ out, 
 
 int relu_bwd_f32(float *out, const float *g, const float *y, int64_t n, hipStream_t st) {
     if (n == 0) return NDCN_OK;
-    ProfScope prof(PROF_STAGE, st, 12.0 * n, 0.0);
+    ProfScope prof(PROF_RELU_BWD, st, 12.0 * n, 0.0);
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid_full(n, 256)), dim3(256), 0, st, out, g, y, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;

@@ -358,7 +358,7 @@ int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c
     for (int j = 0; j < n_k; ++j) vec = vec && aligned16(t.k[j]) && (!t.gk[j] || aligned16(t.gk[j])) && (!t.acc[j] || aligned16(t.acc[j]));
     int n_out = gy0 ? 2 : 0;
     for (int j = 0; j < n_k; ++j) n_out += t.gk[j] ? (t.acc[j] ? 2 : 1) : 0;
-    ProfScope prof(PROF_COMBINE, st, 4.0 * n * (n_k + 1 + n_out), 2.0 * n * n_k);
+    ProfScope prof(PROF_COMBINE_BWD, st, 4.0 * n * (n_k + 1 + n_out), 2.0 * n * n_k);
     const int grid = bwd_grid(vec ? n / 4 : n);
     if (vec) hipLaunchKernelGGL(combine_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, g, t, gy0, acc_y0, n / 4, static_cast<double *>(d_ws));
     else hipLaunchKernelGGL(combine_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, g, t, gy0, acc_y0, n, static_cast<double *>(d_ws));
@@ -379,7 +379,7 @@ int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, 
                (!p.acc_y0 || aligned16(p.acc_y0)) && (!p.acc_y1 || aligned16(p.acc_y1));
     for (int j = 0; j < n_k; ++j) vec = vec && aligned16(p.t.k[j]) && (!p.t.gk[j] || aligned16(p.t.gk[j])) && (!p.t.acc[j] || aligned16(p.t.acc[j]));
     const int grid = bwd_grid(vec ? n / 4 : n);
-    ProfScope prof(PROF_ERROR, st, 4.0 * n * (2 * n_k + 4), 2.0 * n * (3 * n_k + 12));
+    ProfScope prof(PROF_ERROR_BWD, st, 4.0 * n * (2 * n_k + 4), 2.0 * n * (3 * n_k + 12));
     if (vec) hipLaunchKernelGGL(error_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, p, n / 4, static_cast<double *>(d_ws));
     else hipLaunchKernelGGL(error_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
     hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
@@ -389,7 +389,7 @@ int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, 
 
 int rk_rms_bwd_f32(const float *a, const float *b, const float *y, float rtol, float atol, float coef, float *ga, float *gb,
                    float *gy, int64_t n, hipStream_t st) {
-    ProfScope prof(PROF_SUMSQ, st, 4.0 * n * 5, 10.0 * n);
+    ProfScope prof(PROF_SUMSQ_BWD, st, 4.0 * n * 5, 10.0 * n);
     hipLaunchKernelGGL(rms_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, a, b, y, rtol, atol, coef, ga, gb, gy, n);
     NDCN_LAUNCH_CHECK();
     return NDCN_OK;
@@ -415,7 +415,7 @@ int rk_dense_bwd_f32(const float *g, const float *y0, const float *y1, const flo
         p.cm[j] = dt * (float)kCMidBwd[j];
     }
     const int grid = bwd_grid(n);
-    ProfScope prof(PROF_EVAL, st, 4.0 * n * 19, 2.0 * n * 60);
+    ProfScope prof(PROF_DENSE_BWD, st, 4.0 * n * 19, 2.0 * n * 60);
     hipLaunchKernelGGL(dense_bwd_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
     hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
     NDCN_LAUNCH_CHECK();
@@ -443,7 +443,7 @@ int rk_dense_bwd_multi_f32(const float *const *h_g, int nt, const float *y0, con
         p.cm[j] = dt * (float)kCMidBwd[j];
     }
     const int grid = bwd_grid(n);
-    ProfScope prof(PROF_EVAL, st, 4.0 * n * (27 + nt), 2.0 * n * (30 + 30 * nt));
+    ProfScope prof(PROF_DENSE_BWD, st, 4.0 * n * (27 + nt), 2.0 * n * (30 + 30 * nt));
     hipLaunchKernelGGL(dense_bwd_multi_kernel, dim3(grid), dim3(256), 0, st, p, n, static_cast<double *>(d_ws));
     hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
     NDCN_LAUNCH_CHECK();

@@ -358,11 +358,13 @@ class HipOps:
         return out
 
     @staticmethod
-    def rhs(A, X, W, b, no_graph=False, no_control=False, X_halo=None, out=None):
-        """The whole ODEFunc.forward: relu(W (A X) + b)   (neural_dynamics.py:20-39, dropout 0)."""
+    def rhs(A, X, W, b, no_graph=False, no_control=False, X_halo=None, out=None, relu=True):
+        """The whole ODEFunc.forward: relu(W (A X) + b)   (neural_dynamics.py:20-39, dropout 0).
+        relu=False: the same launch without the activation - the transposed half of the adjoint right-hand side,
+        (A^T gZ) W with the operator / weight pair (A^T, W^T) and no bias (_impl/adjoint_fused.py)."""
         X = _panel(X)
         H = X.shape[1]
-        flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
+        flags = (_lib.F_RELU if relu else 0) | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
         lib = _lib.load()
         if no_graph:
             view = _lib.empty_csr(X.shape[0])
@@ -397,7 +399,7 @@ class HipOps:
 
     @staticmethod
     def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None, record=None):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None, record=None, relu=True):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
         record (mode 'error'): an ErrorRecord of the caller's that receives / accumulates the result instead of the
         per-device one (split evaluations: new_error_record()).
@@ -411,7 +413,7 @@ class HipOps:
         the same pass: returns (K, y_next, sum aux_cs[m] kprev[m] + aux_cs[-1] K) - dopri5's partial error sum E."""
         X = _panel(X)
         H = X.shape[1]
-        flags = _lib.F_RELU | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
+        flags = (_lib.F_RELU if relu else 0) | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
         lib = _lib.load()
         if no_graph:
             view_ref = ctypes.byref(_lib.empty_csr(X.shape[0]))

@@ -99,6 +99,19 @@ class _AdjointMethod(torch.autograd.Function):
                     vjp_p = torch.cat([vW.view(-1), vb]) if f0.wt.bias is not None else vW.view(-1)
                 return (K, vjp_y, zero_t, vjp_p if len(f_params) else no_params)
 
+        fused = None
+        if native is not None and method in (None, 'dopri5'):
+            # the reverse pass on the fused launches of the inference path (adjoint_fused.py): stage algebra in the epilogues of the
+            # forward launch and of the transposed launch; the closure above serves the initial step of every interval only
+            from . import adjoint_fused
+            if adjoint_fused.applicable(native, ans[0]):
+                fused = adjoint_fused
+                fused_w = adjoint_fused._Weights(native)
+                native_rhs = augmented
+
+                def reversed_rhs(tau, y_aug):                    # misc.py:184-187: func(-t, y) negated
+                    return tuple(-v for v in native_rhs(-tau, y_aug))
+
         T = ans[0].shape[0]
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
@@ -119,12 +132,20 @@ class _AdjointMethod(torch.autograd.Function):
                 time_vjps.append(dLd_t)
                 if adj_params.numel() == 0:
                     adj_params = torch.tensor(0.).to(adj_y[0])
-                aug0 = (*ans_i, *adj_y, adj_time, adj_params)
-                aug = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=rtol, atol=atol, method=method,
-                             options=options)
-                adj_y = tuple(a[1] for a in aug[n:2 * n])
-                adj_time = aug[2 * n][1]
-                adj_params = aug[2 * n + 1][1]
+                if fused is not None:
+                    _, a_lo, adj_time, adj_params = fused.integrate_interval(
+                        hip, native, fused_w, ans_i[0].contiguous(), adj_y[0].contiguous(), adj_time, adj_params, t[i], t[i - 1],
+                        rtol, atol, options, reversed_rhs, step_log=getattr(native, 'ndcn_adjoint_step_log', None))
+                    adj_y = (a_lo,)
+                    aug0 = aug = None
+                else:
+                    aug0 = (*ans_i, *adj_y, adj_time, adj_params)
+                    slog = getattr(native, 'ndcn_adjoint_step_log', None) if native is not None and method in (None, 'dopri5') else None
+                    aug = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=rtol, atol=atol, method=method,
+                                 options=options, **({'step_log': slog} if slog is not None else {}))
+                    adj_y = tuple(a[1] for a in aug[n:2 * n])
+                    adj_time = aug[2 * n][1]
+                    adj_params = aug[2 * n + 1][1]
                 if native is not None:
                     adj_y = (hip.combine(adj_y[0].contiguous(), [grad_output[0][i - 1].contiguous()], [1.0]),)
                 else:

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""odeint_adjoint at the sizes it exists for (reference torchdiffeq/_impl/adjoint.py:23-102): one Adam step of
+the heat driver's loop (heat_dynamics.py:313-334: NDCN forward through dopri5, L1 loss on every tick, backward, Adam) with the
+O(1)-memory reverse pass on the fused launches (_impl/adjoint_fused.py), next to backpropagation through the solver where both fit.
+
+Per case one JSON line: ms per step (median), peak device memory (torch allocator high-water mark over the step), the per-kernel-
+family breakdown of the step by HIP events (ndcn_prof_*: launches, average ms, algorithmic GB/s, fraction of the 8 TB/s HBM peak)
+and `roofline` for the dominant family.
+
+    python tools/bench_adjoint.py [--cases 100k,M] [--ticks 3] [--modes adjoint,backprop,adjoint_generic]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HBM_PEAK_GBS = 8000.0
+
+
+def build(side, H, ticks, dev):
+    from ndcn_amd import graphs
+    from ndcn_amd.neural_dynamics import NDCN
+    L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    n = side * side
+    A = graphs.to_device(L, dev)
+    torch.manual_seed(0)
+    model = NDCN(input_size=1, hidden_size=H, A=A, num_classes=1, rtol=.01, atol=.001, method='dopri5').to(dev)
+    x0 = torch.from_numpy(graphs.x0_blocks(side)[:n]).to(dev)
+    t = torch.linspace(0., 5., ticks).to(dev)
+    target = torch.rand(n, ticks, device=dev)
+    return model, x0, t, target, L.nnz
+
+
+def run_case(name, side, H, ticks, mode, dev, reps):
+    from ndcn_amd import _lib
+    from ndcn_amd.torchdiffeq._impl import adjoint_fused
+    model, x0, t, target, nnz = build(side, H, ticks, dev)
+    model.neural_dynamic_layer.adjoint = mode.startswith('adjoint')
+    adjoint_fused.ENABLED = mode != 'adjoint_generic'
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=1e-3)
+    log = []
+    model.neural_dynamic_layer.odefunc.ndcn_adjoint_step_log = None
+
+    def step():
+        opt.zero_grad()
+        pred = model(t, x0).squeeze(-1).t()
+        loss = F.l1_loss(pred, target)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    peak = torch.cuda.max_memory_allocated()
+    # instrumented step: HIP events around every library launch
+    lib = _lib.load()
+    nk = lib.ndcn_prof_kinds()
+    buf = (_lib.ctypes.c_double * (4 * nk))()
+    lib.ndcn_prof_enable(1)
+    lib.ndcn_prof_read(buf, nk)
+    step()
+    torch.cuda.synchronize()
+    lib.ndcn_prof_enable(0)
+    lib.ndcn_prof_read(buf, nk)
+    breakdown, tot = {}, 0.0
+    for i, kname in enumerate(_lib.PROF_KINDS):
+        cnt, ms, byt, fl = buf[4 * i:4 * i + 4]
+        if cnt:
+            breakdown[kname] = {'launches': int(cnt), 'ms_total': round(ms, 3), 'avg_ms': round(ms / cnt, 4),
+                                'alg_GBps': round(byt / ms / 1e6, 1), 'frac_of_hbm_peak': round(byt / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                'TFLOPs': round(fl / ms / 1e9, 2)}
+            tot += ms
+    n = side * side
+    rec = {'case': name, 'mode': mode, 'n': n, 'H': H, 'ticks': ticks, 'nnz': int(nnz), 'ms_per_adam_step': round(1e3 * float(np.median(times)), 2),
+           'peak_device_memory_GB': round(peak / 1e9, 3), 'resident_before_step_GB': round(base / 1e9, 3),
+           'library_kernel_ms_per_step': round(tot, 2), 'breakdown': breakdown}
+    if breakdown:
+        dom = max(breakdown, key=lambda k: breakdown[k]['ms_total'])
+        b = breakdown[dom]
+        rec['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': b['alg_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': b['frac_of_hbm_peak'], 'avg_ms': b['avg_ms'], 'launches': b['launches'], 'traffic': None,
+                           'share_of_kernel_time': round(b['ms_total'] / tot, 3)}
+    del model, opt
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', default='100k,M')
+    ap.add_argument('--ticks', type=int, default=3)
+    ap.add_argument('--modes', default='adjoint,backprop,adjoint_generic')
+    ap.add_argument('--reps', type=int, default=5)
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    sides = {'32': 32, '10k': 100, '100k': 316, 'M': 1000}
+    for c in a.cases.split(','):
+        for mode in a.modes.split(','):
+            if c == 'M' and mode == 'adjoint_generic':
+                continue                                    # (the unfused tuple stepper holds ~60 one-gigabyte panels: measured at 100k only)
+            try:
+                rec = run_case('%s-node grid, H=256, dopri5 rtol .01 atol .001, %d ticks on [0, 5]' % (c, a.ticks), sides[c], 256, a.ticks, mode, dev,
+                               a.reps if c != 'M' else 3)
+            except torch.cuda.OutOfMemoryError as e:
+                rec = {'case': c, 'mode': mode, 'error': 'out of device memory: ' + str(e)[:120]}
+                torch.cuda.empty_cache()
+            print(json.dumps(rec), flush=True)
+
+
+if __name__ == '__main__':
+    main()
