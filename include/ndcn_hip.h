@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 12
+#define NDCN_ABI_VERSION 13
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -377,6 +377,22 @@ NDCN_API int ndcn_rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, i
 NDCN_API int ndcn_rhs_rk_xadd_f32(const ndcn_csr *A, const float *X, const float *x_add, float x_add_c, const float *W,
                                   const float *b, float *K, float *work, int H, uint32_t flags, const float *y0,
                                   const float *k_prev, const float *h_c, float *y_next, void *stream);
+
+/* The two halves of odeint_adjoint's right-hand side on the fused launch (reference torchdiffeq/_impl/adjoint.py:34-59, where
+ * torch.autograd.grad forms -a^T df/dy and -a^T df/dtheta at every evaluation; ndcn_amd/torchdiffeq/_impl/adjoint_fused.py):
+ *   s_out  (forward half, launch over (A, W, b)): besides K and the stage algebra, S = A X is written - the weight gradient
+ *          gZ^T S of the same evaluation needs it (otherwise a second SpMM);
+ *   x_mask (transposed half, launch over (A^T, W^T) without bias / activation): the evaluation's input is X (.) [x_mask > 0],
+ *          formed on the rows the kernel stages - X = the adjoint state, x_mask = K of the forward half, i.e. the gathered rows are
+ *          gZ = a (.) [K > 0] without a panel of its own (3 panels of traffic).
+ * Exactly one of the two per call; arguments otherwise as ndcn_rhs_rk_f32 (no halo panel, no y_aux).  Provided for the operators /
+ * launches ndcn_rhs_adj_supported() accepts: H = 256, a 2-D lattice's group-record plan, NDCN_RK_COMBINE with n_prev = 1..4 and
+ * NDCN_RK_ERROR with n_prev = 5 (the launches of a dopri5 step); NDCN_EINVAL otherwise.                                           */
+NDCN_API int ndcn_rhs_adj_supported(const ndcn_csr *A, int H, uint32_t flags, int rk_mode, int n_prev);
+NDCN_API int ndcn_rhs_rk_adj_f32(const ndcn_csr *A, const float *X, const float *x_mask, float *s_out, const float *W, const float *b,
+                                 float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
+                                 const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1,
+                                 float rtol, float atol, double *d_out, void *d_ws, void *stream);
 
 /* Pack rows `idx[0..n_idx)` of X into out (halo send buffers).  out[i, :] = X[idx[i], :] */
 NDCN_API int ndcn_gather_rows_f32(const float *X, const int32_t *idx, int64_t n_idx, int H, float *out, void *stream);

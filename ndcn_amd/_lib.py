@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO, PATH_SWEEP = 1, 2, 4, 8, 16
 
 OK = 0
@@ -135,6 +135,9 @@ SIGNATURES = {
     'ndcn_adjoint_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
                         _P, _P, _P, ctypes.POINTER(_F), _F, _F, _P, _P, _P]),
+    'ndcn_rhs_adj_supported': (_I, [_CSR, _I, _U, _I, _I]),
+    'ndcn_rhs_rk_adj_f32': (_I, [_CSR, _P, _P, _P, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _P, _P,
+                            _F, _F, _P, _P, _P]),
     'ndcn_rhs_xadd_supported': (_I, [_CSR, _I, _U, _I, _I]),
     'ndcn_rhs_rk_xadd_f32': (_I, [_CSR, _P, _P, _F, _P, _P, _P, _P, _I, _U, _P, _P, ctypes.POINTER(_F), _P, _P]),
     'ndcn_solve_small_supported': (_I, [_CSR, _I, _U, _I, _I]),

@@ -234,7 +234,7 @@ static int rhs_rk_entry(const ndcn_csr *A, const float *X, const float *X_halo, 
                         float *K, float *work, int H, uint32_t flags, int rk_mode, const float *y0,
                         const float *const *h_kprev, const float *h_c, int n_prev, float *y_next, const float *y1, float *y_aux,
                         const float *h_c_aux, float rtol, float atol, double *d_out, void *d_ws, const float *x_add, float x_add_c,
-                        void *stream) {
+                        void *stream, const float *x_mask = nullptr, float *s_out = nullptr) {
     NDCN_CHECK_ARG(A, "null operator descriptor");
     NDCN_CHECK_ARG(H > 0, "H must be positive");
     NDCN_CHECK_ARG(rk_mode >= 0 && rk_mode <= 3, "rk_mode must be 0, NDCN_RK_COMBINE, NDCN_RK_ERROR or NDCN_RK_RK4");
@@ -259,7 +259,12 @@ static int rhs_rk_entry(const ndcn_csr *A, const float *X, const float *X_halo, 
         NDCN_CHECK_ARG(!X_halo && x_add != K && x_add != y_next && rk_mode == NDCN_RK_COMBINE && rhs_xadd_supported(A, H, flags, rk_mode, n_prev),
                        "x_add: not supported for this operator / mode (ndcn_rhs_xadd_supported), or aliased");
     }
-    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0, y_aux, h_c_aux, x_add, x_add_c};
+    if (x_mask || s_out) {
+        NDCN_CHECK_ARG(!X_halo && !x_add && !(x_mask && s_out) && (!x_mask || (x_mask != K && x_mask != y_next)) &&
+                           (!s_out || (s_out != K && s_out != y_next && s_out != X)) && rhs_adj_supported(A, H, flags, rk_mode, n_prev),
+                       "x_mask / s_out: not supported for this operator / mode (ndcn_rhs_adj_supported), both given, or aliased");
+    }
+    const RkOpt opt = {y1, (flags & NDCN_F_ACCUM) ? 1 : 0, y_aux, h_c_aux, x_add, x_add_c, x_mask, s_out};
     return rhs_rk_f32(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                       d_out, d_ws, ST(stream), &opt);
 }
@@ -270,6 +275,18 @@ int ndcn_rhs_rk_f32(const ndcn_csr *A, const float *X, const float *X_halo, int6
                     const float *h_c_aux, float rtol, float atol, double *d_out, void *d_ws, void *stream) {
     return rhs_rk_entry(A, X, X_halo, n_own, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, y1, y_aux, h_c_aux,
                         rtol, atol, d_out, d_ws, nullptr, 0.f, stream);
+}
+
+int ndcn_rhs_adj_supported(const ndcn_csr *A, int H, uint32_t flags, int rk_mode, int n_prev) {
+    return A ? rhs_adj_supported(A, H, flags, rk_mode, n_prev) : 0;
+}
+
+int ndcn_rhs_rk_adj_f32(const ndcn_csr *A, const float *X, const float *x_mask, float *s_out, const float *W, const float *b, float *K,
+                        float *work, int H, uint32_t flags, int rk_mode, const float *y0, const float *const *h_kprev, const float *h_c,
+                        int n_prev, float *y_next, const float *y1, float rtol, float atol, double *d_out, void *d_ws, void *stream) {
+    NDCN_CHECK_ARG(x_mask || s_out, "one of x_mask / s_out expected (ndcn_rhs_rk_f32 otherwise)");
+    return rhs_rk_entry(A, X, nullptr, A ? A->n_cols : 0, W, b, K, work, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, y1, nullptr,
+                        nullptr, rtol, atol, d_out, d_ws, nullptr, 0.f, stream, x_mask, s_out);
 }
 
 int ndcn_rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int rk_mode, int n_prev) {

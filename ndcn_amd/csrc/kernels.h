@@ -19,7 +19,8 @@ namespace ndcn {
 //   xadd / xadd_c (plain and COMBINE with one earlier stage, operators on the rhs_fused3 path without a halo panel -
 //          rhs_xadd_supported()): the evaluation's input is X + xadd_c * xadd, formed on the rows the kernel stages instead of by a
 //          combine launch in front (3 panels); same product-then-sum rounding per element.
-struct RkOpt { const float *y1; int accum; float *y_aux; const float *c_aux; const float *xadd; float xadd_c; };
+struct RkOpt { const float *y1; int accum; float *y_aux; const float *c_aux; const float *xadd; float xadd_c;
+               const float *xmask; float *s_out; };      // (xmask, s_out: rhs_adj_supported)
 
 int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
              uint32_t flags, hipStream_t st);
@@ -56,6 +57,7 @@ int partials_finish(const double *partials, int n, double *d_out, hipStream_t st
 // split weights of pack_weight_256, i.e. Wp + 256 * 256 floats)
 int rhs_fused3_supported(const ndcn_csr *A);
 int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev);   // RkOpt::xadd can be honoured
+int rhs_adj_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev);    // RkOpt::xmask / s_out can be honoured
 int rhs_fused3_variant(int mode, int n_prev);
 int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const void *Wq, const float *b, float *K,
                    uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c, int n_prev,

@@ -625,7 +625,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     // Column-sweep plan (struct ndcn_csr; spmm_sweep.hip): S = A X by the sweep into the operator's scratch panel, then this
     // kernel on the IDENTITY operator over S - the Linear, the ReLU and the RK epilogue as on any operator (row i folds
     // fma(1, S[i], 0) = S[i]).  One profiled unit: the two launches are one evaluation of the right-hand side.
-    if (!Xh && A->sweep_S && !(opt && opt->xadd) && spmm_sweep_supported(A, kH2) && aligned16(X)) {
+    if (!Xh && A->sweep_S && !(opt && (opt->xadd || opt->xmask || opt->s_out)) && spmm_sweep_supported(A, kH2) && aligned16(X)) {
         const double P = 4.0 * kH2 * (double)A->n_rows;
         double bytes = 8.0 * A->nnz + 4.0 * (A->n_rows + 1) + 4.0 * kH2 * (double)(A->n_rows + A->n_cols) + 4.0 * kH2 * kH2;
         if (mode != MODE_PLAIN) bytes += P * (n_prev + 2 + ((mode == MODE_COMBINE && opt && opt->y_aux && opt->c_aux) ? 1 : 0));
@@ -682,7 +682,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
         return rhs_fused3_f32(A, X, Xh, n_own, Wp + kH2 * kH2, b, K, flags, mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out,
                               d_ws, st, opt);
     }
-    if (opt && opt->xadd) { set_error("rhs_fused2: RkOpt::xadd needs the rhs_fused3 path (rhs_xadd_supported)"); return NDCN_EINVAL; }
+    if (opt && (opt->xadd || opt->xmask || opt->s_out)) { set_error("rhs_fused2: RkOpt::xadd / xmask / s_out need the rhs_fused3 path (rhs_xadd_supported, rhs_adj_supported)"); return NDCN_EINVAL; }
     g_last_rhs_path = NDCN_PATH_FUSED2 | path_bits;
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;

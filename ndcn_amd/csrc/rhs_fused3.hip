@@ -118,8 +118,9 @@ struct F3Args {
     const int *rec;
     int n_groups;
     const float *X, *Xh;
-    const float *Xadd;               // XADD variants: the evaluation's input is X + xadd_c * Xadd, formed on the staged rows
+    const float *Xadd;               // XOP 1: the evaluation's input is X + xadd_c * Xadd; XOP 2: X (.) [Xadd > 0] - formed on the staged rows
     float xadd_c;
+    float *S_out;                    // SOUT variants: S = A X (the folded rows, fp32) is written too
     int n_own;
     const void *Wq;                  // split weights (pack_weight_256: two fp16 planes in MFMA B-operand order + scales)
     const float *bias;
@@ -156,11 +157,16 @@ constexpr int kF3EpiKernargOffset = (int)((sizeof(F3Args) + 7) / 8 * 8);       /
 // formed where it is needed instead of by a kernel of its own (3 panels): every wave fetches the Xadd rows of the union rows
 // it stages, a step ahead like them, and adds them into its LDS rows - one product, one sum per element, the roundings of
 // combine_kernel - before the barrier that hands the group to the fold.  One more gather (1.07 panels) instead of 3 panels.
+// XOP 2 (round 5): the input is X (.) [M > 0] with the mask panel M in Xadd - the transposed half of odeint_adjoint's right-hand side
+// gathers gZ = a (.) [K > 0] this way (adjoint.py:34-59; _impl/adjoint_fused.py) instead of reading it from a panel that a launch
+// of its own (3 panels) would have to write first.  SOUT: the folded rows S = A X leave the kernel too (one more store per row):
+// the weight gradient of the same right-hand side, gZ^T S, needs them (instead of a second SpMM).
 // NT: the epilogue's stores carry the non-temporal hint - right for panels far beyond the 256 MiB Infinity Cache (the metric's 1 GB
 // panels: 8.35 against 8.58 ms per step without it), wrong for panels that live in it and are read right back by the next launch
 // (BASELINE config 2, 102 MB: 1.323 against 1.290 ms per RK4 step); the launcher decides by the panel's size
-template <bool HALO, int MODE, int NP, bool XADD = false, bool NT = true>
+template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false>
 __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
+    constexpr bool XADD = XOP != 0;                          // a second panel is gathered alongside X
     static_assert(!(XADD && HALO), "the halo rows of Xadd are not exchanged");
     (void)epi_by_kernarg_only;
     constexpr int kF3WP = f3_producers(MODE, NP), kF3Waves = kF3WP + kF3WM;   // producer waves (LDS-DMA + fold + epilogue) | MFMA waves
@@ -404,7 +410,14 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
 #pragma unroll
         for (int k = 0; k < kF3CapD; ++k) {
             asm volatile("" : "+v"(xk[k]));
-            xb[k * 64] = xb[k * 64] + xk[k] * a.xadd_c;
+            if constexpr (XOP == 2) {
+                f32x4 v = xb[k * 64];
+                v.x = xk[k].x > 0.f ? v.x : 0.f; v.y = xk[k].y > 0.f ? v.y : 0.f;
+                v.z = xk[k].z > 0.f ? v.z : 0.f; v.w = xk[k].w > 0.f ? v.w : 0.f;
+                xb[k * 64] = v;
+            } else {
+                xb[k * 64] = xb[k * 64] + xk[k] * a.xadd_c;
+            }
         }
     };
     auto ldp = [&](const float *base /*uniform*/, int voff) {
@@ -520,7 +533,11 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
                     if (XADD) {
                         f32x4 w;
                         asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(lane_off), "s"(a.Xadd + (size_t)c * 256) : "memory");
-                        v = v + w * a.xadd_c;
+                        if constexpr (XOP == 2) {
+                            v.x = w.x > 0.f ? v.x : 0.f; v.y = w.y > 0.f ? v.y : 0.f; v.z = w.z > 0.f ? v.z : 0.f; v.w = w.w > 0.f ? v.w : 0.f;
+                        } else {
+                            v = v + w * a.xadd_c;
+                        }
                     }
                     return v;
                 }, acc);
@@ -566,6 +583,10 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
             float *srow = s_tiles + sl * kF3Ld + 4 * lane;
             if (MODE != F3_PLAIN) { rec_wait_vmcnt_rt(since_p[q]); arrived(pan[q]); }
             if (er >= 0 && !(f3_dbg(a) & 4)) epilogue(er, *reinterpret_cast<const f32x4 *>(srow), pan[q]);
+            if (SOUT && row >= 0) {
+                stp(a.S_out, (row << 10) + lane_off, acc);
+                issued(1);
+            }
             if (row >= 0) {
                 // the row leaves this wave as its two fp16 pieces (split16.h), scaled by a power of two from its largest
                 // magnitude: [256 high | 256 low] in the 1 KiB the fp32 row (and later its K row) occupies
@@ -630,6 +651,19 @@ int rhs_fused3_variant(int mode, int n_prev) {
     return mode == F3_ERROR && (n_prev == kF3MaxPrev || n_prev == 1);
 }
 
+// RkOpt::xmask / s_out (the two halves of odeint_adjoint's right-hand side): the dopri5 launches - COMBINE with 1..4 earlier stages,
+// ERROR with 5
+int rhs_adj_variant(int mode, int n_prev) {
+    return (mode == F3_COMBINE && n_prev >= 1 && n_prev <= 4) || (mode == F3_ERROR && n_prev == 5);
+}
+
+int rhs_adj_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev) {
+    static const int enabled = env_int_f3("NDCN_F3_ADJ", 1);
+    if (!enabled || H != 256 || (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) || !rhs_fused3_supported(A)) return 0;
+    if (A->hub_n > 0 || A->sweep_S) return 0;
+    return rhs_adj_variant(mode, n_prev);
+}
+
 // RkOpt::xadd: the lattice plan, no halo panel, the launch that opens a dopri5 step (COMBINE with one earlier stage: k2) and the
 // second evaluation of the initial step (ERROR with one earlier stage: f(y0 + h0 f0) carrying the d2 norm)
 int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n_prev) {
@@ -640,9 +674,9 @@ int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n
     return ((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) ? 1 : 0;
 }
 
-template <bool HALO, int MODE, int NP, bool XADD = false, bool NT = true>
+template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false>
 static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st) {
-    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XADD, NT>;
+    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XOP, NT, SOUT>;
     static bool attr_set = false;
     if (!attr_set) {
         NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
@@ -660,10 +694,16 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (!rhs_fused3_variant(mode, n_prev)) { set_error("rhs_fused3: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     F3Args a;
     a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
-    a.Xadd = (opt && opt->xadd) ? opt->xadd : nullptr;
-    a.xadd_c = a.Xadd ? opt->xadd_c : 0.f;
-    if (a.Xadd && (Xh || !((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1))) {
+    const bool masked = opt && opt->xmask;
+    a.Xadd = masked ? opt->xmask : ((opt && opt->xadd) ? opt->xadd : nullptr);
+    a.xadd_c = (a.Xadd && !masked) ? opt->xadd_c : 0.f;
+    a.S_out = (opt && opt->s_out) ? opt->s_out : nullptr;
+    if (a.Xadd && !masked && (Xh || !((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1))) {
         set_error("rhs_fused3: X + c Xadd is formed in the one-stage COMBINE / ERROR launches of an operator without a halo panel");
+        return NDCN_EINVAL;
+    }
+    if ((masked || a.S_out) && (Xh || (masked && a.S_out) || (masked && opt->xadd) || !rhs_adj_variant(mode, n_prev))) {
+        set_error("rhs_fused3: the masked input / the S output exist for the dopri5 launches of an operator without a halo panel (rhs_adj_supported)");
         return NDCN_EINVAL;
     }
     a.relu = (flags & NDCN_F_RELU) ? 1 : 0;
@@ -692,13 +732,14 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (mode != F3_PLAIN) bytes += P * (n_prev + 2);
     if (e.y_aux) bytes += P;
     if (a.Xadd) bytes += P;                                          // the second gather
+    if (a.S_out) bytes += P;
     ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
     int rc = NDCN_OK;
     // panels that fit the Infinity Cache with room for the next launch's (<= 128 MiB): plain stores (operators without a halo panel)
     const bool cached = !Xh && (int64_t)A->n_rows * 1024 <= (128ll << 20);
 #define NDCN_F3(HALO_, MODE_, NP_)                                                        \
     do {                                                                                  \
-        if (!HALO_ && cached) rc = launch_f3<false, MODE_, NP_, false, false>(a, e, grid, st); \
+        if (!HALO_ && cached) rc = launch_f3<false, MODE_, NP_, 0, false>(a, e, grid, st); \
         else rc = launch_f3<HALO_, MODE_, NP_>(a, e, grid, st);                           \
     } while (0)
 #define NDCN_F3_DISPATCH(HALO_)                                       \
@@ -720,12 +761,25 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
             default: NDCN_F3(HALO_, F3_COMBINE, 5); break;            \
         }                                                             \
     } while (0)
-    if (a.Xadd) {
-        if (mode == F3_COMBINE) rc = launch_f3<false, F3_COMBINE, 1, true>(a, e, grid, st);
-        else rc = launch_f3<false, F3_ERROR, 1, true>(a, e, grid, st);
+#define NDCN_F3_ADJ(XOP_, SOUT_)                                                                   \
+    do {                                                                                            \
+        if (mode == F3_ERROR) { if (cached) rc = launch_f3<false, F3_ERROR, 5, XOP_, false, SOUT_>(a, e, grid, st); else rc = launch_f3<false, F3_ERROR, 5, XOP_, true, SOUT_>(a, e, grid, st); } \
+        else switch (n_prev) {                                                                      \
+            case 1: if (cached) rc = launch_f3<false, F3_COMBINE, 1, XOP_, false, SOUT_>(a, e, grid, st); else rc = launch_f3<false, F3_COMBINE, 1, XOP_, true, SOUT_>(a, e, grid, st); break; \
+            case 2: if (cached) rc = launch_f3<false, F3_COMBINE, 2, XOP_, false, SOUT_>(a, e, grid, st); else rc = launch_f3<false, F3_COMBINE, 2, XOP_, true, SOUT_>(a, e, grid, st); break; \
+            case 3: if (cached) rc = launch_f3<false, F3_COMBINE, 3, XOP_, false, SOUT_>(a, e, grid, st); else rc = launch_f3<false, F3_COMBINE, 3, XOP_, true, SOUT_>(a, e, grid, st); break; \
+            default: if (cached) rc = launch_f3<false, F3_COMBINE, 4, XOP_, false, SOUT_>(a, e, grid, st); else rc = launch_f3<false, F3_COMBINE, 4, XOP_, true, SOUT_>(a, e, grid, st); break; \
+        }                                                                                           \
+    } while (0)
+    if (masked) NDCN_F3_ADJ(2, false);
+    else if (a.S_out) NDCN_F3_ADJ(0, true);
+    else if (a.Xadd) {
+        if (mode == F3_COMBINE) rc = launch_f3<false, F3_COMBINE, 1, 1>(a, e, grid, st);
+        else rc = launch_f3<false, F3_ERROR, 1, 1>(a, e, grid, st);
     } else if (Xh) NDCN_F3_DISPATCH(true);
     else NDCN_F3_DISPATCH(false);
 #undef NDCN_F3_DISPATCH
+#undef NDCN_F3_ADJ
 #undef NDCN_F3
     if (rc) return rc;
     NDCN_LAUNCH_CHECK();

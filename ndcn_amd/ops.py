@@ -399,7 +399,8 @@ class HipOps:
 
     @staticmethod
     def rhs_rk(A, X, W, b, mode, y0, kprev, cs, rtol=0.0, atol=0.0, no_graph=False, no_control=False, X_halo=None,
-               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None, record=None, relu=True):
+               out_K=None, out_y=None, y1=None, accum=False, fetch=True, aux_cs=None, out_aux=None, record=None, relu=True,
+               x_mask=None, s_out=None):
         """K = ODEFunc(X) plus, in the same pass, the stage algebra consuming K (ndcn_rhs_rk_f32).
         record (mode 'error'): an ErrorRecord of the caller's that receives / accumulates the result instead of the
         per-device one (split evaluations: new_error_record()).
@@ -410,7 +411,9 @@ class HipOps:
         accum: add the record to the one already in the device buffer (an evaluation split into several launches);
         fetch=False: leave the record on the device (returns (K, None); the last launch of the split fetches).
         mode 'combine' only - aux_cs: coefficients of a second linear combination of the same stages (no y0), formed in
-        the same pass: returns (K, y_next, sum aux_cs[m] kprev[m] + aux_cs[-1] K) - dopri5's partial error sum E."""
+        the same pass: returns (K, y_next, sum aux_cs[m] kprev[m] + aux_cs[-1] K) - dopri5's partial error sum E.
+        x_mask / s_out (ndcn_rhs_rk_adj_f32, where rhs_adj_supported says so): the input is X (.) [x_mask > 0] formed on the staged
+        rows / S = A X is written into s_out too - the two halves of odeint_adjoint's right-hand side (_impl/adjoint_fused.py)."""
         X = _panel(X)
         H = X.shape[1]
         flags = (_lib.F_RELU if relu else 0) | (_lib.F_NO_GRAPH if no_graph else 0) | (_lib.F_NO_CONTROL if no_control else 0)
@@ -456,6 +459,16 @@ class HipOps:
         rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR, 'rk4': _lib.RK_RK4}[mode]
         y_next = (out_y if out_y is not None else torch.empty_like(K)) if mode in ('combine', 'rk4') else None
         red = _Reducer.get(X.device)
+        if x_mask is not None or s_out is not None:
+            assert X_halo is None and aux_cs is None and not accum
+            x_mask = _panel(x_mask, 'mask panel') if x_mask is not None else None
+            with _REDUCE_LOCK, torch.cuda.device(X.device):
+                check(lib.ndcn_rhs_rk_adj_f32(view_ref, ptr(X), ptr(x_mask), ptr(s_out), ptr(W), ptr(b), ptr(K), ptr(work), H, flags, rk,
+                                              ptr(y0), arr_k, arr_c, len(kprev), ptr(y_next), ptr(y1), float(rtol), float(atol),
+                                              ptr((record or red).out), ptr(red.ws), stream_ptr()))
+                if mode == 'combine':
+                    return K, y_next
+                return K, ((record or red).fetch() if fetch else None)
         with _REDUCE_LOCK, torch.cuda.device(X.device):
             check(lib.ndcn_rhs_rk_f32(view_ref, ptr(X), ptr(X_halo), X.shape[0], ptr(None if no_control else W),
                                       ptr(None if no_control else b), ptr(K), ptr(work), H, flags, rk, ptr(y0), arr_k,
@@ -466,6 +479,15 @@ class HipOps:
             if mode in ('combine', 'rk4'):
                 return K, y_next
             return K, ((record or red).fetch() if fetch else None)
+
+    @staticmethod
+    def rhs_adj_supported(A, H, mode, n_prev, no_control=False):
+        """can rhs_rk honour x_mask / s_out for this operator and launch?"""
+        A = as_csr(A)
+        A.ensure_plans(H)
+        flags = _lib.F_NO_CONTROL if no_control else 0
+        rk = {'combine': _lib.RK_COMBINE, 'error': _lib.RK_ERROR}.get(mode, 0)
+        return bool(_lib.load().ndcn_rhs_adj_supported(A.view_ref(), H, flags, rk, n_prev))
 
     @staticmethod
     def new_error_record(device):

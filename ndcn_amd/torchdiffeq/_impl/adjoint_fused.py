@@ -84,29 +84,51 @@ class FusedAdjointDopri5:
         self.has_theta = theta.numel() > 0 and not self.w.no_control
         self.n_theta = theta.numel()
         self.a_t_host = float(a_t)                          # constant over the interval (a_t' = 0)
+        # lattice plans (rhs_fused3): S = A x leaves the forward launch, gZ = a (.) [K > 0] is formed on the rows the transposed launch
+        # stages (ndcn_rhs_rk_adj_f32) - no SpMM and no mask pass of their own
+        ctl = not self.w.no_control
+        self.fuse_s = ctl and self.has_theta and hip.rhs_adj_supported(self.A, 256, 'combine', 1)
+        self.fuse_mask = ctl and hip.rhs_adj_supported(self.At, 256, 'combine', 1)
         self.log = []
         self.nfe = 0
 
     # ---- one evaluation of the augmented right-hand side on the fused launches ------------------------------------------------
-    def _transposed(self, gZ, mode, y0, prev, cs, rtol=0.0, atol=0.0, y1=None):
+    def _transposed(self, gZ, mode, y0, prev, cs, rtol=0.0, atol=0.0, y1=None, x_mask=None):
         w = self.w
         if mode is None:
             return self.hip.rhs(self.At, gZ, w.Wt, None, no_control=w.no_control, relu=False), None
-        return self.hip.rhs_rk(self.At, gZ, w.Wt, None, mode, y0, prev, cs, rtol, atol, no_control=w.no_control, relu=False, y1=y1)
+        return self.hip.rhs_rk(self.At, gZ, w.Wt, None, mode, y0, prev, cs, rtol, atol, no_control=w.no_control, relu=False, y1=y1,
+                               x_mask=x_mask)
 
-    def _forward(self, x, mode, y0, prev, cs, rtol=0.0, atol=0.0):
+    def _forward(self, x, mode, y0, prev, cs, rtol=0.0, atol=0.0, s_out=None):
         w = self.w
         if mode is None:
             return self.hip.rhs(self.A, x, w.W, w.b, no_control=w.no_control), None
-        return self.hip.rhs_rk(self.A, x, w.W, w.b, mode, y0, prev, cs, rtol, atol, no_control=w.no_control)
+        return self.hip.rhs_rk(self.A, x, w.W, w.b, mode, y0, prev, cs, rtol, atol, no_control=w.no_control, s_out=s_out)
 
-    def _theta(self, x, gZ):
-        """(gZ^T S, sum_rows gZ) flattened like the parameter list [weight, bias]"""
+    def _theta(self, x, g, mask=None, S=None):
+        """((g (.) [mask > 0])^T S, its row sum) flattened like the parameter list [weight, bias]; S = A x unless handed in"""
         if not self.has_theta:
             return None
-        S = self.hip.spmm(self.A, x)
-        _, gW, gb = self.hip.linear_bwd(gZ, self.w.W, S=S, Y=None, need_gS=False, need_gW=True, need_gb=self.w.b is not None)
+        if S is None:
+            S = self.hip.spmm(self.A, x)
+        _, gW, gb = self.hip.linear_bwd(g, self.w.W, S=S, Y=mask, need_gS=False, need_gW=True, need_gb=self.w.b is not None)
         return torch.cat([gW.view(-1), gb]) if gb is not None else gW.view(-1)
+
+    def _evaluate(self, x, xa, mode, Y0, A0, prevY, cY, prevA, cA, tol_y=(0.0, 0.0), tol_a=(0.0, 0.0)):
+        """both halves of one evaluation at the stage inputs (x, xa) + the stage algebra / error records in their epilogues"""
+        hip = self.hip
+        S = torch.empty_like(x) if self.fuse_s else None
+        K, ry = self._forward(x, mode, Y0, prevY, cY, tol_y[0], tol_y[1], s_out=S)
+        y1 = xa if mode == 'error' else None
+        if self.fuse_mask:
+            KA, ra = self._transposed(xa, mode, A0, prevA, cA, tol_a[0], tol_a[1], y1=y1, x_mask=K)
+            kp = self._theta(x, xa, K, S)
+        else:
+            gZ = hip.relu_bwd(xa, K)
+            KA, ra = self._transposed(gZ, mode, A0, prevA, cA, tol_a[0], tol_a[1], y1=y1)
+            kp = self._theta(x, gZ, None, S)
+        return K, ry, KA, ra, kp
 
     # ---- dopri5.py:76-83 ------------------------------------------------------------------------------------------------------
     def begin(self, tau0):
@@ -152,10 +174,9 @@ class FusedAdjointDopri5:
             prevY, cY = dt_terms(dty, DP_BETA[i][:i], kY)
             prevA, cA = dt_terms(dt32, DP_BETA[i][:i], kA)
             self.nfe += 1
-            K, x_next = self._forward(x, 'combine', Y0, prevY, cY + [f32(dty * f32(DP_BETA[i][i]))])
-            gZ = hip.relu_bwd(xa, K)
-            KA, xa_next = self._transposed(gZ, 'combine', A0, prevA, cA + [f32(dt32 * f32(DP_BETA[i][i]))])
-            kP.append(self._theta(x, gZ))
+            K, x_next, KA, xa_next, kp = self._evaluate(x, xa, 'combine', Y0, A0, prevY, cY + [f32(dty * f32(DP_BETA[i][i]))],
+                                                        prevA, cA + [f32(dt32 * f32(DP_BETA[i][i]))])
+            kP.append(kp)
             kY.append(K)
             kA.append(KA)
             x, xa = x_next, xa_next
@@ -163,10 +184,10 @@ class FusedAdjointDopri5:
         prevY, cY = dt_terms(dty, DP_C_ERR[:6], kY)
         prevA, cA = dt_terms(dt32, DP_C_ERR[:6], kA)
         self.nfe += 1
-        K, (sY, badY) = self._forward(y1, 'error', Y0, prevY, cY + [f32(dty * f32(DP_C_ERR[6]))], self.rtol[0], self.atol[0])
-        gZ = hip.relu_bwd(a1, K)
-        KA, (sA, badA) = self._transposed(gZ, 'error', A0, prevA, cA + [f32(dt32 * f32(DP_C_ERR[6]))], self.rtol[1], self.atol[1], y1=a1)
-        kP.append(self._theta(y1, gZ))
+        K, (sY, badY), KA, (sA, badA), kp = self._evaluate(y1, a1, 'error', Y0, A0, prevY, cY + [f32(dty * f32(DP_C_ERR[6]))],
+                                                           prevA, cA + [f32(dt32 * f32(DP_C_ERR[6]))], (self.rtol[0], self.atol[0]),
+                                                           (self.rtol[1], self.atol[1]))
+        kP.append(kp)
         kY.append(K)
         kA.append(KA)
         n = Y0.numel()

@@ -1138,3 +1138,37 @@ def test_packed_weight_cache_is_not_fooled_by_address_reuse(dev):
             assert float((k - torch.relu(hip.spmm(A, X) @ W.t())).abs().max()) < 1e-4, i
             del W
     assert len(seen) < 4                                            # the allocator did reuse an address
+
+
+@pytest.mark.parametrize('mode,n_prev', [('combine', 1), ('combine', 2), ('combine', 3), ('combine', 4), ('error', 5)])
+@pytest.mark.parametrize('side', [24, 112])
+def test_adjoint_halves_of_the_fused_launch_equal_the_composed_kernels(dev, side, mode, n_prev):
+    """ndcn_rhs_rk_adj_f32 (ABI 13): the forward half also writes S = A X - bit-equal to ndcn_spmm_f32, K / y_next / the error record
+    unchanged; the transposed half gathers X (.) [M > 0] - bit-equal to the same launch over the panel ndcn_relu_bwd_f32 writes."""
+    from ndcn_amd import hip, CsrOperator, graphs, _lib
+    H = 256
+    A = CsrOperator.from_scipy(graphs.normalized_laplacian(graphs.grid_8_neighbor(side)), dev)
+    n = side * side
+    g = torch.Generator().manual_seed(side + n_prev)
+    X = torch.rand(n, H, generator=g).to(dev)
+    M = (torch.rand(n, H, generator=g) - 0.4).to(dev)
+    W = ((torch.rand(H, H, generator=g) - 0.5) / 8).to(dev)
+    b = ((torch.rand(H, generator=g) - 0.5) / 8).to(dev)
+    y0 = torch.rand(n, H, generator=g).to(dev)
+    kprev = [torch.rand(n, H, generator=g).to(dev) for _ in range(n_prev)]
+    cs = [np.float32(0.1 * (j + 1)) for j in range(n_prev + 1)]
+    assert hip.rhs_adj_supported(A, H, mode, n_prev)
+    with torch.no_grad():
+        tol = (1e-2, 1e-3) if mode == 'error' else (0.0, 0.0)
+        ref = hip.rhs_rk(A, X, W, b, mode, y0, kprev, cs, *tol)
+        S = torch.empty_like(X)
+        got = hip.rhs_rk(A, X, W, b, mode, y0, kprev, cs, *tol, s_out=S)
+        assert int(_lib.load().ndcn_debug_last_rhs_path()) == _lib.PATH_FUSED3
+        assert torch.equal(got[0], ref[0]) and torch.equal(S, hip.spmm(A, X))
+        assert torch.equal(got[1], ref[1]) if mode == 'combine' else got[1] == ref[1]
+        Wt = W.t().contiguous()
+        kw = dict(relu=False, y1=X) if mode == 'error' else dict(relu=False)
+        ref = hip.rhs_rk(A, hip.relu_bwd(X, M), Wt, None, mode, y0, kprev, cs, *tol, **kw)
+        got = hip.rhs_rk(A, X, Wt, None, mode, y0, kprev, cs, *tol, x_mask=M, **kw)
+        assert torch.equal(got[0], ref[0])
+        assert torch.equal(got[1], ref[1]) if mode == 'combine' else got[1] == ref[1]
