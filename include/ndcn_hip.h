@@ -415,6 +415,14 @@ NDCN_API int ndcn_rk_combine_f32(float *out, const float *y0, const float *const
 NDCN_API int ndcn_rk_error_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k,
                       float rtol, float atol, int64_t n_elem, double *d_out, void *d_ws, void *stream);
 
+/* Reductions of ndcn_rk_error_f32 / ndcn_scaled_sumsq_f32 over at most this many elements reproduce ATen's float32 summation order
+ * (torch.mean / Tensor.norm: misc.py:71-76,156 - one workgroup, serial: the reference-sized solves, whose accept / reject decisions
+ * hang on the last bit); larger ones use the parallel fixed-order fp64 reduction.  Default 2^18 (environment NDCN_ATEN_NORM_MAX).
+ * This call overrides the bound PROCESS-WIDE at run time (n_elem < 0: back to the default) and returns the previous override
+ * (-1: none).  odeint_adjoint's fused reverse pass lowers it around its parameter-gradient vector (65 792 elements riding next
+ * to 10^5..10^6-row panels: 0.6 ms serial against 10 us parallel).                                                               */
+NDCN_API int64_t ndcn_set_aten_norm_max(int64_t n_elem);
+
 /* d_out[0] = sum ((a - b) / (atol + |y| * rtol))^2  (b nullable), d_out[1] = non-finite count of a.
  * The three RMS norms of misc.py:123-138 (d0, d1, d2).                                               */
 NDCN_API int ndcn_scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol, float atol,

@@ -135,6 +135,7 @@ SIGNATURES = {
     'ndcn_adjoint_rhs_work_bytes': (_L, [_L, _I, _U]),
     'ndcn_rhs_rk_f32': (_I, [_CSR, _P, _P, _L, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I,
                         _P, _P, _P, ctypes.POINTER(_F), _F, _F, _P, _P, _P]),
+    'ndcn_set_aten_norm_max': (_L, [_L]),
     'ndcn_rhs_adj_supported': (_I, [_CSR, _I, _U, _I, _I]),
     'ndcn_rhs_rk_adj_f32': (_I, [_CSR, _P, _P, _P, _P, _P, _P, _P, _I, _U, _I, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _P, _P,
                             _F, _F, _P, _P, _P]),

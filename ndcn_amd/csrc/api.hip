@@ -331,6 +331,8 @@ int ndcn_scaled_sumsq_f32(const float *a, const float *b, const float *y, float 
 
 int64_t ndcn_reduce_ws_bytes(void) { return reduce_ws_bytes(); }
 
+int64_t ndcn_set_aten_norm_max(int64_t n_elem) { return set_aten_order_max_elems(n_elem); }
+
 int ndcn_dopri5_interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt,
                                float *a, float *b, float *c, float *d, int64_t n_elem, void *stream) {
     NDCN_CHECK_ARG(n_elem >= 0 && h_k && h_cmid, "bad argument");

@@ -131,6 +131,7 @@ int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol,
 int64_t reduce_ws_bytes();
 int scaled_sumsq_pair_f32(const float *f, const float *y, float rtol, float atol, int64_t n, double *d_out4, void *d_ws,
                           void *d_ws2, hipStream_t st);
+int64_t set_aten_order_max_elems(int64_t v);   // run-time override of the bound below (< 0: back to the environment's); returns the previous override
 int64_t aten_order_max_elems();   // rk_error_f32 / scaled_sumsq_f32 reduce panels up to this size in ATen's float32 order (0: disabled)
 int interp_fit_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_cmid, float dt, float *a,
                    float *b, float *c, float *d, int64_t n, hipStream_t st);

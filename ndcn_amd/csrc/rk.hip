@@ -5,6 +5,7 @@
 // (misc.py:25), products and sums are rounded separately and added left to right.  FP contraction is
 // therefore switched OFF for this translation unit - an fma here would change the last bit relative to
 // the reference's separate mul / add kernels.
+#include <atomic>
 #include <stdlib.h>
 
 #include "common.h"
@@ -621,7 +622,13 @@ int rk_combine_f32(float *out, const float *y0, const float *const *h_k, const f
     return NDCN_OK;
 }
 
+// run-time override (ndcn_set_aten_norm_max): < 0 = none, the environment's bound applies
+static std::atomic<int64_t> g_aten_override{-1};
+int64_t set_aten_order_max_elems(int64_t v) { return g_aten_override.exchange(v < 0 ? (int64_t)-1 : (v > ((int64_t)1 << 24) ? ((int64_t)1 << 24) : v)); }
+
 int64_t aten_order_max_elems() {
+    const int64_t ov = g_aten_override.load(std::memory_order_relaxed);
+    if (ov >= 0) return ov;
     static const int64_t bound = []() -> int64_t {
         const char *e = getenv("NDCN_ATEN_NORM");
         if (e && e[0] == '0') return (int64_t)0;

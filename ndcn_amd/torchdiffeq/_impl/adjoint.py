@@ -113,46 +113,56 @@ class _AdjointMethod(torch.autograd.Function):
                     return tuple(-v for v in native_rhs(-tau, y_aug))
 
         T = ans[0].shape[0]
-        with torch.no_grad():
-            adj_y = tuple(g[-1] for g in grad_output)
-            adj_params = torch.zeros_like(flat_params)
-            adj_time = torch.tensor(0.).to(t)
-            time_vjps = []
-            for i in range(T - 1, 0, -1):
-                ans_i = tuple(a[i] for a in ans)
-                grad_i = tuple(g[i] for g in grad_output)
-                f_i = func(t[i], ans_i)
-                # effect of moving the measurement time                               adjoint.py:72-77
-                if native is not None:                           # <f, g> by the library's fixed-order reduction (fp64 partials)
-                    _, dots = hip.combine_bwd(grad_i[0].contiguous(), [f_i[0]], [1.0], [False], need_dots=True)
-                    dLd_t = torch.tensor([dots[0]], dtype=t.dtype, device=adj_y[0].device)
-                else:
-                    dLd_t = sum(torch.dot(f.reshape(-1), g.reshape(-1)).view(1) for f, g in zip(f_i, grad_i))
-                adj_time = adj_time - dLd_t
-                time_vjps.append(dLd_t)
-                if adj_params.numel() == 0:
-                    adj_params = torch.tensor(0.).to(adj_y[0])
-                if fused is not None:
-                    _, a_lo, adj_time, adj_params = fused.integrate_interval(
-                        hip, native, fused_w, ans_i[0].contiguous(), adj_y[0].contiguous(), adj_time, adj_params, t[i], t[i - 1],
-                        rtol, atol, options, reversed_rhs, step_log=getattr(native, 'ndcn_adjoint_step_log', None))
-                    adj_y = (a_lo,)
-                    aug0 = aug = None
-                else:
-                    aug0 = (*ans_i, *adj_y, adj_time, adj_params)
-                    slog = getattr(native, 'ndcn_adjoint_step_log', None) if native is not None and method in (None, 'dopri5') else None
-                    aug = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=rtol, atol=atol, method=method,
-                                 options=options, **({'step_log': slog} if slog is not None else {}))
-                    adj_y = tuple(a[1] for a in aug[n:2 * n])
-                    adj_time = aug[2 * n][1]
-                    adj_params = aug[2 * n + 1][1]
-                if native is not None:
-                    adj_y = (hip.combine(adj_y[0].contiguous(), [grad_output[0][i - 1].contiguous()], [1.0]),)
-                else:
-                    adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
-                del aug0, aug
-            time_vjps.append(adj_time.reshape(1))
-            time_vjps = torch.cat([v.reshape(1) for v in time_vjps[::-1]])
+        # panels beyond the ATen-order bound are reduced in parallel anyway: let the 65 792-element parameter-gradient vector riding
+        # next to them follow (0.6 ms serial per reduction otherwise; include/ndcn_hip.h: ndcn_set_aten_norm_max)
+        restore = None
+        if fused is not None and ans[0][0].numel() > (1 << 18):
+            from ... import _lib
+            restore = (_lib.load(), _lib.load().ndcn_set_aten_norm_max(0))
+        try:
+            with torch.no_grad():
+                adj_y = tuple(g[-1] for g in grad_output)
+                adj_params = torch.zeros_like(flat_params)
+                adj_time = torch.tensor(0.).to(t)
+                time_vjps = []
+                for i in range(T - 1, 0, -1):
+                    ans_i = tuple(a[i] for a in ans)
+                    grad_i = tuple(g[i] for g in grad_output)
+                    f_i = func(t[i], ans_i)
+                    # effect of moving the measurement time                               adjoint.py:72-77
+                    if native is not None:                           # <f, g> by the library's fixed-order reduction (fp64 partials)
+                        _, dots = hip.combine_bwd(grad_i[0].contiguous(), [f_i[0]], [1.0], [False], need_dots=True)
+                        dLd_t = torch.tensor([dots[0]], dtype=t.dtype, device=adj_y[0].device)
+                    else:
+                        dLd_t = sum(torch.dot(f.reshape(-1), g.reshape(-1)).view(1) for f, g in zip(f_i, grad_i))
+                    adj_time = adj_time - dLd_t
+                    time_vjps.append(dLd_t)
+                    if adj_params.numel() == 0:
+                        adj_params = torch.tensor(0.).to(adj_y[0])
+                    if fused is not None:
+                        _, a_lo, adj_time, adj_params = fused.integrate_interval(
+                            hip, native, fused_w, ans_i[0].contiguous(), adj_y[0].contiguous(), adj_time, adj_params, t[i], t[i - 1],
+                            rtol, atol, options, reversed_rhs, step_log=getattr(native, 'ndcn_adjoint_step_log', None))
+                        adj_y = (a_lo,)
+                        aug0 = aug = None
+                    else:
+                        aug0 = (*ans_i, *adj_y, adj_time, adj_params)
+                        slog = getattr(native, 'ndcn_adjoint_step_log', None) if native is not None and method in (None, 'dopri5') else None
+                        aug = odeint(augmented, aug0, torch.stack([t[i], t[i - 1]]), rtol=rtol, atol=atol, method=method,
+                                     options=options, **({'step_log': slog} if slog is not None else {}))
+                        adj_y = tuple(a[1] for a in aug[n:2 * n])
+                        adj_time = aug[2 * n][1]
+                        adj_params = aug[2 * n + 1][1]
+                    if native is not None:
+                        adj_y = (hip.combine(adj_y[0].contiguous(), [grad_output[0][i - 1].contiguous()], [1.0]),)
+                    else:
+                        adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
+                    del aug0, aug
+                time_vjps.append(adj_time.reshape(1))
+                time_vjps = torch.cat([v.reshape(1) for v in time_vjps[::-1]])
+        finally:
+            if restore is not None:
+                restore[0].ndcn_set_aten_norm_max(restore[1])
         return (None, None, None, time_vjps, adj_params, None, None, None, None) + tuple(adj_y)
 
 

@@ -664,7 +664,10 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
     lazy = carry and _lazy() and y0[0].numel() >= int(os.environ.get('NDCN_GRAD_LAZY_MIN', 1 << 20))
     # a plain ODEFunc on one state tensor (odeint checked): its evaluations carry the next stage input in their epilogue
     fused = None
-    if carry and odefunc is not None and len(y0) == 1 and os.environ.get('NDCN_GRAD_FUSED_STAGE', '1') != '0':
+    # (reference-sized states - 400 x 20 - are host-bound: the one-node-per-evaluation form costs them 35 %, 14.1 against 10.4 ms
+    # per README-sized dopri5 step, profiles/r04i_train_ab.txt; they keep one node per operation)
+    if carry and odefunc is not None and len(y0) == 1 and os.environ.get('NDCN_GRAD_FUSED_STAGE', '1') != '0' and \
+            y0[0].numel() >= int(os.environ.get('NDCN_GRAD_FUSED_STAGE_MIN', 1 << 16)):
         from ...csr import as_csr
         fused = ((None if odefunc.no_graph else as_csr(odefunc.A), bool(odefunc.no_graph), bool(odefunc.no_control)),
                  odefunc.wt.weight, odefunc.wt.bias)
