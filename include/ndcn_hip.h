@@ -618,6 +618,9 @@ NDCN_API int ndcn_prof_kinds(void);
 #define NDCN_PATH_HUB    4
 #define NDCN_PATH_HALO   8
 #define NDCN_PATH_SWEEP 16
+#define NDCN_PATH_REC   32   /* no_control: relu(A X) + the stage algebra in the epilogue of the group-record SpMM (spmm_rec.hip) */
+#define NDCN_PATH_WIDE  64   /* no_control: the same in the epilogue of the row SpMM (spmm.hip: spmm_wide_kernel)                */
+#define NDCN_PATH_SMALL 128  /* H <= 128: the whole ODEFunc + epilogue in one launch (rhs_small.hip)                            */
 NDCN_API int ndcn_debug_last_rhs_path(void);
 
 #ifdef __cplusplus

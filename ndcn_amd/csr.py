@@ -137,11 +137,22 @@ class CsrOperator:
     def _release(self):
         # (only in the process that created the handle: a fork()ed child - multiprocessing's Manager server, a DataLoader worker -
         # inherits this object, and its garbage collector must not call into a HIP context that does not exist there)
-        if getattr(self, '_handle', None) and getattr(self, '_handle_pid', None) == os.getpid():
-            try:
-                _lib.load().ndcn_csr_destroy(self._handle)
-            except Exception:
-                pass
+        handles = ([self._handle] if getattr(self, '_handle', None) else []) + getattr(self, '_retired', [])
+        if handles and getattr(self, '_handle_pid', None) == os.getpid():
+            for h in handles:
+                try:
+                    _lib.load().ndcn_csr_destroy(h)
+                except Exception:
+                    pass
+        self._handle = None
+        self._retired = []
+        self._view = None
+
+    def _retire(self):
+        """A re-plan (build_plans on an operator that has plans) keeps the old handle - and with it the device arrays that views
+        handed out earlier point into (a DeviceSolver keeps its view for its lifetime) - until this operator dies."""
+        if getattr(self, '_handle', None):
+            self._retired = getattr(self, '_retired', []) + [self._handle]
         self._handle = None
         self._view = None
 
@@ -161,7 +172,7 @@ class CsrOperator:
         if self.device.type != 'cuda':
             raise _lib.NdcnHipError(_lib.EINVAL, 'operator plans are built on the device; this operator lives on %s' % self.device)
         lib = _lib.load()
-        self._release()
+        self._retire()
         user_order = self.group_order is not None
         hints = self._hints(H, rec_shape, hub_threshold, flags)
         handle = ctypes.c_void_p()
@@ -232,40 +243,32 @@ class CsrOperator:
         self._plans_tried = True
         return self.build_plans(H)
 
-    def view(self):
-        """struct ndcn_csr of this operator: the handle's view when plans were built, a bare view of the arrays otherwise."""
+    def view(self, need_symmetric=False):
+        """struct ndcn_csr of this operator: a COPY of the handle's view when plans were built (never an alias of library-owned
+        memory: this object writes max_row_len / symmetric into it, and a later re-plan must not pull it from under a solver that
+        kept it), a bare view of the arrays otherwise.  need_symmetric: the caller reads ndcn_csr::symmetric (the one-launch
+        reverse sweep) - found on first request: a transpose build and three comparisons that inference never pays."""
         if self._view is None:
             if getattr(self, '_handle', None):
-                self._view = _lib.load().ndcn_csr_view(self._handle).contents
+                self._view = _lib.CsrView.from_buffer_copy(_lib.load().ndcn_csr_view(self._handle).contents)
             else:
                 self._view = _lib.CsrView(self.shape[0], self.shape[1], self.nnz,
                                           self.rowptr.data_ptr(), self.colidx.data_ptr() if self.nnz else None,
                                           self.val.data_ptr() if self.nnz else None,
                                           self.row_order.data_ptr() if self.row_order is not None else None, None)
-            width, sym = self.facts()
-            if width:
-                self._view.max_row_len, self._view.symmetric = width, sym
+            small = self.nnz > 0 and self.shape[0] <= (1 << 16)          # (only the one-launch solves read the two facts)
+            if small:
+                self._view.max_row_len = int((self.rowptr[1:] - self.rowptr[:-1]).max())
+        if need_symmetric and self._view.symmetric == 0 and self.nnz > 0 and self.shape[0] <= (1 << 16):
+            sym = 2
+            if self.shape[0] == self.shape[1]:
+                t = self.transpose()
+                sym = 1 if (torch.equal(t.rowptr, self.rowptr) and torch.equal(t.colidx, self.colidx) and torch.equal(t.val, self.val)) else 2
+            self._view.symmetric = sym
         return self._view
 
-    def facts(self):
-        """(longest row, 1 if the stored arrays equal the transpose's else 2): ndcn_csr::max_row_len / symmetric, found once per
-        operator object (its arrays are never mutated) - only for operators small enough for the one-launch solves that ask."""
-        f = getattr(self, '_facts', None)
-        if f is None:
-            if self.nnz == 0 or self.shape[0] * 1 > (1 << 16):
-                f = (0, 0)
-            else:
-                width = int((self.rowptr[1:] - self.rowptr[:-1]).max())
-                sym = 2
-                if self.shape[0] == self.shape[1]:
-                    t = self.transpose()
-                    sym = 1 if (torch.equal(t.rowptr, self.rowptr) and torch.equal(t.colidx, self.colidx) and torch.equal(t.val, self.val)) else 2
-                f = (width, sym)
-            self._facts = f
-        return f
-
-    def view_ref(self):
-        return ctypes.byref(self.view())
+    def view_ref(self, need_symmetric=False):
+        return ctypes.byref(self.view(need_symmetric))
 
     def scaled(self, alpha):
         return CsrOperator(self.rowptr, self.colidx, self.val * float(alpha), self.shape)

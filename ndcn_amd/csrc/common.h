@@ -1,5 +1,6 @@
 // Internal helpers shared by the kernels of libndcn_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -39,6 +40,22 @@ void set_error(const char *fmt, ...);
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kXcds = 8;        // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
 constexpr int kCus = 256;
+// The persistent grids (one workgroup per CU, XCD = blockIdx % 8) are LAID OUT for the whole chip; on a partitioned or smaller device
+// (CPX / DPX modes report 32 / 128 compute units) they stay correct - every workgroup strides over the work - and merely
+// oversubscribe.  Kernels that NEED all their workgroups co-resident (the column sweep's progress words, spmm_sweep.hip) ask this
+// first and refuse otherwise (their callers fall back to the row kernels).  Cached per device.
+inline bool device_is_whole_chip() {
+    static std::atomic<int> known[64];                     // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    int k = known[dev].load(std::memory_order_relaxed);
+    if (k == 0) {
+        int cus = 0;
+        k = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == kCus) ? 1 : 2;
+        known[dev].store(k, std::memory_order_relaxed);
+    }
+    return k == 1;
+}
 
 // torch's relu / max propagate NaN (F.relu, neural_dynamics.py:36; torch.max, misc.py:149): v_max_f32 (fmaxf) does not - it
 // returns the other operand, which would turn a NaN born inside the right-hand side into K = 0 and hide it from the
@@ -73,5 +90,14 @@ inline int stream_grid(int64_t n_items, int block) {
 // alternate between a burst of loads and a burst of stores in step, while the dispatcher's stream of short-lived
 // workgroups keeps reads and writes mixed.  NDCN_STREAM_FULL=0 restores the capped grid (A/B).
 int stream_grid_full(int64_t n_items, int block);
+
+// A per-kernel one-off (hipFuncSetAttribute is per DEVICE): true exactly once per device of this process for the flag word it
+// is handed - a model on cuda:1, a thread per rank (round-4 advisor: a process-wide `static bool` skipped the second device).
+inline bool once_per_device(std::atomic<unsigned long long> &seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;       // unknown: set the attribute again (cheap, idempotent)
+    const unsigned long long bit = 1ull << dev;
+    return (seen.fetch_or(bit) & bit) == 0;
+}
 
 }  // namespace ndcn

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void sweep_eye_kernel(int64_t n, int32_t *rowp
 // The right-hand side pays one more write and read of S for the sweep, so the plan is taken from 1.5 x upwards, and only
 // when the panel is larger than what an XCD's L2 holds anyway (8 192 rows of 1 KiB = 2 x 4 MiB).
 bool sweep_pays(const ndcn_csr &A, int passes) {
-    return A.n_cols >= 8192 && (double)A.nnz >= 1.5 * (double)passes * kXcds * (double)A.n_cols;
+    return device_is_whole_chip() && A.n_cols >= 8192 && (double)A.nnz >= 1.5 * (double)passes * kXcds * (double)A.n_cols;   // (the sweep needs the whole chip: common.h)
 }
 
 int build_sweep_plan(ndcn_csr_handle *h, bool external_scratch, hipStream_t st) {

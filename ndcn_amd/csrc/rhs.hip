@@ -96,19 +96,26 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
         return rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
                               d_out, d_ws, st, opt);
     }
-    if (both && rhs_small_supported(A, H, flags))
+    if (both && rhs_small_supported(A, H, flags)) {
+        g_last_rhs_path = NDCN_PATH_SMALL;
         return rhs_small_f32(A, X, Xh, n_own, W, b, K, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws,
                              st, nullptr, opt);
+    }
     // no_control: relu(A X) with the stage algebra in the epilogue of the group-record SpMM (spmm_rec.hip)
     const bool graph_only = !(flags & NDCN_F_NO_GRAPH) && (flags & NDCN_F_NO_CONTROL);
     if (graph_only && spmm_rec_supported(A, H) && spmm_rec_variant(rk_mode, n_prev) && A->n_rows * (int64_t)1024 < (1ll << 32) &&
-        aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))
+        aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh))) {
+        g_last_rhs_path = NDCN_PATH_REC | ((Xh && A->n_cols > n_own) ? NDCN_PATH_HALO : 0);
         return spmm_rec_f32(A, X, Xh, n_own, K, 1.f, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st,
                             nullptr, opt);
+    }
     const bool swept = graph_only && !Xh && H == 256 && spmm_sweep_supported(A, H) && aligned16(X) && aligned16(K);
-    if (!swept && graph_only && spmm_wide_rk_supported(A, H) && aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh)))     // any other graph
+    if (!swept && graph_only && spmm_wide_rk_supported(A, H) && aligned16(X) && aligned16(K) && (!Xh || aligned16(Xh))) {   // any other graph
+        g_last_rhs_path = NDCN_PATH_WIDE | ((Xh && A->n_cols > n_own) ? NDCN_PATH_HALO : 0);
         return spmm_wide_rk_f32(A, X, Xh, n_own, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws, st,
                                 nullptr, opt);
+    }
+    g_last_rhs_path = 0;
     // composition with the same term order: K first, then the algebra over {kprev..., K}
     int rc = rhs_f32(A, X, Xh, n_own, W, b, K, work, H, flags, st);
     if (rc) return rc;

@@ -677,10 +677,9 @@ int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n
 template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false>
 static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st) {
     auto kern = rhs_fused3_kernel<HALO, MODE, NP, XOP, NT, SOUT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_seen{0};
+    if (once_per_device(attr_seen)) {
         NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * (f3_producers(MODE, NP) + kF3WM)), kF3Lds, st, a, e);
     return NDCN_OK;

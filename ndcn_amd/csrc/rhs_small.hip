@@ -221,11 +221,10 @@ int rhs_small_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_
 #define NDCN_SM(NH_, HALO_, MODE_)                                                                                    \
     do {                                                                                                              \
         auto kern = rhs_small_kernel<NH_, HALO_, MODE_>;                                                              \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
+        static std::atomic<unsigned long long> attr_seen{0};                                                                                 \
+        if (once_per_device(attr_seen)) {                                                                                              \
             NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,              \
                                          (int)(((size_t)kSmMaxH * (kSmMaxH + 1) + 4 * kSmMaxH) * sizeof(float))));     \
-            attr_set = true;                                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, e);                                               \
     } while (0)

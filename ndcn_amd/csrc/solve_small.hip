@@ -821,8 +821,8 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
 #define NDCN_GO(M_, IT_, C_, HT_)                                                              \
         do {                                                                                   \
             auto kern = solve_small_kernel<M_, IT_, C_, HT_>;                                  \
-            static bool cap_set = false;                                                       \
-            if (!cap_set) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; cap_set = true; } \
+            static std::atomic<unsigned long long> cap_seen{0};                                                       \
+            if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; }       \
             hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a);                         \
         } while (0)
 #define NDCN_GO_IT(M_, C_, HT_)                                                                \
@@ -942,8 +942,8 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
 #define NDCN_FGO(IT_, HT_)                                                                     \
             do {                                                                               \
                 auto kern = solve_small_bwd_fast_kernel<IT_, HT_>;                             \
-                static bool cap_set = false;                                                   \
-                if (!cap_set) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; cap_set = true; } \
+                static std::atomic<unsigned long long> cap_seen{0};                                                   \
+                if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; }       \
                 hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_fast, st, a, n_groups, rows_per_group); \
             } while (0)
             if (H == 20) { if (np <= 4) NDCN_FGO(4, 20); else NDCN_FGO(12, 20); }
@@ -953,8 +953,8 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
 #define NDCN_GO(IT_, C_)                                                                       \
         do {                                                                                   \
             auto kern = solve_small_bwd_kernel<IT_, C_>;                                       \
-            static bool cap_set = false;                                                       \
-            if (!cap_set) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; cap_set = true; } \
+            static std::atomic<unsigned long long> cap_seen{0};                                                       \
+            if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; }       \
             hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a, symmetric);              \
         } while (0)
         if (np <= 4) { if (csr) NDCN_GO(4, true); else NDCN_GO(4, false); }

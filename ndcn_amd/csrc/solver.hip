@@ -189,6 +189,7 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
             c_dev = s->d_coef + s->n_coef;
             s->n_coef += 8;                                   // slices stay 32-byte aligned
         }
+        g_last_rhs_path = s->small_epi ? NDCN_PATH_SMALL : (s->wide_epi ? NDCN_PATH_WIDE : NDCN_PATH_REC);
         if (s->small_epi)
             return rhs_small_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, K, s->d.H, s->d.rhs_flags, mode, y0, kp, cp,
                                  n_prev, y_next, rtol, atol, d_out, d_ws, st, c_dev, opt);

@@ -384,10 +384,9 @@ static int launch_rec(const RecArgs &a, const RecEpi &e, int mode, bool halo, hi
 #define NDCN_REC(HALO_, MODE_)                                                                                        \
     do {                                                                                                              \
         auto kern = spmm_rec_kernel<R, CAP, RECW, HALO_, MODE_>;                                                      \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
+        static std::atomic<unsigned long long> attr_seen{0};                                                                                 \
+        if (once_per_device(attr_seen)) {                                                                                              \
             NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-            attr_set = true;                                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a, e);                                                         \
     } while (0)

@@ -226,8 +226,9 @@ __global__ __launch_bounds__(kSweepWaves * 64) void spmm_sweep_kernel(SweepArgs 
 
 int spmm_sweep_supported(const ndcn_csr *A, int H) {
     static const int enabled = [] { const char *e = getenv("NDCN_SWEEP"); return e ? atoi(e) : 1; }();
+    // (256 workgroups of a pass wait on each other's progress words: all of them must be resident, one per CU of the whole chip)
     return enabled && A && H == 256 && A->sweep_ent && A->sweep_slab && A->sweep_prog && A->sweep_passes > 0 &&
-           A->sweep_rpw > 0 && A->sweep_rpw <= kSweepRows && A->n_cols * (int64_t)1024 < (1ll << 32);
+           A->sweep_rpw > 0 && A->sweep_rpw <= kSweepRows && A->n_cols * (int64_t)1024 < (1ll << 32) && device_is_whole_chip();
 }
 
 // Y = A X through the operator's column-sweep plan (H = 256, no halo panel, alpha = 1, no activation)

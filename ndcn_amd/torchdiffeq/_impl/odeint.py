@@ -143,22 +143,27 @@ class _SmallEulerSolve(torch.autograd.Function):
         with torch.cuda.device(y0.device):
             _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, _lib.M_EULER, _lib.ptr(out[0]), arr,
                                                 n_ticks, _lib.ptr(out[1:]), _lib.stream_ptr()))
-        ctx.csr, ctx.flags, ctx.dts, ctx.keep = csr, flags, arr, (Wd, bd)
-        ctx.save_for_backward(out)
+        ctx.csr, ctx.flags, ctx.dts = csr, flags, arr
+        ctx.has_W, ctx.has_b = Wd is not None, bd is not None
+        # (W and b through save_for_backward: an in-place parameter change between forward and backward raises, as it does for
+        # every other autograd node, instead of differentiating the wrong weights)
+        ctx.save_for_backward(out, *([W] if Wd is not None else []), *([b] if bd is not None else []))
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        (out,) = ctx.saved_tensors
+        out, *wb = ctx.saved_tensors
         lib = _lib.load()
-        Wd, bd = ctx.keep
+        Wd = wb[0].detach().contiguous() if ctx.has_W else None
+        bd = wb[1 if ctx.has_W else 0].detach().contiguous() if ctx.has_b else None
         H = out.shape[2]
         g = g.contiguous()
         g_y0 = torch.empty_like(out[0])
         g_W = torch.empty((H, H), dtype=torch.float32, device=out.device) if Wd is not None else None
         g_b = torch.empty((H,), dtype=torch.float32, device=out.device) if Wd is not None else None
         csr = ctx.csr
-        view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(out.shape[1]))
+        view = csr.view_ref(need_symmetric=True) if csr is not None else ctypes.byref(_lib.empty_csr(out.shape[1]))
         view_t = csr.transpose().view_ref() if csr is not None else view
         with torch.cuda.device(out.device):
             _lib.check(lib.ndcn_solve_small_bwd_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, _lib.M_EULER, _lib.ptr(out),
@@ -227,6 +232,7 @@ class _FixedGridSolve(torch.autograd.Function):
         return gu, gW, gb
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         out, W, b = ctx.saved_tensors
         csr, no_graph, no_control, method, dts = ctx.meta
@@ -274,7 +280,7 @@ class _FixedGridSolve(torch.autograd.Function):
                 gu1, gW, gb = vj(u1, K1, gk1, 1.0)
                 acc(gW, gb, 1.0)
                 a = hip.lincomb([gu4, gu3, gu2, gu1, g[i]], [1.0] * 5, y0=a)
-        return a, gW_tot, gb_tot, None, None, None, None
+        return a, gW_tot, (gb_tot if b is not None else None), None, None, None, None
 
 
 def _fixed_grid_with_grad(odefunc, y0, t, method):

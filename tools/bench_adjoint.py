@@ -17,6 +17,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -69,33 +70,14 @@ def run_case(name, side, H, ticks, mode, dev, reps):
         times.append(time.perf_counter() - t0)
     peak = torch.cuda.max_memory_allocated()
     # instrumented step: HIP events around every library launch
-    lib = _lib.load()
-    nk = lib.ndcn_prof_kinds()
-    buf = (_lib.ctypes.c_double * (4 * nk))()
-    lib.ndcn_prof_enable(1)
-    lib.ndcn_prof_read(buf, nk)
-    step()
-    torch.cuda.synchronize()
-    lib.ndcn_prof_enable(0)
-    lib.ndcn_prof_read(buf, nk)
-    breakdown, tot = {}, 0.0
-    for i, kname in enumerate(_lib.PROF_KINDS):
-        cnt, ms, byt, fl = buf[4 * i:4 * i + 4]
-        if cnt:
-            breakdown[kname] = {'launches': int(cnt), 'ms_total': round(ms, 3), 'avg_ms': round(ms / cnt, 4),
-                                'alg_GBps': round(byt / ms / 1e6, 1), 'frac_of_hbm_peak': round(byt / ms / 1e6 / HBM_PEAK_GBS, 4),
-                                'TFLOPs': round(fl / ms / 1e9, 2)}
-            tot += ms
+    import _prof
+    breakdown, tot = _prof.breakdown(step)
     n = side * side
     rec = {'case': name, 'mode': mode, 'n': n, 'H': H, 'ticks': ticks, 'nnz': int(nnz), 'ms_per_adam_step': round(1e3 * float(np.median(times)), 2),
            'peak_device_memory_GB': round(peak / 1e9, 3), 'resident_before_step_GB': round(base / 1e9, 3),
            'library_kernel_ms_per_step': round(tot, 2), 'breakdown': breakdown}
     if breakdown:
-        dom = max(breakdown, key=lambda k: breakdown[k]['ms_total'])
-        b = breakdown[dom]
-        rec['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': b['alg_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                           'frac': b['frac_of_hbm_peak'], 'avg_ms': b['avg_ms'], 'launches': b['launches'], 'traffic': None,
-                           'share_of_kernel_time': round(b['ms_total'] / tot, 3)}
+        rec['roofline'] = _prof.roofline_of(breakdown, tot)
     del model, opt
     torch.cuda.empty_cache()
     return rec

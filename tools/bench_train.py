@@ -10,6 +10,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -47,6 +48,15 @@ def one_case(name, side, H, ticks, method, dev, cpu_reps):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     res = {'case': name, 'n': n, 'H': H, 'method': method, 'ticks': ticks, 'gpu_ms_per_adam_step': round(1e3 * float(np.median(times)), 3)}
+    if n * H >= (1 << 20):
+        # a roofline per kernel family of the step (HIP events around every library launch; algorithmic bytes of each launch over
+        # its duration against the 8 TB/s HBM peak): the backward kernels - combine_bwd, error_bwd, dense_bwd (dense output),
+        # linear_gs, linear_wgrad - next to the forward ones
+        import _prof
+        bd, tot = _prof.breakdown(step)
+        res['library_kernel_ms_per_step'] = round(tot, 2)
+        res['breakdown'] = bd
+        res['roofline'] = _prof.roofline_of(bd, tot)
     if cpu_reps:
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         Ac = orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape)
