@@ -489,6 +489,11 @@ NDCN_API int ndcn_comm_unique_id(char h_id[128]);
 NDCN_API int ndcn_comm_create(const char h_id[128], int world, int rank, ndcn_comm **out);
 /* or adopt the caller's ncclComm_t (passed as void*; not destroyed by ndcn_comm_destroy) */
 NDCN_API int ndcn_comm_adopt(void *nccl_comm, int world, int rank, ndcn_comm **out);
+/* TEST transport: the same communicator interface over POSIX shared memory, host-staged and synchronous (csrc/comm.hip) - ranks
+ * that share ONE device (RCCL refuses those) or have no RCCL at all can run every multi-rank entry point of this header, the
+ * device-resident sharded solver included.  `name`: the same string on every rank, unique per communicator (<= 99 characters,
+ * no '/'); world <= 64.  Collective: returns when every rank has joined (120 s bound).  Never the production path.               */
+NDCN_API int ndcn_comm_create_loopback(const char *name, int world, int rank, ndcn_comm **out);
 NDCN_API int ndcn_comm_destroy(ndcn_comm *c);
 /* d_buf[0..n) <- sum over ranks (in place, enqueued on `stream`; a no-op for world 1) */
 NDCN_API int ndcn_comm_allreduce_sum_f64(ndcn_comm *c, double *d_buf, int n, void *stream);

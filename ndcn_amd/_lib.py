@@ -160,6 +160,7 @@ SIGNATURES = {
     'ndcn_comm_unique_id': (_I, [ctypes.c_char_p]),
     'ndcn_comm_create': (_I, [ctypes.c_char_p, _I, _I, ctypes.POINTER(_P)]),
     'ndcn_comm_adopt': (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
+    'ndcn_comm_create_loopback': (_I, [ctypes.c_char_p, _I, _I, ctypes.POINTER(_P)]),
     'ndcn_comm_destroy': (_I, [_P]),
     'ndcn_comm_allreduce_sum_f64': (_I, [_P, _P, _I, _P]),
     'ndcn_halo_plan_create': (_I, [_P, _L, ctypes.POINTER(_L), ctypes.POINTER(_L), _P, _I, ctypes.POINTER(_P)]),

@@ -421,8 +421,9 @@ class DeviceShard:
     `DeviceSolver(..., shard=)` steps the whole solve inside libndcn_hip.so: exchange on a side stream, launches, the
     16-byte all-reduce and the controller - no Python between the evaluations."""
 
-    def __init__(self, plan, n_global_rows, group=None):
+    def __init__(self, plan, n_global_rows, group=None, transport=None):
         import ctypes
+        import time
         from . import _lib
         self.plan = plan
         self.lib = lib = _lib.load()
@@ -432,21 +433,31 @@ class DeviceShard:
         # communicator: rank 0 draws the id, everybody learns it over the caller's process group.  Every rank reaches the
         # broadcast whatever happened before it (a rank that raised earlier would leave its peers waiting in it): rank 0's
         # failure travels as an all-zero id with a set flag byte, and then every rank raises together.
-        idbuf = ctypes.create_string_buffer(128)
-        rc0 = lib.ndcn_comm_unique_id(idbuf) if plan.rank == 0 else 0
-        if plan.world > 1:
-            comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
-            t = torch.tensor(list(idbuf.raw) + [1 if rc0 != 0 else 0], dtype=torch.uint8, device=comm_dev)
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            raw = bytes(t.cpu().tolist())
-            if raw[128]:
-                raise _lib.NdcnHipError(_lib.EHIP, 'rank 0 could not draw an RCCL unique id')
-            idbuf = ctypes.create_string_buffer(raw[:128], 128)
-        else:
-            _lib.check(rc0)
         self.comm = ctypes.c_void_p()
-        with torch.cuda.device(dev):
-            _lib.check(lib.ndcn_comm_create(idbuf, plan.world, plan.rank, ctypes.byref(self.comm)))
+        self.transport = transport or os.environ.get('NDCN_COMM_TRANSPORT', 'rccl')
+        if self.transport == 'loopback':
+            # TEST transport (include/ndcn_hip.h: ndcn_comm_create_loopback): host-staged shared memory with the RCCL communicator's
+            # call sequence - several ranks on ONE device.  Rank 0 draws the name, everybody learns it over the caller's group.
+            name = [('ndcn_lb_%d_%x' % (os.getpid(), int(time.time() * 1e6) & 0xffffffffff)) if plan.rank == 0 else None]
+            if plan.world > 1:
+                dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            with torch.cuda.device(dev):
+                _lib.check(lib.ndcn_comm_create_loopback(name[0].encode(), plan.world, plan.rank, ctypes.byref(self.comm)))
+        else:
+            idbuf = ctypes.create_string_buffer(128)
+            rc0 = lib.ndcn_comm_unique_id(idbuf) if plan.rank == 0 else 0
+            if plan.world > 1:
+                comm_dev = dev if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+                t = torch.tensor(list(idbuf.raw) + [1 if rc0 != 0 else 0], dtype=torch.uint8, device=comm_dev)
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                raw = bytes(t.cpu().tolist())
+                if raw[128]:
+                    raise _lib.NdcnHipError(_lib.EHIP, 'rank 0 could not draw an RCCL unique id')
+                idbuf = ctypes.create_string_buffer(raw[:128], 128)
+            else:
+                _lib.check(rc0)
+            with torch.cuda.device(dev):
+                _lib.check(lib.ndcn_comm_create(idbuf, plan.world, plan.rank, ctypes.byref(self.comm)))
         L = ctypes.c_int64 * plan.world
         self.send_idx = plan.send_idx.contiguous()
         self.halo = ctypes.c_void_p()

@@ -167,3 +167,109 @@ def test_eight_shards_on_one_device_equal_the_unsharded_solver(case):
                 json.dump(record, fh, indent=1)
     finally:
         shutil.rmtree(shm, ignore_errors=True)
+
+
+# ---- the DEVICE-RESIDENT sharded solver (ndcn_solver_desc::shard: exchange, launches, all-reduce, controller inside the library) with
+# world = 8 on the one device, over the loopback transport (include/ndcn_hip.h: ndcn_comm_create_loopback - the RCCL communicator's
+# call sequence on shared memory; RCCL itself refuses two ranks per device)
+
+def _device_worker(rank, world, port, case, shm, ret):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('OMP_NUM_THREADS', '4')
+    import scipy.sparse as sp
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ndcn_amd import sharding, hip
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from ndcn_amd.torchdiffeq._impl.odeint import DeviceSolver
+        dev = torch.device('cuda:0')
+        bounds = np.load(os.path.join(shm, 'bounds.npy')).tolist()
+        lo, hi = bounds[rank], bounds[rank + 1]
+        indptr = np.load(os.path.join(shm, 'indptr.npy'), mmap_mode='r')
+        a, b = int(indptr[lo]), int(indptr[hi])
+        block = sp.csr_matrix((np.load(os.path.join(shm, 'data.npy'), mmap_mode='r')[a:b],
+                               np.load(os.path.join(shm, 'indices.npy'), mmap_mode='r')[a:b],
+                               np.asarray(indptr[lo:hi + 1]) - a), shape=(hi - lo, bounds[-1]))
+        f = ODEFunc(H, None).to(dev)
+        f.load_state_dict({'wt.weight': torch.from_numpy(np.load(os.path.join(shm, 'W.npy'))),
+                           'wt.bias': torch.from_numpy(np.load(os.path.join(shm, 'b.npy')))})
+        plan = sharding.HaloPlan(block, bounds, rank, dev)
+        xl = _x_block(rank, hi - lo).to(dev)
+        ticks = [0., 0.3, 0.6]
+        shard = sharding.DeviceShard(plan, bounds[-1], transport='loopback')
+        out = {'transport': shard.transport, 'n_halo': plan.n_halo}
+        with torch.no_grad():
+            solver = DeviceSolver(f, hi - lo, 'dopri5', RTOL, ATOL, shard=shard)
+            yd = torch.empty(2, hi - lo, H, device=dev)
+            solver.begin(xl, 0.0)
+            solver.advance_many(ticks[1:], yd)
+            torch.cuda.synchronize()
+            out['dopri5_log'] = [tuple(float(v) for v in r[:4]) for r in solver.steplog()]
+            out['dopri5_nfe'] = int(solver.stats()['nfe'])
+            np.save(os.path.join(shm, 'yd_dopri5_%d.npy' % rank), yd[-1].cpu().numpy())
+            rk = DeviceSolver(f, hi - lo, 'rk4', shard=shard)
+            y4 = torch.empty(2, hi - lo, H, device=dev)
+            rk.begin(xl, 0.0)
+            rk.advance_many(ticks[1:], y4)
+            torch.cuda.synchronize()
+            np.save(os.path.join(shm, 'yd_rk4_%d.npy' % rank), y4[-1].cpu().numpy())
+            # the Python-stepped form of the same shard (gloo): the two implementations of the N > 1 path against each other
+            lp = []
+            yp = sharding.sharded_odeint(hip, f, plan, bounds[-1], xl, torch.tensor(ticks, device=dev), rtol=RTOL, atol=ATOL,
+                                         method='dopri5', step_log=lp)
+            out['python_log'] = [tuple(float(v) for v in r[:4]) for r in lp if r[0] != 'nfe']
+            out['device_vs_python_max_abs'] = float((yd[-1] - yp[-1]).abs().max())
+            solver.close(); rk.close()
+        shard.close()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['small_world', 'grid'])
+def test_eight_shards_device_resident_solver_over_the_loopback_transport(case):
+    import torch.multiprocessing as mp
+    from ndcn_amd import CsrOperator
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq import odeint
+    dev = torch.device('cuda:0')
+    per_rank = 40000 if case == 'small_world' else 64000         # (host-staged: every byte crosses PCIe twice and shared memory once)
+    L, bounds = _graph(case, per_rank)
+    torch.manual_seed(0)
+    f = ODEFunc(H, None)
+    shm = tempfile.mkdtemp(prefix='ndcn8d_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        for name, arr in (('indptr', L.indptr), ('indices', L.indices), ('data', L.data), ('bounds', np.asarray(bounds)),
+                          ('W', f.wt.weight.detach().numpy()), ('b', f.wt.bias.detach().numpy())):
+            np.save(os.path.join(shm, name + '.npy'), arr)
+        ret = mp.get_context('spawn').Manager().dict()
+        port = 29000 + os.getpid() % 250 + (0 if case == 'grid' else 251)
+        mp.spawn(_device_worker, args=(WORLD, port, case, shm, ret), nprocs=WORLD, join=True)
+        assert len(ret) == WORLD
+        for r in range(WORLD):
+            o = ret[r]
+            assert o['transport'] == 'loopback' and o['n_halo'] > 0
+            assert o['dopri5_log'] == ret[0]['dopri5_log'] and len(o['dopri5_log']) >= 1          # identical decisions on all ranks
+            assert [bool(x[2]) for x in o['dopri5_log']] == [bool(x[2]) for x in o['python_log']]    # ... and in both implementations
+            assert o['device_vs_python_max_abs'] < 1e-5
+        A = CsrOperator.from_arrays(L.indptr, L.indices, L.data, L.shape, dev)
+        fd = ODEFunc(H, A).to(dev).eval()
+        fd.load_state_dict(f.state_dict())
+        x = torch.cat([_x_block(r, bounds[r + 1] - bounds[r]) for r in range(WORLD)]).to(dev)
+        t = torch.tensor([0., 0.3, 0.6], device=dev)
+        with torch.no_grad():
+            for method in ('rk4', 'dopri5'):
+                log = []
+                ref = odeint(fd, x, t, rtol=RTOL, atol=ATOL, method=method, step_log=log)[-1]
+                scale = max(1.0, float(ref.abs().max()))
+                for r in range(WORLD):
+                    got = torch.from_numpy(np.load(os.path.join(shm, 'yd_%s_%d.npy' % (method, r)))).to(dev)
+                    assert float((got - ref[bounds[r]:bounds[r + 1]]).abs().max()) < 2e-5 * scale, (method, r)
+                if method == 'dopri5':
+                    rows = [r for r in log if r[0] != 'nfe']
+                    assert [bool(r[2]) for r in rows] == [bool(m[2]) for m in ret[0]['dopri5_log']]
+    finally:
+        shutil.rmtree(shm, ignore_errors=True)
