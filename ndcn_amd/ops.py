@@ -106,6 +106,11 @@ class _PackedWeights:
     def get(cls, W, nbytes, tag='fwd'):
         if not cls.enabled:
             return torch.empty(nbytes, dtype=torch.uint8, device=W.device), 0
+        # a whole-tensor alias (the training path hands W on from evaluation to evaluation as `W.view_as(W)`: a new tensor object each
+        # time) is the tensor it views: same storage, same version counter
+        base = W._base
+        if base is not None and base.data_ptr() == W.data_ptr() and base.shape == W.shape and base.is_contiguous():
+            W = base
         key = (id(W), torch.cuda.current_stream(W.device).cuda_stream, nbytes, tag)
         hit = cls._cache.get(key)
         if hit is not None and hit[0]() is W and hit[1] == W._version and hit[2] == W.data_ptr():

@@ -390,8 +390,97 @@ class _StageCarryFn(torch.autograd.Function):
         return (None, g_y0) + tuple(gk_all) + tuple(gc_all)
 
 
+# ---- a fixed summation order for tensors with SEVERAL consumers (round 5: same seed -> same bits) ---------------------------------
+# The scalar chain of the step-size controller lives on the host, the panels on the device: autograd runs the two kinds of nodes on
+# two threads, so WHEN a panel node becomes ready depends on the host thread's progress, and with it the order in which the engine
+# adds the gradients a tensor receives from three or more consumers - fp32 sums in a different order, one ulp apart, once every
+# ~10-20 training steps (found with tools/bench_dgnn.py: the first tensor that differed between two runs of one seed was the gradient
+# leaving the ODE block, at epoch 9 resp. 18, by 5e-10 - with h, the solve, the logits, the loss and the incoming gradient still
+# bit-equal).  What the carry forms leave with several consumers gets ONE consumer here:
+#   _FanOut      the solve's y0 (first evaluation, the three norms and the probe step of the initial-step selection, the first stage
+#                chain, the trajectory's first tick) and f0 inside the initial-step selection: n aliases, their gradients added left to
+#                right by one ndcn_rk_combine_f32 launch;
+#   W, b         ride through the evaluations of the fused path like the panels do (carried outputs): evaluation i adds its g_W to what
+#                evaluations i + 1 .. sent - a chain the data dependencies order, whatever the threads do.
+
+class _FanOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g.contiguous() for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        if not live[0].is_cuda:                                      # scalars of the controller chain: left to right on the host
+            tot = live[0]
+            for g in live[1:]:
+                tot = tot + g
+            return tot, None
+        return hip.lincomb(live, [1.0] * len(live)), None
+
+
+def _fan(x, n):
+    return _FanOut.apply(x, n) if (n > 2 and x.requires_grad) else (x,) * n
+
+
+# The ~28 products dt * beta_ij, dt * c_err_j of one attempted step as ONE multiplication by the tableau (bit-identical products:
+# float32 x float32 either way) and one unbind: `dts` then has one consumer instead of 28 whose gradients - each born on the device
+# thread, each a float32 scalar - the engine would add in arrival order.
+_TABLEAU = None
+
+
+def _step_coefficients(dts):
+    """-> (rows, c_err): rows[i][j] = dts * DP_BETA[i][j], c_err[j] = dts * DP_C_ERR[j] as 0-d float32 tensors"""
+    global _TABLEAU
+    if _TABLEAU is None:
+        flat = [b for row in core.DP_BETA for b in row] + list(core.DP_C_ERR)
+        _TABLEAU = torch.tensor(flat, dtype=torch.float32)
+    prod = (dts * _TABLEAU.to(dts.dtype)).unbind(0)
+    rows, o = [], 0
+    for row in core.DP_BETA:
+        rows.append(list(prod[o:o + len(row)]))
+        o += len(row)
+    return rows, list(prod[o:o + len(core.DP_C_ERR)])
+
+
+def _add_carried(own, carried):
+    """own + carried for the small parameter gradients of the chain (either may be None)"""
+    if own is None:
+        return carried
+    return own if carried is None else own + carried
+
+
+class _RhsCarryFn(torch.autograd.Function):
+    """(K, W', b') = (relu(W (A u) + b), W, b): a plain evaluation of the fused path with the parameters handed on (see above)."""
+
+    @staticmethod
+    def forward(ctx, op, u, W, b):
+        A, no_graph, no_control = op
+        K = hip.rhs(A, u, W, b, no_graph=no_graph, no_control=no_control)
+        ctx.op, ctx.has_b = op, b is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(u, W, K)
+        return K, W.view_as(W), (b.view_as(b) if b is not None else None)
+
+    @staticmethod
+    def backward(ctx, g_K, g_Wc, g_bc):
+        from ...autograd_ops import rhs_vjp
+        u, W, K = ctx.saved_tensors
+        needs = ctx.needs_input_grad                                  # (op, u, W, b)
+        gu = gW = gb = None
+        if g_K is not None:
+            A, no_graph, no_control = ctx.op
+            gu, gW, gb = rhs_vjp(A, no_graph, no_control, u, W, K, g_K.contiguous(), needs[1], needs[2], ctx.has_b and needs[3])
+        return None, gu, _add_carried(gW, g_Wc) if needs[2] else None, _add_carried(gb, g_bc) if (ctx.has_b and needs[3]) else None
+
+
 class _RhsStageCarryFn(torch.autograd.Function):
-    """(K, u', y0', k_1', ..) = (relu(W (A u) + b), y0 + sum_j c_j k_j + c_new K, y0, k_1, ..): one evaluation of ODEFunc and the
+    """(K, u', y0', W', b', k_1', ..) = (relu(W (A u) + b), y0 + sum_j c_j k_j + c_new K, y0, k_1, ..): one evaluation of ODEFunc and the
     NEXT stage input in ONE launch (ndcn_rhs_rk_f32, mode combine - the launch of the inference solver), i.e. `_Rhs` followed by
     `_StageCarryFn` as one node: the forward saves the combine launch (5 of a dopri5 step's 6), the backward runs the same two
     VJPs - the combine's first (its gradient for K joins what K's later consumers sent), then the right-hand side's."""
@@ -407,10 +496,10 @@ class _RhsStageCarryFn(torch.autograd.Function):
         ctx.lazy = _LAZY_NOW[0]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(u, W, K, *kk, *cs)
-        return (K, u_next, y0) + tuple(ks)
+        return (K, u_next, y0, W.view_as(W), (b.view_as(b) if b is not None else None)) + tuple(ks)
 
     @staticmethod
-    def backward(ctx, g_K, g_u, g_y0c, *g_kc):
+    def backward(ctx, g_K, g_u, g_y0c, g_Wc, g_bc, *g_kc):
         from ...autograd_ops import rhs_vjp
         n, idx, cc = ctx.n, ctx.idx, ctx.cc
         saved = ctx.saved_tensors
@@ -443,6 +532,8 @@ class _RhsStageCarryFn(torch.autograd.Function):
         if g_K is not None:
             A, no_graph, no_control = ctx.op
             gu_in, gW, gb = rhs_vjp(A, no_graph, no_control, u, W, K, g_K.contiguous(), need_u, need_w, need_b)
+        gW = _add_carried(gW, g_Wc) if need_w else None
+        gb = _add_carried(gb, g_bc) if need_b else None
         return (None, None, gu_in, gW, gb, g_y0) + tuple(gk_all) + tuple(gc_all)
 
 
@@ -464,10 +555,10 @@ class _RhsErrorCarryFn(torch.autograd.Function):
         ctx.lazy = _LAZY_NOW[0]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(y0, y1, W, K, *kk, *cs)
-        return (K, torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1) + tuple(ks)
+        return (K, torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1, W.view_as(W), (b.view_as(b) if b is not None else None)) + tuple(ks)
 
     @staticmethod
-    def backward(ctx, g_K, g, g_y0c, g_y1c, *g_kc):
+    def backward(ctx, g_K, g, g_y0c, g_y1c, g_Wc, g_bc, *g_kc):
         from ...autograd_ops import rhs_vjp
         n, idx, cc = ctx.n, ctx.idx, ctx.cc
         saved = ctx.saved_tensors
@@ -500,6 +591,8 @@ class _RhsErrorCarryFn(torch.autograd.Function):
             gx, gW, gb = rhs_vjp(A, no_graph, no_control, y1, W, K, g_K.contiguous(), need_y1, need_w, need_b)
             if need_y1 and gx is not None:
                 gy1 = gx if gy1 is None else hip.combine(gy1.contiguous(), [gx], [f32(1)])      # y1 is the evaluation's input AND the record's state
+        gW = _add_carried(gW, g_Wc) if need_w else None
+        gb = _add_carried(gb, g_bc) if need_b else None
         return (None, None, None, None, None, gW, gb, gy0, gy1) + tuple(gk_all) + tuple(gc_all)
 
 
@@ -621,21 +714,25 @@ class _DenseMultiCarryFn(torch.autograd.Function):
 # ---- the solver, scalar chain in torch exactly as the reference keeps it -----------------------------------------
 
 def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
-    """misc.py:84-143; returns a float32 0-d tensor with autograd history through the three norms."""
-    d0 = [_rms(y, None, y, rtol, atol, bad_out) for y in y0]
-    d1 = [_rms(f, None, y, rtol, atol) for f, y in zip(f0, y0)]
+    """misc.py:84-143; returns a float32 0-d tensor with autograd history through the three norms.  Every state tensor has four
+    consumers in here and every f0 three: each gets an alias of its own (_FanOut: gradients added in a fixed order)."""
+    ya = [_fan(y, 4) for y in y0]
+    fa = [_fan(f, 3) for f in f0]
+    d0 = [_rms(y[0], None, y[0], rtol, atol, bad_out) for y in ya]
+    d1 = [_rms(f[0], None, y[1], rtol, atol) for f, y in zip(fa, ya)]
     if max(d0).item() < 1e-5 or max(d1).item() < 1e-5:
         h0 = torch.tensor(1e-6, dtype=torch.float32)
     else:
         h0 = 0.01 * max(a / b for a, b in zip(d0, d1))
-    y1 = tuple(_combine(y, [f], [h0]) for y, f in zip(y0, f0))
+    hs = _fan(h0, 2 + len(y0)) if h0.requires_grad else (h0,) * (2 + len(y0))     # (combine per state tensor, d2, the result)
+    y1 = tuple(_combine(y[2], [f[1]], [hs[2 + j]]) for j, (y, f) in enumerate(zip(ya, fa)))
     f1 = func(targ(f32(t0) + f32(h0.item())), y1)
-    d2 = [_rms(b, a, y, rtol, atol) / h0 for b, a, y in zip(f1, f0, y0)]
+    d2 = [_rms(b, f[2], y[3], rtol, atol) / hs[0] for b, f, y in zip(f1, fa, ya)]
     if max(d1).item() <= 1e-15 and max(d2).item() <= 1e-15:
-        h1 = torch.max(torch.tensor(1e-6, dtype=torch.float32), h0 * 1e-3)
+        h1 = torch.max(torch.tensor(1e-6, dtype=torch.float32), hs[1] * 1e-3)
     else:
         h1 = (0.01 / max(d1 + d2)) ** (1. / float(order + 1))
-    return torch.min(100 * h0, h1)
+    return torch.min(100 * hs[1], h1)
 
 
 def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=None, odefunc=None, **options):
@@ -650,14 +747,6 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
     rtols, atols = core.per_state_tolerance(rtol, len(y0)), core.per_state_tolerance(atol, len(y0))
     rtol, atol = rtols[0], atols[0]                                # dopri5.py:80: the initial step uses the first pair
     bad = []
-    f_cur = func(targ(f32(tt[0].item())), y0)
-    nfe = 2
-    if opt['first_step'] is None:
-        dt = _initial_step(func, targ, tt[0].item(), y0, 4, rtol, atol, f_cur, bad).to(torch.float64)
-    else:
-        dt = torch.tensor(0.01, dtype=torch.float64)
-        bad.append(0)
-    pending_bad = bad[0] if bad else 0
     carry = _carry()
     # deferred scalar gradients pay where a read-back stalls real GPU work; on the reference's own sizes (400 x 20) the extra
     # autograd node per coefficient costs more than the stall (README-sized dopri5 step 11 -> 19 ms, tools/micro/train_ab.py)
@@ -677,10 +766,32 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
         os.environ.get('NDCN_GRAD_FUSED_ERROR', '1') != '0'
     _LAZY_NOW[0] = lazy
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
-    y_cur = y0
+    # ---- the first evaluation and the initial step (dopri5.py:76-83).  y0 has four consumers - this evaluation, the initial-step
+    # selection, the first stage chain, the trajectory's first tick: one alias each (_FanOut: a fixed summation order for its
+    # gradient); in the fused path every evaluation goes through a carry node that hands W and b on (a chain instead of a dozen
+    # contributions to the leaf in whatever order the engine's two threads produce them)
+    first = opt['first_step'] is None
+    ys = [_fan(y, 4 if first else 3) for y in y0] if carry else [(y,) * 4 for y in y0]
+    chain = list(fused[1:]) if fused is not None else None             # [W, b] as handed on from evaluation to evaluation
+
+    def evaluate(tval, yy):
+        if fused is None:
+            return func(targ(tval), yy)
+        K_, chain[0], chain[1] = _RhsCarryFn.apply(fused[0], yy[0], chain[0], chain[1])
+        return (K_,)
+
+    f_cur = evaluate(f32(tt[0].item()), tuple(y[0] for y in ys))
+    nfe = 2
+    if first:
+        dt = _initial_step(lambda targ_t, yy: evaluate(targ_t, yy), (lambda v: v), tt[0].item(), tuple(y[3] for y in ys), 4, rtol, atol, f_cur, bad).to(torch.float64)
+    else:
+        dt = torch.tensor(0.01, dtype=torch.float64)
+        bad.append(0)
+    pending_bad = bad[0] if bad else 0
+    y_cur = tuple(y[1] for y in ys)
     t_lo = t_hi = tt[0]
     stage = None
-    sol = [y0]
+    sol = [tuple(y[2] for y in ys)]
     i = 0
     while i + 1 < len(tt):
         i += 1
@@ -699,38 +810,39 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             # in front of the step's first launch, where 50 tiny host operations would sit between the accept decision's
             # read-back and the next kernel)
             coef = (lambda v: _Await.apply(v)) if lazy else (lambda v: v)
+            beta_dt, cerr_dt = _step_coefficients(dts)
             fused_bads, fused_ratio = [], None
             if fused is not None:
                 # stage input 1 by a combine launch; evaluations 2 .. 6 form the next stage input themselves; evaluation 7 (at
                 # y1, the next step's k1) is the plain right-hand side
-                op_, W_, b_ = fused
-                outs_ = _StageCarryFn.apply(1, yc[0], k[0][0], coef(dts * core.DP_BETA[0][0]))
+                op_ = fused[0]
+                outs_ = _StageCarryFn.apply(1, yc[0], k[0][0], coef(beta_dt[0][0]))
                 u_, yc[0], k[0] = outs_[0], outs_[1], list(outs_[2:])
                 for st_ in range(6):
                     if st_ < 5:
-                        outs_ = _RhsStageCarryFn.apply(len(k[0]), op_, u_, W_, b_, yc[0], *k[0],
-                                                       *[coef(dts * bb) for bb in core.DP_BETA[st_ + 1]])
-                        u_, yc[0], k[0] = outs_[1], outs_[2], list(outs_[3:]) + [outs_[0]]
+                        outs_ = _RhsStageCarryFn.apply(len(k[0]), op_, u_, chain[0], chain[1], yc[0], *k[0],
+                                                       *[coef(v) for v in beta_dt[st_ + 1]])
+                        u_, yc[0], chain[0], chain[1], k[0] = outs_[1], outs_[2], outs_[3], outs_[4], list(outs_[5:]) + [outs_[0]]
                     elif fuse_err:
                         yi = (u_,)                                    # evaluation 7 with the error record in its epilogue
-                        outs_ = _RhsErrorCarryFn.apply(len(k[0]), op_, rtols[0], atols[0], fused_bads, W_, b_, yc[0], u_, *k[0],
-                                                       *[coef(dts * c) for c in core.DP_C_ERR])
-                        fused_ratio, yc[0], yi, k[0] = outs_[1], outs_[2], (outs_[3],), list(outs_[4:]) + [outs_[0]]
+                        outs_ = _RhsErrorCarryFn.apply(len(k[0]), op_, rtols[0], atols[0], fused_bads, chain[0], chain[1], yc[0], u_, *k[0],
+                                                       *[coef(v) for v in cerr_dt])
+                        fused_ratio, yc[0], yi, chain[0], chain[1], k[0] = outs_[1], outs_[2], (outs_[3],), outs_[4], outs_[5], list(outs_[6:]) + [outs_[0]]
                     else:
                         yi = (u_,)
-                        k[0].append(func(targ((t0s + core.DP_ALPHA[5] * dts).item()), yi)[0])
+                        k[0].append(evaluate((t0s + core.DP_ALPHA[5] * dts).item(), yi)[0])
                     nfe += 1
-            for a_i, b_i in (() if fused is not None else zip(core.DP_ALPHA, core.DP_BETA)):
+            for (a_i, _), b_i in (() if fused is not None else zip(zip(core.DP_ALPHA, core.DP_BETA), beta_dt)):
                 ti = t0s + a_i * dts
                 if carry:
                     us = []
                     for s_, (y_, k_) in enumerate(zip(yc, k)):
-                        outs_ = _StageCarryFn.apply(len(k_), y_, *k_, *[coef(dts * b) for b in b_i])
+                        outs_ = _StageCarryFn.apply(len(k_), y_, *k_, *[coef(v) for v in b_i])
                         us.append(outs_[0])
                         yc[s_], k[s_] = outs_[1], list(outs_[2:])
                     yi = tuple(us)
                 else:
-                    yi = tuple(_combine(y_, k_, [dts * b for b in b_i]) for y_, k_ in zip(y_cur, k))
+                    yi = tuple(_combine(y_, k_, list(b_i)) for y_, k_ in zip(y_cur, k))
                 for k_, f_ in zip(k, func(targ(ti.item()), yi)):
                     k_.append(f_)
                 nfe += 1
@@ -741,13 +853,13 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
             elif carry:
                 ratios, y1c = [], []
                 for s_, (a_, b_, k_, rt_, at_) in enumerate(zip(yc, y1, k, rtols, atols)):
-                    outs_ = _ErrorCarryFn.apply(len(k_), rt_, at_, bads, a_, b_, *k_, *[coef(dts * c) for c in core.DP_C_ERR])
+                    outs_ = _ErrorCarryFn.apply(len(k_), rt_, at_, bads, a_, b_, *k_, *[coef(v) for v in cerr_dt])
                     ratios.append(outs_[0])
                     yc[s_], k[s_] = outs_[1], list(outs_[3:])
                     y1c.append(outs_[2])
                 y1 = tuple(y1c)
             else:
-                ratios = [_error_ratio(a_, b_, k_, [dts * c for c in core.DP_C_ERR], rt_, at_, bads)
+                ratios = [_error_ratio(a_, b_, k_, list(cerr_dt), rt_, at_, bads)
                           for a_, b_, k_, rt_, at_ in zip(y_cur, y1, k, rtols, atols)]
             f1 = tuple(k_[-1] for k_ in k)
             accept = bool((torch.stack([r.detach() for r in ratios]) <= 1).all())      # dopri5.py:109

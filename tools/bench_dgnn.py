@@ -47,6 +47,7 @@ def load_case(name):
 
 
 HID, T_END, TICKS, RTOL, ATOL, LR, WD = 256, 1.2, 16, 0.1, 0.1, 0.01, 0.024          # the README command
+NO_CONTROL = os.environ.get('NDCN_DGNN_CONTROL', '0') != '1'                          # (NDCN_DGNN_CONTROL=1: with the Linear - the determinism probe of W / b)
 
 
 def build_hip(case, dev, seed=0):
@@ -57,7 +58,7 @@ def build_hip(case, dev, seed=0):
     torch.manual_seed(seed)
     t = torch.linspace(0, T_END, TICKS).float().to(dev)
     model = nn.Sequential(nn.Linear(feats.shape[1], HID), nn.Tanh(),
-                          ODEBlock2(ODEFunc(HID, adj, dropout=0.0, no_control=True), t, rtol=RTOL, atol=ATOL, method='dopri5', terminal=True),
+                          ODEBlock2(ODEFunc(HID, adj, dropout=0.0, no_control=NO_CONTROL), t, rtol=RTOL, atol=ATOL, method='dopri5', terminal=True),
                           nn.Linear(HID, ncls)).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=WD)
     return model, opt, torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev), torch.from_numpy(itr).to(dev), torch.from_numpy(iva).to(dev)
@@ -97,26 +98,43 @@ def time_hip(case, dev, epochs):
 
 
 def determinism(case, dev, epochs, deterministic_flag):
-    """the same seed twice: loss bits per epoch, every parameter's gradient after step 1, the final parameters"""
+    """the same seed twice: run A records, per epoch, the tensors along the step - encoder output (torch Linear + tanh), ODE block
+    output (the HIP dopri5 solve), logits, loss, the gradient arriving at the ODE block's output and leaving its input (the HIP
+    backward through the solver), every parameter gradient; run B compares with torch.equal as it goes and names the FIRST tensor
+    that differs."""
     torch.use_deterministic_algorithms(deterministic_flag, warn_only=True)
-    runs = []
-    for _ in range(2):
-        model, opt, x, y, itr, iva = build_hip(case, dev, seed=0)
-        losses, g1 = [], None
-        for e in range(epochs):
-            lt, lv, grads, _ = epoch_hip(model, opt, x, y, itr, iva)
-            losses.append((lt, lv))
-            if e == 0:
-                g1 = grads
-        runs.append((losses, g1, [p.detach().clone() for p in model.parameters()]))
-    torch.use_deterministic_algorithms(False)
-    (la, ga, pa), (lb, gb, pb) = runs
     names = ['0.weight', '0.bias', '2.odefunc.wt.weight', '2.odefunc.wt.bias', '3.weight', '3.bias']
-    first = next((i for i, (u, v) in enumerate(zip(la, lb)) if u != v), None)
-    gdiff = {n: (None if a is None else float((a - b).abs().max())) for n, a, b in zip(names, ga, gb)}
-    return {'use_deterministic_algorithms': deterministic_flag, 'epochs': epochs, 'losses_identical': first is None,
-            'first_differing_epoch': first, 'grad_step1_max_abs_diff': gdiff,
-            'final_params_identical': all(torch.equal(a, b) for a, b in zip(pa, pb))}
+    record, first = [], None
+    for run in range(2):
+        model, opt, x, y, itr, iva = build_hip(case, dev, seed=0)
+        keep = {}
+        model[2].register_forward_hook(lambda m, i, o: keep.update(h_in=i[0].detach().clone(), h_out=o.detach().clone()))
+        model[2].register_full_backward_hook(lambda m, gi, go: keep.update(g_h_out=go[0].detach().clone(),
+                                                                          g_h_in=None if gi[0] is None else gi[0].detach().clone()))
+        for e in range(epochs):
+            model.train()
+            opt.zero_grad()
+            out = model(x)
+            loss = F.cross_entropy(out[itr], y[itr])
+            loss.backward()
+            row = [('h_in', keep['h_in']), ('h_out', keep['h_out']), ('logits', out.detach().clone()), ('loss', loss.detach().clone()),
+                   ('g_h_out', keep['g_h_out']), ('g_h_in', keep.get('g_h_in'))]
+            row += [('grad ' + n, None if p.grad is None else p.grad.detach().clone()) for n, p in zip(names, model.parameters())]
+            opt.step()
+            if run == 0:
+                record.append(row)
+            elif first is None:
+                for (n, a), (_, b) in zip(record[e], row):
+                    if a is not None and not torch.equal(a, b):
+                        first = {'epoch': e, 'tensor': n, 'max_abs_diff': float((a - b).abs().max()), 'max_abs': float(a.abs().max()),
+                                 'elements_differing': int((a != b).sum()), 'elements': a.numel()}
+                        break
+        final = [p.detach().clone() for p in model.parameters()]
+        if run == 0:
+            final_a = final
+    torch.use_deterministic_algorithms(False)
+    return {'use_deterministic_algorithms': deterministic_flag, 'epochs': epochs, 'first_difference': first,
+            'final_params_identical': all(torch.equal(a, b) for a, b in zip(final_a, final))}
 
 
 def time_oracle(case, epochs):
@@ -156,7 +174,7 @@ def main():
     ap.add_argument('--case', default='all')
     ap.add_argument('--epochs', type=int, default=30)
     ap.add_argument('--oracle-epochs', type=int, default=2)
-    ap.add_argument('--det-epochs', type=int, default=10)
+    ap.add_argument('--det-epochs', type=int, default=60)
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.set_num_threads(min(32, os.cpu_count() or 1))

@@ -53,8 +53,16 @@ static double run(const float *X, const int *col, float *Y, int n, int deg, int 
 }
 
 int main() {
-    struct Case { const char *name; int n, deg; } cases[] = {{"C2-like: 100k rows x 41 (X = 102 MB, Infinity-Cache resident)", 100000, 41},
-                                                             {"C3-like: 1M rows x 11 (X = 1 GB, HBM resident)", 1000000, 11}};
+    // hot_rows / hot_pct (round 5, BASELINE config 3's last lever): hot_pct % of the indices fall into the first hot_rows rows - the
+    // hub rows of a Barabasi-Albert graph packed in front by --layout degree (256 MB = the Infinity Cache's size): does the memory
+    // system serve a skewed gather faster than a uniform one?
+    struct Case { const char *name; int n, deg, hot_rows, hot_pct; } cases[] = {
+        {"C2-like: 100k rows x 41 (X = 102 MB, Infinity-Cache resident)", 100000, 41, 0, 0},
+        {"C3-like: 1M rows x 11 (X = 1 GB, HBM resident)", 1000000, 11, 0, 0},
+        {"C3-like, 50 % of the gathers into the first 250k rows (256 MB)", 1000000, 11, 250000, 50},
+        {"C3-like, 50 % of the gathers into the first 125k rows (128 MB)", 1000000, 11, 125000, 50},
+        {"C3-like, 75 % of the gathers into the first 125k rows (128 MB)", 1000000, 11, 125000, 75},
+        {"C3-like, 50 % of the gathers into the first 30k rows (31 MB: the L2s)", 1000000, 11, 30000, 50}};
     for (const Case &cs : cases) {
         float *X, *Y;
         int *col;
@@ -64,7 +72,11 @@ int main() {
         hipMemset(X, 0, (size_t)cs.n * 1024);
         std::vector<int> h((size_t)cs.n * cs.deg);
         unsigned long long s = 88172645463325252ull;
-        for (auto &v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int)(s % (unsigned long long)cs.n); }
+        for (auto &v : h) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            const bool hot = cs.hot_rows > 0 && (int)((s >> 40) % 100) < cs.hot_pct;
+            v = (int)((s & 0xffffffffffull) % (unsigned long long)(hot ? cs.hot_rows : cs.n));
+        }
         hipMemcpy(col, h.data(), h.size() * 4, hipMemcpyHostToDevice);
         const double gathered = (double)cs.n * cs.deg * 1024.0, written = (double)cs.n * 1024.0;
         printf("%s\n  gathered %.2f GB + written %.2f GB per launch\n", cs.name, gathered / 1e9, written / 1e9);
