@@ -149,10 +149,27 @@ __global__ __launch_bounds__(512) void linear_wgrad_256_split_kernel(const float
     // every request is unconditional (rows past the chunk re-read its last row and are zeroed in stage()): a predicated
     // load is waited for where its value merges with the zero - 48 round trips in a row (measured: 0.128 ms for the fetches
     // alone)
+    // (round 5: 48 requests per thread and pair, each with a clamped 64-bit row index, were half of the kernel's 615 VALU instructions
+    // per pair - SQ_INSTS_VALU, tools/gpu.sh sqk - and the VALU work of the two waves of a SIMD is serial with their MFMA work: pairs
+    // that lie inside the chunk - all but the last - take ONE base address per panel and constant offsets)
     auto fetch = [&](int pair, Rows &q) {
+        const int64_t p0 = r_lo + 32 * (int64_t)pair;
+        if (p0 + 32 <= r_hi) {                                      // wave-uniform
+            const size_t base = (size_t)(p0 + 8 * half) * 256 + col;
+            const float *gp = g + base, *sp = S + base, *yp = Y ? Y + base : nullptr;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    q.gv[u][e] = gp[(16 * u + e) * 256];
+                    q.sv[u][e] = sp[(16 * u + e) * 256];
+                    q.yv[u][e] = yp ? yp[(16 * u + e) * 256] : 1.f;
+                }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int64_t r0 = r_lo + 32 * (int64_t)pair + 16 * u + 8 * half;
+            const int64_t r0 = p0 + 16 * u + 8 * half;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 int64_t r = r0 + e;
@@ -164,13 +181,14 @@ __global__ __launch_bounds__(512) void linear_wgrad_256_split_kernel(const float
         }
     };
     auto stage = [&](const Rows &q, int pair) {
+        const bool whole = r_lo + 32 * (int64_t)pair + 32 <= r_hi;    // wave-uniform: no row of the pair lies past the chunk
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t r0 = r_lo + 32 * (int64_t)pair + 16 * u + 8 * half;
             float gz[8], sz[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool ok = r0 + e < r_hi;
+                const bool ok = whole || r0 + e < r_hi;
                 gz[e] = (ok && q.yv[u][e] > 0.f) ? q.gv[u][e] : 0.f;         // gZ = g where Y > 0 (masked())
                 sz[e] = ok ? q.sv[u][e] : 0.f;
                 bsum += gz[e];
@@ -363,28 +381,34 @@ __global__ __launch_bounds__(256) void linear_gs_kernel(const float *__restrict_
 // 16 rows: mask, row maximum by DPP, scale), wave w then owns output columns [64 w, 64 w + 64) of both 32-row m-tiles; the
 // packed weights (pack_weight_256_t16: planes of W^T in MFMA B-operand order, 256 KiB, L2-resident) come through a four-k-step
 // register ring.  fp32 MFMA version (linear_gs_kernel<256>): 0.44 ms at n = 10^5; this one is bound by its 0.3 GB of HBM traffic.
-constexpr int kGsRows = 64, kGsLd = 260;
+constexpr int kGsLd = 260;
+// MT m-tiles of 32 rows per workgroup.  MT = 2 (64 rows, rounds 3-4) leaves room for two workgroups per CU (67 KB of LDS each): the load
+// phase of a workgroup (two round trips to HBM) and its product phase do not overlap, and two workgroups per CU hide little of either
+// (0.104 ms for the 0.31 GB of n = 10^5: 0.39 of the HBM peak).  MT = 1 (32 rows, 33.5 KB, 98 registers) runs four to five workgroups per
+// CU in different phases; the price - the planes of W^T cross L2 -> CU once per 32 rows instead of 64 - is paid out of the L2's 34 TB/s.
+template <int MT>
 __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *__restrict__ g, const float *__restrict__ Y,
                                                                   const void *__restrict__ Wq, float *__restrict__ gS, int64_t n) {
-    __shared__ __attribute__((aligned(16))) float s_A[kGsRows * kGsLd];
-    __shared__ float s_sc[kGsRows], s_un[kGsRows];
+    constexpr int kRows = 32 * MT, kRpw = 8 * MT;             // rows per workgroup / per wave in the load phase
+    __shared__ __attribute__((aligned(16))) float s_A[kRows * kGsLd];
+    __shared__ float s_sc[kRows], s_un[kRows];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t row0 = (int64_t)blockIdx.x * kGsRows;
+    const int64_t row0 = (int64_t)blockIdx.x * kRows;
     const float *w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Wq) + kS16Bytes);     // [256]: per output column
     // eight rows' requests fly together, unconditionally (rows past n re-read row n - 1 and are zeroed afterwards)
 #pragma unroll
-    for (int i0 = 0; i0 < 16; i0 += 8) {
+    for (int i0 = 0; i0 < kRpw; i0 += 8) {
         f32x4 gv[8], yv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            int64_t gr = row0 + 16 * wave + i0 + i;
+            int64_t gr = row0 + kRpw * wave + i0 + i;
             gr = gr < n ? gr : n - 1;
             gv[i] = *reinterpret_cast<const f32x4 *>(g + gr * 256 + 4 * lane);
             yv[i] = Y ? *reinterpret_cast<const f32x4 *>(Y + gr * 256 + 4 * lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int r = 16 * wave + i0 + i;
+            const int r = kRpw * wave + i0 + i;
             const bool ok = row0 + r < n;
             f32x4 v;
             v.x = (ok && yv[i].x > 0.f) ? gv[i].x : 0.f;
@@ -414,21 +438,23 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int pl = 0; pl < kPl; ++pl) Bq[u][jj][pl] = ldq(jj, u, pl);
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][jj][i] = 0.f;
     __syncthreads();
     const float *ap = s_A + (lane & 31) * kGsLd + 8 * (lane >> 5);
-    const float sc[2] = {s_sc[lane & 31], s_sc[32 + (lane & 31)]};
+    float sc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) sc[mt] = s_sc[32 * mt + (lane & 31)];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         const int u = ks % kRingQ;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const f32x4 r0 = *reinterpret_cast<const f32x4 *>(ap + mt * 32 * kGsLd + 16 * ks);
             const f32x4 r1 = *reinterpret_cast<const f32x4 *>(ap + mt * 32 * kGsLd + 16 * ks + 4);
             u32x4_s16 A0, A1;
@@ -449,16 +475,17 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
     }
     // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31], multiplied back by 1 / (column n's weight-row scale), then 1 / (row scale)
     const float wu[2] = {w_unscale[64 * wave + (lane & 31)], w_unscale[64 * wave + 32 + (lane & 31)]};
+    float *out0 = gS + row0 * 256 + 64 * wave + (lane & 31);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int64_t gr = row0 + m;
-            if (gr >= n) continue;
+            if (row0 + m >= n) continue;
             const float un = s_un[m];
+            float *op = out0 + m * 256;                              // (one 64-bit base per lane, 32-bit row offsets)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) gS[gr * 256 + 64 * wave + 32 * jj + (lane & 31)] = (acc[mt][jj][r] * wu[jj]) * un;
+            for (int jj = 0; jj < 2; ++jj) op[32 * jj] = (acc[mt][jj][r] * wu[jj]) * un;
         }
 }
 
@@ -512,7 +539,9 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
             void *Wq = static_cast<char *>(work) + wgrad_work_bytes(n, Hi, Ho);
             int rcp = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256_t16(W, Wq, st);
             if (rcp) return rcp;
-            hipLaunchKernelGGL(linear_gs_256_split_kernel, dim3((unsigned)((n + kGsRows - 1) / kGsRows)), dim3(256), 0, st, g, Y, Wq, gS, n);
+            static const int gs_rows = [] { const char *e = getenv("NDCN_GS_ROWS"); return (e && atoi(e) == 64) ? 64 : 32; }();
+            if (gs_rows == 64) hipLaunchKernelGGL(linear_gs_256_split_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, g, Y, Wq, gS, n);
+            else hipLaunchKernelGGL(linear_gs_256_split_kernel<1>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, g, Y, Wq, gS, n);
         } else {
             const unsigned gx = (unsigned)((n + kBM2 - 1) / kBM2);
             if (Hi > 128) hipLaunchKernelGGL((linear_gs_kernel<256>), dim3(gx, (unsigned)((Hi + 255) / 256)), dim3(256), 0, st, g, Y, W, gS, n, Hi, Ho);

@@ -200,6 +200,44 @@ with open('gpurun_out/sq/summary.txt', 'w') as fh:
 print(open('gpurun_out/sq/summary.txt').read()[:6000])
 PY
   ;;
+sqk)
+  # sqk 'KERNEL_REGEX' script.py [args]: the SQ issue / stall counter groups of `sq` for the kernels matching the regex, under any script
+  RX=$1; shift
+  rm -rf gpurun_out/sqk; mkdir -p gpurun_out/sqk
+  groups=(
+   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU"
+   "SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS"
+   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY"
+   "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
+   "SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH"
+   "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_BANK_CONFLICT"
+   "SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE"
+   "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"
+   "GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE"
+  )
+  i=0
+  for g in "${groups[@]}"; do
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/sqk/g$i" -o p -- python "$GRAFT_REPO_ROOT/$1" "${@:2}" > "$GRAFT_REPO_ROOT/gpurun_out/sqk/g$i.log" 2>&1)
+    i=$((i+1))
+  done
+  python - "$RX" <<'PY'
+import csv, glob, collections, re, sys
+rx = re.compile(sys.argv[1])
+out = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('gpurun_out/sqk/g*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        m_ = rx.search(r['Kernel_Name'])
+        if m_:
+            out[m_.group(0)][r['Counter_Name']].append(float(r['Counter_Value']))
+with open('gpurun_out/sqk/summary.txt', 'w') as fh:
+    for mode in sorted(out):
+        fh.write('== %s\n' % mode)
+        for c in sorted(out[mode]):
+            v = out[mode][c]
+            fh.write('  %-32s n=%3d mean=%.4g\n' % (c, len(v), sum(v) / len(v)))
+print(open('gpurun_out/sqk/summary.txt').read()[:8000])
+PY
+  ;;
 power)
   ( for i in $(seq 1 60); do rocm-smi --showpower --showclocks --showuse --showmaxpower 2>/dev/null | grep -E "Power|sclk|mclk|GPU use|Max Graphics" | tr '\n' ' '; echo; sleep 0.25; done ) > gpurun_out/power_probe.log 2>&1 &
   SMI=$!
