@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, ROOT, load_golden
 from oracle import ndcn_oracle as orc
 from ndcn_amd.torchdiffeq._impl import core
 from _oracle_ops import OracleOps
@@ -164,3 +164,63 @@ def test_bench_cpu_legs_on_a_tiny_sample(monkeypatch):
     monkeypatch.setattr(bench, 'FIXED_GRID_METHOD', 'euler')
     base, parity = bench.cpu_baseline('M', 8, 5.0, .01, .001, threads=2, runs=5, dev=None, at_scale=False)
     assert parity is None and base['kind'] == 'port' and base['value'] > 0 and 'euler' in base['sample'] and 'at_scale' not in base
+
+
+def test_split_product_scale_target_emulation():
+    """csrc/split16.h's guarantee, emulated on the CPU (tools/micro/split_emul.py: fp16 pieces incl. subnormals, three products, exact
+    accumulation): with the row maximum at [2^14, 2^15) and one scale per output row of W every outlier family of the round-4 review
+    stays below 1e-6 of sum |s w|; with the old target [0.5, 1) and one global weight scale the same operands lose up to 10 bits."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('split_emul', os.path.join(ROOT, 'tools', 'micro', 'split_emul.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(0)
+    n, H = 128, 256
+    S = rng.random((n, H))
+    W = (rng.random((H, H)) - 0.5) / 8
+
+    def ratio(S_, W_, top, per_row):
+        S_, W_ = S_.astype(np.float32), W_.astype(np.float32)
+        ref = S_.astype(np.float64) @ W_.astype(np.float64).T
+        mag = np.abs(S_).astype(np.float64) @ np.abs(W_).astype(np.float64).T
+        return float(np.max(np.abs(m.split_product(S_, W_, top, per_row) - ref) / mag))
+
+    W12 = W.copy(); W12[17, 33] *= 2.0 ** 12
+    Wrow = W.copy(); Wrow[17, :] *= 2.0 ** 12
+    Sch = S.copy(); Sch[:, 5] *= 2.0 ** 12
+    Wch = W.copy(); Wch[:, 5] *= 2.0 ** -12
+    Wlog = 10.0 ** rng.uniform(-6, 0, size=(H, H)) * np.sign(rng.random((H, H)) - 0.5)
+    for S_, W_ in ((S, W), (S, W12), (S, Wrow), (Sch, Wch), (Sch, W), (S, Wlog)):
+        assert ratio(S_, W_, 15, True) < 1e-6
+    assert ratio(S, W12, 0, False) > 1e-5 and ratio(S, Wrow, 0, False) > 1e-5 and ratio(Sch, Wch, 0, True) > 1e-5
+
+
+def test_step_coefficient_table_is_bit_identical_to_the_products():
+    """autograd_path._step_coefficients: dt * beta_ij and dt * c_err_j as ONE product with the tableau (so that `dts` has one
+    consumer: deterministic gradient accumulation) must give the very bits of the 28 separate float32 products."""
+    from ndcn_amd.torchdiffeq._impl import autograd_path as ap, core
+    g = torch.Generator().manual_seed(0)
+    for _ in range(200):
+        d = (torch.rand((), generator=g) * 10.0 ** float(torch.randint(-6, 2, (), generator=g))).to(torch.float32)
+        rows, cerr = ap._step_coefficients(d)
+        for row, ref in zip(rows, core.DP_BETA):
+            assert all(torch.equal(a, d * b) for a, b in zip(row, ref))
+        assert all(torch.equal(a, d * c) for a, c in zip(cerr, core.DP_C_ERR))
+
+
+def test_fan_out_adds_gradients_in_a_fixed_order():
+    """autograd_path._FanOut: n aliases of one tensor, their gradients added left to right by one call (here: on the host) - the
+    same sum whatever order the consumers' backward nodes run in."""
+    from ndcn_amd.torchdiffeq._impl import autograd_path as ap
+    x = torch.randn(64, dtype=torch.float32).requires_grad_(True)
+    a, b, c, d = ap._fan(x, 4)
+    (a * 1e8).sum().backward(retain_graph=True)
+    assert torch.equal(x.grad, torch.full_like(x, 1e8))
+    x.grad = None
+    loss = (a * 3.0).sum() + (b * b).sum() + c.exp().sum() + (d * 1e-3).sum()
+    loss.backward()
+    xd = x.detach()
+    want = ((torch.full_like(xd, 3.0) + 2 * xd) + xd.exp()) + torch.full_like(xd, 1e-3)      # left to right, float32
+    assert torch.equal(x.grad, want)
+    y = torch.randn(8)                                               # no gradient required: the tensor itself, n times
+    assert all(t is y for t in ap._fan(y, 5))
