@@ -128,10 +128,14 @@ __device__ __forceinline__ float err_ratio_sq(float e, float a, float b, float r
 // last bit to matter, so panels up to aten_order_max_elems() elements are reduced in exactly this order (one workgroup: all threads
 // form r^2 of a 2048-element chunk in LDS, 32 lanes of the first wave run the cascade); larger panels keep the parallel
 // fp64 reduction, as do the error records formed inside the fused right-hand sides.
-__global__ __launch_bounds__(256) void rk_error_aten_kernel(const float *__restrict__ y0, const float *__restrict__ y1, Terms t,
-                                                            float rtol, float atol, int64_t n, double *__restrict__ out, int accum) {
+// Round 5: 1024 threads.  Waves 1 .. 15 form r^2 of chunk c + 1 into the other half of a double buffer while 32 lanes of wave 0 run the
+// cascade over chunk c, whose LDS reads are requested 16 steps at a time ahead of the (serial, order-defining) additions: the
+// 8000-element record of the README-sized solves 66 -> ~15 us under rocprofv3 (it was longer than the step's six evaluations).
+constexpr int kAtenThreads = 1024;
+__global__ __launch_bounds__(kAtenThreads) void rk_error_aten_kernel(const float *__restrict__ y0, const float *__restrict__ y1, Terms t,
+                                                                     float rtol, float atol, int64_t n, double *__restrict__ out, int accum) {
     apply_dt(t);
-    __shared__ float v[kAtenBlock];
+    __shared__ float v2[2][kAtenBlock];
     __shared__ float lane32[32];
     __shared__ int bad_cnt;
     const int tid = threadIdx.x;
@@ -151,27 +155,43 @@ __global__ __launch_bounds__(256) void rk_error_aten_kernel(const float *__restr
         bad += (int)nonfinite(b);
         return err_ratio_sq(wsum1(t, e), y0[e], b, rtol, atol);
     };
-    for (int64_t base = 0; base < n_main; base += kAtenBlock) {
+    auto produce = [&](int64_t base, float *dst, int first, int stride) {
         const int cnt = (int)((n_main - base) < kAtenBlock ? (n_main - base) : kAtenBlock);
-        __syncthreads();
-        for (int q = tid; q < cnt; q += 256) v[q] = ratio_sq(base + q);
-        __syncthreads();
-        if (tid < 32) {
-            for (int q = tid; q < cnt; q += 32) {
-                // whole runs of level_step steps cascade upwards; a trailing partial run stays in level 0
-                a0 = a0 + v[q];
-                ++i; ++in_level;
-                if (in_level == level_step && i <= (size_ilp / level_step) * level_step) {
-                    in_level = 0;
-                    a1 = a1 + a0; a0 = 0.f;
-                    if ((i & (level_mask << level_power)) == 0) {
-                        a2 = a2 + a1; a1 = 0.f;
-                        if ((i & (level_mask << (2 * level_power))) == 0) { a3 = a3 + a2; a2 = 0.f; }
+        for (int q = first; q < cnt; q += stride) dst[q] = ratio_sq(base + q);
+    };
+    if (n_main > 0) produce(0, v2[0], tid, kAtenThreads);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t base = 0; base < n_main; base += kAtenBlock, buf ^= 1) {
+        const int cnt = (int)((n_main - base) < kAtenBlock ? (n_main - base) : kAtenBlock);
+        if (tid >= 64) {
+            if (base + kAtenBlock < n_main) produce(base + kAtenBlock, v2[buf ^ 1], tid - 64, kAtenThreads - 64);
+        } else if (tid < 32) {
+            const float *v = v2[buf];
+            for (int q0 = tid; q0 < cnt; q0 += 32 * 16) {
+                float x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) x[u] = (q0 + 32 * u < cnt) ? v[q0 + 32 * u] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (q0 + 32 * u >= cnt) break;
+                    // whole runs of level_step steps cascade upwards; a trailing partial run stays in level 0
+                    a0 = a0 + x[u];
+                    ++i; ++in_level;
+                    if (in_level == level_step && i <= (size_ilp / level_step) * level_step) {
+                        in_level = 0;
+                        a1 = a1 + a0; a0 = 0.f;
+                        if ((i & (level_mask << level_power)) == 0) {
+                            a2 = a2 + a1; a1 = 0.f;
+                            if ((i & (level_mask << (2 * level_power))) == 0) { a3 = a3 + a2; a2 = 0.f; }
+                        }
                     }
                 }
             }
         }
+        __syncthreads();
     }
+    float *v = v2[0];
     __syncthreads();
     if (tid < 32) {
         a0 = a0 + a1; a0 = a0 + a2; a0 = a0 + a3;
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(256) void rk_error_aten_kernel(const float *__restr
     // the left-over elements (fewer than 32 + 8): r^2 into LDS, then the serial finish by one thread
     const int n_left = (int)(n - n_main);
     __syncthreads();
-    for (int q = tid; q < n_left; q += 256) v[q] = ratio_sq(n_main + q);
+    for (int q = tid; q < n_left; q += kAtenThreads) v[q] = ratio_sq(n_main + q);
     if (bad) atomicAdd(&bad_cnt, bad);
     __syncthreads();
     if (tid == 0) {
@@ -240,10 +260,10 @@ __device__ __forceinline__ float scaled_sq(float a, float b, float y, float rtol
 // q = (a - b) / scale computed by all threads into LDS, then 8 lanes walk their chains.  Larger panels keep the parallel
 // fp64 reduction (8 sequential chains over 10^8 elements would take tens of milliseconds per norm).
 template <bool HASB>
-__global__ __launch_bounds__(256) void scaled_sumsq_aten_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                                const float *__restrict__ y, float rtol, float atol, int64_t n,
-                                                                double *__restrict__ out) {
-    __shared__ float q[kAtenBlock];
+__global__ __launch_bounds__(kAtenThreads) void scaled_sumsq_aten_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                         const float *__restrict__ y, float rtol, float atol, int64_t n,
+                                                                         double *__restrict__ out) {
+    __shared__ float q2[2][kAtenBlock];
     __shared__ float lane_sum[8];
     __shared__ int bad_cnt;
     const int tid = threadIdx.x;
@@ -251,18 +271,37 @@ __global__ __launch_bounds__(256) void scaled_sumsq_aten_kernel(const float *__r
     float acc = 0.f;
     int bad = 0;
     const int64_t n8 = n - (n % 8);
-    for (int64_t base = 0; base < n8; base += kAtenBlock) {
+    // (as rk_error_aten_kernel: waves 1 .. 15 form the quotients of the next chunk while 8 lanes of wave 0 walk their chains over this one)
+    auto produce = [&](int64_t base, float *dst, int first, int stride) {
         const int cnt = (int)((n8 - base) < kAtenBlock ? (n8 - base) : kAtenBlock);
-        __syncthreads();
-        for (int i = tid; i < cnt; i += 256) {
+        for (int i = first; i < cnt; i += stride) {
             const float av = a[base + i];
             const float scale = atol + fabsf(y[base + i]) * rtol;
-            q[i] = HASB ? (av - b[base + i]) / scale : av / scale;
+            dst[i] = HASB ? (av - b[base + i]) / scale : av / scale;
             bad += (int)nonfinite(av);
         }
+    };
+    if (n8 > 0) produce(0, q2[0], tid, kAtenThreads);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t base = 0; base < n8; base += kAtenBlock, buf ^= 1) {
+        const int cnt = (int)((n8 - base) < kAtenBlock ? (n8 - base) : kAtenBlock);
+        if (tid >= 64) {
+            if (base + kAtenBlock < n8) produce(base + kAtenBlock, q2[buf ^ 1], tid - 64, kAtenThreads - 64);
+        } else if (tid < 8) {
+            const float *q = q2[buf];
+            for (int i0 = tid; i0 < cnt; i0 += 8 * 16) {
+                float x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) x[u] = (i0 + 8 * u < cnt) ? q[i0 + 8 * u] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (i0 + 8 * u >= cnt) break;
+                    acc = fmaf(x[u], x[u], acc);
+                }
+            }
+        }
         __syncthreads();
-        if (tid < 8)
-            for (int i = tid; i < cnt; i += 8) acc = fmaf(q[i], q[i], acc);
     }
     if (tid < 8) lane_sum[tid] = acc;
     if (bad) atomicAdd(&bad_cnt, bad);
@@ -661,7 +700,7 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
     if (!fill_terms(t, h_k, h_c, n_k, vec)) { set_error("rk_error: need 1..%d non-null terms", kMaxTerms); return NDCN_EINVAL; }
     if (n >= 8 && n <= aten_order_max_elems()) {
         ProfScope prof(PROF_ERROR, st, 4.0 * n * (n_k + 2), 2.0 * n * (n_k + 4));
-        hipLaunchKernelGGL(rk_error_aten_kernel, dim3(1), dim3(256), 0, st, y0, y1, t, rtol, atol, n, d_out, accum);
+        hipLaunchKernelGGL(rk_error_aten_kernel, dim3(1), dim3(kAtenThreads), 0, st, y0, y1, t, rtol, atol, n, d_out, accum);
         NDCN_LAUNCH_CHECK();
         return NDCN_OK;
     }
@@ -680,8 +719,8 @@ int scaled_sumsq_f32(const float *a, const float *b, const float *y, float rtol,
                      void *d_ws, hipStream_t st) {
     if (n > 0 && n <= aten_order_max_elems()) {
         ProfScope prof(PROF_SUMSQ, st, 4.0 * n * (b ? 3 : 2), 6.0 * n);
-        if (b) hipLaunchKernelGGL(scaled_sumsq_aten_kernel<true>, dim3(1), dim3(256), 0, st, a, b, y, rtol, atol, n, d_out);
-        else hipLaunchKernelGGL(scaled_sumsq_aten_kernel<false>, dim3(1), dim3(256), 0, st, a, b, y, rtol, atol, n, d_out);
+        if (b) hipLaunchKernelGGL(scaled_sumsq_aten_kernel<true>, dim3(1), dim3(kAtenThreads), 0, st, a, b, y, rtol, atol, n, d_out);
+        else hipLaunchKernelGGL(scaled_sumsq_aten_kernel<false>, dim3(1), dim3(kAtenThreads), 0, st, a, b, y, rtol, atol, n, d_out);
         NDCN_LAUNCH_CHECK();
         return NDCN_OK;
     }

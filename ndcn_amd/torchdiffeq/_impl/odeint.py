@@ -9,8 +9,10 @@ Two execution paths, both on the GPU:
     HIP kernel per bookkeeping chain and `func` called back in Python.
 Host tensors are refused: there is no CPU fallback.
 """
+import collections
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -476,6 +478,45 @@ def _small_solve(odefunc, y0, tt, method):
     return out
 
 
+# Reference-sized solves (the README commands: 400 x 20) spend a third of their time CREATING the solver - workspace, streams,
+# events and above all the capture + instantiation of the per-step hipGraph (~0.5 ms of a 1.7 ms dopri5 solve, rocprofv3 kernel
+# trace) - and every odeint call of a training loop's evaluation pass builds the same one again.  Solvers of launch-bound sizes are
+# therefore kept (a handful, least recently used out) and re-begun: ndcn_solver_begin resets the state, the captured graph reads the
+# weights, the operator and the workspace through pointers that the key pins.
+_SOLVERS = collections.OrderedDict()
+_SOLVER_CACHE_MAX_ELEMS = 1 << 20
+_SOLVER_CACHE_SIZE = 4
+
+
+def _cached_solver(odefunc, y0, method, rtol, atol, opt, use_graph):
+    """(solver, key or None): a kept solver re-used when everything its captured graph points at is unchanged."""
+    def make():
+        return DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, opt.get('max_num_steps', 2 ** 31 - 1), use_graph=use_graph,
+                            safety=opt.get('safety', core.SAFETY), ifactor=opt.get('ifactor', core.IFACTOR),
+                            dfactor=opt.get('dfactor', core.DFACTOR))
+    if not use_graph or y0.numel() > _SOLVER_CACHE_MAX_ELEMS or os.environ.get('NDCN_SOLVER_CACHE', '1') == '0':
+        return make(), None
+    W, b = odefunc.wt.weight, odefunc.wt.bias
+    key = (id(odefunc), W.data_ptr(), None if b is None else b.data_ptr(), id(getattr(odefunc, 'A', None)), tuple(y0.shape), method,
+           float(rtol), float(atol), tuple(sorted((k, v) for k, v in opt.items() if v is not None)), y0.device.index,
+           torch.cuda.current_stream(y0.device).cuda_stream, bool(odefunc.no_graph), bool(odefunc.no_control))
+    hit = _SOLVERS.get(key)
+    if hit is not None and hit[0]() is odefunc and not getattr(hit[1], '_in_use', False) and hit[1].handle:
+        _SOLVERS.move_to_end(key)
+        hit[1]._in_use = True
+        return hit[1], key
+    solver = make()
+    solver._in_use = True
+    if hit is None:
+        _SOLVERS[key] = (weakref.ref(odefunc), solver)
+        while len(_SOLVERS) > _SOLVER_CACHE_SIZE:
+            _, (_, old) = _SOLVERS.popitem(last=False)
+            if not getattr(old, '_in_use', False):
+                old.close()
+        return solver, key
+    return solver, None                                      # the kept one is busy (another thread): a solver of its own
+
+
 def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     core.assert_increasing(t)
     tt = t.detach().to('cpu', torch.float64).tolist()
@@ -490,9 +531,7 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     # step size in device memory (the library declines where a path has no replayable form)
     use_graph = y0.numel() <= GRAPH_MAX_ELEMS and os.environ.get('NDCN_HIPGRAPH', '1') != '0'
     opt = core.dopri5_options(options, 1) if method == 'dopri5' else {}
-    solver = DeviceSolver(odefunc, y0.shape[0], method, rtol, atol, opt.get('max_num_steps', 2 ** 31 - 1),
-                          use_graph=use_graph, safety=opt.get('safety', core.SAFETY), ifactor=opt.get('ifactor', core.IFACTOR),
-                          dfactor=opt.get('dfactor', core.DFACTOR))
+    solver, cache_key = _cached_solver(odefunc, y0, method, rtol, atol, opt, use_graph)
     try:
         out = torch.empty((len(tt),) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         out[0].copy_(y0)
@@ -507,7 +546,10 @@ def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
         if step_log is not None:
             step_log.extend(solver.steplog())
             step_log.append(('nfe', int(solver.stats()['nfe'])))
-        torch.cuda.current_stream().synchronize()    # the workspace is released below
+        torch.cuda.current_stream().synchronize()    # the workspace is released (or handed to the next solve) below
         return out
     finally:
-        solver.close()
+        if cache_key is None:
+            solver.close()
+        else:
+            solver._in_use = False
