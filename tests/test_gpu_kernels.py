@@ -1141,7 +1141,7 @@ def test_packed_weight_cache_is_not_fooled_by_address_reuse(dev):
 
 
 @pytest.mark.parametrize('mode,n_prev', [('combine', 1), ('combine', 2), ('combine', 3), ('combine', 4), ('error', 5)])
-@pytest.mark.parametrize('side', [24, 112])
+@pytest.mark.parametrize('side', [24, 112, 400])        # (400: panels beyond 128 MiB - the launches with non-temporal stores)
 def test_adjoint_halves_of_the_fused_launch_equal_the_composed_kernels(dev, side, mode, n_prev):
     """ndcn_rhs_rk_adj_f32 (ABI 13): the forward half also writes S = A X - bit-equal to ndcn_spmm_f32, K / y_next / the error record
     unchanged; the transposed half gathers X (.) [M > 0] - bit-equal to the same launch over the panel ndcn_relu_bwd_f32 writes."""
