@@ -489,6 +489,94 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
         }
 }
 
+// gS for Hi = Ho = 256, third form (round 5): PERSISTENT workgroups with the weights resident.  The tile kernels above stream the
+// 256 KiB of W^T planes from L2 once per 32 / 64 rows - 0.8 GB per launch at n = 10^5, four fifths of what the vector-memory path of a CU
+// carries (TCP_TCC_READ_REQ: 8 M requests against 1.6 M for the panels; SQ_VMEM_TA_*_FIFO_FULL ~ the kernel's whole busy time, tools/gpu.sh
+// sqk) - and their load phase and product phase alternate.  Here a workgroup of 8 waves walks row tiles of 32: wave w owns output columns
+// [32 w, 32 w + 32) and keeps ALL 16 k-steps x 2 planes of its weights in registers (128 VGPRs) for the whole launch; every wave loads
+// 4 rows of the NEXT tile (g and the mask panel: 8 requests in flight under the current tile's products), masks them, forms the row
+// maximum by DPP and writes the row as its two fp16 pieces into the other half of a double buffer - the row layout and operand
+// addressing of rhs_fused3 (32 x 1040 bytes).  Same pieces, same three products per k-step in the same order: bit-identical to the tile
+// kernels.
+constexpr int kGrLd = 260;                                   // floats per tile row: [256 fp16 high | 256 fp16 low] + 16 bytes
+__global__ __launch_bounds__(512) void linear_gs_256_res_kernel(const float *__restrict__ g, const float *__restrict__ Y,
+                                                                const void *__restrict__ Wq, float *__restrict__ gS, int64_t n,
+                                                                int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float s_A[2][32 * kGrLd];
+    __shared__ float s_un[2][32];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *w_unscale = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Wq) + kS16Bytes);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(Wq), 0, kS16Bytes, 0x00020000);
+    u32x4_s16 B[16][2];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            B[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane * 16, ((wave * 16 + ks) * 2 + pl) * 1024, 0);
+    const float wu = w_unscale[32 * wave + (lane & 31)];
+    f32x4 gv[4], yv[4];
+    auto request = [&](int tile) {                           // this wave's 4 rows of `tile` (rows past n re-read row n - 1, zeroed later)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t gr = (int64_t)tile * 32 + 4 * wave + i;
+            gr = gr < n ? gr : n - 1;
+            gv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(g + gr * 256) + lane);
+            yv[i] = Y ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Y + gr * 256) + lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+    };
+    auto stage = [&](int tile, int buf) {                    // mask, scale, split, write the pieces
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * wave + i;
+            const bool ok = (int64_t)tile * 32 + r < n;
+            f32x4 v;
+            v.x = (ok && yv[i].x > 0.f) ? gv[i].x : 0.f;
+            v.y = (ok && yv[i].y > 0.f) ? gv[i].y : 0.f;
+            v.z = (ok && yv[i].z > 0.f) ? gv[i].z : 0.f;
+            v.w = (ok && yv[i].w > 0.f) ? gv[i].w : 0.f;
+            unsigned sb, ub;
+            s16_scale_bits(s16_wave_umax(s16_row_max_bits(v)), sb, ub);
+            u32x2_s16 h0, h1;
+            s16_split4(v, __builtin_bit_cast(float, sb), h0, h1);
+            char *hrow = reinterpret_cast<char *>(s_A[buf] + r * kGrLd) + 8 * lane;
+            *reinterpret_cast<u32x2_s16 *>(hrow) = h0;
+            *reinterpret_cast<u32x2_s16 *>(hrow + 512) = h1;
+            if (lane == 0) s_un[buf][r] = __builtin_bit_cast(float, ub);
+        }
+    };
+    int tile = blockIdx.x, buf = 0;
+    if (tile < n_tiles) { request(tile); stage(tile, 0); }
+    __syncthreads();
+    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) request(next);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const char *ap = reinterpret_cast<const char *>(s_A[buf]) + (lane & 31) * (kGrLd * 4) + 16 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const u32x4_s16 A0 = *reinterpret_cast<const u32x4_s16 *>(ap + 32 * ks);
+            const u32x4_s16 A1 = *reinterpret_cast<const u32x4_s16 *>(ap + 32 * ks + 512);
+            s16_mfma(acc, A1, B[ks][0]);
+            s16_mfma(acc, A0, B[ks][1]);
+            s16_mfma(acc, A0, B[ks][0]);
+            if (ks & 1) __builtin_amdgcn_sched_barrier(0);     // (all 32 operand reads hoisted to the top cost 128 registers: spills)
+        }
+        // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]: column scale, then row scale (both exact)
+        float *tb = gS + (int64_t)tile * 32 * 256;            // wave-uniform base + 32-bit lane offsets (16 address registers, not 32)
+        const unsigned o0 = 32u * wave + (lane & 31) + 1024u * (lane >> 5);
+        const int rows_left = (int)(n - (int64_t)tile * 32 < 32 ? n - (int64_t)tile * 32 : 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < rows_left) __builtin_nontemporal_store((acc[r] * wu) * s_un[buf][m], tb + (o0 + 256u * ((r & 3) + 8 * (r >> 2))));
+        }
+        if (next < n_tiles) stage(next, buf ^ 1);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void linear_gs_small_kernel(const float *__restrict__ g, const float *__restrict__ Y,
                                                               const float *__restrict__ W, float *__restrict__ gS, int64_t n,
                                                               int Hi, int Ho) {
@@ -539,8 +627,11 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
             void *Wq = static_cast<char *>(work) + wgrad_work_bytes(n, Hi, Ho);
             int rcp = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256_t16(W, Wq, st);
             if (rcp) return rcp;
-            static const int gs_rows = [] { const char *e = getenv("NDCN_GS_ROWS"); return (e && atoi(e) == 64) ? 64 : 32; }();
-            if (gs_rows == 64) hipLaunchKernelGGL(linear_gs_256_split_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, g, Y, Wq, gS, n);
+            static const int gs_rows = [] { const char *e = getenv("NDCN_GS_ROWS"); return e ? atoi(e) : 0; }();     // 0: resident weights (default); 32 / 64: the tile kernels
+            const int n_tiles = (int)((n + 31) / 32);
+            if (gs_rows != 32 && gs_rows != 64)
+                hipLaunchKernelGGL(linear_gs_256_res_kernel, dim3((unsigned)(n_tiles < kCus ? n_tiles : kCus)), dim3(512), 0, st, g, Y, Wq, gS, n, n_tiles);
+            else if (gs_rows == 64) hipLaunchKernelGGL(linear_gs_256_split_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, g, Y, Wq, gS, n);
             else hipLaunchKernelGGL(linear_gs_256_split_kernel<1>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, g, Y, Wq, gS, n);
         } else {
             const unsigned gx = (unsigned)((n + kBM2 - 1) / kBM2);

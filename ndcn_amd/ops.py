@@ -154,20 +154,22 @@ class _BwdDots:
     # whoever reads them first calls `await_lazy` (autograd_path._Await, the only consumer): by then the panel launches of the
     # whole solver step are queued behind the copy.  Same bits as `fetch`: the fp64 sums, times `scale` in fp64, rounded to fp32.
     RING = 1 << 15
+    _ring_lock = threading.Lock()
     _ring = None
     _ring_pos = 0
     _pending = {}
 
     def lazy(self, n, scale=1.0):
         cls = _BwdDots
-        if cls._ring is None:
-            cls._ring = torch.zeros(cls.RING, dtype=torch.float32).pin_memory()
         src = self.out[:n]
         m = int(n)
-        if cls._ring_pos + m > cls.RING:
-            cls._ring_pos = 0
-        lo = cls._ring_pos
-        cls._ring_pos += m
+        with cls._ring_lock:                # (ring position and pending table: written by the device's autograd worker, read by the caller's thread)
+            if cls._ring is None:
+                cls._ring = torch.zeros(cls.RING, dtype=torch.float32).pin_memory()
+            if cls._ring_pos + m > cls.RING:
+                cls._ring_pos = 0
+            lo = cls._ring_pos
+            cls._ring_pos += m
         dst = cls._ring[lo:lo + m]
         vals = (src * scale) if scale != 1.0 else src
         dst.copy_(vals.to(torch.float32), non_blocking=True)
@@ -175,19 +177,22 @@ class _BwdDots:
         ev.record()
         outs = [dst[i] for i in range(m)]
         rec = (ev, [o.data_ptr() for o in outs])
-        for p in rec[1]:
-            cls._pending[p] = rec          # (a slot the ring hands out again replaces the stale record of its previous use)
+        with cls._ring_lock:
+            for p in rec[1]:
+                cls._pending[p] = rec      # (a slot the ring hands out again replaces the stale record of its previous use)
         return outs
 
     @classmethod
     def await_lazy(cls, t):
         if t is not None and cls._pending:
-            rec = cls._pending.get(t.data_ptr())
+            with cls._ring_lock:
+                rec = cls._pending.get(t.data_ptr())
             if rec is not None:
                 rec[0].synchronize()
-                for p in rec[1]:           # one copy filled all the slots of this read-back: none of them needs the event again
-                    if cls._pending.get(p) is rec:
-                        del cls._pending[p]
+                with cls._ring_lock:
+                    for p in rec[1]:       # one copy filled all the slots of this read-back: none of them needs the event again
+                        if cls._pending.get(p) is rec:
+                            del cls._pending[p]
         return t
 
 

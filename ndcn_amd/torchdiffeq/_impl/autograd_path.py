@@ -14,6 +14,7 @@ the gradients of the scalar coefficients).  The RHS itself (`func`) is different
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -327,7 +328,13 @@ def _lazy():
     return os.environ.get('NDCN_GRAD_LAZY', '1') != '0'
 
 
-_LAZY_NOW = [False]          # set by the solver loop for the solve it runs: do the carry ops of this solve defer their scalars?
+class _LazyFlag(threading.local):
+    """Do the carry ops of the solve THIS THREAD is building defer their scalars?  Per thread (a thread per device builds its own
+    solve), saved and restored around a solve (a right-hand side that solves an inner problem): round-4 advisor."""
+    on = False
+
+
+_LAZY = _LazyFlag()
 
 
 class _Await(torch.autograd.Function):
@@ -354,7 +361,7 @@ class _StageCarryFn(torch.autograd.Function):
         ks, cs = rest[:n], rest[n:]
         idx, kk, cc = _active(ks, cs)
         ctx.n, ctx.idx, ctx.cc = n, idx, cc
-        ctx.lazy = _LAZY_NOW[0]                  # (the solver below routes every coefficient of a carry op through _Await)
+        ctx.lazy = _LAZY.on                  # (the solver below routes every coefficient of a carry op through _Await)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*kk, *cs)
         u = hip.combine(y0, kk, cc) if kk else y0.clone()
@@ -493,7 +500,7 @@ class _RhsStageCarryFn(torch.autograd.Function):
         c_new = f32(float(cs[n]))
         K, u_next = hip.rhs_rk(A, u, W, b, 'combine', y0, kk, cc + [c_new], no_graph=no_graph, no_control=no_control)
         ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b = n, idx, cc + [c_new], op, b is not None
-        ctx.lazy = _LAZY_NOW[0]
+        ctx.lazy = _LAZY.on
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(u, W, K, *kk, *cs)
         return (K, u_next, y0, W.view_as(W), (b.view_as(b) if b is not None else None)) + tuple(ks)
@@ -552,7 +559,7 @@ class _RhsErrorCarryFn(torch.autograd.Function):
         K, (s, bad) = hip.rhs_rk(A, y1, W, b, 'error', y0, kk, cc + [c_new], rtol=rtol, atol=atol, no_graph=no_graph, no_control=no_control)
         bad_out.append(bad)
         ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b, ctx.tol = n, idx, cc + [c_new], op, b is not None, (rtol, atol)
-        ctx.lazy = _LAZY_NOW[0]
+        ctx.lazy = _LAZY.on
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(y0, y1, W, K, *kk, *cs)
         return (K, torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1, W.view_as(W), (b.view_as(b) if b is not None else None)) + tuple(ks)
@@ -606,7 +613,7 @@ class _ErrorCarryFn(torch.autograd.Function):
         s, bad = hip.error(y0, y1, kk, cc, rtol, atol)
         bad_out.append(bad)
         ctx.n, ctx.idx, ctx.cc, ctx.tol = n, idx, cc, (rtol, atol)
-        ctx.lazy = _LAZY_NOW[0]
+        ctx.lazy = _LAZY.on
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(y0, y1, *kk, *cs)
         return (torch.tensor(f32(s / y0.numel()), dtype=torch.float32), y0, y1) + tuple(ks)
@@ -673,7 +680,7 @@ class _DenseMultiCarryFn(torch.autograd.Function):
     def forward(ctx, nt, a0, a1, *rest):
         kk, dt_, xs = rest[:7], rest[7], rest[8:8 + nt]
         ctx.nt = nt
-        ctx.lazy = _LAZY_NOW[0]
+        ctx.lazy = _LAZY.on
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(a0, a1, *rest)
         dt32 = f32(float(dt_))
@@ -735,7 +742,15 @@ def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
     return torch.min(100 * hs[1], h1)
 
 
-def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=None, odefunc=None, **options):
+def integrate_dopri5_grad(*args, **kwargs):
+    before = _LAZY.on
+    try:
+        return _integrate_dopri5_grad(*args, **kwargs)
+    finally:
+        _LAZY.on = before
+
+
+def _integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=None, odefunc=None, **options):
     core.assert_increasing(t)
     dtype = y0[0].dtype
     targ = core.TimeArg(y0[0], autonomous)
@@ -764,7 +779,7 @@ def integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=No
     # the range of the ATen-order reductions), so that both paths see the same ratio
     fuse_err = fused is not None and y0[0].numel() > int(os.environ.get('NDCN_ATEN_NORM_MAX', 1 << 18)) and \
         os.environ.get('NDCN_GRAD_FUSED_ERROR', '1') != '0'
-    _LAZY_NOW[0] = lazy
+    _LAZY.on = lazy
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     # ---- the first evaluation and the initial step (dopri5.py:76-83).  y0 has four consumers - this evaluation, the initial-step
     # selection, the first stage chain, the trajectory's first tick: one alias each (_FanOut: a fixed summation order for its
