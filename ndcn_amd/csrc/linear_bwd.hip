@@ -654,6 +654,8 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
         if (small) {
             hipLaunchKernelGGL(linear_wgrad_small_kernel, dim3((unsigned)used), dim3(256), 0, st, g, Y, S, part_w, gb ? part_b : nullptr, n, Hi, Ho, rpc);
         } else if (wsplit_on && Hi == 256 && Ho == 256) {
+            // (a role-split form - 4 fetch / split waves + 8 product waves - was built and measured in round 5: no faster, because a
+            // SIMD's VALU work and MFMA work add up on gfx950 whichever wave issues them: profiles/r05_wgrad_roles.txt)
             hipLaunchKernelGGL(linear_wgrad_256_split_kernel, dim3((unsigned)used), dim3(512), 0, st, g, Y, S, part_w,
                                gb ? part_b : nullptr, n, rpc);
         } else {
