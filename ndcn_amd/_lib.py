@@ -23,7 +23,7 @@ M_EULER, M_MIDPOINT, M_RK4, M_DOPRI5 = 0, 1, 2, 3
 METHODS = {'euler': M_EULER, 'midpoint': M_MIDPOINT, 'rk4': M_RK4, 'dopri5': M_DOPRI5}
 PROF_KINDS = ('spmm', 'linear', 'rhs_fused', 'combine', 'error', 'sumsq', 'interp_fit', 'interp_eval',
               'fixed_stage', 'gather_rows', 'truth_dynamics', 'combine_bwd', 'error_bwd', 'sumsq_bwd', 'dense_bwd', 'linear_gs',
-              'linear_wgrad', 'relu_bwd')
+              'linear_wgrad', 'relu_bwd', 'rhs_adjoint_forward_half', 'rhs_adjoint_transposed_half')
 
 
 class NdcnHipError(RuntimeError):

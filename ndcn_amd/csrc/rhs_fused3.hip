@@ -732,7 +732,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (e.y_aux) bytes += P;
     if (a.Xadd) bytes += P;                                          // the second gather
     if (a.S_out) bytes += P;
-    ProfScope prof(PROF_RHS_FUSED, st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
+    ProfScope prof(masked ? PROF_RHS_ADJ_T : (a.S_out ? PROF_RHS_ADJ_FWD : PROF_RHS_FUSED), st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
     int rc = NDCN_OK;
     // panels that fit the Infinity Cache with room for the next launch's (<= 128 MiB): plain stores (operators without a halo panel)
     const bool cached = !Xh && (int64_t)A->n_rows * 1024 <= (128ll << 20);
