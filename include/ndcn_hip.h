@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 13
+#define NDCN_ABI_VERSION 14
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -285,6 +285,10 @@ NDCN_API int64_t ndcn_rk_bwd_ws_bytes(void);
 NDCN_API int ndcn_rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk,
                                      const float *const *h_acc, float *gy0, const float *acc_y0, double *d_dots, void *d_ws,
                                      int64_t n_elem, void *stream);
+/* d_dots[0] = <g, a - b> (b nullable: <g, a>), fp64 partial sums in a fixed order.  For a stage sum u = y0 + dt sum_j beta_j k_j the
+ * gradient of dt is <g_u, u - y0> / dt - three panels read instead of one per term (rk_common.py:41-51 differentiated).            */
+NDCN_API int ndcn_rk_dot_diff_f32(const float *g, const float *a, const float *b, double *d_dots, void *d_ws, int64_t n_elem,
+                                  void *stream);
 NDCN_API int ndcn_rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k,
                                    float rtol, float atol, float g_r, double inv_n, float *gy0, float *gy1,
                                    float *const *h_gk, const float *acc_y0, const float *acc_y1, const float *const *h_acc,

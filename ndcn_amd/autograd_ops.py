@@ -62,14 +62,16 @@ class _Rhs(torch.autograd.Function):
         return gX, gW, gb, None, None, None
 
 
-def rhs_vjp(A, no_graph, no_control, X, W, Y, g, need_x, need_w, need_b):
+def rhs_vjp(A, no_graph, no_control, X, W, Y, g, need_x, need_w, need_b, S=None):
     """(g_X, g_W, g_b) of Y = relu(W (A X) + b) for the upstream gradient g - the closed form every differentiable wrapper of the
     right-hand side shares: ReLU mask fused into the operand loads of the two GEMMs, g_W = gZ^T S split over row chunks (S = A X
-    recomputed instead of stored), g_b with it, g_X = A^T g_S through the SpMM on the transposed CSR."""
+    recomputed instead of stored, unless the caller kept the one the forward launch wrote), g_b with it, g_X = A^T g_S through the
+    SpMM on the transposed CSR."""
     gW = gb = None
     if not no_control:
-        S = None
-        if need_w:
+        if not need_w:
+            S = None
+        elif S is None:
             S = X.detach() if no_graph else hip.spmm(A, X.detach())
         # (W itself, not a detached alias: linear_bwd keeps the packed planes of W^T per weight tensor object and version)
         gS, gW, gb = hip.linear_bwd(g, W, S=S, Y=Y, need_gS=need_x, need_gW=need_w, need_gb=need_b)

@@ -152,6 +152,11 @@ int ndcn_linear_bwd_f32(const float *g, const float *Y, const float *S, const fl
 
 int64_t ndcn_rk_bwd_ws_bytes(void) { return rk_bwd_ws_bytes(); }
 
+int ndcn_rk_dot_diff_f32(const float *g, const float *a, const float *b, double *d_dots, void *d_ws, int64_t n_elem, void *stream) {
+    NDCN_CHECK_ARG(n_elem >= 0 && g && a && d_dots && d_ws, "bad argument");
+    return rk_dot_diff_f32(g, a, b, d_dots, d_ws, n_elem, ST(stream));
+}
+
 int ndcn_rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk,
                             const float *const *h_acc, float *gy0, const float *acc_y0, double *d_dots, void *d_ws, int64_t n_elem,
                             void *stream) {

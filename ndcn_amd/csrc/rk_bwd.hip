@@ -367,6 +367,39 @@ int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c
     return NDCN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ <g, a - b>
+// The gradient of a step size through ONE stage sum u = y0 + dt sum_j beta_j k_j is <g_u, sum_j beta_j k_j> = <g_u, u - y0> / dt:
+// three panels read whatever the number of terms (the per-coefficient products of combine_bwd read one panel per term).
+template <bool VEC>
+__global__ __launch_bounds__(256) void dot_diff_kernel(const float *__restrict__ g, const float *__restrict__ a, const float *__restrict__ b,
+                                                       int64_t n, double *__restrict__ partial) {
+    double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const bw_f4 gv = ld4(g, i);
+            bw_f4 e = ld4(a, i);
+            if (b) e = e - ld4(b, i);
+            d[0] += (double)(gv.x * e.x) + (double)(gv.y * e.y) + (double)(gv.z * e.z) + (double)(gv.w * e.w);
+        } else {
+            const float e = b ? a[i] - b[i] : a[i];
+            d[0] += (double)(g[i] * e);
+        }
+    }
+    block_store_dots(d, partial);
+}
+
+int rk_dot_diff_f32(const float *g, const float *a, const float *b, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
+    if (!g || !a || !d_dots || !d_ws || n < 0) { set_error("rk dot_diff: null pointer"); return NDCN_EINVAL; }
+    const bool vec = n % 4 == 0 && aligned16(g) && aligned16(a) && (!b || aligned16(b));
+    ProfScope prof(PROF_COMBINE_BWD, st, 4.0 * n * (b ? 3 : 2), 2.0 * n);
+    const int grid = bwd_grid(vec ? n / 4 : n);
+    if (vec) hipLaunchKernelGGL(dot_diff_kernel<true>, dim3(grid), dim3(256), 0, st, g, a, b, n / 4, static_cast<double *>(d_ws));
+    else hipLaunchKernelGGL(dot_diff_kernel<false>, dim3(grid), dim3(256), 0, st, g, a, b, n, static_cast<double *>(d_ws));
+    hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 int rk_error_bwd_f32(const float *y0, const float *y1, const float *const *h_k, const float *h_c, int n_k, float rtol, float atol,
                      float g_r, double inv_n, float *gy0, float *gy1, float *const *h_gk, const float *acc_y0, const float *acc_y1,
                      const float *const *h_acc, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {

@@ -604,6 +604,16 @@ class HipOps:
         return (gk, dots) if acc_y0 is None else (gk, dots, gy0)
 
     @staticmethod
+    def dot_diff(g, a, b=None, scale=1.0, lazy=False):
+        """scale * <g, a - b> (fp64 sum, fixed order): a float, or with lazy a deferred 0-d float32 host tensor (_BwdDots.lazy)"""
+        g, a = _panel(g), _panel(a)
+        b = _panel(b) if b is not None else None
+        d = _BwdDots.get(g.device)
+        with _REDUCE_LOCK, torch.cuda.device(g.device):
+            check(_lib.load().ndcn_rk_dot_diff_f32(ptr(g), ptr(a), ptr(b), ptr(d.out), ptr(d.ws), g.numel(), stream_ptr()))
+            return d.lazy(1, scale)[0] if lazy else d.fetch()[0] * scale
+
+    @staticmethod
     def error_bwd(y0, y1, ks, cs, rtol, atol, g_r, need_y0, need_y1, need_k, need_dots=True, accs=None, acc_y0=None, acc_y1=None, lazy=False):
         """VJP of the error ratio mean(((sum c_j k_j) / tol)^2) for upstream gradient g_r:
         (gy0, gy1, [gk_j], [d ratio / d c_j] (NOT yet multiplied by g_r) as host floats); accs / acc_y0 / acc_y1 as combine_bwd."""

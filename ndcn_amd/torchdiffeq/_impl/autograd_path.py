@@ -332,6 +332,7 @@ class _LazyFlag(threading.local):
     """Do the carry ops of the solve THIS THREAD is building defer their scalars?  Per thread (a thread per device builds its own
     solve), saved and restored around a solve (a right-hand side that solves an inner problem): round-4 advisor."""
     on = False
+    keep_s = False                          # do the fused evaluations keep S = A x for the weight gradient? (_keep_s_enabled)
 
 
 _LAZY = _LazyFlag()
@@ -544,6 +545,167 @@ class _RhsStageCarryFn(torch.autograd.Function):
         return (None, None, gu_in, gW, gb, g_y0) + tuple(gk_all) + tuple(gc_all)
 
 
+# ---- the stage sums' VJPs in PULL form (round 5) ---------------------------------------------------------------------------------
+# In the carry forms above every stage's backward PUSHES its contribution c_mj g_u_m into the received gradient of every earlier k_j
+# (and of y0): one read-modify-write per (stage, earlier stage) pair - 88 panels per attempted step, `combine_bwd` 21-29 % of the
+# kernel time of a dopri5 training step.  Here a stage's backward only NOTES (c_mj, g_u_m) in the step's `_StepPull`; the node that
+# produced k_j adds up what was noted for it when its own turn comes (one ndcn_rk_combine_f32 over <= 7 panels, left to right: a fixed
+# order), and the first node of the step does the same for y0 and k_1.  The inner products <g_u_m, k_j> that become the coefficients'
+# gradients still cost one read of the k panels per stage (ndcn_rk_combine_bwd_f32 without outputs).  67 panels instead of 88.
+# The data dependencies of the carried tensors order the nodes of a step whatever autograd's threads do, so the notes are complete
+# when they are read.  NDCN_GRAD_PULL=0: the push forms.
+
+class _StepPull:
+    def __init__(self):
+        self.for_k = {}                                              # k index within the step -> [(c, g_u), ...]
+        self.for_y0 = []
+
+    def note(self, j, c, g):
+        self.for_k.setdefault(j, []).append((c, g))
+
+    def take(self, j, received):
+        """received (may be None) + sum of the noted c g_u for k_j, added left to right in one launch"""
+        terms = self.for_k.pop(j, [])
+        panels = ([received.contiguous()] if received is not None else []) + [g for _, g in terms]
+        coefs = ([f32(1)] if received is not None else []) + [c for c, _ in terms]
+        if not panels:
+            return None
+        if len(panels) == 1 and float(coefs[0]) == 1.0:
+            return panels[0]
+        return hip.lincomb(panels, coefs)
+
+    def take_y0(self, received):
+        panels = ([received.contiguous()] if received is not None else []) + self.for_y0
+        self.for_y0 = []
+        if not panels:
+            return None
+        return panels[0] if len(panels) == 1 else hip.lincomb(panels, [f32(1)] * len(panels))
+
+
+def _pull_enabled():
+    return os.environ.get('NDCN_GRAD_PULL', '1') != '0'
+
+
+def _keep_s(op, mode, n_prev, x):
+    """a panel for S = A x when the fused launch can write it on the side (ndcn_rhs_rk_adj_f32) and the solve keeps it for the weight
+    gradient (one panel per evaluation held until backward instead of one SpMM per evaluation in backward), else None"""
+    A, no_graph, no_control = op
+    if not getattr(_LAZY, 'keep_s', False) or no_graph or no_control or x.shape[1] != 256:
+        return None
+    return torch.empty_like(x) if hip.rhs_adj_supported(A, 256, mode, n_prev) else None
+
+
+def _keep_s_enabled(y):
+    """NDCN_GRAD_KEEP_S = 1 / 0 / auto (default): keep S when ~60 more panels (a long solve's evaluations) fit the free device memory
+    four times over; otherwise the SpMM is recomputed in backward as before"""
+    v = os.environ.get('NDCN_GRAD_KEEP_S', 'auto')
+    if v in ('0', '1'):
+        return v == '1'
+    free, _ = torch.cuda.mem_get_info(y.device)
+    return 240 * y.numel() * 4 <= free
+
+
+def _row_dot_enabled():
+    return os.environ.get('NDCN_GRAD_ROW_DOT', '1') != '0'
+
+
+class _StagePullFn(torch.autograd.Function):
+    """_StageCarryFn with one earlier stage - the first node of a fused step: (u, y0', k_1') = (y0 + c k_1, y0, k_1) - in pull form:
+    its backward runs LAST in the step and hands y0 and k_1 everything the step noted for them."""
+
+    @staticmethod
+    def forward(ctx, pull, y0, k1, c):
+        cc = f32(float(c))
+        ctx.pull, ctx.cc, ctx.lazy = pull, cc, _LAZY.on
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(k1, c)
+        return hip.combine(y0, [k1], [cc]), y0, k1
+
+    @staticmethod
+    def backward(ctx, g, g_y0c, g_k1c):
+        k1, c = ctx.saved_tensors
+        need_y0, need_k, need_c = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        pull, gc = ctx.pull, None
+        if g is not None:
+            g = g.contiguous()
+            if need_c:
+                res = hip.combine_bwd(g, [k1], [ctx.cc], [False], need_dots=True, lazy=ctx.lazy)
+                gc = _grad_scalar(c, res[1][0])
+            pull.note(0, ctx.cc, g)
+            pull.for_y0.append(g)
+        g_k1 = pull.take(0, g_k1c)
+        g_y0 = pull.take_y0(g_y0c)
+        return None, (g_y0 if need_y0 else None), (g_k1 if need_k else None), gc
+
+
+class _RhsStagePullFn(torch.autograd.Function):
+    """_RhsStageCarryFn in pull form: same forward (one ndcn_rhs_rk_f32 launch: K and the next stage input).
+
+    The coefficients of a stage sum are ONE step size times the tableau row (c_j = dt beta_j: _step_coefficients), so what the scalar
+    chain needs from this node is d/d dt = sum_j beta_j <g_u, k_j> = <g_u, u_next - y0> / dt - one ndcn_rk_dot_diff_f32 pass over three
+    panels instead of one panel per term.  It is handed back on the LAST coefficient (the new K's: never zero in a tableau) as
+    <g_u, u_next - y0> / c_last, the others get none: beta_last * that = the row's whole contribution to dt.  (NDCN_GRAD_ROW_DOT=0: one
+    product per coefficient, as the push form has them.)"""
+
+    @staticmethod
+    def forward(ctx, n, pull, op, u, W, b, y0, *rest):
+        ks, cs = rest[:n], rest[n:]
+        A, no_graph, no_control = op
+        idx, kk, cc = _active(ks, cs[:n])
+        c_new = f32(float(cs[n]))
+        S = _keep_s(op, 'combine', len(kk), u) if ctx.needs_input_grad[4] else None
+        K, u_next = hip.rhs_rk(A, u, W, b, 'combine', y0, kk, cc + [c_new], no_graph=no_graph, no_control=no_control, s_out=S)
+        ctx.S = S                                                     # (not an input or output of the node: kept on the context)
+        ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b, ctx.pull = n, idx, cc + [c_new], op, b is not None, pull
+        ctx.lazy = _LAZY.on
+        ctx.row_dot = _row_dot_enabled() and float(c_new) != 0.0
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(u, W, K, u_next, y0, *kk, *cs)
+        return (K, u_next, y0, W.view_as(W), (b.view_as(b) if b is not None else None)) + tuple(ks)
+
+    @staticmethod
+    def backward(ctx, g_K, g_u, g_y0c, g_Wc, g_bc, *g_kc):
+        from ...autograd_ops import rhs_vjp
+        n, idx, cc, pull = ctx.n, ctx.idx, ctx.cc, ctx.pull
+        saved = ctx.saved_tensors
+        u, W, K, u_next, y0s = saved[:5]
+        saved = saved[2:]
+        kk, cs = saved[3:3 + len(idx)], saved[3 + len(idx):]
+        needs = ctx.needs_input_grad                                  # (n, pull, op, u, W, b, y0, k.., c..)
+        need_u, need_w, need_b, need_y0 = needs[3], needs[4], ctx.has_b and needs[5], needs[6]
+        need_k, need_c = needs[7:7 + n], needs[7 + n:]
+        gc_all = [None] * (n + 1)
+        if g_u is not None:
+            g_u = g_u.contiguous()
+            if ctx.row_dot and need_c[n]:
+                d = hip.dot_diff(g_u, u_next, y0s, scale=1.0 / float(cc[len(idx)]), lazy=ctx.lazy)
+                gc_all[n] = _grad_scalar(cs[n], d)
+            elif any(need_c[j] for j in idx) or need_c[n]:
+                res = hip.combine_bwd(g_u, list(kk) + [K], cc, [False] * (len(idx) + 1), need_dots=True, lazy=ctx.lazy)
+                dots = res[1]
+                for q, j in enumerate(idx):
+                    if need_c[j]:
+                        gc_all[j] = _grad_scalar(cs[j], dots[q])
+                if need_c[n]:
+                    gc_all[n] = _grad_scalar(cs[n], dots[len(idx)])
+            for q, j in enumerate(idx):
+                if need_k[j]:
+                    pull.note(j, cc[q], g_u)
+            pull.note(n, cc[len(idx)], g_u)
+            if need_y0:
+                pull.for_y0.append(g_u)
+        g_K = pull.take(n, g_K)                                       # what this evaluation's K received: later stages, error, dense output
+        gu_in = gW = gb = None
+        if g_K is not None:
+            A, no_graph, no_control = ctx.op
+            gu_in, gW, gb = rhs_vjp(A, no_graph, no_control, u, W, K, g_K.contiguous(), need_u, need_w, need_b, S=ctx.S)
+        ctx.S = None
+        gW = _add_carried(gW, g_Wc) if need_w else None
+        gb = _add_carried(gb, g_bc) if need_b else None
+        gk_all = [g_kc[j] if need_k[j] else None for j in range(n)]    # handed through untouched: their producers pull
+        return (None, None, None, gu_in, gW, gb, (g_y0c if need_y0 else None)) + tuple(gk_all) + tuple(gc_all)
+
+
 class _RhsErrorCarryFn(torch.autograd.Function):
     """(K, ratio, y0', y1', k_1', ..) = (relu(W (A y1) + b), mean((sum_j c_j k_j + c_new K)^2 / tol^2), y0, y1, k_1, ..): the LAST
     evaluation of a dopri5 step with the error record in its epilogue (ndcn_rhs_rk_f32, mode error - the inference solver's
@@ -556,7 +718,10 @@ class _RhsErrorCarryFn(torch.autograd.Function):
         A, no_graph, no_control = op
         idx, kk, cc = _active(ks, cs[:n])
         c_new = f32(float(cs[n]))
-        K, (s, bad) = hip.rhs_rk(A, y1, W, b, 'error', y0, kk, cc + [c_new], rtol=rtol, atol=atol, no_graph=no_graph, no_control=no_control)
+        S = _keep_s(op, 'error', len(kk), y1) if ctx.needs_input_grad[5] else None
+        K, (s, bad) = hip.rhs_rk(A, y1, W, b, 'error', y0, kk, cc + [c_new], rtol=rtol, atol=atol, no_graph=no_graph, no_control=no_control,
+                                 s_out=S)
+        ctx.S = S
         bad_out.append(bad)
         ctx.n, ctx.idx, ctx.cc, ctx.op, ctx.has_b, ctx.tol = n, idx, cc + [c_new], op, b is not None, (rtol, atol)
         ctx.lazy = _LAZY.on
@@ -595,7 +760,7 @@ class _RhsErrorCarryFn(torch.autograd.Function):
         gW = gb = None
         if g_K is not None:
             A, no_graph, no_control = ctx.op
-            gx, gW, gb = rhs_vjp(A, no_graph, no_control, y1, W, K, g_K.contiguous(), need_y1, need_w, need_b)
+            gx, gW, gb = rhs_vjp(A, no_graph, no_control, y1, W, K, g_K.contiguous(), need_y1, need_w, need_b, S=ctx.S)
             if need_y1 and gx is not None:
                 gy1 = gx if gy1 is None else hip.combine(gy1.contiguous(), [gx], [f32(1)])      # y1 is the evaluation's input AND the record's state
         gW = _add_carried(gW, g_Wc) if need_w else None
@@ -743,11 +908,11 @@ def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
 
 
 def integrate_dopri5_grad(*args, **kwargs):
-    before = _LAZY.on
+    before = (_LAZY.on, _LAZY.keep_s)
     try:
         return _integrate_dopri5_grad(*args, **kwargs)
     finally:
-        _LAZY.on = before
+        _LAZY.on, _LAZY.keep_s = before
 
 
 def _integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=None, odefunc=None, **options):
@@ -780,6 +945,8 @@ def _integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=N
     fuse_err = fused is not None and y0[0].numel() > int(os.environ.get('NDCN_ATEN_NORM_MAX', 1 << 18)) and \
         os.environ.get('NDCN_GRAD_FUSED_ERROR', '1') != '0'
     _LAZY.on = lazy
+    pull_on = fused is not None and _pull_enabled()
+    _LAZY.keep_s = fused is not None and _keep_s_enabled(y0[0])
     multi_tick = os.environ.get('NDCN_GRAD_MULTI_TICK', '1') != '0'
     # ---- the first evaluation and the initial step (dopri5.py:76-83).  y0 has four consumers - this evaluation, the initial-step
     # selection, the first stage chain, the trajectory's first tick: one alias each (_FanOut: a fixed summation order for its
@@ -831,12 +998,20 @@ def _integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=N
                 # stage input 1 by a combine launch; evaluations 2 .. 6 form the next stage input themselves; evaluation 7 (at
                 # y1, the next step's k1) is the plain right-hand side
                 op_ = fused[0]
-                outs_ = _StageCarryFn.apply(1, yc[0], k[0][0], coef(beta_dt[0][0]))
+                pull_ = _StepPull() if pull_on else None
+                if pull_ is not None:
+                    outs_ = _StagePullFn.apply(pull_, yc[0], k[0][0], coef(beta_dt[0][0]))
+                else:
+                    outs_ = _StageCarryFn.apply(1, yc[0], k[0][0], coef(beta_dt[0][0]))
                 u_, yc[0], k[0] = outs_[0], outs_[1], list(outs_[2:])
                 for st_ in range(6):
                     if st_ < 5:
-                        outs_ = _RhsStageCarryFn.apply(len(k[0]), op_, u_, chain[0], chain[1], yc[0], *k[0],
-                                                       *[coef(v) for v in beta_dt[st_ + 1]])
+                        if pull_ is not None:
+                            outs_ = _RhsStagePullFn.apply(len(k[0]), pull_, op_, u_, chain[0], chain[1], yc[0], *k[0],
+                                                          *[coef(v) for v in beta_dt[st_ + 1]])
+                        else:
+                            outs_ = _RhsStageCarryFn.apply(len(k[0]), op_, u_, chain[0], chain[1], yc[0], *k[0],
+                                                           *[coef(v) for v in beta_dt[st_ + 1]])
                         u_, yc[0], chain[0], chain[1], k[0] = outs_[1], outs_[2], outs_[3], outs_[4], list(outs_[5:]) + [outs_[0]]
                     elif fuse_err:
                         yi = (u_,)                                    # evaluation 7 with the error record in its epilogue

@@ -41,12 +41,25 @@ def one_case(name, side, H, ticks, method, dev, cpu_reps):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    # every timed repetition is the SAME Adam step (parameters and optimizer moments put back before it, outside the timed region):
+    # an adaptive solve's cost moves with the parameters - 5 or 6 attempted dopri5 steps from one training step to the next, 31 vs 36 ms
+    # at 100k nodes - and a median over consecutive training steps then measures which kind was in the majority
+    import copy
+    frozen = (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()))
+
+    def rewind():
+        model.load_state_dict(frozen[0])
+        opt.load_state_dict(copy.deepcopy(frozen[1]))
+        torch.cuda.synchronize()
+
     times = []
     for _ in range(10):
+        rewind()
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+    rewind()
     res = {'case': name, 'n': n, 'H': H, 'method': method, 'ticks': ticks, 'gpu_ms_per_adam_step': round(1e3 * float(np.median(times)), 3)}
     if n * H >= (1 << 20):
         # a roofline per kernel family of the step (HIP events around every library launch; algorithmic bytes of each launch over
@@ -55,6 +68,7 @@ def one_case(name, side, H, ticks, method, dev, cpu_reps):
         import _prof
         bd, tot = _prof.breakdown(step)
         res['library_kernel_ms_per_step'] = round(tot, 2)
+        res['rhs_evaluations_per_step'] = sum(v['launches'] for k, v in bd.items() if k in ('rhs_fused', 'rhs_adjoint_forward_half'))
         res['breakdown'] = bd
         res['roofline'] = _prof.roofline_of(bd, tot)
     if cpu_reps:
