@@ -233,7 +233,12 @@ def test_dopri5_training_with_the_error_record_in_the_last_evaluation(dev, no_co
     t = torch.tensor([0., 0.4, 0.9, 1.5]).to(dev)
     w = torch.randn(4, side * side, H, generator=torch.Generator().manual_seed(1)).to(dev)
     res = {}
-    for name, env in (('fused', {}), ('separate_error', {'NDCN_GRAD_FUSED_ERROR': '0'}), ('separate', {'NDCN_GRAD_FUSED_STAGE': '0'})):
+    # round 5: the stage sums' VJPs in pull form (_RhsStagePullFn; 'push' = the accumulating form), the step size's gradient per
+    # tableau row as one <g_u, u - y0> pass ('per_coefficient' = one product per term), S = A x kept from the forward launch for the
+    # weight gradient ('recompute_s' = the SpMM again in backward) - one switched off at a time
+    for name, env in (('fused', {'NDCN_GRAD_KEEP_S': '1'}), ('separate_error', {'NDCN_GRAD_FUSED_ERROR': '0'}), ('separate', {'NDCN_GRAD_FUSED_STAGE': '0'}),
+                      ('push', {'NDCN_GRAD_PULL': '0', 'NDCN_GRAD_KEEP_S': '1'}), ('per_coefficient', {'NDCN_GRAD_ROW_DOT': '0', 'NDCN_GRAD_KEEP_S': '1'}),
+                      ('recompute_s', {'NDCN_GRAD_KEEP_S': '0'})):
         os.environ.update(env)
         try:
             torch.manual_seed(0)
@@ -253,6 +258,25 @@ def test_dopri5_training_with_the_error_record_in_the_last_evaluation(dev, no_co
         assert float((res[name][0] - res['fused'][0]).abs().max()) <= 1e-5 * float(res['fused'][0].abs().max())
         for got, ref in zip(res[name][2], res['fused'][2]):
             assert rel(got, ref) < 2e-3, (name, rel(got, ref))
+    for name in ('push', 'per_coefficient', 'recompute_s'):
+        assert res[name][1] == res['fused'][1] and torch.equal(res[name][0], res['fused'][0])      # the forward launches' values do not move
+        for got, ref in zip(res[name][2], res['fused'][2]):
+            assert rel(got, ref) < (1e-6 if name == 'recompute_s' else 2e-4), (name, rel(got, ref))
+
+
+def test_dot_diff_kernel(dev):
+    """ndcn_rk_dot_diff_f32: <g, a - b> (and <g, a>) against float64, vector and scalar element paths, repeatable bit for bit"""
+    from ndcn_amd.ops import hip
+    gen = torch.Generator().manual_seed(5)
+    for n in (256 * 1000, 100003):
+        g, a = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+        b = a + 1e-2 * torch.randn(n, generator=gen)
+        gd, ad, bd = g.to(dev), a.to(dev), b.to(dev)
+        want = float((g.double() * (a - b).double()).sum())
+        got = hip.dot_diff(gd, ad, bd)
+        assert abs(got - want) <= 1e-6 * float((g * (a - b)).abs().sum()), (got, want)
+        assert hip.dot_diff(gd, ad, bd) == got
+        assert abs(hip.dot_diff(gd, ad, None, scale=0.5) - 0.5 * float((g.double() * a.double()).sum())) <= 1e-6 * float((g * a).abs().sum())
 
 
 @pytest.mark.parametrize('variant', ['default', 'no_control', 'no_graph'])
