@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 14
+#define NDCN_ABI_VERSION 15
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -631,6 +631,28 @@ NDCN_API int ndcn_prof_kinds(void);
 #define NDCN_PATH_WIDE  64   /* no_control: the same in the epilogue of the row SpMM (spmm.hip: spmm_wide_kernel)                */
 #define NDCN_PATH_SMALL 128  /* H <= 128: the whole ODEFunc + epilogue in one launch (rhs_small.hip)                            */
 NDCN_API int ndcn_debug_last_rhs_path(void);
+
+/* ---- training through the adaptive solver: the solve that keeps its tape, and its reverse pass ---------------------------------
+ * Replaces, for a plain ODEFunc on one state tensor, what the reference's drivers do by autograd through odeint
+ * (heat_dynamics.py:313-334, dgnn.py:192-222; torchdiffeq/_impl/dopri5.py:58-122, rk_common.py:41-61, misc.py:84-170, interp.py:21-65):
+ * ndcn_tape_dopri5_f32 integrates y' = relu(W (A y) + b) over the n_t strictly increasing ticks (out: n_t panels, the first is y0)
+ * with the launches of the per-operation path (same kernels, same order: bit-identical values and accept / reject decisions) and
+ * records every attempted step; ndcn_tape_backward_f32 turns g_out (n_t panels: the gradient of the trajectory) into the gradients
+ * of y0, W and b - the panel operations' VJP kernels of this header plus the adjoint of the step-size controller's scalar chain
+ * (dt, t0 / t1, the initial step and the interpolation abscissa carry gradient in the reference: csrc/tape.hip).  Once per tape.
+ * opts: {first_step given (0 / 1), safety, ifactor, dfactor, max_num_steps}.  At: the transposed operator (unused with NDCN_F_NO_GRAPH).
+ * alloc: device memory for the tape (12 panels per attempted step; ~24 more during the reverse pass), owned by the caller and kept
+ * until ndcn_tape_destroy.  y0, W, b and the operators must stay valid and unchanged until then.
+ * Errors as the solver's: NDCN_EMAXSTEPS, NDCN_EUNDERFLOW, NDCN_ENONFINITE; the tape handle is set on every path - destroy it.     */
+typedef struct ndcn_tape ndcn_tape;
+typedef void *(*ndcn_alloc_fn)(void *ctx, int64_t bytes);
+NDCN_API int ndcn_tape_dopri5_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags,
+                                  const float *y0, const double *ticks, int64_t n_t, double rtol, double atol, const double *opts,
+                                  float *out, ndcn_alloc_fn alloc, void *alloc_ctx, ndcn_tape **tape, void *stream);
+NDCN_API int ndcn_tape_backward_f32(ndcn_tape *tape, const float *g_out, float *g_y0, float *g_W, float *g_b, void *stream);
+NDCN_API int64_t ndcn_tape_steplog(const ndcn_tape *tape, double *rows, int64_t cap);   /* 5 doubles per attempt, as ndcn_solver_steplog */
+NDCN_API int64_t ndcn_tape_nfe(const ndcn_tape *tape);
+NDCN_API void ndcn_tape_destroy(ndcn_tape *tape);
 
 #ifdef __cplusplus
 }

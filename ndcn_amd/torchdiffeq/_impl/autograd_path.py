@@ -907,6 +907,24 @@ def _initial_step(func, targ, t0, y0, order, rtol, atol, f0, bad_out):
     return torch.min(100 * hs[1], h1)
 
 
+class _Sqrt32(torch.autograd.Function):
+    """sqrt of a float32 0-d host tensor, CORRECTLY ROUNDED (numpy / libm sqrtf - what the inference solvers and the reference's
+    fixtures have).  torch.sqrt on a CPU with AVX-512 returns values one ulp off (PyTorch 2.10 + AVX512 dispatch, measured:
+    tools/micro/sqrt_probe.py - sqrt(5.2355666e-08f) = 2.28813617e-04 instead of 2.28813602e-04), which moved dt_next of the
+    training path by 1e-8 against the inference path's on such hosts.  Backward as torch's: g / (2 sqrt(x))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out = torch.tensor(np.sqrt(f32(float(x))), dtype=torch.float32)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        return g / (2 * out)
+
+
 def integrate_dopri5_grad(*args, **kwargs):
     before = (_LAZY.on, _LAZY.keep_s)
     try:
@@ -1059,7 +1077,7 @@ def _integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=N
                 dt_next = dt * ifactor
             else:
                 dfac = 1.0 if worst.item() < 1 else dfactor
-                er = torch.sqrt(worst).to(torch.float64)
+                er = _Sqrt32.apply(worst).to(torch.float64)
                 expo = torch.tensor(1 / 5).to(torch.float64)
                 factor = torch.max(torch.tensor(1 / ifactor, dtype=torch.float64),
                                    torch.min(er ** expo / safety, torch.tensor(1 / dfac, dtype=torch.float64)))

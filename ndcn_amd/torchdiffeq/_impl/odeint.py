@@ -102,6 +102,11 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
         from .autograd_path import odeint_with_grad
         plain = method == 'dopri5' and _device_resident_ok(user_func, tensor_input, y0, t_user, method, options) and \
             _small_operator(user_func, y0[0]) is not None
+        if plain:
+            # one autograd node per solve: the native tape (csrc/tape.hip) runs the launches below and their reverse pass itself
+            from . import tape
+            if tape.applicable(user_func, y0[0], t_user):
+                return tape.solve(user_func, y0[0], t, rtol, atol, options, step_log)
         sol = odeint_with_grad(func, y0, t, rtol, atol, method, options, autonomous=_autonomous(user_func),
                                step_log=step_log, odefunc=user_func if plain else None)
     elif _device_resident_ok(user_func, tensor_input, y0, t_user, method, options):

@@ -1,0 +1,116 @@
+"""The native training tape (csrc/tape.hip: ndcn_tape_dopri5_f32 / ndcn_tape_backward_f32) against the per-operation autograd path
+(autograd_path.integrate_dopri5_grad, itself checked against the reference's gradients and the oracle's autograd in
+test_gpu_autograd.py): the SAME launches forward - trajectory and accept / reject log bit for bit - and the same gradient up to the
+order of float32 sums, including the part that flows through the step-size controller (reference: torchdiffeq/_impl/dopri5.py:76-122,
+misc.py:84-170, interp.py:38-65 differentiated by autograd)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+def _solve(dev, tape, make_func, x0_host, ticks, rtol, atol, w_host):
+    from ndcn_amd import torchdiffeq as ode
+    os.environ['NDCN_GRAD_TAPE'] = '1' if tape else '0'
+    try:
+        f = make_func()
+        x0 = x0_host.clone().to(dev).requires_grad_(True)
+        log = []
+        y = ode.odeint(f, x0, torch.tensor(ticks).to(dev), rtol=rtol, atol=atol, method='dopri5', step_log=log)
+        (y * w_host.to(dev)).sum().backward()
+        grads = [x0.grad.cpu()] + [p.grad.cpu() for p in f.parameters() if p.grad is not None]
+        return y.detach().cpu(), log, grads
+    finally:
+        del os.environ['NDCN_GRAD_TAPE']
+
+
+@pytest.mark.parametrize('variant', ['default', 'no_control', 'no_graph'])
+@pytest.mark.parametrize('ticks,rtol,atol', [([0., 0.3, 0.6, 0.9, 1.0], 1e-3, 1e-5), (list(np.linspace(0., 5., 80)), 1e-2, 1e-3)])
+def test_tape_equals_the_per_operation_path_on_the_reference_size(dev, variant, ticks, rtol, atol):
+    """400 nodes x 20 hidden (heat_dynamics.py:33): narrow-panel kernels, ATen-order error norms, up to 7 ticks per dense pass"""
+    from ndcn_amd import CsrOperator
+    from ndcn_amd.neural_dynamics import ODEFunc
+    d = load_golden('fixed_rk4_equal')
+    x0 = torch.from_numpy(np.asarray(d['x0'], dtype=np.float32))
+    w = torch.randn(len(ticks), *x0.shape, generator=torch.Generator().manual_seed(3))
+
+    def make():
+        f = ODEFunc(20, CsrOperator.from_arrays(d['indptr'], d['indices'], d['data'], d['shape'], dev), no_control=variant == 'no_control',
+                    no_graph=variant == 'no_graph').to(dev)
+        f.load_state_dict({'wt.weight': torch.from_numpy(np.asarray(d['W'], dtype=np.float32)),
+                           'wt.bias': torch.from_numpy(np.asarray(d['b'], dtype=np.float32))})
+        return f
+
+    ya, la, ga = _solve(dev, True, make, x0, ticks, rtol, atol, w)
+    yb, lb, gb = _solve(dev, False, make, x0, ticks, rtol, atol, w)
+    assert la == lb and torch.equal(ya, yb)
+    assert len(ga) == len(gb)
+    for a, b in zip(ga, gb):
+        assert rel(a, b) < 2e-4, rel(a, b)
+
+
+@pytest.mark.parametrize('side,no_control', [(12, False), (36, False), (36, True)])
+def test_tape_equals_the_per_operation_path_at_the_fused_width(dev, side, no_control):
+    """H = 256: the fused MFMA launches with the stage algebra in their epilogues; side 36 (331 776 elements) is past the ATen-order
+    range, so the error record rides in the seventh evaluation (both paths)."""
+    from ndcn_amd import graphs
+    from ndcn_amd.neural_dynamics import ODEFunc
+    H = 256
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    ticks = [0., 0.4, 0.9, 1.5]
+    x0 = torch.rand(side * side, H, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(4, side * side, H, generator=torch.Generator().manual_seed(1))
+
+    def make():
+        torch.manual_seed(0)
+        return ODEFunc(H, graphs.to_device(op, dev), no_control=no_control).to(dev)
+
+    ya, la, ga = _solve(dev, True, make, x0, ticks, 1e-3, 1e-4, w)
+    yb, lb, gb = _solve(dev, False, make, x0, ticks, 1e-3, 1e-4, w)
+    assert la == lb and torch.equal(ya, yb)
+    assert len([r for r in la if r[0] != 'nfe']) >= 3
+    for a, b in zip(ga, gb):
+        assert rel(a, b) < 2e-4, rel(a, b)
+
+
+def test_tape_with_rejected_attempts_and_a_power_law_graph(dev):
+    """rejected attempts (their stage gradients flow through the ratio only), a hub-heavy operator, and the reference's error texts"""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    n, H = 1500, 32
+    op = graphs.normalized_laplacian(graphs.barabasi_albert(n, 4, seed=1))
+    ticks = [0., 0.01, 0.02, 0.9, 1.0, 2.5]
+    x0 = 25.0 * torch.rand(n, H, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(len(ticks), n, H, generator=torch.Generator().manual_seed(1))
+
+    def make():
+        torch.manual_seed(0)
+        return ODEFunc(H, graphs.to_device(op, dev)).to(dev)
+
+    ya, la, ga = _solve(dev, True, make, x0, ticks, 1e-5, 1e-7, w)
+    yb, lb, gb = _solve(dev, False, make, x0, ticks, 1e-5, 1e-7, w)
+    assert la == lb and torch.equal(ya, yb)
+    assert any(r[2] == 0.0 for r in la if r[0] != 'nfe')
+    for a, b in zip(ga, gb):
+        # (the gradient through a controller that rejects steps is ill-conditioned: test_gpu_autograd's carry-form test has the figures)
+        assert rel(a, b) < 5e-2, rel(a, b)
+    f = make()
+    with pytest.raises(AssertionError, match='max_num_steps exceeded'):
+        ode.odeint(f, x0.to(dev).requires_grad_(True), torch.tensor(ticks).to(dev), rtol=1e-5, atol=1e-7, method='dopri5',
+                   options={'max_num_steps': 2})
