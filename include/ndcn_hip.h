@@ -640,7 +640,9 @@ NDCN_API int ndcn_debug_last_rhs_path(void);
  * records every attempted step; ndcn_tape_backward_f32 turns g_out (n_t panels: the gradient of the trajectory) into the gradients
  * of y0, W and b - the panel operations' VJP kernels of this header plus the adjoint of the step-size controller's scalar chain
  * (dt, t0 / t1, the initial step and the interpolation abscissa carry gradient in the reference: csrc/tape.hip).  Once per tape.
- * opts: {first_step given (0 / 1), safety, ifactor, dfactor, max_num_steps}.  At: the transposed operator (unused with NDCN_F_NO_GRAPH).
+ * opts: {first_step given (0 / 1), safety, ifactor, dfactor, max_num_steps, keep S (0 / 1: evaluations that can - ndcn_rhs_adj_supported -
+ * also store S = A u on the tape, one panel more per evaluation, instead of one SpMM per evaluation in the reverse pass)}.
+ * At: the transposed operator (unused with NDCN_F_NO_GRAPH).
  * alloc: device memory for the tape (12 panels per attempted step; ~24 more during the reverse pass), owned by the caller and kept
  * until ndcn_tape_destroy.  y0, W, b and the operators must stay valid and unchanged until then.
  * Errors as the solver's: NDCN_EMAXSTEPS, NDCN_EUNDERFLOW, NDCN_ENONFINITE; the tape handle is set on every path - destroy it.     */

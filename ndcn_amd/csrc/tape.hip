@@ -41,6 +41,7 @@ struct Attempt {
     const float *y0 = nullptr;
     const float *k[7] = {};
     const float *u[8] = {};            // u[2..6]: stage inputs, u[7] = y1
+    const float *S[8] = {};            // S[e] = A u[e] where the evaluation's launch wrote it on the side (keep_s), else null
     std::vector<int> dense;            // indices into ndcn_tape::groups, in forward order
 };
 
@@ -79,6 +80,8 @@ struct ndcn_tape {
     double rtol = 0, atol = 0, safety = 0, ifactor = 0, dfactor = 0;
     int64_t max_steps = 0;
     bool first_given = false;
+    bool keep_s = false;               // opts[5]: evaluations on the lattice-plan kernel also store S = A u (ndcn_rhs_rk_adj_f32's s_out): one panel
+                                       // more per evaluation on the tape instead of one SpMM per evaluation in the reverse pass
     ndcn_alloc_fn alloc = nullptr;
     void *alloc_ctx = nullptr;
     // arena
@@ -220,9 +223,10 @@ int terms(float dts, const double *beta, int n, const float *const *kall, const 
 
 int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, double &bad_out) {
     int rc;
-    float *u[8] = {}, *k[7] = {};
+    float *u[8] = {}, *k[7] = {}, *S[8] = {};
     for (int e = 2; e <= 7; ++e)
         if ((rc = panel(t, &u[e]))) return rc;
+    const bool both = !(t->flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
     for (int j = 1; j < 7; ++j)
         if ((rc = panel(t, &k[j]))) return rc;
     const float *kall[7] = {a.k[0], k[1], k[2], k[3], k[4], k[5], k[6]};
@@ -245,8 +249,13 @@ int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, d
         }
         cp[mp] = dts * (float)kBeta[i + 1][i + 1];
         t->nfe++;
+        RkOpt opt = {};
+        if (t->keep_s && both && rhs_adj_supported(&t->A, t->H, fl, NDCN_RK_COMBINE, mp)) {
+            if ((rc = panel(t, &S[i + 2]))) return rc;
+            opt.s_out = S[i + 2];
+        }
         rc = rhs_rk_f32(&t->A, u[i + 2], nullptr, t->A.n_cols, t->W, t->b, k[i + 1], t->work, t->H, fl | (t->packed ? NDCN_F_PACKED : 0u),
-                        NDCN_RK_COMBINE, a.y0, kp, cp, mp, u[i + 3], 0.f, 0.f, nullptr, nullptr, st, nullptr);
+                        NDCN_RK_COMBINE, a.y0, kp, cp, mp, u[i + 3], 0.f, 0.f, nullptr, nullptr, st, opt.s_out ? &opt : nullptr);
         if (rc) return rc;
     }
     a.fused_err = t->n > aten_order_max_elems();
@@ -261,8 +270,14 @@ int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, d
         }
         cp[mp] = dts * (float)kCErr[6];
         t->nfe++;
+        RkOpt opt = {};
+        if (t->keep_s && both && rhs_adj_supported(&t->A, t->H, fl, NDCN_RK_ERROR, mp)) {
+            if ((rc = panel(t, &S[7]))) return rc;
+            opt.s_out = S[7];
+        }
         rc = rhs_rk_f32(&t->A, u[7], nullptr, t->A.n_cols, t->W, t->b, k[6], t->work, t->H, fl | (t->packed ? NDCN_F_PACKED : 0u),
-                        NDCN_RK_ERROR, a.y0, kp, cp, mp, nullptr, (float)t->rtol, (float)t->atol, t->d_red, t->d_ws2, st, nullptr);
+                        NDCN_RK_ERROR, a.y0, kp, cp, mp, nullptr, (float)t->rtol, (float)t->atol, t->d_red, t->d_ws2, st,
+                        opt.s_out ? &opt : nullptr);
         if (rc) return rc;
     } else {
         rc = rhs_plain(t, u[7], k[6], st);
@@ -275,7 +290,7 @@ int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, d
     if (rc) return rc;
     a.ratio = (float)(hs->h[0] / (double)t->n);
     bad_out = hs->h[1];
-    for (int e = 2; e <= 7; ++e) a.u[e] = u[e];
+    for (int e = 2; e <= 7; ++e) a.u[e] = u[e], a.S[e] = S[e];
     for (int j = 1; j < 7; ++j) a.k[j] = k[j];
     return NDCN_OK;
 }
@@ -296,7 +311,7 @@ int add_into(float *acc, const float *x, int64_t n, hipStream_t st) {
 }
 
 // (g_X into gx (nullable: not wanted); g_W, g_b accumulated) of K = f(X) for the upstream gradient g: autograd_ops.rhs_vjp
-int rhs_vjp(Bwd &B, const float *X, const float *K, const float *g, float *gx) {
+int rhs_vjp(Bwd &B, const float *X, const float *K, const float *g, float *gx, const float *S_kept = nullptr) {
     ndcn_tape *t = B.t;
     const bool no_graph = t->flags & NDCN_F_NO_GRAPH, no_control = t->flags & NDCN_F_NO_CONTROL;
     const float *mask = (t->flags & NDCN_F_RELU) ? K : nullptr;
@@ -304,7 +319,9 @@ int rhs_vjp(Bwd &B, const float *X, const float *K, const float *g, float *gx) {
     const float *gS = nullptr;
     if (!no_control) {
         const float *S = X;
-        if (!no_graph) {
+        if (!no_graph && S_kept) {
+            S = S_kept;
+        } else if (!no_graph) {
             rc = spmm_f32(&t->A, X, nullptr, t->A.n_cols, B.tmpS, t->H, 1.f, 0, B.st);
             if (rc) return rc;
             S = B.tmpS;
@@ -409,6 +426,7 @@ int ndcn_tape_dopri5_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, 
     t->ifactor = opts[2];
     t->dfactor = opts[3];
     t->max_steps = (int64_t)opts[4];
+    t->keep_s = opts[5] != 0.0;
     t->alloc = alloc;
     t->alloc_ctx = alloc_ctx;
     t->panel_bytes = (size_t)t->n * sizeof(float) + 16;
@@ -658,7 +676,7 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
         {
             const float *g7 = cur_gk[6];
             if (g7) {
-                rc = rhs_vjp(B, a.u[7], a.k[6], g7, GU[7]);
+                rc = rhs_vjp(B, a.u[7], a.k[6], g7, GU[7], a.S[7]);
                 if (rc) return rc;
                 if (cur_gy1) {
                     if ((rc = add_into(GU[7], cur_gy1, n, st))) return rc;     // gx + what y1 received (a + b in float32: order-free)
@@ -696,7 +714,7 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
                 break;
             }
             if (tot) {
-                rc = rhs_vjp(B, a.u[e], a.k[e - 1], tot, GU[e]);
+                rc = rhs_vjp(B, a.u[e], a.k[e - 1], tot, GU[e], a.S[e]);
                 if (rc) return rc;
                 gu[e] = GU[e];
             }

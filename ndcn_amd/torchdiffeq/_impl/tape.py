@@ -67,7 +67,7 @@ class _TapeDopri5(torch.autograd.Function):
         out = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float32, device=y0c.device)
         tape = Tape(y0c.device)
         tk = (ctypes.c_double * n_t)(*ticks)
-        op_arr = (ctypes.c_double * 5)(*opts)
+        op_arr = (ctypes.c_double * 6)(*opts)
         view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0c.shape[0]))
         view_t = csr_t.view_ref() if csr_t is not None else None
         with torch.cuda.device(y0c.device):
@@ -147,5 +147,8 @@ def solve(odefunc, y0, t, rtol, atol, options, step_log):
     if not odefunc.no_control:
         W, b = odefunc.wt.weight, odefunc.wt.bias
     ticks = [float(v) for v in t.detach().to('cpu', torch.float64)]
-    opts = (0.0 if opt['first_step'] is None else 1.0, opt['safety'], opt['ifactor'], opt['dfactor'], float(min(opt['max_num_steps'], 2 ** 53)))
+    from .autograd_path import _keep_s_enabled
+    keep_s = (not odefunc.no_graph) and (not odefunc.no_control) and odefunc.hidden_size == 256 and _keep_s_enabled(y0)
+    opts = (0.0 if opt['first_step'] is None else 1.0, opt['safety'], opt['ifactor'], opt['dfactor'], float(min(opt['max_num_steps'], 2 ** 53)),
+            1.0 if keep_s else 0.0)
     return _TapeDopri5.apply(y0, W, b, (csr, csr_t, flags, odefunc.hidden_size), ticks, rt, at, opts, step_log)

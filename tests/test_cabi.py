@@ -93,3 +93,13 @@ print('ok')
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+def test_documented_bindings_state_the_current_abi_version():
+    """the stub a reference maintainer would copy (examples/ndcn_hip_binding.py) asserts the ABI version:
+    it must be the library's"""
+    from ndcn_amd import _lib
+    for rel in ('examples/ndcn_hip_binding.py', 'INTEGRATION.md'):
+        text = open(os.path.join(ROOT, rel)).read()
+        found = re.findall(r'ndcn_abi_version\(\) == (\d+)', text)
+        assert found and all(int(v) == _lib.ABI_VERSION for v in found), (rel, found, _lib.ABI_VERSION)
