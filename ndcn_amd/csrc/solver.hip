@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "dopri5_tableau.h"
+#include "hostrec.h"
 #include "kernels.h"
 
 using namespace ndcn;
@@ -37,6 +38,7 @@ struct ndcn_solver {
     void *d_ws = nullptr;
     void *d_ws2 = nullptr;         // fused2 error partials
     double *h_red = nullptr;       // pinned host mirror
+    bool poll = false;             // d_red IS the device alias of h_red: the kernels store the record into host memory, the host polls (hostrec.h)
     hipEvent_t ev = nullptr;
     // scalar state
     bool begun = false;
@@ -183,16 +185,27 @@ int fetch_record(ndcn_solver *s, hipStream_t st, double &sum, double &bad) {
         int rc = comm_allreduce_sum_f64(s->shard.comm, s->d_red, 2, st);
         if (rc) return rc;
     }
-    NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    NDCN_HIP(hipEventRecord(s->ev, st));
-    NDCN_HIP(hipEventSynchronize(s->ev));
+    if (s->poll) {
+        int rc = rec_wait(s->h_red, 2, st);
+        if (rc) return rc;
+    } else {
+        NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        NDCN_HIP(hipEventRecord(s->ev, st));
+        NDCN_HIP(hipEventSynchronize(s->ev));
+    }
     sum = s->h_red[0];
     bad = s->h_red[1];
     return NDCN_OK;
 }
 
+// before the launches whose last kernel writes an n-double record (polling mode: the sentinel the host waits on)
+inline void arm(ndcn_solver *s, int n = 2) {
+    if (s->poll) rec_arm(s->h_red, n);
+}
+
 int rms_scaled(ndcn_solver *s, const float *a, const float *b, const float *y, float rtol, float atol, hipStream_t st,
                float &rms, double &bad) {
+    arm(s);
     int rc = scaled_sumsq_f32(a, b, y, rtol, atol, s->n_elem, s->d_red, s->d_ws, st);
     if (rc) return rc;
     double sum;
@@ -214,15 +227,20 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     if (fuse_on && (s->sharded || s->n_elem > aten_order_max_elems())) {
         // d0 = || y0 / scale || and d1 = || f0 / scale || in one pass over {y0, f0}, one read-back (large panels: the
         // double-precision sums of scaled_sumsq_f32; small ones keep ATen's float32 order, section 2)
+        arm(s, 4);
         rc = scaled_sumsq_pair_f32(s->k[0], s->ycur, rtol, atol, s->n_elem, s->d_red, s->d_ws, s->d_ws2, st);
         if (rc) return rc;
         if (s->sharded) {
             rc = comm_allreduce_sum_f64(s->shard.comm, s->d_red, 4, st);
             if (rc) return rc;
         }
-        NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-        NDCN_HIP(hipEventRecord(s->ev, st));
-        NDCN_HIP(hipEventSynchronize(s->ev));
+        if (s->poll) {
+            if ((rc = rec_wait(s->h_red, 4, st))) return rc;
+        } else {
+            NDCN_HIP(hipMemcpyAsync(s->h_red, s->d_red, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+            NDCN_HIP(hipEventRecord(s->ev, st));
+            NDCN_HIP(hipEventSynchronize(s->ev));
+        }
         bad0 = s->h_red[1];
         d0 = (float)sqrt(s->h_red[0]) / (float)sqrt(s->n_mean);
         d1 = (float)sqrt(s->h_red[2]) / (float)sqrt(s->n_mean);
@@ -256,6 +274,7 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
         const float *kq[1] = {s->k[0]};
         const float cq[2] = {-1.f, 1.f};
         const RkOpt opt = {s->ycur, 0, nullptr, nullptr, xadd ? s->k[0] : nullptr, xadd ? h0 : 0.f};
+        arm(s);
         rc = rhs_epi(s, xadd ? s->ycur : s->ytmp, s->k[1], 2, s->ycur, kq, cq, 1, nullptr, rtol, atol, s->d_red, s->d_ws2, st, nullptr,
                      &opt);
         if (rc) return rc;
@@ -520,6 +539,7 @@ int dopri5_step(ndcn_solver *s, hipStream_t st) {
     }
     const float dt32 = (float)dt;
     int rc;
+    arm(s);
     if (s->graph_on) {
         // one captured graph per attempt, the step size handed over through device memory
         if (!s->gexec && (rc = graph_setup_dopri5(s))) return rc;
@@ -776,9 +796,16 @@ int solver_create(const ndcn_solver_desc *desc, void *workspace, int64_t ws_byte
     s->d_ws = q;
     if ((rc = carve(s, (size_t)reduce_ws_bytes(), &q))) return fail(rc);      // partials of any RHS epilogue
     s->d_ws2 = q;
-    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 4 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_red), 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         return fail(NDCN_EHIP);
+    }
+    if (!s->sharded && poll_records_enabled()) {      // (a shard's record passes through an all-reduce on the device first)
+        void *alias = nullptr;
+        if (hipHostGetDevicePointer(&alias, s->h_red, 0) == hipSuccess && alias) {
+            s->d_red = static_cast<double *>(alias);
+            s->poll = true;
+        }
     }
     if (hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(NDCN_EHIP); }
     if ((rc = carve(s, 256 + 2 * kCoefCap * sizeof(float), &q))) return fail(rc);

@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "dopri5_tableau.h"
+#include "hostrec.h"
 #include "kernels.h"
 
 using namespace ndcn;
@@ -53,7 +54,9 @@ struct DenseGroup {
 };
 
 struct HostScratch {                   // per host thread: pinned mirror of the device records + an event
-    double *h = nullptr;
+    double *h = nullptr;               // kDotSlots x 8 doubles (inner products) ...
+    double *rec = nullptr;             // ... + 8 (a reduction record), same allocation
+    double *h_dev = nullptr, *rec_dev = nullptr;      // their device aliases (polling mode: hostrec.h), else null
     hipEvent_t ev = nullptr;
 };
 
@@ -62,8 +65,14 @@ constexpr int kDotSlots = 40;          // 8 doubles each
 int host_scratch(HostScratch **out) {
     static thread_local HostScratch hs;
     if (!hs.h) {
-        NDCN_HIP(hipHostMalloc(reinterpret_cast<void **>(&hs.h), (size_t)kDotSlots * 8 * sizeof(double), hipHostMallocDefault));
+        NDCN_HIP(hipHostMalloc(reinterpret_cast<void **>(&hs.h), (size_t)(kDotSlots + 1) * 8 * sizeof(double), hipHostMallocDefault));
+        hs.rec = hs.h + (size_t)kDotSlots * 8;
         NDCN_HIP(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+        void *alias = nullptr;
+        if (poll_records_enabled() && hipHostGetDevicePointer(&alias, hs.h, 0) == hipSuccess && alias) {
+            hs.h_dev = static_cast<double *>(alias);
+            hs.rec_dev = hs.h_dev + (size_t)kDotSlots * 8;
+        }
     }
     *out = &hs;
     return NDCN_OK;
@@ -142,12 +151,28 @@ int rhs_plain(ndcn_tape *t, const float *x, float *out, hipStream_t st) {
     return rc;
 }
 
+// the n doubles the launches enqueued since the matching arm wrote at `d_src` -> hs->h[0..n) (polling mode: d_src IS hs->h's alias)
 int fetch(ndcn_tape *t, const double *d_src, int n_doubles, hipStream_t st, HostScratch *hs) {
     (void)t;
+    if (hs->h_dev && d_src == hs->h_dev) return rec_wait(hs->h, n_doubles, st);
     NDCN_HIP(hipMemcpyAsync(hs->h, d_src, (size_t)n_doubles * sizeof(double), hipMemcpyDeviceToHost, st));
     NDCN_HIP(hipEventRecord(hs->ev, st));
     NDCN_HIP(hipEventSynchronize(hs->ev));
     return NDCN_OK;
+}
+
+// the 2-double reduction record: armed before the launches, then read into hs->h[0..1]
+void arm_record(ndcn_tape *t, HostScratch *hs) {
+    if (hs->rec_dev && t->d_red == hs->rec_dev) rec_arm(hs->rec, 2);
+}
+int fetch_record(ndcn_tape *t, hipStream_t st, HostScratch *hs) {
+    if (hs->rec_dev && t->d_red == hs->rec_dev) {
+        int rc = rec_wait(hs->rec, 2, st);
+        hs->h[0] = hs->rec[0];
+        hs->h[1] = hs->rec[1];
+        return rc;
+    }
+    return fetch(t, t->d_red, 2, st, hs);
 }
 
 // misc.py:71-76: x.norm() / numel ** 0.5 as float32 values (autograd_path._rms_value)
@@ -157,9 +182,10 @@ float rms_value(double s, double numel) {
 }
 
 int rms(ndcn_tape *t, const float *a, const float *b, const float *y, hipStream_t st, HostScratch *hs, double &sum, double &bad) {
+    arm_record(t, hs);
     int rc = scaled_sumsq_f32(a, b, y, (float)t->rtol, (float)t->atol, t->n, t->d_red, t->d_ws, st);
     if (rc) return rc;
-    rc = fetch(t, t->d_red, 2, st, hs);
+    rc = fetch_record(t, st, hs);
     if (rc) return rc;
     sum = hs->h[0];
     bad = hs->h[1];
@@ -223,6 +249,7 @@ int terms(float dts, const double *beta, int n, const float *const *kall, const 
 
 int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, double &bad_out) {
     int rc;
+    arm_record(t, hs);
     float *u[8] = {}, *k[7] = {}, *S[8] = {};
     for (int e = 2; e <= 7; ++e)
         if ((rc = panel(t, &u[e]))) return rc;
@@ -286,7 +313,7 @@ int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, d
         rc = rk_error_f32(a.y0, u[7], kp, cp, m, (float)t->rtol, (float)t->atol, t->n, t->d_red, t->d_ws, st);
         if (rc) return rc;
     }
-    rc = fetch(t, t->d_red, 2, st, hs);
+    rc = fetch_record(t, st, hs);
     if (rc) return rc;
     a.ratio = (float)(hs->h[0] / (double)t->n);
     bad_out = hs->h[1];
@@ -432,8 +459,12 @@ int ndcn_tape_dopri5_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, 
     t->panel_bytes = (size_t)t->n * sizeof(float) + 16;
     t->ticks.assign(ticks, ticks + n_t);
     void *p;
-    if ((rc = arena(t, 2 * sizeof(double) + 256, &p))) return rc;
-    t->d_red = static_cast<double *>(p);
+    if (hs->rec_dev) {
+        t->d_red = hs->rec_dev;                    // the record lands in pinned host memory, the host polls (hostrec.h)
+    } else {
+        if ((rc = arena(t, 2 * sizeof(double) + 256, &p))) return rc;
+        t->d_red = static_cast<double *>(p);
+    }
     if ((rc = arena(t, (size_t)reduce_ws_bytes(), &t->d_ws))) return rc;
     if ((rc = arena(t, (size_t)reduce_ws_bytes(), &t->d_ws2))) return rc;
     const int64_t wb = rhs_work_bytes(t->n_rows, H, flags);
@@ -577,8 +608,12 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
     B.st = st;
     void *p;
     // ---- scratch
-    if ((rc = arena(t, (size_t)kDotSlots * 8 * sizeof(double), &p))) return rc;
-    t->d_dots = static_cast<double *>(p);
+    if (hs->h_dev) {
+        t->d_dots = hs->h_dev;
+    } else {
+        if ((rc = arena(t, (size_t)kDotSlots * 8 * sizeof(double), &p))) return rc;
+        t->d_dots = static_cast<double *>(p);
+    }
     if ((rc = arena(t, (size_t)rk_bwd_ws_bytes(), &t->d_bws))) return rc;
     if (!no_control) {
         if ((rc = arena(t, (size_t)linear_bwd_work_bytes(t->n_rows, H, H), &t->bwork))) return rc;
@@ -607,6 +642,7 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
     for (int s = (int)t->attempts.size() - 1; s >= 0; --s) {
         const Attempt &a = t->attempts[(size_t)s];
         int slot = 0;
+        if (hs->h_dev) rec_arm(hs->h, kDotSlots * 8);
         auto dots_at = [&](int sl) { return t->d_dots + 8 * sl; };
         // ---- scalar chain, part 1: the error ratio's gradient comes from the NEXT step size (misc.py:160-170)
         double g_dt = 0.0;                         // adjoint of this attempt's dt (float64)
@@ -827,6 +863,7 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
             have_yh = true;
         }
         if (have_yh) {
+            if (hs->h_dev) rec_arm(hs->h, 8);
             rc = rk_dot_diff_f32(gyh, t->f0, nullptr, t->d_dots, t->d_bws, n, st);
             if (rc) return rc;
             rc = fetch(t, t->d_dots, 8, st, hs);
