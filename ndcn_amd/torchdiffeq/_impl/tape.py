@@ -96,6 +96,9 @@ class _TapeDopri5(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g):
         tape = ctx.tape
+        if tape is None or not tape.handle:
+            raise RuntimeError('Trying to backward through the dopri5 tape a second time: its panels are freed by the first reverse pass '
+                               '(solve again; the per-operation graph, NDCN_GRAD_TAPE=0, honours retain_graph)')
         y0c, Wc, bc, csr, csr_t = ctx.keep
         g = g.contiguous()
         gy = torch.empty_like(y0c)

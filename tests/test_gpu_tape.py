@@ -114,3 +114,28 @@ def test_tape_with_rejected_attempts_and_a_power_law_graph(dev):
     with pytest.raises(AssertionError, match='max_num_steps exceeded'):
         ode.odeint(f, x0.to(dev).requires_grad_(True), torch.tensor(ticks).to(dev), rtol=1e-5, atol=1e-7, method='dopri5',
                    options={'max_num_steps': 2})
+
+
+def test_tape_without_polled_records(dev):
+    """NDCN_POLL_RECORD=0: the reduction records come back by copy + event instead of through pinned host memory (csrc/hostrec.h);
+    the switch is read once per process, so the case runs in a process of its own."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NDCN_POLL_RECORD='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.abspath(__file__), '-k',
+                        'reference_size and default and ticks0 or fused_width and 36-False'], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
+def test_second_backward_through_the_tape_is_refused(dev):
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(10))
+    f = ODEFunc(16, graphs.to_device(op, dev)).to(dev)
+    x0 = torch.rand(100, 16, device=dev, requires_grad=True)
+    y = ode.odeint(f, x0, torch.tensor([0., 0.5, 1.0], device=dev), rtol=1e-3, atol=1e-4, method='dopri5')
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='second time'):
+        y.sum().backward()
