@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 15
+#define NDCN_ABI_VERSION 16
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -655,6 +655,17 @@ NDCN_API int ndcn_tape_backward_f32(ndcn_tape *tape, const float *g_out, float *
 NDCN_API int64_t ndcn_tape_steplog(const ndcn_tape *tape, double *rows, int64_t cap);   /* 5 doubles per attempt, as ndcn_solver_steplog */
 NDCN_API int64_t ndcn_tape_nfe(const ndcn_tape *tape);
 NDCN_API void ndcn_tape_destroy(ndcn_tape *tape);
+/* The fixed-grid methods (solvers.py:79-99 with fixed_grid.py:7-29, rk_common.py:72-78; method: NDCN_M_EULER / _MIDPOINT / _RK4) the same
+ * way, without a tape object - the reverse pass re-forms the stages of a step from the stored trajectory:
+ * ndcn_fixed_grid_train_f32 writes the n_ticks + 1 states (out[0] = y0) for the step sizes h_dt (the grid's differences in the state
+ * dtype, solvers.py:81), ndcn_fixed_grid_backward_f32 maps g_out (n_ticks + 1 panels) to the gradients of y0, W and b.  Any size; the
+ * launches of _impl/odeint.py::_FixedGridSolve.  alloc: scratch (<= 22 panels), may be released when the call returns (stream-ordered). */
+NDCN_API int ndcn_fixed_grid_train_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method,
+                                       const float *y0, const float *h_dt, int64_t n_ticks, float *out, ndcn_alloc_fn alloc,
+                                       void *alloc_ctx, void *stream);
+NDCN_API int ndcn_fixed_grid_backward_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags,
+                                          int method, const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks,
+                                          float *g_y0, float *g_W, float *g_b, ndcn_alloc_fn alloc, void *alloc_ctx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO, PATH_SWEEP, PATH_REC, PATH_WIDE, PATH_SMALL = 1, 2, 4, 8, 16, 32, 64, 128
 
 OK = 0
@@ -126,6 +126,8 @@ SIGNATURES = {
     'ndcn_tape_steplog': (_L, [_P, ctypes.POINTER(_D), _L]),
     'ndcn_tape_nfe': (_L, [_P]),
     'ndcn_tape_destroy': (None, [_P]),
+    'ndcn_fixed_grid_train_f32': (_I, [_P, _P, _P, _I, ctypes.c_uint32, _I, _P, ctypes.POINTER(_F), _L, _P, _P, _P, _P]),
+    'ndcn_fixed_grid_backward_f32': (_I, [_P, _P, _P, _P, _I, ctypes.c_uint32, _I, _P, _P, ctypes.POINTER(_F), _L, _P, _P, _P, _P, _P, _P]),
     'ndcn_rk_dot_diff_f32': (_I, [_P, _P, _P, _P, _P, _L, _P]),
     'ndcn_rk_error_bwd_f32': (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _F, _D, _P, _P,
                               ctypes.POINTER(_P), _P, _P, ctypes.POINTER(_P), _P, _P, _L, _P]),

@@ -31,7 +31,7 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
             float *work, int H, uint32_t flags, hipStream_t st);
 int64_t rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb, void *work,
-                   int64_t n, int Hi, int Ho, hipStream_t st, uint32_t flags = 0);
+                   int64_t n, int Hi, int Ho, hipStream_t st, uint32_t flags = 0, float acc_scale = 1.f, bool accumulate = false);
 int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho);
 int scale_f32(float *out, const float *x, float w, int64_t n, hipStream_t st);
 int relu_bwd_f32(float *out, const float *g, const float *y, int64_t n, hipStream_t st);

@@ -278,8 +278,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_small_kernel(const float *__
 }
 
 // out[e] = sum over chunks, ascending (fixed order)
+// (acc != 0: out[e] = out[e] + scale * sum, product and sum rounded separately - the caller's running total of a reverse pass)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float *__restrict__ part, float *__restrict__ out, int n_elem,
-                                                        int n_chunks) {
+                                                        int n_chunks, float scale = 1.f, int acc = 0) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n_elem) return;
     float s = 0.f;
@@ -292,13 +293,13 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float *__restrict_
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; c < n_chunks; ++c) s += part[(size_t)c * n_elem + e];
-    out[e] = s;
+    out[e] = acc ? __fadd_rn(out[e], __fmul_rn(scale, s)) : s;
 }
 
 // g_W and g_b in ONE launch (a training step makes ~30 Linear backwards: one small launch less each)
 __global__ __launch_bounds__(256) void chunk_sum2_kernel(const float *__restrict__ part_w, float *__restrict__ out_w, int n_w,
                                                          const float *__restrict__ part_b, float *__restrict__ out_b, int n_b,
-                                                         int n_chunks) {
+                                                         int n_chunks, float scale = 1.f, int acc = 0) {
     int e = blockIdx.x * 256 + threadIdx.x;
     const float *part = part_w;
     float *out = out_w;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void chunk_sum2_kernel(const float *__restrict
         for (int u = 0; u < 8; ++u) s += v[u];
     }
     for (; c < n_chunks; ++c) s += part[(size_t)c * n_elem + e];
-    out[e] = s;
+    out[e] = acc ? __fadd_rn(out[e], __fmul_rn(scale, s)) : s;
 }
 
 // ---------------------------------------------------------------------------------------------------- gS
@@ -609,7 +610,10 @@ int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho) {
 }
 
 int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb, void *work,
-                   int64_t n, int Hi, int Ho, hipStream_t st, uint32_t flags) {
+                   int64_t n, int Hi, int Ho, hipStream_t st, uint32_t flags, float acc_scale, bool accumulate) {
+    // accumulate: gW / gb hold a running total: total + acc_scale * (this call's), each rounded on its own (the native reverse passes
+    // of tape.hip: one small launch per evaluation instead of three)
+    if (n == 0 && accumulate) return NDCN_OK;
     if (n == 0) {
         if (gW) NDCN_HIP(hipMemsetAsync(gW, 0, (size_t)Ho * Hi * sizeof(float), st));
         if (gb) NDCN_HIP(hipMemsetAsync(gb, 0, (size_t)Ho * sizeof(float), st));
@@ -677,9 +681,11 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
         NDCN_LAUNCH_CHECK();
         if (gW && gb)
             hipLaunchKernelGGL(chunk_sum2_kernel, dim3((unsigned)((Ho * Hi + Ho + 255) / 256)), dim3(256), 0, st, part_w, gW, Ho * Hi, part_b, gb,
-                               Ho, (int)used);
-        else if (gW) hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho * Hi + 255) / 256)), dim3(256), 0, st, part_w, gW, Ho * Hi, (int)used);
-        else hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho + 255) / 256)), dim3(256), 0, st, part_b, gb, Ho, (int)used);
+                               Ho, (int)used, acc_scale, accumulate ? 1 : 0);
+        else if (gW) hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho * Hi + 255) / 256)), dim3(256), 0, st, part_w, gW, Ho * Hi, (int)used,
+                                        acc_scale, accumulate ? 1 : 0);
+        else hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((Ho + 255) / 256)), dim3(256), 0, st, part_b, gb, Ho, (int)used, acc_scale,
+                                accumulate ? 1 : 0);
         NDCN_LAUNCH_CHECK();
     }
     return NDCN_OK;

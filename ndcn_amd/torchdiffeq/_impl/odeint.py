@@ -301,6 +301,10 @@ def _fixed_grid_with_grad(odefunc, y0, t, method):
     core.assert_increasing(t)
     tt = t.detach().to('cpu').to(y0.dtype)
     dts = (tt[1:] - tt[:-1]).tolist()
+    from . import tape
+    sol = tape.fixed_grid(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags, method, dts)
+    if sol is not None:
+        return sol
     return _FixedGridSolve.apply(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags,
                                  method, dts)
 

@@ -155,3 +155,70 @@ def solve(odefunc, y0, t, rtol, atol, options, step_log):
     opts = (0.0 if opt['first_step'] is None else 1.0, opt['safety'], opt['ifactor'], opt['dfactor'], float(min(opt['max_num_steps'], 2 ** 53)),
             1.0 if keep_s else 0.0)
     return _TapeDopri5.apply(y0, W, b, (csr, csr_t, flags, odefunc.hidden_size), ticks, rt, at, opts, step_log)
+
+
+# ---- fixed grids ---------------------------------------------------------------------------------------------------------------
+
+class _NativeFixedGrid(torch.autograd.Function):
+    """Euler / midpoint / RK4 over ODEFunc with the loops of `_impl/odeint.py::_FixedGridSolve` inside the library
+    (ndcn_fixed_grid_train_f32 / ndcn_fixed_grid_backward_f32): the same launches, two calls instead of ~10 per step."""
+
+    @staticmethod
+    def forward(ctx, y0, W, b, csr, flags, method, dts):
+        lib = _lib.load()
+        y0c = y0.detach().contiguous()
+        Wc = W.detach().contiguous() if W is not None else None
+        bc = b.detach().contiguous() if b is not None else None
+        n_ticks = len(dts)
+        out = torch.empty((n_ticks + 1,) + tuple(y0c.shape), dtype=torch.float32, device=y0c.device)
+        scratch = Tape(y0c.device)
+        arr = (ctypes.c_float * n_ticks)(*dts)
+        view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0c.shape[0]))
+        H = y0c.shape[1]
+        with torch.cuda.device(y0c.device):
+            rc = lib.ndcn_fixed_grid_train_f32(view, ptr(Wc), ptr(bc), H, flags, _lib.METHODS[method], ptr(y0c), arr, n_ticks, ptr(out),
+                                               ctypes.cast(scratch.cb, ctypes.c_void_p), None, stream_ptr())
+        err = scratch.error
+        scratch.close()
+        if rc < 0:
+            if err is not None:
+                raise err
+            check(rc)
+        ctx.keep = (out, Wc, bc, csr, flags, method, arr, n_ticks)
+        ctx.has = (W is not None, b is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        out, Wc, bc, csr, flags, method, arr, n_ticks = ctx.keep
+        lib = _lib.load()
+        g = g.contiguous()
+        no_control = bool(flags & _lib.F_NO_CONTROL)
+        gy = torch.empty_like(out[0])
+        gW = torch.empty_like(Wc) if (Wc is not None and not no_control) else None
+        gb = torch.empty_like(bc) if (bc is not None and not no_control) else None
+        scratch = Tape(g.device)
+        view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(out.shape[1]))
+        view_t = csr.transpose().view_ref() if csr is not None else None
+        with torch.cuda.device(g.device):
+            rc = lib.ndcn_fixed_grid_backward_f32(view, view_t, ptr(Wc), ptr(bc), out.shape[2], flags, _lib.METHODS[method], ptr(out), ptr(g), arr,
+                                                  n_ticks, ptr(gy), ptr(gW), ptr(gb), ctypes.cast(scratch.cb, ctypes.c_void_p), None, stream_ptr())
+        err = scratch.error
+        scratch.close()
+        if rc < 0:
+            if err is not None:
+                raise err
+            check(rc)
+        needs = ctx.needs_input_grad
+        return (gy if needs[0] else None, gW if needs[1] else None, gb if needs[2] else None, None, None, None, None)
+
+
+def fixed_grid(y0, W, b, csr, flags, method, dts):
+    """-> trajectory (T, N, H), or None when the native loops are switched off (NDCN_FIXED_GRID_NATIVE=0)"""
+    if os.environ.get('NDCN_FIXED_GRID_NATIVE', '1') == '0' or os.environ.get('NDCN_VJP', 'hip') == 'torch':
+        return None
+    if csr is not None:
+        csr.ensure_plans(y0.shape[1])
+        csr.transpose().ensure_plans(y0.shape[1])
+    return _NativeFixedGrid.apply(y0, W, b, csr, flags, method, dts)

@@ -139,3 +139,38 @@ def test_second_backward_through_the_tape_is_refused(dev):
     y.sum().backward(retain_graph=True)
     with pytest.raises(RuntimeError, match='second time'):
         y.sum().backward()
+
+
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('shape', ['reference_size', 'no_control', 'no_graph', 'fused_width'])
+def test_native_fixed_grid_training_equals_the_python_loops(dev, method, shape):
+    """ndcn_fixed_grid_train_f32 / _backward_f32 issue the launches of `_FixedGridSolve` (whose gradients test_gpu_autograd.py pins to
+    the reference's): trajectory and the state's gradient bit for bit, the parameter gradients up to the rounding of their
+    accumulation (torch's `add_(alpha=)` contracts to an fma, the library's combine rounds product and sum separately)."""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    side, H = (20, 20) if shape != 'fused_width' else (24, 256)
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    n = side * side
+    ticks = torch.linspace(0., 1.5, 9)
+    x0h = torch.rand(n, H, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(9, n, H, generator=torch.Generator().manual_seed(1))
+    res = {}
+    for native in ('1', '0'):
+        os.environ['NDCN_FIXED_GRID_NATIVE'] = native
+        os.environ['NDCN_SOLVE_SMALL_GRAD'] = '0'                      # (Euler at this size would take the one-launch kernel)
+        try:
+            torch.manual_seed(0)
+            f = ODEFunc(H, graphs.to_device(op, dev), no_control=shape == 'no_control', no_graph=shape == 'no_graph').to(dev)
+            x0 = x0h.clone().to(dev).requires_grad_(True)
+            y = ode.odeint(f, x0, ticks.to(dev), method=method)
+            (y * w.to(dev)).sum().backward()
+            res[native] = (y.detach().cpu(), x0.grad.cpu(), [p.grad.cpu() for p in f.parameters() if p.grad is not None])
+        finally:
+            del os.environ['NDCN_FIXED_GRID_NATIVE'], os.environ['NDCN_SOLVE_SMALL_GRAD']
+    assert torch.equal(res['1'][0], res['0'][0])
+    assert torch.equal(res['1'][1], res['0'][1])
+    assert len(res['1'][2]) == len(res['0'][2]) == (0 if shape == 'no_control' else 2)
+    for a, b in zip(res['1'][2], res['0'][2]):
+        assert rel(a, b) < 2e-6, rel(a, b)
