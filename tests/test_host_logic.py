@@ -224,3 +224,30 @@ def test_fan_out_adds_gradients_in_a_fixed_order():
     assert torch.equal(x.grad, want)
     y = torch.randn(8)                                               # no gradient required: the tensor itself, n times
     assert all(t is y for t in ap._fan(y, 5))
+
+
+def test_training_tape_scope_and_exact_sqrt(monkeypatch):
+    """When does a dopri5 solve with gradient take the native tape (csrc/tape.hip)?  A plain ODEFunc state with a constant time grid;
+    NDCN_GRAD_TAPE=0 / NDCN_VJP=torch / a time grid with gradient keep the per-operation graph.  And the controller chain's square
+    root is the correctly rounded one (torch.sqrt is one ulp off where PyTorch dispatches AVX-512)."""
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq._impl import tape
+    from ndcn_amd.torchdiffeq._impl.autograd_path import _Sqrt32
+    f = ODEFunc(8, None, no_graph=True)
+    y = torch.zeros(5, 8)
+    t = torch.linspace(0, 1, 3)
+    assert tape.applicable(f, y, t)
+    assert not tape.applicable(f, y, t.clone().requires_grad_(True))
+    assert not tape.applicable(f, y.double(), t)
+    assert not tape.applicable(f, torch.zeros(5, 2, 8), t)
+    monkeypatch.setenv('NDCN_GRAD_TAPE', '0')
+    assert not tape.applicable(f, y, t)
+    monkeypatch.delenv('NDCN_GRAD_TAPE')
+    monkeypatch.setenv('NDCN_VJP', 'torch')
+    assert not tape.applicable(f, y, t)
+    for v in (5.235566646888401e-08, 0.3, 2.0, 1e-30):
+        x = torch.tensor(np.float32(v), requires_grad=True)
+        r = _Sqrt32.apply(x)
+        assert float(r) == float(np.sqrt(np.float32(v)))
+        r.backward()
+        assert abs(float(x.grad) - 0.5 / float(np.sqrt(np.float32(v)))) <= 1e-6 * 0.5 / float(np.sqrt(np.float32(v)))
