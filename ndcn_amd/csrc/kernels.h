@@ -111,6 +111,8 @@ int rk_error_f32(const float *y0, const float *y1, const float *const *h_k, cons
                  float atol, int64_t n, double *d_out, void *d_ws, hipStream_t st, const float *dt_dev = nullptr, int accum = 0);
 // VJPs of the dopri5 panel operations (rk_bwd.hip); d_dots receives 8 doubles, d_ws: rk_bwd_ws_bytes() bytes
 int64_t rk_bwd_ws_bytes();
+int rk_pull_f32(float *out, const float *base, const float *const *h_p, const float *h_c, int n_p, const float *mask, const float *ua,
+                const float *ub, double *d_dots, void *d_ws, int64_t n, hipStream_t st);      // tape.hip's reverse pass (not exported)
 int rk_dot_diff_f32(const float *g, const float *a, const float *b, double *d_dots, void *d_ws, int64_t n, hipStream_t st);
 int rk_combine_bwd_f32(const float *g, const float *const *h_k, const float *h_c, int n_k, float *const *h_gk, const float *const *h_acc,
                        float *gy0, const float *acc_y0, double *d_dots, void *d_ws, int64_t n, hipStream_t st);

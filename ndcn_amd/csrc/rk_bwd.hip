@@ -388,6 +388,86 @@ __global__ __launch_bounds__(256) void dot_diff_kernel(const float *__restrict__
     block_store_dots(d, partial);
 }
 
+// ------------------------------------------------------------------------------------------------ pull (tape.hip)
+// The total gradient of a stage derivative in the reverse pass of an attempted step, as ONE pass:
+//   out = [mask > 0 ?] base + ((c_0 p_0 + c_1 p_1) + ...)        (rk_combine's order and rounding; base nullable; mask nullable: the ReLU
+//                                                                 output of the evaluation this gradient enters - its VJP then reads no mask)
+//   d_dots[0] = <p_0, ua - ub>                                    (ua nullable: no product; the step size's gradient through the stage sum
+//                                                                 whose input's gradient p_0 is: rk_dot_diff_f32's sum)
+// instead of a combine pass, a dot_diff pass and two reads of the mask by the Linear backward's kernels.
+struct PullArgs {
+    const float *base, *mask, *ua, *ub;
+    const float *p[kBwdMaxK];
+    float c[kBwdMaxK];
+    int n;
+    float *out;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void pull_kernel(PullArgs a, int64_t n, double *__restrict__ partial) {
+    double d[kBwdDots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (VEC) {
+            const bw_f4 p0 = ld4(a.p[0], i);
+            bw_f4 s;
+            s.x = __fmul_rn(a.c[0], p0.x); s.y = __fmul_rn(a.c[0], p0.y); s.z = __fmul_rn(a.c[0], p0.z); s.w = __fmul_rn(a.c[0], p0.w);
+#pragma unroll
+            for (int j = 1; j < kBwdMaxK; ++j)
+                if (j < a.n) {
+                    const bw_f4 k = ld4(a.p[j], i);
+                    const float c = a.c[j];
+                    s.x = __fadd_rn(s.x, __fmul_rn(c, k.x)); s.y = __fadd_rn(s.y, __fmul_rn(c, k.y));
+                    s.z = __fadd_rn(s.z, __fmul_rn(c, k.z)); s.w = __fadd_rn(s.w, __fmul_rn(c, k.w));
+                }
+            if (a.base) {
+                const bw_f4 y = ld4(a.base, i);
+                s.x = __fadd_rn(y.x, s.x); s.y = __fadd_rn(y.y, s.y); s.z = __fadd_rn(y.z, s.z); s.w = __fadd_rn(y.w, s.w);
+            }
+            if (a.mask) {
+                const bw_f4 m = ld4(a.mask, i);
+                s.x = m.x > 0.f ? s.x : 0.f; s.y = m.y > 0.f ? s.y : 0.f; s.z = m.z > 0.f ? s.z : 0.f; s.w = m.w > 0.f ? s.w : 0.f;
+            }
+            st4(a.out, i, s);
+            if (a.ua) {
+                bw_f4 e = ld4(a.ua, i);
+                if (a.ub) e = e - ld4(a.ub, i);
+                d[0] += (double)__fmul_rn(p0.x, e.x) + (double)__fmul_rn(p0.y, e.y) + (double)__fmul_rn(p0.z, e.z) + (double)__fmul_rn(p0.w, e.w);
+            }
+        } else {
+            const float p0 = a.p[0][i];
+            float s = __fmul_rn(a.c[0], p0);
+            for (int j = 1; j < a.n; ++j) s = __fadd_rn(s, __fmul_rn(a.c[j], a.p[j][i]));
+            if (a.base) s = __fadd_rn(a.base[i], s);
+            if (a.mask && !(a.mask[i] > 0.f)) s = 0.f;
+            a.out[i] = s;
+            if (a.ua) d[0] += (double)__fmul_rn(p0, a.ub ? a.ua[i] - a.ub[i] : a.ua[i]);
+        }
+    }
+    if (a.ua) block_store_dots(d, partial);
+}
+
+int rk_pull_f32(float *out, const float *base, const float *const *h_p, const float *h_c, int n_p, const float *mask, const float *ua,
+                const float *ub, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
+    if (!out || !h_p || !h_c || n_p < 1 || n_p > kBwdMaxK || n < 0 || (ua && (!d_dots || !d_ws))) { set_error("rk pull: bad argument"); return NDCN_EINVAL; }
+    PullArgs a;
+    a.base = base; a.mask = mask; a.ua = ua; a.ub = ub; a.n = n_p; a.out = out;
+    bool vec = n % 4 == 0 && aligned16(out) && (!base || aligned16(base)) && (!mask || aligned16(mask)) && (!ua || aligned16(ua)) && (!ub || aligned16(ub));
+    for (int j = 0; j < kBwdMaxK; ++j) {
+        a.p[j] = j < n_p ? h_p[j] : h_p[0];
+        a.c[j] = j < n_p ? h_c[j] : 0.f;
+        if (j < n_p && !h_p[j]) { set_error("rk pull: null term"); return NDCN_EINVAL; }
+        if (j < n_p) vec = vec && aligned16(h_p[j]);
+    }
+    if (n == 0) return NDCN_OK;
+    ProfScope prof(PROF_COMBINE_BWD, st, 4.0 * n * (n_p + 1 + (base ? 1 : 0) + (mask ? 1 : 0) + (ua ? (ub ? 2 : 1) : 0)), 2.0 * n * (n_p + 1));
+    const int grid = bwd_grid(vec ? n / 4 : n);
+    if (vec) hipLaunchKernelGGL(pull_kernel<true>, dim3(grid), dim3(256), 0, st, a, n / 4, static_cast<double *>(d_ws));
+    else hipLaunchKernelGGL(pull_kernel<false>, dim3(grid), dim3(256), 0, st, a, n, static_cast<double *>(d_ws));
+    if (ua) hipLaunchKernelGGL(dots_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const double *>(d_ws), grid, d_dots);
+    NDCN_LAUNCH_CHECK();
+    return NDCN_OK;
+}
+
 int rk_dot_diff_f32(const float *g, const float *a, const float *b, double *d_dots, void *d_ws, int64_t n, hipStream_t st) {
     if (!g || !a || !d_dots || !d_ws || n < 0) { set_error("rk dot_diff: null pointer"); return NDCN_EINVAL; }
     const bool vec = n % 4 == 0 && aligned16(g) && aligned16(a) && (!b || aligned16(b));

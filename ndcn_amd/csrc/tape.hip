@@ -338,10 +338,11 @@ int add_into(float *acc, const float *x, int64_t n, hipStream_t st) {
 }
 
 // (g_X into gx (nullable: not wanted); g_W, g_b accumulated) of K = f(X) for the upstream gradient g: autograd_ops.rhs_vjp
-int rhs_vjp(Bwd &B, const float *X, const float *K, const float *g, float *gx, const float *S_kept = nullptr) {
+// premasked: g already IS gZ = g (.) [K > 0] (rk_pull_f32 applied the mask where it formed g)
+int rhs_vjp(Bwd &B, const float *X, const float *K, const float *g, float *gx, const float *S_kept = nullptr, bool premasked = false) {
     ndcn_tape *t = B.t;
     const bool no_graph = t->flags & NDCN_F_NO_GRAPH, no_control = t->flags & NDCN_F_NO_CONTROL;
-    const float *mask = (t->flags & NDCN_F_RELU) ? K : nullptr;
+    const float *mask = ((t->flags & NDCN_F_RELU) && !premasked) ? K : nullptr;
     int rc;
     const float *gS = nullptr;
     if (!no_control) {
@@ -713,15 +714,11 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
         }
         int row_slot[8];
         for (int m = 2; m <= 7; ++m) row_slot[m] = -1;
+        static const bool fused_pull = [] { const char *e = getenv("NDCN_TAPE_PULL_FUSED"); return !(e && e[0] == '0'); }();
         for (int e = 6; e >= 1; --e) {
-            // the step size through stage sum m = e + 1 (all its g_u is known now): <g_u_m, u_m - y0> / dt
+            // total gradient of k_e: received + sum_{m' > e} dt beta[m' - 2][e - 1] g_u_m', and the step size through stage sum
+            // m = e + 1 (all its g_u is known now): <g_u_m, u_m - y0> / dt
             const int m = e + 1;
-            if (gu[m]) {
-                row_slot[m] = slot++;
-                rc = rk_dot_diff_f32(gu[m], a.u[m], a.y0, dots_at(row_slot[m]), t->d_bws, n, st);
-                if (rc) return rc;
-            }
-            // total gradient of k_e: received + sum_{m' > e} dt beta[m' - 2][e - 1] g_u_m'
             const float *pp_[8];
             float cc_[8];
             int np = 0;
@@ -732,14 +729,35 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
             }
             float *dst = (e == 1) ? CF[1 - pp] : T;
             const float *tot;
-            rc = gather_sum(t, dst, cur_gk[e - 1], pp_, cc_, np, st, &tot, e == 1);
-            if (rc) return rc;
+            bool premasked = false;
+            if (fused_pull && gu[m]) {
+                // one pass: the sum, the ReLU mask of evaluation e (none for k_1: that evaluation belongs to the previous attempt), the product
+                const float *kp[8];
+                float cp[8];
+                int mm = 0;
+                for (int q = 0; q < np; ++q)
+                    if (pp_[q] && cc_[q] != 0.f) { kp[mm] = pp_[q]; cp[mm] = cc_[q]; ++mm; }
+                const float *mask = (e > 1 && (t->flags & NDCN_F_RELU)) ? a.k[e - 1] : nullptr;
+                row_slot[m] = slot++;
+                rc = rk_pull_f32(dst, cur_gk[e - 1], kp, cp, mm, mask, a.u[m], a.y0, dots_at(row_slot[m]), t->d_bws, n, st);
+                if (rc) return rc;
+                tot = dst;
+                premasked = mask != nullptr;
+            } else {
+                if (gu[m]) {
+                    row_slot[m] = slot++;
+                    rc = rk_dot_diff_f32(gu[m], a.u[m], a.y0, dots_at(row_slot[m]), t->d_bws, n, st);
+                    if (rc) return rc;
+                }
+                rc = gather_sum(t, dst, cur_gk[e - 1], pp_, cc_, np, st, &tot, e == 1);
+                if (rc) return rc;
+            }
             if (e == 1) {
                 Gf = tot;
                 break;
             }
             if (tot) {
-                rc = rhs_vjp(B, a.u[e], a.k[e - 1], tot, GU[e], a.S[e]);
+                rc = rhs_vjp(B, a.u[e], a.k[e - 1], tot, GU[e], a.S[e], premasked);
                 if (rc) return rc;
                 gu[e] = GU[e];
             }

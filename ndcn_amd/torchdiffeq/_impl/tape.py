@@ -90,6 +90,9 @@ class _TapeDopri5(torch.autograd.Function):
             raise _lib.NdcnHipError(rc, text)
         ctx.tape, ctx.keep = tape, (y0c, Wc, bc, csr, csr_t)
         ctx.has = (W is not None, b is not None)
+        # (the library reads y0 / W / b again in the reverse pass: saved through autograd, so that an in-place change between forward
+        # and backward raises instead of giving a gradient at other parameters - round-4 advisor on the fixed-grid Functions)
+        ctx.save_for_backward(y0, W, b)
         return out
 
     @staticmethod
@@ -99,6 +102,7 @@ class _TapeDopri5(torch.autograd.Function):
         if tape is None or not tape.handle:
             raise RuntimeError('Trying to backward through the dopri5 tape a second time: its panels are freed by the first reverse pass '
                                '(solve again; the per-operation graph, NDCN_GRAD_TAPE=0, honours retain_graph)')
+        ctx.saved_tensors                           # (version check of y0 / W / b)
         y0c, Wc, bc, csr, csr_t = ctx.keep
         g = g.contiguous()
         gy = torch.empty_like(y0c)
@@ -186,11 +190,13 @@ class _NativeFixedGrid(torch.autograd.Function):
             check(rc)
         ctx.keep = (out, Wc, bc, csr, flags, method, arr, n_ticks)
         ctx.has = (W is not None, b is not None)
+        ctx.save_for_backward(W, b)                 # (version check in backward; `out` is this node's own output)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        ctx.saved_tensors
         out, Wc, bc, csr, flags, method, arr, n_ticks = ctx.keep
         lib = _lib.load()
         g = g.contiguous()

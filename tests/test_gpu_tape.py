@@ -174,3 +174,19 @@ def test_native_fixed_grid_training_equals_the_python_loops(dev, method, shape):
     assert len(res['1'][2]) == len(res['0'][2]) == (0 if shape == 'no_control' else 2)
     for a, b in zip(res['1'][2], res['0'][2]):
         assert rel(a, b) < 2e-6, rel(a, b)
+
+
+def test_in_place_parameter_change_between_forward_and_backward_is_refused(dev):
+    """the reverse passes read W again: autograd's saved-tensor version check must see the change (as for any torch op)"""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(10))
+    for method in ('dopri5', 'rk4'):
+        f = ODEFunc(16, graphs.to_device(op, dev)).to(dev)
+        x0 = torch.rand(100, 16, device=dev, requires_grad=True)
+        y = ode.odeint(f, x0, torch.tensor([0., 0.5, 1.0], device=dev), rtol=1e-3, atol=1e-4, method=method)
+        with torch.no_grad():
+            f.wt.weight.mul_(2.0)
+        with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+            y.sum().backward()
