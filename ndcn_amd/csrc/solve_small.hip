@@ -535,6 +535,227 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_kernel(BwdArgs b, int sy
     }
 }
 
+// ------------------------------------------------------------------------------------------------ midpoint / RK4 reverse sweep
+// The same workgroup, the same LDS layout [T | S | Z | W^T | srow | CSR] as the Euler sweep above; per step, in reverse:
+//   the stage inputs are re-formed from y_i by the forward kernel's formulas (fixed_grid.py:18-19, rk_common.py:75-77; the stage
+//   derivatives stay in the registers of the thread that owns the element), then the stages' vector-Jacobian products in reverse -
+//   each the Euler sweep's block (S = A u, mask, g_W / g_b, gS = gZ W, A^T gS) - with the recurrences of `_FixedGridSolve.backward`
+//   (_impl/odeint.py) kept as running prefixes in registers:  RK4 3/8:  g_k3 = 3c a + dt g_u4;  g_k2 = 3c a - dt g_u4 + dt g_u3;
+//   g_k1 = c a + dt g_u4 - (dt/3) g_u3 + (dt/3) g_u2, c = dt / 8;  a <- a + g_u4 + g_u3 + g_u2 + g_u1 + g_out[i].
+template <int METHOD, int MAXIT, bool CSR_LDS>
+__global__ __launch_bounds__(1024) void solve_small_bwd_rk_kernel(BwdArgs b, int symmetric) {
+    extern __shared__ float lds_raw[];
+    const int H = b.H, n_elem = b.n_rows * H, ldw = H + 1;
+    float *T = lds_raw, *S = T + n_elem, *Z = S + n_elem, *wt = Z + n_elem, *srow_all = wt + H * ldw;
+    int *l_rp = reinterpret_cast<int *>(srow_all + kWaves * 64), *l_ci = l_rp + (CSR_LDS ? b.n_rows + 1 : 0);
+    float *l_va = reinterpret_cast<float *>(l_ci + (CSR_LDS ? b.nnz : 0));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int RPW = 64 / H;
+    const int q = lane / H, o = lane - q * H;
+    const bool lane_on = q < RPW;
+    const int e0 = lane_on ? (wave * RPW + q) * H + o : n_elem, estride = kWaves * RPW * H;
+    if (!b.no_control)
+        for (int i = tid; i < H * H; i += 1024) {
+            const int oo = i / H, h = i - oo * H;
+            wt[h * ldw + oo] = b.W[i];
+        }
+    if (CSR_LDS) {
+        for (int i = tid; i <= b.n_rows; i += 1024) l_rp[i] = b.rowptr[i];
+        for (int i = tid; i < b.nnz; i += 1024) { l_ci[i] = b.colidx[i]; l_va[i] = b.val[i]; }
+    }
+    const int *rp = CSR_LDS ? l_rp : b.rowptr, *ci = CSR_LDS ? l_ci : b.colidx;
+    const float *va = CSR_LDS ? l_va : b.val;
+    const int *trp = symmetric ? rp : b.t_rowptr, *tci = symmetric ? ci : b.t_colidx;
+    const float *tva = symmetric ? va : b.t_val;
+    const float bias_o = (!b.no_control && b.bias && lane_on) ? b.bias[o] : 0.f;
+    float adj[MAXIT];
+    {
+        const float *a0 = b.a_in ? b.a_in : b.g_out + (size_t)b.n_ticks * n_elem;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            adj[it] = e < n_elem ? a0[e] : 0.f;
+        }
+    }
+    const int HH = H * H;
+    const bool gw_on = !b.no_control && tid < 2 * HH, gb_on = !b.no_control && tid >= 2 * HH && tid < 2 * HH + 2 * H;
+    const int half = gw_on ? tid / HH : gb_on ? (tid - 2 * HH) / H : 0;
+    const int gw_o = gw_on ? (tid % HH) / H : gb_on ? (tid - 2 * HH) % H : 0, gw_h = gw_on ? tid % H : 0;
+    const int r_lo = half ? b.n_rows / 2 : 0, r_hi = half ? b.n_rows : b.n_rows / 2;
+    float gacc = 0.f;
+    lds_barrier();
+
+    // S[r][o] = (A T)[r][o] (or T itself) for the rows of pass `it`; returns the value of this lane's element
+    auto gather = [&](int it, const int *prp, const int *pci, const float *pva, bool &valid, int &r) -> float {
+        r = (it * kWaves + wave) * RPW + q;
+        valid = lane_on && r < b.n_rows;
+        float s = 0.f;
+        if (b.no_graph) {
+            if (valid) s = T[r * H + o];
+        } else {
+            int j0 = 0, cnt = 0;
+            if (valid) { j0 = prp[r]; cnt = prp[r + 1] - j0; }
+            s = gather_row<4>(pci, pva, T, j0, cnt, H, o, s);
+        }
+        return s;
+    };
+    // pre-activation of the Linear for this lane's element from the wave's S row (through srow)
+    auto linear = [&](float s, bool valid) -> float {
+        if (b.no_control) return s;
+        float *srow = srow_all + wave * 64;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) srow[lane] = s;
+        __builtin_amdgcn_wave_barrier();
+        float k = 0.f;
+        if (valid) {
+            const float *sr = srow + q * H;
+#pragma unroll 4
+            for (int h = 0; h < H; ++h) k = fmaf(sr[h], wt[h * ldw + o], k);
+            k = k + bias_o;
+        }
+        return k;
+    };
+#define NDCN_PUT_T(expr)                                                                       \
+    _Pragma("unroll") for (int it = 0; it < MAXIT; ++it) {                                     \
+        const int e = e0 + it * estride;                                                       \
+        if (e < n_elem) T[e] = (expr);                                                         \
+    }                                                                                          \
+    lds_barrier();
+    // K = f(T) for the owned elements
+#define NDCN_EVAL_K(dst)                                                                       \
+    _Pragma("nounroll") for (int it = 0; it < MAXIT; ++it) {                                   \
+        if ((it * kWaves + wave) * RPW >= b.n_rows) break;                                     \
+        bool valid; int r;                                                                     \
+        const float s_ = gather(it, rp, ci, va, valid, r);                                     \
+        const float k_ = linear(s_, valid);                                                    \
+        dst[it] = valid ? (b.relu ? relu_nan(k_) : k_) : 0.f;                                  \
+    }                                                                                          \
+    lds_barrier();
+    // g[it] = alpha (J(T)^T z)[owned element];  g_W / g_b += scale * (gZ^T S, sum gZ)   (T is consumed)
+#define NDCN_VJP(z, alpha, scale, g)                                                           \
+    _Pragma("unroll") for (int it = 0; it < MAXIT; ++it) {                                     \
+        const int e = e0 + it * estride;                                                       \
+        if (e < n_elem) Z[e] = z[it];                                                          \
+    }                                                                                          \
+    _Pragma("nounroll") for (int it = 0; it < MAXIT; ++it) {                                   \
+        if ((it * kWaves + wave) * RPW >= b.n_rows) break;                                     \
+        bool valid; int r;                                                                     \
+        const float s_ = gather(it, rp, ci, va, valid, r);                                     \
+        const float k_ = linear(s_, valid);                                                    \
+        if (valid) {                                                                           \
+            S[r * H + o] = s_;                                                                 \
+            if (b.relu && !(k_ > 0.f)) Z[r * H + o] = 0.f;                                     \
+        }                                                                                      \
+    }                                                                                          \
+    lds_barrier();                                                                             \
+    if (gw_on) {                                                                               \
+        float acc_ = 0.f;                                                                      \
+        _Pragma("unroll 4") for (int r = r_lo; r < r_hi; ++r) acc_ = fmaf(Z[r * H + gw_o], S[r * H + gw_h], acc_); \
+        gacc += (scale) * acc_;                                                                \
+    } else if (gb_on) {                                                                        \
+        float acc_ = 0.f;                                                                      \
+        _Pragma("unroll 4") for (int r = r_lo; r < r_hi; ++r) acc_ += Z[r * H + gw_o];         \
+        gacc += (scale) * acc_;                                                                \
+    }                                                                                          \
+    _Pragma("nounroll") for (int e = tid; e < n_elem; e += 1024) {                             \
+        float gs_;                                                                             \
+        if (b.no_control) gs_ = Z[e];                                                          \
+        else {                                                                                 \
+            const int r = e / H, h = e - r * H;                                                \
+            gs_ = 0.f;                                                                         \
+            _Pragma("unroll 4") for (int oo = 0; oo < H; ++oo) gs_ = fmaf(Z[r * H + oo], wt[h * ldw + oo], gs_); \
+        }                                                                                      \
+        T[e] = gs_;                                                                            \
+    }                                                                                          \
+    lds_barrier();                                                                             \
+    _Pragma("nounroll") for (int it = 0; it < MAXIT; ++it) {                                   \
+        if ((it * kWaves + wave) * RPW >= b.n_rows) { g[it] = 0.f; continue; }                 \
+        bool valid; int r;                                                                     \
+        const float s_ = gather(it, trp, tci, tva, valid, r);                                  \
+        g[it] = valid ? (alpha) * s_ : 0.f;                                                    \
+    }                                                                                          \
+    lds_barrier();
+
+    for (int i = b.n_ticks - 1; i >= 0; --i) {
+        const float dt = b.dt[i];
+        const float *yp = b.traj + (size_t)i * n_elem, *gi = b.g_out + (size_t)i * n_elem;
+        float y[MAXIT], k1[MAXIT], g[MAXIT], A[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int e = e0 + it * estride;
+            y[it] = e < n_elem ? yp[e] : 0.f;
+        }
+        NDCN_PUT_T(y[it])
+        NDCN_EVAL_K(k1)
+        if (METHOD == NDCN_M_MIDPOINT) {
+            const float h = dt / 2.f;
+            NDCN_PUT_T(y[it] + k1[it] * dt / 2.f)                                     // ym
+            NDCN_VJP(adj, dt, dt, g)                                                   // dL / d ym
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) { A[it] = adj[it] + g[it]; k1[it] = g[it]; }
+            NDCN_PUT_T(y[it])
+            NDCN_VJP(k1, h, h, g)
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                adj[it] = e < n_elem ? (A[it] + g[it]) + gi[e] : 0.f;
+            }
+        } else {
+            float k2[MAXIT], B2[MAXIT], B1[MAXIT];
+            const float c8 = dt / 8.f, c38 = 3.f * c8, d3 = dt / 3.f;
+            NDCN_PUT_T(y[it] + dt * k1[it] / 3.f)                                      // u2
+            NDCN_EVAL_K(k2)
+            NDCN_PUT_T(y[it] + dt * (k1[it] / -3.f + k2[it]))                          // u3
+            NDCN_EVAL_K(g)                                                             // k3 (only u4 needs it)
+            NDCN_PUT_T(y[it] + dt * (k1[it] - k2[it] + g[it]))                         // u4
+            NDCN_VJP(adj, c8, c8, g)                                                   // g_u4 = J4^T (c8 a)
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                A[it] = adj[it] + g[it];
+                B2[it] = c38 * adj[it] + (-dt) * g[it];
+                B1[it] = c8 * adj[it] + dt * g[it];
+                adj[it] = c38 * adj[it] + dt * g[it];                                  // g_k3 (a itself lives on in A)
+            }
+            NDCN_PUT_T(y[it] + dt * (k1[it] / -3.f + k2[it]))                          // u3
+            NDCN_VJP(adj, 1.f, 1.f, g)                                                 // g_u3
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                A[it] = A[it] + g[it];
+                B2[it] = B2[it] + dt * g[it];                                          // g_k2
+                B1[it] = B1[it] + (-d3) * g[it];
+            }
+            NDCN_PUT_T(y[it] + dt * k1[it] / 3.f)                                      // u2
+            NDCN_VJP(B2, 1.f, 1.f, g)                                                  // g_u2
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                A[it] = A[it] + g[it];
+                B1[it] = B1[it] + d3 * g[it];                                          // g_k1
+            }
+            NDCN_PUT_T(y[it])
+            NDCN_VJP(B1, 1.f, 1.f, g)                                                  // g_u1
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                adj[it] = e < n_elem ? (A[it] + g[it]) + gi[e] : 0.f;
+            }
+        }
+    }
+#undef NDCN_PUT_T
+#undef NDCN_EVAL_K
+#undef NDCN_VJP
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int e = e0 + it * estride;
+        if (e < n_elem) b.g_y0[e] = adj[it];
+    }
+    if (!b.no_control) {
+        if ((gw_on || gb_on) && half) T[gw_on ? tid - HH : HH + gw_o] = gacc;
+        lds_barrier();
+        if (gw_on && !half) b.g_W[tid] += gacc + T[tid];
+        else if (gb_on && !half) b.g_b[gw_o] += gacc + T[HH + gw_o];
+    }
+}
+
 // The reverse sweep on the fast path (HT = H at compile time, the plain ODEFunc, a SYMMETRIC operator - the reference's
 // normalised Laplacian / adjacency - so that one packed copy of the entries serves A and A^T):
 //   forward pieces   the forward kernel's chains (packed entries, this lane's row of W in registers)
@@ -856,8 +1077,16 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
 }
 
 int solve_small_bwd_supported(const ndcn_csr *A, int H, uint32_t flags, int method) {
-    if (method != NDCN_M_EULER || !solve_small_supported(A, H, flags, method)) return 0;
+    if (!solve_small_supported(A, H, flags, method)) return 0;
     const int64_t n_elem = A->n_rows * (int64_t)H;
+    if (method != NDCN_M_EULER) {
+        // midpoint / RK4 have the generic sweep only (no register-resident weights, no ELL image): one compute unit beats the library's
+        // multi-launch loops (ndcn_fixed_grid_backward_f32: ~28 dependent launches per RK4 step whatever the size) up to ~4 600
+        // state elements - tools/micro/small_rk_ab.py: 1.4 against 5.9 ms at 64 x 16, 5.9 / 8.3 at 196 x 20, 11.2 / 8.7 at 400 x 20
+        const char *env = getenv("NDCN_SOLVE_SMALL_RK_MAX");              // (read per call: once per solve)
+        const int64_t rk_max = env ? atoll(env) : (int64_t)4608;
+        if (n_elem > rk_max) return 0;
+    }
     return lds_bytes(n_elem, H, A->n_rows, 0, false, 2 * n_elem) <= kLdsMax && 2 * (H * H + H) <= 1024 && n_elem <= 12 * 1024 ? 1 : 0;
 }
 
@@ -938,7 +1167,25 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         const size_t lds_fast = lds_bytes_fast(4 * n_elem, A->n_rows, width, H);
         const bool fast = fast_shape && width >= 1 && width <= 16 && lds_fast <= kLdsMax && (int64_t)n_groups * (H * H + H) <= 3 * n_elem;
         a.width = width;
-        if (fast) {
+        if (method != NDCN_M_EULER) {
+#define NDCN_RGO(M_, IT_, C_)                                                                  \
+            do {                                                                               \
+                auto kern = solve_small_bwd_rk_kernel<M_, IT_, C_>;                            \
+                static std::atomic<unsigned long long> cap_seen{0};                            \
+                if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; } \
+                hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a, symmetric);          \
+            } while (0)
+#define NDCN_RGO_IT(M_, C_)                                                                    \
+            do {                                                                               \
+                if (np <= 4) NDCN_RGO(M_, 4, C_);                                              \
+                else if (np <= 9) NDCN_RGO(M_, 9, C_);                                         \
+                else NDCN_RGO(M_, 12, C_);                                                     \
+            } while (0)
+            if (method == NDCN_M_MIDPOINT) { if (csr) NDCN_RGO_IT(NDCN_M_MIDPOINT, true); else NDCN_RGO_IT(NDCN_M_MIDPOINT, false); }
+            else { if (csr) NDCN_RGO_IT(NDCN_M_RK4, true); else NDCN_RGO_IT(NDCN_M_RK4, false); }
+#undef NDCN_RGO_IT
+#undef NDCN_RGO
+        } else if (fast) {
 #define NDCN_FGO(IT_, HT_)                                                                     \
             do {                                                                               \
                 auto kern = solve_small_bwd_fast_kernel<IT_, HT_>;                             \

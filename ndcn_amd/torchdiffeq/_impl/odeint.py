@@ -93,7 +93,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
     if f0 is not None:
         func = _reuse_first_evaluation(func, y0, f0)
     if needs_grad and method in ('euler', 'midpoint', 'rk4') and _device_resident_ok(user_func, tensor_input, y0, t_user, method, options):
-        sol = _small_solve_with_grad(user_func, y0[0], t) if method == 'euler' else None    # one launch forward, one backward
+        sol = _small_solve_with_grad(user_func, y0[0], t, method)                            # one launch forward, one backward
         if sol is None:
             sol = _fixed_grid_with_grad(user_func, y0[0], t, method)   # any size: fused launches forward, closed-form sweep backward
         if sol is not None:
@@ -131,15 +131,17 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_lo
 # ---------------------------------------------------------------------------------------------------
 
 class _SmallEulerSolve(torch.autograd.Function):
-    """FixedGridODESolver.integrate with Euler steps (solvers.py:79-99, fixed_grid.py:7-8) over ODEFunc, differentiated the
+    """FixedGridODESolver.integrate with Euler (and, round 5, midpoint / RK4 3-8) steps (solvers.py:79-99, fixed_grid.py:7-29,
+    rk_common.py:72-78) over ODEFunc, differentiated the
     way the reference's drivers train - plain backpropagation through every step (heat_dynamics.py:313-334) - with
     ndcn_solve_small_f32 / ndcn_solve_small_bwd_f32 (csrc/solve_small.hip): the forward's trajectory IS the saved state."""
 
     @staticmethod
-    def forward(ctx, y0, W, b, csr, flags, dts):
+    def forward(ctx, y0, W, b, csr, flags, dts, method='euler'):
         lib = _lib.load()
         n_ticks = len(dts)
         H = y0.shape[1]
+        ctx.method = _lib.METHODS[method]
         out = torch.empty((n_ticks + 1,) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         out[0].copy_(y0)
         arr = (ctypes.c_float * n_ticks)(*dts)
@@ -148,7 +150,7 @@ class _SmallEulerSolve(torch.autograd.Function):
         bd = None if (no_control or b is None) else b.detach().contiguous()
         view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0.shape[0]))
         with torch.cuda.device(y0.device):
-            _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, _lib.M_EULER, _lib.ptr(out[0]), arr,
+            _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, ctx.method, _lib.ptr(out[0]), arr,
                                                 n_ticks, _lib.ptr(out[1:]), _lib.stream_ptr()))
         ctx.csr, ctx.flags, ctx.dts = csr, flags, arr
         ctx.has_W, ctx.has_b = Wd is not None, bd is not None
@@ -173,10 +175,10 @@ class _SmallEulerSolve(torch.autograd.Function):
         view = csr.view_ref(need_symmetric=True) if csr is not None else ctypes.byref(_lib.empty_csr(out.shape[1]))
         view_t = csr.transpose().view_ref() if csr is not None else view
         with torch.cuda.device(out.device):
-            _lib.check(lib.ndcn_solve_small_bwd_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, _lib.M_EULER, _lib.ptr(out),
+            _lib.check(lib.ndcn_solve_small_bwd_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, ctx.method, _lib.ptr(out),
                                                     _lib.ptr(g), ctx.dts, len(ctx.dts), _lib.ptr(g_y0), _lib.ptr(g_W), _lib.ptr(g_b),
                                                     _lib.stream_ptr()))
-        return g_y0, g_W, (g_b if bd is not None else None), None, None, None
+        return g_y0, g_W, (g_b if bd is not None else None), None, None, None, None
 
 
 class _FixedGridSolve(torch.autograd.Function):
@@ -309,7 +311,7 @@ def _fixed_grid_with_grad(odefunc, y0, t, method):
                                  method, dts)
 
 
-def _small_solve_with_grad(odefunc, y0, t):
+def _small_solve_with_grad(odefunc, y0, t, method='euler'):
     """The one-launch training path when the library supports the shape (H <= 31, the state and three work panels in one
     CU's LDS: the reference's README commands), else None - the caller falls back to the per-step autograd path."""
     from ...csr import as_csr
@@ -324,12 +326,14 @@ def _small_solve_with_grad(odefunc, y0, t):
         if csr.device != y0.device or csr.shape[0] != y0.shape[0]:
             return None
     view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0.shape[0]))
-    if not lib.ndcn_solve_small_supported(view, H, flags, _lib.M_EULER, 1):
+    if not lib.ndcn_solve_small_supported(view, H, flags, _lib.METHODS[method], 1):
+        return None
+    if method != 'euler' and os.environ.get('NDCN_SOLVE_SMALL_RK_GRAD', '1') == '0':
         return None
     core.assert_increasing(t)
     tt = t.detach().to('cpu').to(y0.dtype)                    # solvers.py:81: the grid in the state dtype
     dts = (tt[1:] - tt[:-1]).tolist()
-    return _SmallEulerSolve.apply(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags, dts)
+    return _SmallEulerSolve.apply(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags, dts, method)
 
 
 # ---------------------------------------------------------------------------------------------------

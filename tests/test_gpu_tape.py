@@ -190,3 +190,42 @@ def test_in_place_parameter_change_between_forward_and_backward_is_refused(dev):
             f.wt.weight.mul_(2.0)
         with pytest.raises(RuntimeError, match='modified by an inplace operation'):
             y.sum().backward()
+
+
+@pytest.mark.parametrize('method', ['midpoint', 'rk4'])
+@pytest.mark.parametrize('shape', ['reference_size', 'no_control', 'no_graph', 'four_passes', 'asymmetric'])
+def test_one_launch_midpoint_and_rk4_reverse_sweeps(dev, method, shape):
+    """solve_small.hip: the whole midpoint / RK4 solve and its reverse sweep in one launch each (states that fit one compute unit)
+    against the library's multi-launch loops (NDCN_SOLVE_SMALL_RK_GRAD=0: ndcn_fixed_grid_*): the same trajectory bit for bit, the
+    gradients up to the order of their float32 sums."""
+    import scipy.sparse as sp
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    side, H = (20, 20) if shape != 'four_passes' else (10, 16)
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    if shape == 'asymmetric':
+        op = sp.csr_matrix(sp.triu(op, k=-1) + 0.3 * sp.tril(op, k=-2))
+    n = side * side
+    ticks = torch.linspace(0., 2.0, 12)
+    x0h = torch.rand(n, H, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(12, n, H, generator=torch.Generator().manual_seed(1))
+    res = {}
+    for one_launch in ('1', '0'):
+        os.environ['NDCN_SOLVE_SMALL_RK_GRAD'] = one_launch
+        os.environ['NDCN_SOLVE_SMALL_RK_MAX'] = '1000000'               # (read once per process: the default gate is 4 608 elements)
+        try:
+            torch.manual_seed(0)
+            f = ODEFunc(H, graphs.to_device(op, dev), no_control=shape == 'no_control', no_graph=shape == 'no_graph').to(dev)
+            x0 = x0h.clone().to(dev).requires_grad_(True)
+            y = ode.odeint(f, x0, ticks.to(dev), method=method)
+            (y * w.to(dev)).sum().backward()
+            res[one_launch] = (y.detach().cpu(), x0.grad.cpu(), [p.grad.cpu() for p in f.parameters() if p.grad is not None])
+            assert (type(y.grad_fn).__name__ == '_SmallEulerSolveBackward') == (one_launch == '1'), type(y.grad_fn).__name__
+        finally:
+            del os.environ['NDCN_SOLVE_SMALL_RK_GRAD'], os.environ['NDCN_SOLVE_SMALL_RK_MAX']
+    assert torch.equal(res['1'][0], res['0'][0])
+    assert rel(res['1'][1], res['0'][1]) < 1e-5, rel(res['1'][1], res['0'][1])
+    assert len(res['1'][2]) == len(res['0'][2])
+    for a, b in zip(res['1'][2], res['0'][2]):
+        assert rel(a, b) < 1e-5, rel(a, b)
