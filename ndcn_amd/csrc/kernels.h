@@ -19,8 +19,10 @@ namespace ndcn {
 //   xadd / xadd_c (plain and COMBINE with one earlier stage, operators on the rhs_fused3 path without a halo panel -
 //          rhs_xadd_supported()): the evaluation's input is X + xadd_c * xadd, formed on the rows the kernel stages instead of by a
 //          combine launch in front (3 panels); same product-then-sum rounding per element.
+//   no_k   (a hint; COMBINE / RK4 modes) the caller reads only y_next: a kernel that can skips the store of K - an Euler step's K, the
+//          fourth stage of an RK4 step.  Honoured by rhs_fused3 (one panel of HBM writes less); K must still point at a panel.
 struct RkOpt { const float *y1; int accum; float *y_aux; const float *c_aux; const float *xadd; float xadd_c;
-               const float *xmask; float *s_out; };      // (xmask, s_out: rhs_adj_supported)
+               const float *xmask; float *s_out; int no_k; };      // (xmask, s_out: rhs_adj_supported)
 
 int spmm_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, float *Y, int H, float alpha,
              uint32_t flags, hipStream_t st);

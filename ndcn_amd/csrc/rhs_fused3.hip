@@ -450,8 +450,10 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
     // RK epilogue of one K row (as rhs_fused2.hip: epi_finish)
     auto epilogue = [&](int row, f32x4 kn, const Panels &p) {
         const int voff = (row << 10) + lane_off;
-        stp(a.K, voff, kn);
-        issued(1);
+        if (a.K) {                                                  // (uniform; null: RkOpt::no_k - only y_next is wanted)
+            stp(a.K, voff, kn);
+            issued(1);
+        }
         if (MODE == F3_PLAIN) return;
         const F3EpiPtr e = epi_args();
         if (MODE == F3_RK4) {
@@ -693,6 +695,8 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (!rhs_fused3_variant(mode, n_prev)) { set_error("rhs_fused3: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     F3Args a;
     a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
+    const bool skip_k = opt && opt->no_k && (mode == F3_COMBINE || mode == F3_RK4) && y_next;
+    if (skip_k) a.K = nullptr;
     const bool masked = opt && opt->xmask;
     a.Xadd = masked ? opt->xmask : ((opt && opt->xadd) ? opt->xadd : nullptr);
     a.xadd_c = (a.Xadd && !masked) ? opt->xadd_c : 0.f;
@@ -732,6 +736,7 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (e.y_aux) bytes += P;
     if (a.Xadd) bytes += P;                                          // the second gather
     if (a.S_out) bytes += P;
+    if (skip_k) bytes -= P;
     ProfScope prof(masked ? PROF_RHS_ADJ_T : (a.S_out ? PROF_RHS_ADJ_FWD : PROF_RHS_FUSED), st, bytes, 2.0 * A->nnz * 256 + 2.0 * (double)A->n_rows * 256 * 256);
     int rc = NDCN_OK;
     // panels that fit the Infinity Cache with room for the next launch's (<= 128 MiB): plain stores (operators without a halo panel)

@@ -998,7 +998,9 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
     if (s->fused2 && s->d.method == NDCN_M_EULER && dst != s->ycur) {
         // y + dt * f in the RHS epilogue (one term: identical rounding to fixed_stage op 0)
         const float c1[1] = {dt};
-        rc = rhs_epi(s, s->ycur, s->k[0], 1, s->ycur, nullptr, c1, 0, dst, 0.f, 0.f, nullptr, nullptr, st);
+        RkOpt opt = {};
+        opt.no_k = 1;                                        // nothing reads an Euler step's K
+        rc = rhs_epi(s, s->ycur, s->k[0], 1, s->ycur, nullptr, c1, 0, dst, 0.f, 0.f, nullptr, nullptr, st, nullptr, &opt);
         if (rc) return rc;
         s->ycur = dst;
         s->cur_is_borrowed = (dst != s->ycur_own);
@@ -1017,7 +1019,9 @@ static int fixed_advance(ndcn_solver *s, double next_t, float *out, hipStream_t 
         const float *in = s->ycur;
         for (int i = 0; i < 4; ++i) {
             float *nxt = (i == 3) ? dst : (in == s->ytmp ? s->ytmp2 : s->ytmp);
-            rc = rhs_epi(s, in, s->k[i], 3, s->ycur, kp, c1, i, nxt, 0.f, 0.f, nullptr, nullptr, st);
+            RkOpt opt = {};
+            opt.no_k = i == 3;                               // the fourth stage's derivative is consumed by its own epilogue
+            rc = rhs_epi(s, in, s->k[i], 3, s->ycur, kp, c1, i, nxt, 0.f, 0.f, nullptr, nullptr, st, nullptr, &opt);
             if (rc) return rc;
             in = nxt;
         }

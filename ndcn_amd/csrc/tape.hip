@@ -960,28 +960,31 @@ int fixed_init(Fixed &F, const ndcn_csr *A, const ndcn_csr *At, const float *W, 
 }
 
 // one step from y into out_y; u / K (nullable arrays of 4): the stage inputs and derivatives, in caller-provided panels
-int fixed_step(Fixed &F, const float *y, float dt, float *out_y, float *const *u, float *const *K) {
+// last_k: the step's last stage derivative is wanted too (the reverse pass needs its sign pattern; the forward pass does not)
+int fixed_step(Fixed &F, const float *y, float dt, float *out_y, float *const *u, float *const *K, bool last_k = true) {
     ndcn_tape *t = &F.t;
     const uint32_t fl = t->flags | (t->packed ? NDCN_F_PACKED : 0u);
-    auto eval = [&](const float *x, float *k, int mode, const float *const *kp, const float *cp, int n_prev, float *y_next) {
+    auto eval = [&](const float *x, float *k, int mode, const float *const *kp, const float *cp, int n_prev, float *y_next, bool need_k = true) {
+        RkOpt opt = {};
+        opt.no_k = need_k ? 0 : 1;
         return rhs_rk_f32(&t->A, x, nullptr, t->A.n_cols, t->W, t->b, k, t->work, t->H, fl, mode, y, kp, cp, n_prev, y_next, 0.f, 0.f, nullptr,
-                          nullptr, F.st, nullptr);
+                          nullptr, F.st, need_k ? nullptr : &opt);
     };
     if (F.method == NDCN_M_EULER) {
         const float c[1] = {dt};
-        return eval(y, K[0], NDCN_RK_COMBINE, nullptr, c, 0, out_y);                  // y + dt k1
+        return eval(y, K[0], NDCN_RK_COMBINE, nullptr, c, 0, out_y, last_k);          // y + dt k1
     }
     if (F.method == NDCN_M_MIDPOINT) {
         const float c1[1] = {(float)((double)dt / 2.0)}, c2[1] = {dt};
         int rc = eval(y, K[0], NDCN_RK_COMBINE, nullptr, c1, 0, u[1]);               // ym = y + k1 dt / 2
         if (rc) return rc;
-        return eval(u[1], K[1], NDCN_RK_COMBINE, nullptr, c2, 0, out_y);              // y + dt k2
+        return eval(u[1], K[1], NDCN_RK_COMBINE, nullptr, c2, 0, out_y, last_k);      // y + dt k2
     }
     const float c[1] = {dt};
     const float *x = y;
     for (int i = 0; i < 4; ++i) {
         const float *kp[3] = {K[0], K[1], K[2]};
-        int rc = eval(x, K[i], NDCN_RK_RK4, kp, c, i, i == 3 ? out_y : u[i + 1]);
+        int rc = eval(x, K[i], NDCN_RK_RK4, kp, c, i, i == 3 ? out_y : u[i + 1], i < 3 || last_k);
         if (rc) return rc;
         x = u[i + 1 < 4 ? i + 1 : 3];
     }
@@ -1004,7 +1007,7 @@ int ndcn_fixed_grid_train_f32(const ndcn_csr *A, const float *W, const float *b,
     const int64_t n = F.t.n;
     NDCN_HIP(hipMemcpyAsync(out, y0, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, F.st));
     for (int64_t i = 0; i < n_ticks; ++i)
-        if ((rc = fixed_step(F, out + (size_t)i * n, h_dt[i], out + (size_t)(i + 1) * n, u, K))) return rc;
+        if ((rc = fixed_step(F, out + (size_t)i * n, h_dt[i], out + (size_t)(i + 1) * n, u, K, false))) return rc;
     return NDCN_OK;
 }
 
