@@ -647,8 +647,12 @@ def test_bench_two_ranks_on_one_device(dev, config):
     import subprocess
     import sys
     env = dict(os.environ, NDCN_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', NDCN_C4_NODES='6000')
+    import socket
+    with socket.socket() as sk:                                       # a port nobody holds (a fixed one collided once in a full run)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     launcher = [] if config == 'M' else ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                                         '127.0.0.1', '--master-port', str(29700 + os.getpid() % 200)]
+                                         '127.0.0.1', '--master-port', str(port)]
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--side', '96', '--steps', '6',
                                          '--warmup', '2', '--config', config]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
