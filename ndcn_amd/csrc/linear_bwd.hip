@@ -594,7 +594,9 @@ __global__ __launch_bounds__(256) void linear_gs_small_kernel(const float *__res
 // narrow shapes (one thread per output element, serial over the chunk's rows) get their parallelism from the number of
 // chunks: 4096 instead of 256 (decoder Linear(256, 1) over 10^6 rows: 1.2 -> 0.2 ms); their partial blocks are tiny
 static int64_t wgrad_chunks(int64_t n, bool small) {
-    int64_t c = (n + 63) / 64;
+    // (few rows - the reference's 400 nodes: a chunk is two rounds of dependent loads instead of eight; the launch was 12.9 us, a sixth
+    // of the kernel time of a README-sized dopri5 backward pass)
+    int64_t c = n <= 4096 ? (n + 15) / 16 : (n + 63) / 64;
     const int64_t cap = small ? 4096 : kGwMaxChunks;
     if (c > cap) c = cap;
     return c < 1 ? 1 : c;
