@@ -59,7 +59,13 @@ __device__ __forceinline__ void block_store_dots(double (&d)[kBwdDots], double *
 __global__ __launch_bounds__(256) void dots_finish_kernel(const double *__restrict__ partial, int n_blocks, double *__restrict__ out) {
     const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
     double s = 0.0;
-    for (int i = l; i < n_blocks; i += 32) s += partial[(size_t)i * kBwdDots + q];
+    for (int i = l; i < n_blocks; i += 32 * 8) {                  // eight requests in flight, added in ascending order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + 32 * u < n_blocks ? partial[(size_t)(i + 32 * u) * kBwdDots + q] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
     if (l == 0) out[q] = s;
