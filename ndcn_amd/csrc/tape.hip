@@ -81,7 +81,7 @@ int host_scratch(HostScratch **out) {
 }  // namespace
 
 struct ndcn_tape {
-    ndcn_csr A, At;
+    ndcn_csr A = {}, At = {};
     const float *W = nullptr, *b = nullptr;
     int H = 0;
     uint32_t flags = 0;
