@@ -907,6 +907,17 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
                 if (e < n_elem) pre[it] = yp[e];
             }
         }
+        // (this tick's loss gradient is requested BEFORE the gather that hides its latency: read where it is added, the round trip to
+        // memory sat on every tick's critical path - ~5 k of the phase's 16.8 k cycles)
+        float gpre[MAXIT];
+        {
+            const float *gi = b.g_out + (size_t)i * n_elem;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                gpre[it] = e < n_elem ? gi[e] : 0.f;
+            }
+        }
 #pragma nounroll
         for (int it = 0; it < MAXIT; ++it) {
             if ((it * kWaves + wave) * RPW >= b.n_rows) break;
@@ -924,11 +935,10 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
             if (valid) S[r * H + o] = s;
         }
         {
-            const float *gi = b.g_out + (size_t)i * n_elem;
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
                 const int e = e0 + it * estride;
-                if (e < n_elem) Adj[e] = (Adj[e] + S[e]) + gi[e];
+                if (e < n_elem) Adj[e] = (Adj[e] + S[e]) + gpre[it];
             }
         }
         lds_barrier();
@@ -1193,8 +1203,9 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
                 if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; }       \
                 hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_fast, st, a, n_groups, rows_per_group); \
             } while (0)
-            if (H == 20) { if (np <= 4) NDCN_FGO(4, 20); else NDCN_FGO(12, 20); }
-            else { if (np <= 4) NDCN_FGO(4, 16); else NDCN_FGO(12, 16); }
+            // (9 passes: the README's 400 x 20 - the 12-pass build of the same kernel spills 22 registers)
+            if (H == 20) { if (np <= 4) NDCN_FGO(4, 20); else if (np <= 9) NDCN_FGO(9, 20); else NDCN_FGO(12, 20); }
+            else { if (np <= 4) NDCN_FGO(4, 16); else if (np <= 9) NDCN_FGO(9, 16); else NDCN_FGO(12, 16); }
 #undef NDCN_FGO
         } else {
 #define NDCN_GO(IT_, C_)                                                                       \
