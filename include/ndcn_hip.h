@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 16
+#define NDCN_ABI_VERSION 17
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -609,6 +609,16 @@ NDCN_API int ndcn_solve_small_f32(const ndcn_csr *A, const float *W, const float
 NDCN_API int ndcn_solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *W, const float *b, int H, uint32_t flags,
                                       int method, const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks,
                                       float *g_y0, float *g_W, float *g_b, void *stream);
+/* Euler training with the evaluations' intermediates KEPT (the README commands' shape: H = 16 / 20, a symmetric operator whose view has
+ * max_row_len and symmetric filled - ndcn_solve_small_keep_supported says whether both launches take the form): the forward launch also
+ * writes, per step, S_i = A y_i and K_i = f(y_i) into `keep` (n_ticks x 2 panels); the reverse sweep reads them instead of re-forming
+ * them from y_i - no gather and no Linear per tick (a third of the sweep's cycles).  Same results as the pair above.                  */
+NDCN_API int ndcn_solve_small_keep_supported(const ndcn_csr *A, int H, uint32_t flags);
+NDCN_API int ndcn_solve_small_keep_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, const float *y0,
+                                       const float *h_dt, int64_t n_ticks, float *out, float *keep, void *stream);
+NDCN_API int ndcn_solve_small_bwd_keep_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *W, const float *b, int H, uint32_t flags,
+                                           const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, const float *keep,
+                                           float *g_y0, float *g_W, float *g_b, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement aid (bench.py `roofline`): when enabled, every kernel launch made by this library is

@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO, PATH_SWEEP, PATH_REC, PATH_WIDE, PATH_SMALL = 1, 2, 4, 8, 16, 32, 64, 128
 
 OK = 0
@@ -120,6 +120,9 @@ SIGNATURES = {
     'ndcn_rk_bwd_ws_bytes': (_L, []),
     'ndcn_rk_combine_bwd_f32': (_I, [_P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, ctypes.POINTER(_P), ctypes.POINTER(_P), _P, _P,
                                 _P, _P, _L, _P]),
+    'ndcn_solve_small_keep_supported': (_I, [_P, _I, ctypes.c_uint32]),
+    'ndcn_solve_small_keep_f32': (_I, [_P, _P, _P, _I, ctypes.c_uint32, _P, ctypes.POINTER(_F), _L, _P, _P, _P]),
+    'ndcn_solve_small_bwd_keep_f32': (_I, [_P, _P, _P, _P, _I, ctypes.c_uint32, _P, _P, ctypes.POINTER(_F), _L, _P, _P, _P, _P, _P]),
     'ndcn_tape_dopri5_f32': (_I, [_P, _P, _P, _P, _I, ctypes.c_uint32, _P, ctypes.POINTER(_D), _L, _D, _D, ctypes.POINTER(_D), _P, _P, _P,
                              ctypes.POINTER(_P), _P]),
     'ndcn_tape_backward_f32': (_I, [_P, _P, _P, _P, _P, _P]),

@@ -90,6 +90,26 @@ int ndcn_solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int 
     return solve_small_f32(A, W, b, H, flags, method, y0, h_dt, n_ticks, out, ST(stream));
 }
 
+int ndcn_solve_small_keep_supported(const ndcn_csr *A, int H, uint32_t flags) { return A ? solve_small_keep_supported(A, H, flags) : 0; }
+
+int ndcn_solve_small_keep_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, const float *y0, const float *h_dt,
+                              int64_t n_ticks, float *out, float *keep, void *stream) {
+    NDCN_CHECK_ARG(A && y0 && W && h_dt && out && keep && n_ticks >= 1, "null argument");
+    int rc = check_csr(A, __func__);
+    if (rc) return rc;
+    return solve_small_f32(A, W, b, H, flags, NDCN_M_EULER, y0, h_dt, n_ticks, out, ST(stream), keep);
+}
+
+int ndcn_solve_small_bwd_keep_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *W, const float *b, int H, uint32_t flags,
+                                  const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, const float *keep, float *g_y0,
+                                  float *g_W, float *g_b, void *stream) {
+    NDCN_CHECK_ARG(A && traj && g_out && g_y0 && h_dt && keep && W && g_W && g_b && n_ticks >= 1, "null argument");
+    int rc = check_csr(A, __func__);
+    if (rc) return rc;
+    if ((rc = check_csr(A_t, __func__))) return rc;
+    return solve_small_bwd_f32(A, A_t, W, b, H, flags, NDCN_M_EULER, traj, g_out, h_dt, n_ticks, g_y0, g_W, g_b, ST(stream), keep);
+}
+
 int ndcn_solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *A_t, const float *W, const float *b, int H, uint32_t flags, int method,
                              const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, float *g_y0, float *g_W,
                              float *g_b, void *stream) {

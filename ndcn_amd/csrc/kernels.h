@@ -93,11 +93,12 @@ int rhs_small_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_
 // the state dtype; out: n_ticks panels.  Euler also has the reverse sweep (traj / g_out: n_ticks + 1 panels, y_0 first).
 int solve_small_supported(const ndcn_csr *A, int H, uint32_t flags, int method);
 int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method, const float *y0,
-                    const float *h_dt, int64_t n_ticks, float *out, hipStream_t st);
+                    const float *h_dt, int64_t n_ticks, float *out, hipStream_t st, float *keep = nullptr);
+int solve_small_keep_supported(const ndcn_csr *A, int H, uint32_t flags);
 int solve_small_bwd_supported(const ndcn_csr *A, int H, uint32_t flags, int method);
 int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags, int method,
                         const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, float *g_y0, float *g_W,
-                        float *g_b, hipStream_t st);
+                        float *g_b, hipStream_t st, const float *keep = nullptr);
 // adjoint.hip: func_eval and the three vector-Jacobian products of the adjoint system's right-hand side for ODEFunc
 int64_t adjoint_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags);
 int adjoint_rhs_f32(const ndcn_csr *A, const ndcn_csr *At, const float *y, const float *a, const float *W, const float *b, float *K,

@@ -71,6 +71,7 @@ struct SolveArgs {
     int n_rows, H, nnz, n_ticks, relu, no_graph, no_control, csr_in_lds;
     int width;                       // fast path: entries per ELL row (the operator's longest row)
     long long *dbg;                  // NDCN_SS_DEBUG=1: {shader cycles total, in evaluations, in stage updates, 100 MHz ticks total}
+    float *keep;                     // nullable (Euler, fast path): [n_ticks][2][n] - S = A y_i and K_i = f(y_i) of every step, for the reverse sweep
     float dt[kChunk];
 };
 
@@ -142,8 +143,7 @@ __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, cons
 template <int HT, int NP>
 __device__ __forceinline__ void eval_fast(const int2 *ell, int width, const float *T, float *srow, const float (&wreg)[HT ? HT : 1],
                                           const int (&r)[NP], const bool (&valid)[NP], int q, int o, int lane, float bias_o, int relu,
-                                          float (&out)[NP]) {
-    float s[NP];
+                                          float (&out)[NP], float (&s)[NP]) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int2 *row = ell + (valid[p] ? r[p] : 0) * width;
@@ -200,7 +200,7 @@ inline size_t lds_bytes_fast(int64_t n_elem, int64_t n_rows, int64_t width, int 
 }
 
 // METHOD: NDCN_M_EULER / MIDPOINT / RK4.  MAXIT: passes a wave makes over its rows (register arrays are indexed by pass)
-template <int METHOD, int MAXIT, bool CSR_LDS, int HT>
+template <int METHOD, int MAXIT, bool CSR_LDS, int HT, bool KEEP = false>
 __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
     extern __shared__ float lds_raw[];
     const int H = HT ? HT : a.H, n_elem = a.n_rows * H;
@@ -258,13 +258,20 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs a) {
             if ((it * kWaves + wave) * RPW < a.n_rows) {                                                       \
                 int rr_[NPF];                                                                                  \
                 bool vv_[NPF];                                                                                 \
-                float oo_[NPF];                                                                                \
+                float oo_[NPF], ss_[NPF];                                                                      \
                 _Pragma("unroll") for (int p = 0; p < NPF; ++p) {                                              \
                     rr_[p] = ((it + p) * kWaves + wave) * RPW + q;                                             \
                     vv_[p] = lane_on && rr_[p] < a.n_rows;                                                     \
                 }                                                                                              \
-                eval_fast<HT, NPF>(f_ent, a.width, l.T, f_srow, wreg, rr_, vv_, q, o, lane, bias_o, a.relu, oo_);      \
-                _Pragma("unroll") for (int p = 0; p < NPF; ++p) dst[it + p] = oo_[p];                          \
+                eval_fast<HT, NPF>(f_ent, a.width, l.T, f_srow, wreg, rr_, vv_, q, o, lane, bias_o, a.relu, oo_, ss_);  \
+                _Pragma("unroll") for (int p = 0; p < NPF; ++p) {                                              \
+                    dst[it + p] = oo_[p];                                                                      \
+                    if (KEEP && METHOD == NDCN_M_EULER && vv_[p]) {                                            \
+                        float *kp_ = a.keep + (size_t)tick * 2 * n_elem + rr_[p] * H + o;                      \
+                        kp_[0] = ss_[p];                                                                       \
+                        kp_[n_elem] = oo_[p];                                                                  \
+                    }                                                                                          \
+                }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
     } else {                                                                                                   \
@@ -345,6 +352,7 @@ struct BwdArgs {
                                      // covered the later ticks (it already holds that tick's g_out); NULL: g_out[n_ticks] itself
     int n_rows, H, nnz, n_ticks, relu, no_graph, no_control;
     int width;                       // fast path: entries per ELL row
+    const float *keep;               // nullable (fast path): what the forward launch kept - [n_ticks][2][n], S_i and K_i
     float dt[kChunk];
 };
 
@@ -764,7 +772,10 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_rk_kernel(BwdArgs b, int
 //                    at the end
 //   gS = gZ W        lane (r, o) holds column o of W in registers: H/4 16-byte reads of the row's gZ + H fmas
 //   LDS: [entries | T | S | Z | srow | rowptr]; registers: the adjoint of the owned elements, the prefetched y_{i-1}
-template <int MAXIT, int HT>
+// KEEP (round 5): the forward launch kept S_i = A y_i and K_i of every step (BwdArgs::keep): the sweep re-forms nothing - no gather, no
+// Linear, no y_i - a third of a tick's cycles; the next tick's S and K are requested during the transposed gather and put into the S and Z
+// panels once their owner is done with them.
+template <int MAXIT, int HT, bool KEEP>
 __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, int n_groups, int rows_per_group) {
     extern __shared__ float lds_raw[];
     constexpr int H = HT, RPW = 64 / HT, NB = HT / 4;        // NB x NB blocks of 4 x 4 outputs
@@ -780,22 +791,23 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
     const int e0 = lane_on ? (wave * RPW + q) * H + o : n_elem, estride = kWaves * RPW * H;
     for (int i = tid; i < H; i += 1024) zrow[i] = 0.f;
     build_ell(ell, width, b.n_rows, H, b.rowptr, b.colidx, b.val, (int)(zrow - T), tid);
-    float wreg[HT], wcol[HT];
+    float wreg[KEEP ? 1 : HT], wcol[HT];
 #pragma unroll
     for (int h = 0; h < HT; ++h) {
-        wreg[h] = lane_on ? b.W[o * H + h] : 0.f;            // row o: K[o] = sum_h S[h] W[o][h]
+        if (!KEEP) wreg[h] = lane_on ? b.W[o * H + h] : 0.f; // row o: K[o] = sum_h S[h] W[o][h]
         wcol[h] = lane_on ? b.W[h * H + o] : 0.f;            // column o: gS[o] = sum_oo gZ[oo] W[oo][o]
     }
     const float bias_o = (b.bias && lane_on) ? b.bias[o] : 0.f;
     float pre[MAXIT];                                        // (the adjoint itself lives in LDS: with it in registers the 12-pass build spilled 40)
     {
         const float *a0 = b.a_in ? b.a_in : b.g_out + (size_t)b.n_ticks * n_elem;
-        const float *yl = b.traj + (size_t)(b.n_ticks - 1) * n_elem;
+        const float *yl = KEEP ? b.keep + (size_t)(b.n_ticks - 1) * 2 * n_elem : b.traj + (size_t)(b.n_ticks - 1) * n_elem;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int e = e0 + it * estride;
             if (e < n_elem) Adj[e] = a0[e];
             pre[it] = e < n_elem ? yl[e] : 0.f;
+            if (KEEP && e < n_elem) { S[e] = pre[it]; Z[e] = yl[n_elem + e]; }      // S_{T-1}, K_{T-1}
         }
     }
     // g_W blocks: thread t < NB * NB * n_groups owns block (ba, bb) = ((t % (NB NB)) / NB, t % NB) over the rows of group t / (NB NB);
@@ -815,6 +827,14 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
     for (int i = b.n_ticks - 1; i >= 0; --i) {
         const float dt = b.dt[i];
         long long t_ = b.dbg ? (long long)__builtin_readcyclecounter() : 0;
+        if (KEEP) {
+            // ---- S holds S_i, Z holds K_i (put there by their owners at the end of the previous tick): gZ = dt a (.) [K_i > 0] in place
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int e = e0 + it * estride;
+                if (e < n_elem) Z[e] = (b.relu && !(Z[e] > 0.f)) ? 0.f : dt * Adj[e];
+            }
+        } else {
         // ---- T <- y_i (requested during the previous step's last phase, by the owners);  Z <- dt a
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -855,6 +875,7 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
                 S[r * H + o] = s;
                 if (b.relu && !(k > 0.f)) Z[r * H + o] = 0.f;
             }
+        }
         }
         lds_barrier();
         if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_a += n_ - t_; t_ = n_; }
@@ -899,12 +920,14 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
         if (b.dbg) { const long long n_ = __builtin_readcyclecounter(); c_b += n_ - t_; t_ = n_; }
         // ---- S <- A^T gS = A gS (symmetric), each element by its owner; then a <- (a + S) + g_out[i];  y_{i-1} is requested here so
         // that its registers are live across this phase only
+        float kpre[KEEP ? MAXIT : 1];
         if (i > 0) {
-            const float *yp = b.traj + (size_t)(i - 1) * n_elem;
+            const float *yp = KEEP ? b.keep + (size_t)(i - 1) * 2 * n_elem : b.traj + (size_t)(i - 1) * n_elem;
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it) {
                 const int e = e0 + it * estride;
                 if (e < n_elem) pre[it] = yp[e];
+                if (KEEP) kpre[it] = e < n_elem ? yp[n_elem + e] : 0.f;
             }
         }
         // (this tick's loss gradient is requested BEFORE the gather that hides its latency: read where it is added, the round trip to
@@ -939,6 +962,7 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
             for (int it = 0; it < MAXIT; ++it) {
                 const int e = e0 + it * estride;
                 if (e < n_elem) Adj[e] = (Adj[e] + S[e]) + gpre[it];
+                if (KEEP && i > 0 && e < n_elem) { S[e] = pre[it]; Z[e] = kpre[it]; }     // the next tick's S and K, by their owner
             }
         }
         lds_barrier();
@@ -1014,9 +1038,27 @@ static int ell_width(const ndcn_csr *A, hipStream_t st, int *out) {
     return NDCN_OK;
 }
 
+// Do the forward AND the reverse launch of an Euler solve take their fast forms, so that the forward may keep S_i / K_i for the sweep?
+// (Decided from the view alone - ndcn_csr::max_row_len and ::symmetric filled - so that asking costs no synchronisation.)
+int solve_small_keep_supported(const ndcn_csr *A, int H, uint32_t flags) {
+    const char *env = getenv("NDCN_SOLVE_SMALL_KEEP");               // (read per call: once per solve)
+    const bool on = !(env && env[0] == '0');
+    static const bool fast_on = [] { const char *e = getenv("NDCN_SOLVE_SMALL_FAST"); return !(e && e[0] == '0'); }();
+    if (!on || !fast_on || !solve_small_bwd_supported(A, H, flags, NDCN_M_EULER)) return 0;
+    if (!(H == 16 || H == 20) || (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) || A->symmetric != 1) return 0;
+    const int width = A->max_row_len;
+    const int64_t n_elem = A->n_rows * (int64_t)H;
+    if (width < 1 || width > 16) return 0;
+    if (lds_bytes_fast(n_elem, A->n_rows, width, H) > kLdsMax || lds_bytes_fast(4 * n_elem, A->n_rows, width, H) > kLdsMax) return 0;
+    const int NBh = H / 4;
+    const int n_groups = std::max(1, std::min<int>(1024 / (NBh * NBh + NBh), (int)A->n_rows));
+    return (int64_t)n_groups * (H * H + H) <= 3 * n_elem ? 1 : 0;
+}
+
 int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, uint32_t flags, int method, const float *y0,
-                    const float *h_dt, int64_t n_ticks, float *out, hipStream_t st) {
+                    const float *h_dt, int64_t n_ticks, float *out, hipStream_t st, float *keep) {
     if (!solve_small_supported(A, H, flags, method)) { set_error("solve_small: unsupported shape"); return NDCN_EINVAL; }
+    if (keep && (method != NDCN_M_EULER || !solve_small_keep_supported(A, H, flags))) { set_error("solve_small: nothing keeps S / K for this shape (ndcn_solve_small_keep_supported)"); return NDCN_EINVAL; }
     const int64_t n_elem = A->n_rows * (int64_t)H;
     const bool no_graph = flags & NDCN_F_NO_GRAPH;
     const int64_t nnz = no_graph ? 0 : A->nnz;
@@ -1041,6 +1083,7 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
         a.relu = (flags & NDCN_F_RELU) ? 1 : 0; a.no_graph = no_graph ? 1 : 0; a.no_control = (flags & NDCN_F_NO_CONTROL) ? 1 : 0;
         a.csr_in_lds = csr ? 1 : 0;
         a.width = width;
+        a.keep = keep ? keep + (size_t)done * 2 * n_elem : nullptr;
         for (int i = 0; i < a.n_ticks; ++i) a.dt[i] = h_dt[done + i];
         static const bool dbg_on = [] { const char *e = getenv("NDCN_SS_DEBUG"); return e && e[0] == '1'; }();
         static long long *dbg_buf = nullptr;
@@ -1067,7 +1110,18 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
             else if (method == NDCN_M_MIDPOINT) NDCN_GO_IT(NDCN_M_MIDPOINT, C_, HT_);          \
             else NDCN_GO_IT(NDCN_M_RK4, C_, HT_);                                              \
         } while (0)
-        if (fast && H == 20) NDCN_GO_M(true, 20);
+        if (fast && a.keep) {                                 // Euler with S / K kept for the reverse sweep
+#define NDCN_KGO(IT_, HT_)                                                                     \
+            do {                                                                               \
+                auto kern = solve_small_kernel<NDCN_M_EULER, IT_, true, HT_, true>;            \
+                static std::atomic<unsigned long long> cap_seen{0};                            \
+                if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; } \
+                hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, st, a);                     \
+            } while (0)
+            if (H == 20) { if (np <= 4) NDCN_KGO(4, 20); else NDCN_KGO(12, 20); }
+            else { if (np <= 4) NDCN_KGO(4, 16); else NDCN_KGO(12, 16); }
+#undef NDCN_KGO
+        } else if (fast && H == 20) NDCN_GO_M(true, 20);
         else if (fast) NDCN_GO_M(true, 16);
         else if (csr) NDCN_GO_M(true, 0);
         else NDCN_GO_M(false, 0);
@@ -1124,8 +1178,9 @@ static int csr_symmetric(const ndcn_csr *A, const ndcn_csr *At, hipStream_t st, 
 
 int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, const float *b, int H, uint32_t flags, int method,
                         const float *traj, const float *g_out, const float *h_dt, int64_t n_ticks, float *g_y0, float *g_W,
-                        float *g_b, hipStream_t st) {
+                        float *g_b, hipStream_t st, const float *keep) {
     if (!solve_small_bwd_supported(A, H, flags, method)) { set_error("solve_small_bwd: unsupported shape / method"); return NDCN_EINVAL; }
+    if (keep && (method != NDCN_M_EULER || !solve_small_keep_supported(A, H, flags))) { set_error("solve_small_bwd: no kept S / K for this shape (ndcn_solve_small_keep_supported)"); return NDCN_EINVAL; }
     const bool no_graph = flags & NDCN_F_NO_GRAPH, no_control = flags & NDCN_F_NO_CONTROL;
     if (!no_graph && (!At || At->n_rows != A->n_cols || At->nnz != A->nnz)) { set_error("solve_small_bwd: the transposed operator is missing"); return NDCN_EINVAL; }
     const int64_t n_elem = A->n_rows * (int64_t)H;
@@ -1159,6 +1214,7 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         a.g_out = g_out + lo * n_elem;
         a.g_y0 = g_y0; a.g_W = g_W; a.g_b = g_b;
         a.a_in = first ? nullptr : g_y0;
+        a.keep = keep ? keep + (size_t)lo * 2 * n_elem : nullptr;
         a.n_rows = (int)A->n_rows; a.H = H; a.nnz = (int)A->nnz; a.n_ticks = (int)(hi - lo);
         a.relu = (flags & NDCN_F_RELU) ? 1 : 0; a.no_graph = no_graph ? 1 : 0; a.no_control = no_control ? 1 : 0;
         for (int i = 0; i < a.n_ticks; ++i) a.dt[i] = h_dt[lo + i];
@@ -1198,10 +1254,17 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         } else if (fast) {
 #define NDCN_FGO(IT_, HT_)                                                                     \
             do {                                                                               \
-                auto kern = solve_small_bwd_fast_kernel<IT_, HT_>;                             \
-                static std::atomic<unsigned long long> cap_seen{0};                                                   \
-                if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; }       \
-                hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_fast, st, a, n_groups, rows_per_group); \
+                if (a.keep) {                                                                  \
+                    auto kern = solve_small_bwd_fast_kernel<IT_, HT_, true>;                   \
+                    static std::atomic<unsigned long long> cap_seen{0};                        \
+                    if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; } \
+                    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_fast, st, a, n_groups, rows_per_group); \
+                } else {                                                                       \
+                    auto kern = solve_small_bwd_fast_kernel<IT_, HT_, false>;                  \
+                    static std::atomic<unsigned long long> cap_seen{0};                        \
+                    if (once_per_device(cap_seen)) { int rc_ = set_lds_cap(kern); if (rc_) return rc_; } \
+                    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds_fast, st, a, n_groups, rows_per_group); \
+                }                                                                              \
             } while (0)
             // (9 passes: the README's 400 x 20 - the 12-pass build of the same kernel spills 22 registers)
             if (H == 20) { if (np <= 4) NDCN_FGO(4, 20); else if (np <= 9) NDCN_FGO(9, 20); else NDCN_FGO(12, 20); }

@@ -148,11 +148,20 @@ class _SmallEulerSolve(torch.autograd.Function):
         no_control = bool(flags & _lib.F_NO_CONTROL)
         Wd = None if no_control else W.detach().contiguous()
         bd = None if (no_control or b is None) else b.detach().contiguous()
-        view = csr.view_ref() if csr is not None else ctypes.byref(_lib.empty_csr(y0.shape[0]))
+        view = csr.view_ref(need_symmetric=True) if csr is not None else ctypes.byref(_lib.empty_csr(y0.shape[0]))
+        # Euler on the README shapes: the forward launch keeps S_i = A y_i and K_i of every step for the reverse sweep (two panels per
+        # tick instead of a gather and a Linear per tick in backward: ndcn_solve_small_keep_*)
+        keep = None
+        if ctx.method == _lib.M_EULER and csr is not None and Wd is not None and lib.ndcn_solve_small_keep_supported(view, H, flags):
+            keep = torch.empty((n_ticks, 2) + tuple(y0.shape), dtype=torch.float32, device=y0.device)
         with torch.cuda.device(y0.device):
-            _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, ctx.method, _lib.ptr(out[0]), arr,
-                                                n_ticks, _lib.ptr(out[1:]), _lib.stream_ptr()))
-        ctx.csr, ctx.flags, ctx.dts = csr, flags, arr
+            if keep is not None:
+                _lib.check(lib.ndcn_solve_small_keep_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, _lib.ptr(out[0]), arr, n_ticks,
+                                                         _lib.ptr(out[1:]), _lib.ptr(keep), _lib.stream_ptr()))
+            else:
+                _lib.check(lib.ndcn_solve_small_f32(view, _lib.ptr(Wd), _lib.ptr(bd), H, flags, ctx.method, _lib.ptr(out[0]), arr,
+                                                    n_ticks, _lib.ptr(out[1:]), _lib.stream_ptr()))
+        ctx.csr, ctx.flags, ctx.dts, ctx.keep = csr, flags, arr, keep
         ctx.has_W, ctx.has_b = Wd is not None, bd is not None
         # (W and b through save_for_backward: an in-place parameter change between forward and backward raises, as it does for
         # every other autograd node, instead of differentiating the wrong weights)
@@ -175,9 +184,15 @@ class _SmallEulerSolve(torch.autograd.Function):
         view = csr.view_ref(need_symmetric=True) if csr is not None else ctypes.byref(_lib.empty_csr(out.shape[1]))
         view_t = csr.transpose().view_ref() if csr is not None else view
         with torch.cuda.device(out.device):
-            _lib.check(lib.ndcn_solve_small_bwd_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, ctx.method, _lib.ptr(out),
-                                                    _lib.ptr(g), ctx.dts, len(ctx.dts), _lib.ptr(g_y0), _lib.ptr(g_W), _lib.ptr(g_b),
-                                                    _lib.stream_ptr()))
+            if ctx.keep is not None:
+                _lib.check(lib.ndcn_solve_small_bwd_keep_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, _lib.ptr(out), _lib.ptr(g),
+                                                             ctx.dts, len(ctx.dts), _lib.ptr(ctx.keep), _lib.ptr(g_y0), _lib.ptr(g_W),
+                                                             _lib.ptr(g_b), _lib.stream_ptr()))
+                ctx.keep = None
+            else:
+                _lib.check(lib.ndcn_solve_small_bwd_f32(view, view_t, _lib.ptr(Wd), _lib.ptr(bd), H, ctx.flags, ctx.method, _lib.ptr(out),
+                                                        _lib.ptr(g), ctx.dts, len(ctx.dts), _lib.ptr(g_y0), _lib.ptr(g_W), _lib.ptr(g_b),
+                                                        _lib.stream_ptr()))
         return g_y0, g_W, (g_b if bd is not None else None), None, None, None, None
 
 

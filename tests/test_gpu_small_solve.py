@@ -216,3 +216,37 @@ def test_fixed_grid_training_through_fused_launches_equals_the_per_op_autograd_p
         close(gba, gbb, 'g_b')
     else:
         assert gWa is None or float(gWa.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('side,H,n_ticks', [(20, 20, 80), (17, 16, 150), (20, 20, 150), (12, 16, 20)])
+def test_euler_reverse_sweep_on_kept_intermediates_is_bit_identical(dev, side, H, n_ticks):
+    """ndcn_solve_small_keep_f32 / _bwd_keep_f32: the forward launch keeps S_i = A y_i and K_i of every step, the sweep reads them
+    instead of re-forming them - the same fma chains produced the kept values, so trajectory and gradients equal the recomputing pair's
+    bit for bit (NDCN_SOLVE_SMALL_KEEP=0).  150 ticks: two launches per direction (128 ticks each at most)."""
+    import os
+    from ndcn_amd import graphs, _lib
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    n = side * side
+    ticks = torch.linspace(0., 3.0, n_ticks + 1)
+    x0h = torch.rand(n, H, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(n_ticks + 1, n, H, generator=torch.Generator().manual_seed(1))
+    A = graphs.to_device(op, dev)
+    # (12 x 12 x 16: too few elements for the fast sweep's row groups - nothing is kept, the pair must still agree)
+    assert _lib.load().ndcn_solve_small_keep_supported(A.view_ref(need_symmetric=True), H, _lib.F_RELU) == (0 if side == 12 else 1)
+    res = {}
+    for keep in ('1', '0'):
+        os.environ['NDCN_SOLVE_SMALL_KEEP'] = keep
+        try:
+            torch.manual_seed(0)
+            f = ODEFunc(H, A).to(dev)
+            x0 = x0h.clone().to(dev).requires_grad_(True)
+            y = ode.odeint(f, x0, ticks.to(dev), method='euler')
+            assert type(y.grad_fn).__name__ == '_SmallEulerSolveBackward'
+            (y * w.to(dev)).sum().backward()
+            res[keep] = (y.detach().cpu(), x0.grad.cpu(), f.wt.weight.grad.cpu(), f.wt.bias.grad.cpu())
+        finally:
+            del os.environ['NDCN_SOLVE_SMALL_KEEP']
+    for a, b in zip(res['1'], res['0']):
+        assert torch.equal(a, b)
