@@ -32,6 +32,7 @@ struct SmallArgs {
     int n_own, n_rows, H, relu;
     const float *W, *bias;
     float *K;
+    float *S_out;                     // nullable: S = A X is written too (RkOpt::s_out - kept for the weight gradient by the training tape)
 };
 struct SmallEpi {
     const float *y0;
@@ -94,6 +95,11 @@ __global__ __launch_bounds__(256) void rhs_small_kernel(SmallArgs a, SmallEpi e)
 #pragma unroll
         for (int u = 0; u < NH; ++u)
             if (lane + 64 * u < H) srow[lane + 64 * u] = s[u];
+        if (a.S_out) {
+#pragma unroll
+            for (int u = 0; u < NH; ++u)
+                if (lane + 64 * u < H) a.S_out[(size_t)r * H + lane + 64 * u] = s[u];
+        }
         __builtin_amdgcn_wave_barrier();                     // (one wave: LDS accesses of a wave are performed in order)
         // ---- linear + activation: K[o] = relu(sum_h S[h] W[o][h] + b[o])
         float k[NH];
@@ -202,6 +208,7 @@ int rhs_small_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_
     SmallArgs a;
     a.rowptr = A->rowptr; a.colidx = A->colidx; a.val = A->val; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.n_rows = n_rows;
     a.H = H; a.relu = (flags & NDCN_F_RELU) ? 1 : 0; a.W = W; a.bias = b; a.K = K;
+    a.S_out = (opt && opt->s_out) ? opt->s_out : nullptr;
     SmallEpi e = {};
     e.y0 = y0; e.y_next = y_next; e.n_prev = n_prev; e.rtol = rtol; e.atol = atol; e.partials = static_cast<double *>(d_ws);
     e.c_dev = c_dev;

@@ -254,6 +254,8 @@ int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, d
     for (int e = 2; e <= 7; ++e)
         if ((rc = panel(t, &u[e]))) return rc;
     const bool both = !(t->flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL));
+    // (the narrow-panel kernel - rhs_small.hip: what rhs_rk_f32 picks for H <= 128 at launch-bound sizes - writes S on the side too)
+    const bool small_s = both && !rhs_fused2_supported(&t->A, t->H, t->flags) && rhs_small_supported(&t->A, t->H, t->flags);
     for (int j = 1; j < 7; ++j)
         if ((rc = panel(t, &k[j]))) return rc;
     const float *kall[7] = {a.k[0], k[1], k[2], k[3], k[4], k[5], k[6]};
@@ -277,7 +279,7 @@ int forward_attempt(ndcn_tape *t, Attempt &a, hipStream_t st, HostScratch *hs, d
         cp[mp] = dts * (float)kBeta[i + 1][i + 1];
         t->nfe++;
         RkOpt opt = {};
-        if (t->keep_s && both && rhs_adj_supported(&t->A, t->H, fl, NDCN_RK_COMBINE, mp)) {
+        if (t->keep_s && both && (rhs_adj_supported(&t->A, t->H, fl, NDCN_RK_COMBINE, mp) || small_s)) {
             if ((rc = panel(t, &S[i + 2]))) return rc;
             opt.s_out = S[i + 2];
         }

@@ -155,7 +155,7 @@ def solve(odefunc, y0, t, rtol, atol, options, step_log):
         W, b = odefunc.wt.weight, odefunc.wt.bias
     ticks = [float(v) for v in t.detach().to('cpu', torch.float64)]
     from .autograd_path import _keep_s_enabled
-    keep_s = (not odefunc.no_graph) and (not odefunc.no_control) and odefunc.hidden_size == 256 and _keep_s_enabled(y0)
+    keep_s = (not odefunc.no_graph) and (not odefunc.no_control) and _keep_s_enabled(y0)      # (the library keeps S where a kernel writes it)
     opts = (0.0 if opt['first_step'] is None else 1.0, opt['safety'], opt['ifactor'], opt['dfactor'], float(min(opt['max_num_steps'], 2 ** 53)),
             1.0 if keep_s else 0.0)
     return _TapeDopri5.apply(y0, W, b, (csr, csr_t, flags, odefunc.hidden_size), ticks, rt, at, opts, step_log)
