@@ -937,7 +937,7 @@ def _integrate_dopri5_grad(func, y0, t, rtol, atol, autonomous=False, step_log=N
     core.assert_increasing(t)
     dtype = y0[0].dtype
     targ = core.TimeArg(y0[0], autonomous)
-    tt = t.detach().to('cpu', torch.float64)
+    tt = core.host_grid(t).to(torch.float64)
     opt = core.dopri5_options(options, len(y0))                    # same validation / warnings as the inference path
     max_steps = opt['max_num_steps']
     safety = torch.tensor(opt['safety'], dtype=torch.float64)

@@ -14,6 +14,8 @@ import math
 import warnings
 
 import numpy as np
+import threading
+
 import torch
 
 f32 = np.float32
@@ -88,6 +90,44 @@ class TimeArg:
         return torch.tensor(float(value), dtype=self.like.dtype, device=self.like.device)
 
 
+# ---- the time grid on the host, fetched ONCE per odeint call ------------------------------------------------------------------------
+# The solvers decide on the host: is t increasing, what are the step sizes.  Asked of a device tensor, every such question is a few
+# tiny kernels and a synchronisation - four of them per odeint call before round 5, ~0.1 ms of a 1.9 ms README training step
+# (tools/micro/trace_gaps.py: the largest idle gaps of the loop sat behind their copies).  odeint() brackets its work with
+# grid_scope(t); inside, host_grid(t) answers from the one copy.  (Per call, never across calls: a tensor may be written between them.)
+
+class _GridScope(threading.local):
+    tensor = None
+    host = None
+
+
+_GRID = _GridScope()
+
+
+class grid_scope:
+    def __init__(self, t):
+        self.t = t
+
+    def __enter__(self):
+        self.prev = (_GRID.tensor, _GRID.host)
+        if torch.is_tensor(self.t) and self.t.device.type != 'cpu':
+            _GRID.tensor, _GRID.host = self.t, self.t.detach().to('cpu')
+        return self
+
+    def __exit__(self, *exc):
+        _GRID.tensor, _GRID.host = self.prev
+        return False
+
+
+def host_grid(t):
+    """t as a CPU tensor of its own dtype (the call's one copy when t is the grid odeint was given)"""
+    if t.device.type == 'cpu':
+        return t.detach()
+    if _GRID.tensor is t:
+        return _GRID.host
+    return t.detach().to('cpu')
+
+
 def check_inputs(func, y0, t):
     """misc.py:173-195.  Returns (tensor_input, func_on_tuples, y0_tuple, t, sign)."""
     tensor_input = False
@@ -99,7 +139,8 @@ def check_inputs(func, y0, t):
     assert isinstance(y0, tuple), 'y0 must be either a torch.Tensor or a tuple'
     for y0_ in y0:
         assert torch.is_tensor(y0_), 'each element must be a torch.Tensor but received {}'.format(type(y0_))
-    if bool((t[1:] < t[:-1]).all()):
+    th = host_grid(t)
+    if bool((th[1:] < th[:-1]).all()):
         t = -t
         rev = func
         func = lambda tt, y: tuple(-f_ for f_ in rev(-tt, y))
@@ -112,7 +153,8 @@ def check_inputs(func, y0, t):
 
 
 def assert_increasing(t):
-    assert bool((t[1:] > t[:-1]).all()), 't must be strictly increasing or decrasing'
+    th = host_grid(t)
+    assert bool((th[1:] > th[:-1]).all()), 't must be strictly increasing or decrasing'
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -123,7 +165,7 @@ def integrate_fixed(ops, func, y0, t, method, autonomous=False):
     """solvers.py:79-99 with the default grid (grid == t).  Returns a list (per tick) of tuples."""
     assert_increasing(t)
     dtype = y0[0].dtype
-    tg = t.detach().to('cpu').to(dtype).numpy()          # solvers.py:81: times in the state dtype
+    tg = host_grid(t).to(dtype).numpy()          # solvers.py:81: times in the state dtype
     targ = TimeArg(y0[0], autonomous)
     sol = [y0]
     y = y0
@@ -421,7 +463,7 @@ def integrate_dopri5(ops, func, y0, t, rtol, atol, autonomous=False, step_log=No
     """solvers.py:25-33."""
     assert_increasing(t)
     opt = dopri5_options(options, len(y0))
-    tt = t.detach().to('cpu', torch.float64).numpy()
+    tt = host_grid(t).to(torch.float64).numpy()
     solver = Dopri5(ops, func, y0, rtol, atol, autonomous=autonomous, max_num_steps=opt['max_num_steps'],
                     first_step=opt['first_step'], fused=fused, safety=opt['safety'], ifactor=opt['ifactor'],
                     dfactor=opt['dfactor'])
@@ -580,7 +622,7 @@ def integrate_adams(ops, func, y0, t, rtol, atol, autonomous=False, step_log=Non
     unused = {k: v for k, v in options.items() if k not in ADAMS_OPTIONS}
     if unused:
         warnings.warn('VariableCoefficientAdamsBashforth: Unexpected arguments {}'.format(unused))
-    tt = t.detach().to('cpu', torch.float64).numpy()
+    tt = host_grid(t).to(torch.float64).numpy()
     solver = Adams(ops, func, y0, rtol, atol, autonomous=autonomous, max_order=options.get('max_order', 12),
                    safety=controller_constant(options.get('safety', 0.9)),
                    ifactor=controller_constant(options.get('ifactor', 10.0)),

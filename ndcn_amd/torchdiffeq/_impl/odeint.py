@@ -63,6 +63,13 @@ def _reuse_first_evaluation(func, y0, out):
 
 
 def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_log=None):
+    """Integrate dy/dt = func(t, y), y(t[0]) = y0; returns y at every t (first dim), y0 first.  (The body is `_odeint`; this frame
+    fetches the time grid to the host once for everything below that asks about it: core.grid_scope.)"""
+    with core.grid_scope(t):
+        return _odeint(func, y0, t, rtol, atol, method, options, step_log)
+
+
+def _odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, step_log=None):
     """Integrate dy/dt = func(t, y), y(t[0]) = y0; returns y at every t (first dim), y0 first.
 
     Same signature, defaults, return layout and exceptions as the reference (odeint.py:20-76):
@@ -316,7 +323,7 @@ def _fixed_grid_with_grad(odefunc, y0, t, method):
         return None
     csr, _, flags = op
     core.assert_increasing(t)
-    tt = t.detach().to('cpu').to(y0.dtype)
+    tt = core.host_grid(t).to(y0.dtype)
     dts = (tt[1:] - tt[:-1]).tolist()
     from . import tape
     sol = tape.fixed_grid(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags, method, dts)
@@ -346,7 +353,7 @@ def _small_solve_with_grad(odefunc, y0, t, method='euler'):
     if method != 'euler' and os.environ.get('NDCN_SOLVE_SMALL_RK_GRAD', '1') == '0':
         return None
     core.assert_increasing(t)
-    tt = t.detach().to('cpu').to(y0.dtype)                    # solvers.py:81: the grid in the state dtype
+    tt = core.host_grid(t).to(y0.dtype)                    # solvers.py:81: the grid in the state dtype
     dts = (tt[1:] - tt[:-1]).tolist()
     return _SmallEulerSolve.apply(_lib.require_device(y0, 'state y0').contiguous(), odefunc.wt.weight, odefunc.wt.bias, csr, flags, dts, method)
 
@@ -368,7 +375,8 @@ def _device_resident_ok(user_func, tensor_input, y0, t, method, options):
         return False
     if options.get('first_step') is not None:                  # dopri5.py:82: then 0.01 is used; host logic handles it
         return False
-    if bool((t[1:] < t[:-1]).any()):            # decreasing grids go through the generic sign flip
+    th = core.host_grid(t)
+    if bool((th[1:] < th[:-1]).any()):          # decreasing grids go through the generic sign flip
         return False
     return method != 'adams'                    # adams steps through the host logic (core.Adams) over the panel kernels
 
@@ -547,10 +555,10 @@ def _cached_solver(odefunc, y0, method, rtol, atol, opt, use_graph):
 
 def _device_resident(odefunc, y0, t, rtol, atol, method, options, step_log):
     core.assert_increasing(t)
-    tt = t.detach().to('cpu', torch.float64).tolist()
+    tt = core.host_grid(t).to(torch.float64).tolist()
     if method != 'dopri5':
         # solvers.py:81: the fixed grid is t in the state dtype
-        tt = t.detach().to('cpu').to(y0.dtype).to(torch.float64).tolist()
+        tt = core.host_grid(t).to(y0.dtype).to(torch.float64).tolist()
     if method != 'dopri5' and len(tt) > 1:
         out = _small_solve(odefunc, y0, tt, method)       # a state that fits one compute unit: the whole grid in ONE launch
         if out is not None:

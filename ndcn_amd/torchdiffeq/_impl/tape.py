@@ -153,7 +153,7 @@ def solve(odefunc, y0, t, rtol, atol, options, step_log):
     W = b = None
     if not odefunc.no_control:
         W, b = odefunc.wt.weight, odefunc.wt.bias
-    ticks = [float(v) for v in t.detach().to('cpu', torch.float64)]
+    ticks = core.host_grid(t).to(torch.float64).tolist()
     from .autograd_path import _keep_s_enabled
     keep_s = (not odefunc.no_graph) and (not odefunc.no_control) and _keep_s_enabled(y0)      # (the library keeps S where a kernel writes it)
     opts = (0.0 if opt['first_step'] is None else 1.0, opt['safety'], opt['ifactor'], opt['dfactor'], float(min(opt['max_num_steps'], 2 ** 53)),
