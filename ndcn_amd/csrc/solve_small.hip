@@ -140,20 +140,30 @@ __device__ __forceinline__ float eval_rhs(const SolveArgs &a, const Lds &l, cons
 // (NP passes of a wave could be evaluated together - independent chains of LDS round trips - but measured, that buys nothing: 16
 // waves share 4 SIMDs and the ~1000 instructions a wave issues per Euler step already keep every SIMD busy: 19 k cycles per step
 // with one pass at a time, 23 k with three in a rolled double-buffered form.  What is left is instruction count, not latency.)
+// One ELL row's gather, entries THREE at a time (the host pads the ELL width to a multiple of three with {zero row, 0.0f} entries - adds
+// of +0 x 0 - so there is no tail): the three {offset, value} pairs are requested together, then the three panel values, then the fmas
+// in stored order.  The rolled form (one entry per trip, `#pragma unroll 3`) compiled to two dependent LDS round trips PER ENTRY with a
+// full wait behind each (llvm does not hoist the second entry's reads over the first's fma): a wave's chain of 9 passes x 9 entries x 2
+// round trips was the floor of every phase that gathers (round 5: the disassembly of the reverse sweep).
+__device__ __forceinline__ float ell_gather3(const int2 *row, int width3, const float *T, int o) {
+    float s = 0.f;
+    for (int j = 0; j < width3; j += 3) {
+        const int2 e0 = row[j], e1 = row[j + 1], e2 = row[j + 2];
+        const float x0 = T[e0.x + o], x1 = T[e1.x + o], x2 = T[e2.x + o];
+        s = fmaf(__int_as_float(e0.y), x0, s);
+        s = fmaf(__int_as_float(e1.y), x1, s);
+        s = fmaf(__int_as_float(e2.y), x2, s);
+    }
+    return s;
+}
+
 template <int HT, int NP>
 __device__ __forceinline__ void eval_fast(const int2 *ell, int width, const float *T, float *srow, const float (&wreg)[HT ? HT : 1],
                                           const int (&r)[NP], const bool (&valid)[NP], int q, int o, int lane, float bias_o, int relu,
                                           float (&out)[NP], float (&s)[NP]) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int2 *row = ell + (valid[p] ? r[p] : 0) * width;
-        float acc = 0.f;
-#pragma unroll 3
-        for (int j = 0; j < width; ++j) {
-            const int2 en = row[j];
-            acc = fmaf(__int_as_float(en.y), T[en.x + o], acc);
-        }
-        s[p] = acc;
+        s[p] = ell_gather3(ell + (valid[p] ? r[p] : 0) * width, width, T, o);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -848,15 +858,7 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
             if ((it * kWaves + wave) * RPW >= b.n_rows) break;
             const int r = (it * kWaves + wave) * RPW + q;
             const bool valid = lane_on && r < b.n_rows;
-            float s = 0.f;
-            {
-                const int2 *row = ell + (valid ? r : 0) * width;
-#pragma unroll 3
-                for (int j = 0; j < width; ++j) {
-                    const int2 en = row[j];
-                    s = fmaf(__int_as_float(en.y), T[en.x + o], s);
-                }
-            }
+            const float s = ell_gather3(ell + (valid ? r : 0) * width, width, T, o);
             __builtin_amdgcn_wave_barrier();
             srow[lane] = s;
             __builtin_amdgcn_wave_barrier();
@@ -946,15 +948,7 @@ __global__ __launch_bounds__(1024) void solve_small_bwd_fast_kernel(BwdArgs b, i
             if ((it * kWaves + wave) * RPW >= b.n_rows) break;
             const int r = (it * kWaves + wave) * RPW + q;
             const bool valid = lane_on && r < b.n_rows;
-            float s = 0.f;
-            {
-                const int2 *row = ell + (valid ? r : 0) * width;
-#pragma unroll 3
-                for (int j = 0; j < width; ++j) {
-                    const int2 en = row[j];
-                    s = fmaf(__int_as_float(en.y), T[en.x + o], s);
-                }
-            }
+            const float s = ell_gather3(ell + (valid ? r : 0) * width, width, T, o);
             if (valid) S[r * H + o] = s;
         }
         {
@@ -1046,9 +1040,9 @@ int solve_small_keep_supported(const ndcn_csr *A, int H, uint32_t flags) {
     static const bool fast_on = [] { const char *e = getenv("NDCN_SOLVE_SMALL_FAST"); return !(e && e[0] == '0'); }();
     if (!on || !fast_on || !solve_small_bwd_supported(A, H, flags, NDCN_M_EULER)) return 0;
     if (!(H == 16 || H == 20) || (flags & (NDCN_F_NO_GRAPH | NDCN_F_NO_CONTROL)) || A->symmetric != 1) return 0;
-    const int width = A->max_row_len;
+    const int width = (A->max_row_len + 2) / 3 * 3;
     const int64_t n_elem = A->n_rows * (int64_t)H;
-    if (width < 1 || width > 16) return 0;
+    if (A->max_row_len < 1 || width > 18) return 0;
     if (lds_bytes_fast(n_elem, A->n_rows, width, H) > kLdsMax || lds_bytes_fast(4 * n_elem, A->n_rows, width, H) > kLdsMax) return 0;
     const int NBh = H / 4;
     const int n_groups = std::max(1, std::min<int>(1024 / (NBh * NBh + NBh), (int)A->n_rows));
@@ -1069,7 +1063,8 @@ int solve_small_f32(const ndcn_csr *A, const float *W, const float *b, int H, ui
     if (fast) {
         int rc = ell_width(A, st, &width);
         if (rc) return rc;
-        fast = width >= 1 && width <= 16 && lds_bytes_fast(n_elem, A->n_rows, width, H) <= kLdsMax;
+        width = (width + 2) / 3 * 3;                           // ell_gather3: entries three at a time
+        fast = width >= 1 && width <= 18 && lds_bytes_fast(n_elem, A->n_rows, width, H) <= kLdsMax;
     }
     const size_t lds = fast ? lds_bytes_fast(n_elem, A->n_rows, width, H) : lds_bytes(n_elem, H, A->n_rows, nnz, csr);
     const int np = passes(A->n_rows, H);
@@ -1229,9 +1224,9 @@ int solve_small_bwd_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, c
         const int n_groups = std::max(1, std::min<int>(1024 / (NBh * NBh + NBh), (int)A->n_rows));
         const int rows_per_group = (int)((A->n_rows + n_groups - 1) / n_groups);
         int width = 0;
-        if (fast_shape) { int rcw = ell_width(A, st, &width); if (rcw) return rcw; }
+        if (fast_shape) { int rcw = ell_width(A, st, &width); if (rcw) return rcw; width = (width + 2) / 3 * 3; }
         const size_t lds_fast = lds_bytes_fast(4 * n_elem, A->n_rows, width, H);
-        const bool fast = fast_shape && width >= 1 && width <= 16 && lds_fast <= kLdsMax && (int64_t)n_groups * (H * H + H) <= 3 * n_elem;
+        const bool fast = fast_shape && width >= 1 && width <= 18 && lds_fast <= kLdsMax && (int64_t)n_groups * (H * H + H) <= 3 * n_elem;
         a.width = width;
         if (method != NDCN_M_EULER) {
 #define NDCN_RGO(M_, IT_, C_)                                                                  \
