@@ -104,10 +104,11 @@ def parse():
     p.add_argument('--no-at-scale', action='store_true', help='skip cpu_baseline.at_scale (one oracle RHS + one solver step at ~10^5 nodes)')
     p.add_argument('--no-profile-pass', action='store_true')
     p.add_argument('--sharded', action='store_true', help='force the multi-GPU code path (works with 1 rank)')
-    p.add_argument('--sharded-impl', default=os.environ.get('NDCN_SHARDED_IMPL', 'python'), choices=['device', 'python'],
-                   help='N > 1: the Python-stepped path over torch.distributed (default: its collectives are PyTorch\'s own '
-                        'RCCL calls, and it is the form the 2- and 8-rank tests run) or the sharded device-resident solver behind '
-                        'the C ABI (RCCL communicator of the library; has run with one rank only - opt in on a multi-GPU box)')
+    p.add_argument('--sharded-impl', default=os.environ.get('NDCN_SHARDED_IMPL', 'device'), choices=['device', 'python'],
+                   help='N > 1: the sharded device-resident solver behind the C ABI (default: the form DESIGN section 6 projects - the '
+                        'library\'s RCCL communicator, halo exchange inside the step loop; passes with world = 8 over the loopback '
+                        'transport, tests/test_gpu_eight_ranks.py; every precondition that can fail on one rank is all-reduced and '
+                        'the run falls back COLLECTIVELY) or the Python-stepped path over torch.distributed')
     p.add_argument('--config', default='M', choices=['M', 'C2', 'C3', 'C4', 'C5'], help='workload (default M = the metric\'s own case)')
     p.add_argument('--no-control', action='store_true', help='config M with ODEFunc(no_control=True): relu(A X), the pure HBM right-hand side (neural_dynamics.py:32)')
     p.add_argument('--layout', default=None, choices=['degree', 'community'], help='C2 / C3: node re-labelling (--layout of the drivers)')

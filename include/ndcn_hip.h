@@ -649,12 +649,14 @@ NDCN_API int ndcn_debug_last_rhs_path(void);
  * with the launches of the per-operation path (same kernels, same order: bit-identical values and accept / reject decisions) and
  * records every attempted step; ndcn_tape_backward_f32 turns g_out (n_t panels: the gradient of the trajectory) into the gradients
  * of y0, W and b - the panel operations' VJP kernels of this header plus the adjoint of the step-size controller's scalar chain
- * (dt, t0 / t1, the initial step and the interpolation abscissa carry gradient in the reference: csrc/tape.hip).  Once per tape.
+ * (dt, t0 / t1, the initial step and the interpolation abscissa carry gradient in the reference: csrc/tape.hip).  The reverse pass
+ * may run any number of times over one tape (retain_graph, Jacobian rows): it only reads the record; memory it asks `alloc` for is
+ * scratch of that call and may be released when the call returns (stream-ordered).
  * opts: {first_step given (0 / 1), safety, ifactor, dfactor, max_num_steps, keep S (0 / 1: evaluations that can - ndcn_rhs_adj_supported -
  * also store S = A u on the tape, one panel more per evaluation, instead of one SpMM per evaluation in the reverse pass)}.
  * At: the transposed operator (unused with NDCN_F_NO_GRAPH).
- * alloc: device memory for the tape (12 panels per attempted step; ~24 more during the reverse pass), owned by the caller and kept
- * until ndcn_tape_destroy.  y0, W, b and the operators must stay valid and unchanged until then.
+ * alloc: device memory for the tape (12 panels per attempted step; ~24 more during a reverse pass), owned by the caller; what
+ * ndcn_tape_dopri5_f32 asked for is kept until ndcn_tape_destroy.  y0, W, b and the operators must stay valid and unchanged until then.
  * Errors as the solver's: NDCN_EMAXSTEPS, NDCN_EUNDERFLOW, NDCN_ENONFINITE; the tape handle is set on every path - destroy it.     */
 typedef struct ndcn_tape ndcn_tape;
 typedef void *(*ndcn_alloc_fn)(void *ctx, int64_t bytes);

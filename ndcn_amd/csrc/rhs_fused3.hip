@@ -164,7 +164,10 @@ constexpr int kF3EpiKernargOffset = (int)((sizeof(F3Args) + 7) / 8 * 8);       /
 // NT: the epilogue's stores carry the non-temporal hint - right for panels far beyond the 256 MiB Infinity Cache (the metric's 1 GB
 // panels: 8.35 against 8.58 ms per step without it), wrong for panels that live in it and are read right back by the next launch
 // (BASELINE config 2, 102 MB: 1.323 against 1.290 ms per RK4 step); the launcher decides by the panel's size
-template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false>
+// NOK: the store of K compiled out (RkOpt::no_k) - a template argument, instantiated only for the two launches that use it (COMBINE
+// with no earlier stage: an Euler step / midpoint's second stage; RK4's fourth stage), so that the dopri5 variants carry no branch
+// for it (as a run-time test of a.K it cost every variant 241 instructions and 33 waits: round-5 review)
+template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false, bool NOK = false>
 __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fused3_kernel(F3Args a, F3Epi epi_by_kernarg_only) {
     constexpr bool XADD = XOP != 0;                          // a second panel is gathered alongside X
     static_assert(!(XADD && HALO), "the halo rows of Xadd are not exchanged");
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
     // RK epilogue of one K row (as rhs_fused2.hip: epi_finish)
     auto epilogue = [&](int row, f32x4 kn, const Panels &p) {
         const int voff = (row << 10) + lane_off;
-        if (a.K) {                                                  // (uniform; null: RkOpt::no_k - only y_next is wanted)
+        if constexpr (!NOK) {                                       // (RkOpt::no_k: only y_next is wanted)
             stp(a.K, voff, kn);
             issued(1);
         }
@@ -676,9 +679,9 @@ int rhs_xadd_supported(const ndcn_csr *A, int H, uint32_t flags, int mode, int n
     return ((mode == F3_COMBINE || mode == F3_ERROR) && n_prev == 1) ? 1 : 0;
 }
 
-template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false>
+template <bool HALO, int MODE, int NP, int XOP = 0, bool NT = true, bool SOUT = false, bool NOK = false>
 static int launch_f3(const F3Args &a, const F3Epi &e, dim3 grid, hipStream_t st) {
-    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XOP, NT, SOUT>;
+    auto kern = rhs_fused3_kernel<HALO, MODE, NP, XOP, NT, SOUT, NOK>;
     static std::atomic<unsigned long long> attr_seen{0};
     if (once_per_device(attr_seen)) {
         NDCN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF3Lds));
@@ -695,8 +698,9 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     if (!rhs_fused3_variant(mode, n_prev)) { set_error("rhs_fused3: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     F3Args a;
     a.rec = A->rec; a.n_groups = A->rec_groups; a.X = X; a.Xh = Xh; a.n_own = (int)n_own; a.Wq = Wq; a.bias = b; a.K = K;
-    const bool skip_k = opt && opt->no_k && (mode == F3_COMBINE || mode == F3_RK4) && y_next;
-    if (skip_k) a.K = nullptr;
+    // (the hint is honoured where a kernel without the store exists: the launches the fixed grids issue with it)
+    const bool skip_k = opt && opt->no_k && y_next && !opt->xmask && !opt->xadd && !opt->s_out && !(opt->y_aux && opt->c_aux) &&
+                        ((mode == F3_COMBINE && n_prev == 0) || (mode == F3_RK4 && n_prev == 3));
     const bool masked = opt && opt->xmask;
     a.Xadd = masked ? opt->xmask : ((opt && opt->xadd) ? opt->xadd : nullptr);
     a.xadd_c = (a.Xadd && !masked) ? opt->xadd_c : 0.f;
@@ -775,7 +779,17 @@ int rhs_fused3_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
             default: if (cached) rc = launch_f3<false, F3_COMBINE, 4, XOP_, false, SOUT_>(a, e, grid, st); else rc = launch_f3<false, F3_COMBINE, 4, XOP_, true, SOUT_>(a, e, grid, st); break; \
         }                                                                                           \
     } while (0)
-    if (masked) NDCN_F3_ADJ(2, false);
+    if (skip_k) {
+        if (mode == F3_COMBINE) {
+            if (Xh) rc = launch_f3<true, F3_COMBINE, 0, 0, true, false, true>(a, e, grid, st);
+            else if (cached) rc = launch_f3<false, F3_COMBINE, 0, 0, false, false, true>(a, e, grid, st);
+            else rc = launch_f3<false, F3_COMBINE, 0, 0, true, false, true>(a, e, grid, st);
+        } else {
+            if (Xh) rc = launch_f3<true, F3_RK4, 3, 0, true, false, true>(a, e, grid, st);
+            else if (cached) rc = launch_f3<false, F3_RK4, 3, 0, false, false, true>(a, e, grid, st);
+            else rc = launch_f3<false, F3_RK4, 3, 0, true, false, true>(a, e, grid, st);
+        }
+    } else if (masked) NDCN_F3_ADJ(2, false);
     else if (a.S_out) NDCN_F3_ADJ(0, true);
     else if (a.Xadd) {
         if (mode == F3_COMBINE) rc = launch_f3<false, F3_COMBINE, 1, 1>(a, e, grid, st);

@@ -61,6 +61,7 @@ struct HostScratch {                   // per host thread: pinned mirror of the 
 };
 
 constexpr int kDotSlots = 40;          // 8 doubles each
+constexpr int kDenseBatch = 24;        // dense-output groups (<= 7 ticks each) whose inner products one read-back carries; the other slots: error + 6 rows
 
 int host_scratch(HostScratch **out) {
     static thread_local HostScratch hs;
@@ -114,7 +115,9 @@ struct ndcn_tape {
     bool packed = false;
     void *bwork = nullptr;             // linear_bwd scratch
     bool bpacked = false;
-    bool done_backward = false;
+    bool bwd_marked = false;           // arena position behind the forward record: every reverse pass starts its scratch there
+    char *mark_chunk = nullptr;
+    size_t mark_left = 0;
 };
 
 namespace {
@@ -591,8 +594,18 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
     NDCN_CHECK_ARG(t && g_out && g_y0, "bad argument");
     const bool no_control = t->flags & NDCN_F_NO_CONTROL;
     NDCN_CHECK_ARG(no_control || (g_W && (g_b || !t->b)), "g_W / g_b missing");
-    NDCN_CHECK_ARG(!t->done_backward, "the tape's reverse pass has run already");
-    t->done_backward = true;
+    // The reverse pass may run more than once over one forward record (loss.backward(retain_graph=True), several torch.autograd.grad
+    // calls, a retry after a failed pass): the record is only read; the scratch of a pass is carved from the arena at the mark the FIRST
+    // pass found, the caller frees the blocks a pass asked for when it returns (the forward record's blocks live until ndcn_tape_destroy).
+    if (!t->bwd_marked) {
+        t->bwd_marked = true;
+        t->mark_chunk = t->chunk;
+        t->mark_left = t->chunk_left;
+    } else {
+        t->chunk = t->mark_chunk;
+        t->chunk_left = t->mark_left;
+    }
+    t->bpacked = false;                            // (the packed W^T lives in this pass's scratch)
     hipStream_t st = static_cast<hipStream_t>(stream);
     HostScratch *hs;
     int rc = host_scratch(&hs);
@@ -665,15 +678,41 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
             cur_gk[0] = Gf;
         }
         // ---- dense output of the ticks this step covers (interp.py:21-65)
-        int dense_slot[16], n_dense = 0;
+        // (a step that covers more ticks than the slots hold - a dense time grid over a long accepted step - hands its inner products
+        // over in batches: read, added to the scalar adjoints, slots re-armed)
+        double g_dts = 0.0;                        // adjoint of the float32 step size dts = float(dt)
+        double g_a0 = 0.0, g_a1 = 0.0;
+        int dense_slot[kDenseBatch], dense_group[kDenseBatch], n_dense = 0;
+        auto take_dense = [&](const double *h) {
+            for (int di = 0; di < n_dense; ++di) {
+                const DenseGroup &g = t->groups[(size_t)dense_group[di]];
+                const double *d = h + 8 * dense_slot[di];
+                g_dts += (double)(float)d[7];
+                const float w = g.a1 - g.a0;
+                for (int q = 0; q < g.nt; ++q) {
+                    const float gx = (float)d[q];
+                    // x = (at - a0) / (a1 - a0):  dx/da0 = (x - 1) / (a1 - a0),  dx/da1 = -x / (a1 - a0)
+                    g_a0 += (double)(gx * ((g.x[q] - 1.f) / w));
+                    g_a1 += (double)(gx * (-g.x[q] / w));
+                }
+            }
+            n_dense = 0;
+        };
         for (int gi = (int)a.dense.size() - 1; gi >= 0; --gi) {
             const DenseGroup &g = t->groups[(size_t)a.dense[(size_t)gi]];
             const float *hg[7];
             for (int q = 0; q < g.nt; ++q) hg[q] = g_out + (size_t)g.tick[q] * n;
-            if (n_dense >= 16 || slot >= kDotSlots - 8) { set_error("tape: too many dense-output groups in one step"); return NDCN_EINVAL; }
+            if (n_dense == kDenseBatch) {
+                rc = fetch(t, t->d_dots, 8 * slot, st, hs);
+                if (rc) return rc;
+                take_dense(hs->h);
+                slot = 0;
+                if (hs->h_dev) rec_arm(hs->h, kDotSlots * 8);
+            }
             rc = rk_dense_bwd_multi_f32(hg, g.nt, a.y0, a.u[7], a.k, a.dts, g.x, own_gy0, own_gy1, own_gk, cur_gy0, cur_gy1, cur_gk,
                                         dots_at(slot), t->d_bws, n, st);
             if (rc) return rc;
+            dense_group[n_dense] = a.dense[(size_t)gi];
             dense_slot[n_dense++] = slot++;
             cur_gy0 = own_gy0;
             cur_gy1 = own_gy1;
@@ -780,25 +819,11 @@ int ndcn_tape_backward_f32(ndcn_tape *t, const float *g_out, float *g_y0, float 
         }
         pp = 1 - pp;
         // ---- scalar chain, part 2: one read of the attempt's inner products
-        double g_dts = 0.0;                        // adjoint of the float32 step size dts = float(dt)
-        double g_a0 = 0.0, g_a1 = 0.0;
         if (slot > 0) {
             rc = fetch(t, t->d_dots, 8 * slot, st, hs);
             if (rc) return rc;
             const double *h = hs->h;
-            int di = 0;
-            for (int gi = (int)a.dense.size() - 1; gi >= 0; --gi, ++di) {
-                const DenseGroup &g = t->groups[(size_t)a.dense[(size_t)gi]];
-                const double *d = h + 8 * dense_slot[di];
-                g_dts += (double)(float)d[7];
-                const float w = g.a1 - g.a0;
-                for (int q = 0; q < g.nt; ++q) {
-                    const float gx = (float)d[q];
-                    // x = (at - a0) / (a1 - a0):  dx/da0 = (x - 1) / (a1 - a0),  dx/da1 = -x / (a1 - a0)
-                    g_a0 += (double)(gx * ((g.x[q] - 1.f) / w));
-                    g_a1 += (double)(gx * (-g.x[q] / w));
-                }
-            }
+            take_dense(h);
             if (err_slot >= 0) {
                 const double *d = h + 8 * err_slot;
                 for (int q = 0; q < err_m; ++q) g_dts += (double)((float)((double)g_r * d[q]) * (float)kCErr[err_idx[q]]);

@@ -10,6 +10,7 @@ trajectory (T x N x H) is kept between the two passes.
 import torch
 import torch.nn as nn
 
+from . import core
 from .odeint import odeint
 
 
@@ -104,7 +105,10 @@ class _AdjointMethod(torch.autograd.Function):
             # the reverse pass on the fused launches of the inference path (adjoint_fused.py): stage algebra in the epilogues of the
             # forward launch and of the transposed launch; the closure above serves the initial step of every interval only
             from . import adjoint_fused
-            if adjoint_fused.applicable(native, ans[0]):
+            # integrate_interval runs in tau = -t from -t[i] UP to -t[i-1]: an increasing grid only.  A decreasing grid (the forward
+            # pass went through odeint's sign flip, misc.py:184-187) keeps the generic odeint(augmented, ...) branch below
+            th = core.host_grid(t)
+            if bool((th[1:] > th[:-1]).all()) and adjoint_fused.applicable(native, ans[0]):
                 fused = adjoint_fused
                 fused_w = adjoint_fused._Weights(native)
                 native_rhs = augmented

@@ -393,6 +393,7 @@ class DeviceSolver:
         H = odefunc.hidden_size
         flags = _lib.F_RELU | (_lib.F_NO_GRAPH if odefunc.no_graph else 0) | (_lib.F_NO_CONTROL if odefunc.no_control else 0)
         dev = odefunc.wt.weight.device
+        self.csr = None
         if shard is not None:
             csr = shard.operator(H)
             assert csr.shape[0] == n_rows
@@ -409,6 +410,7 @@ class DeviceSolver:
             csr.ensure_plans(H)
             view = csr.view()
             self._keep = (csr,)
+            self.csr = csr
         W = odefunc.wt.weight.detach().contiguous()
         b = odefunc.wt.bias.detach().contiguous() if odefunc.wt.bias is not None else None
         _lib.require_device(W, 'weight')
@@ -537,6 +539,16 @@ def _cached_solver(odefunc, y0, method, rtol, atol, opt, use_graph):
            float(rtol), float(atol), tuple(sorted((k, v) for k, v in opt.items() if v is not None)), y0.device.index,
            torch.cuda.current_stream(y0.device).cuda_stream, bool(odefunc.no_graph), bool(odefunc.no_control))
     hit = _SOLVERS.get(key)
+    if hit is not None and not odefunc.no_graph:
+        # id(A) names an object, not its contents: an in-place write to A re-converts (csr.as_csr keys on A._version), and a new
+        # tensor may re-use a freed one's id - the kept solver's captured graph would go on reading the OLD operator arrays that
+        # its _keep holds alive.  The CsrOperator the solver was built on must be the one the operator converts to now.
+        from ...csr import as_csr
+        if getattr(hit[1], 'csr', None) is not as_csr(odefunc.A):
+            del _SOLVERS[key]
+            if not getattr(hit[1], '_in_use', False):
+                hit[1].close()
+            hit = None
     if hit is not None and hit[0]() is odefunc and not getattr(hit[1], '_in_use', False) and hit[1].handle:
         _SOLVERS.move_to_end(key)
         hit[1]._in_use = True

@@ -92,17 +92,21 @@ class _TapeDopri5(torch.autograd.Function):
         ctx.has = (W is not None, b is not None)
         # (the library reads y0 / W / b again in the reverse pass: saved through autograd, so that an in-place change between forward
         # and backward raises instead of giving a gradient at other parameters - round-4 advisor on the fixed-grid Functions)
-        ctx.save_for_backward(y0, W, b)
+        # The forward record's device blocks ride along as saved tensors: autograd releases them with the graph - after the first
+        # backward unless retain_graph - and a reverse pass over a released graph raises autograd's own "second time" error; with
+        # retain_graph the record stays and the pass runs again (round-5 advisor: the reference's graph is re-runnable)
+        blocks, tape.blocks = tape.blocks, []
+        ctx.n_lead = 3
+        ctx.save_for_backward(y0, W, b, *blocks)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         tape = ctx.tape
+        record = ctx.saved_tensors                  # version check of y0 / W / b; raises once the graph (and with it the record) is released
         if tape is None or not tape.handle:
-            raise RuntimeError('Trying to backward through the dopri5 tape a second time: its panels are freed by the first reverse pass '
-                               '(solve again; the per-operation graph, NDCN_GRAD_TAPE=0, honours retain_graph)')
-        ctx.saved_tensors                           # (version check of y0 / W / b)
+            raise RuntimeError('the dopri5 tape of this solve has been destroyed')
         y0c, Wc, bc, csr, csr_t = ctx.keep
         g = g.contiguous()
         gy = torch.empty_like(y0c)
@@ -117,8 +121,8 @@ class _TapeDopri5(torch.autograd.Function):
                     raise tape.error
                 check(rc)
         finally:
-            tape.close()                            # (kernels still queued read the blocks: the caching allocator reuses them stream-ordered)
-            ctx.tape = ctx.keep = None
+            tape.blocks = []                        # this pass's scratch (kernels still queued read it: the caching allocator reuses blocks stream-ordered)
+            del record
         needs = ctx.needs_input_grad
         return (gy if needs[0] else None, gW if (needs[1] and ctx.has[0]) else None, gb if (needs[2] and ctx.has[1]) else None,
                 None, None, None, None, None, None)
@@ -188,16 +192,18 @@ class _NativeFixedGrid(torch.autograd.Function):
             if err is not None:
                 raise err
             check(rc)
-        ctx.keep = (out, Wc, bc, csr, flags, method, arr, n_ticks)
+        ctx.keep = (Wc, bc, csr, flags, method, arr, n_ticks)
         ctx.has = (W is not None, b is not None)
-        ctx.save_for_backward(W, b)                 # (version check in backward; `out` is this node's own output)
+        # `out` is this node's own output: saved through autograd (no out -> grad_fn -> ctx -> out cycle that only the cyclic collector
+        # would break - a (T, N, H) trajectory - and an in-place edit of the returned trajectory before backward raises)
+        ctx.save_for_backward(out, W, b)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        ctx.saved_tensors
-        out, Wc, bc, csr, flags, method, arr, n_ticks = ctx.keep
+        out = ctx.saved_tensors[0]
+        Wc, bc, csr, flags, method, arr, n_ticks = ctx.keep
         lib = _lib.load()
         g = g.contiguous()
         no_control = bool(flags & _lib.F_NO_CONTROL)

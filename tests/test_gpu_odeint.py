@@ -725,8 +725,24 @@ def test_large_grid_properties(dev):
     ref = orc.spmm_f64(sub.indptr, sub.indices, sub.data, X.cpu().numpy())
     assert np.abs(got - ref).max() < 1e-5
     del Z, lin
-    # solver agreement at full size
+    # the FUSED right-hand side at the metric's size (rhs_fused3: the launch bench.py times) against fp64 on sampled rows - first, middle
+    # and last patches of the lattice plan - directly, not through another HIP path; then the same rows out of a launch that carries
+    # an RK epilogue (the dopri5 stage-3 form): K the same bits, y_next = y0 + c1 k1 + c2 K against fp64
     f = ODEFunc(H, A).to(dev).eval()
+    rows = np.r_[0:64, 1000:1032, 499968:500064, S * S - 64:S * S]
+    _sampled_rhs_check(L, A, f, X, dev, rows)
+    from ndcn_amd import _lib
+    assert _lib.load().ndcn_debug_last_rhs_path() == _lib.PATH_FUSED3
+    ridx = torch.from_numpy(rows).to(dev)
+    k1 = torch.rand(S * S, H, device=dev)
+    y0 = torch.rand(S * S, H, device=dev)
+    K0 = hip.rhs(A, X, f.wt.weight, f.wt.bias)[ridx]
+    K, yn = hip.rhs_rk(A, X, f.wt.weight.detach(), f.wt.bias.detach(), 'combine', y0, [k1], [0.075, 0.225])
+    assert torch.equal(K[ridx], K0)
+    want = y0[ridx].double() + (0.075 * k1[ridx].double() + 0.225 * K0.double())
+    assert float((yn[ridx].double() - want).abs().max()) < 4e-7 * float(want.abs().max())
+    del k1, y0, K, yn
+    # solver agreement at full size
     x0 = torch.rand(S * S, H, device=dev)
     t = torch.tensor([0., 0.6], device=dev)
     with torch.no_grad():

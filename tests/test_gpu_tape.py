@@ -128,7 +128,9 @@ def test_tape_without_polled_records(dev):
     assert ' passed' in r.stdout and 'failed' not in r.stdout
 
 
-def test_second_backward_through_the_tape_is_refused(dev):
+def test_second_backward_through_the_tape(dev):
+    """retain_graph keeps the forward record (its device blocks are saved tensors of the node): the reverse pass runs again and gives the
+    same gradient; once the graph is released, autograd's own error (round-5 advisor: the reference's graph is re-runnable)"""
     from ndcn_amd import graphs
     from ndcn_amd import torchdiffeq as ode
     from ndcn_amd.neural_dynamics import ODEFunc
@@ -136,9 +138,60 @@ def test_second_backward_through_the_tape_is_refused(dev):
     f = ODEFunc(16, graphs.to_device(op, dev)).to(dev)
     x0 = torch.rand(100, 16, device=dev, requires_grad=True)
     y = ode.odeint(f, x0, torch.tensor([0., 0.5, 1.0], device=dev), rtol=1e-3, atol=1e-4, method='dopri5')
+    assert type(y.grad_fn).__name__.startswith('_TapeDopri5')
     y.sum().backward(retain_graph=True)
+    g1, w1 = x0.grad.clone(), f.wt.weight.grad.clone()
+    x0.grad = None
+    f.zero_grad(set_to_none=True)
+    # Jacobian rows: several grad calls over one solve
+    rows = [torch.autograd.grad(y[2, i].sum(), x0, retain_graph=True)[0] for i in range(2)]
+    assert not torch.equal(rows[0], rows[1])
+    y.sum().backward()
+    assert torch.equal(x0.grad, g1) and torch.equal(f.wt.weight.grad, w1)
     with pytest.raises(RuntimeError, match='second time'):
         y.sum().backward()
+
+
+def test_tape_with_more_ticks_in_a_step_than_one_read_back_carries(dev):
+    """a dense time grid over few accepted steps: > 24 dense-output groups (7 ticks each) inside one step - their inner products come
+    back in batches (round-5 advisor: EINVAL 'too many dense-output groups' in backward only)"""
+    from ndcn_amd import graphs
+    from ndcn_amd.neural_dynamics import ODEFunc
+    side, H = 10, 16
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    ticks = list(np.linspace(0., 2., 600))
+    x0 = torch.rand(side * side, H, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(len(ticks), side * side, H, generator=torch.Generator().manual_seed(1))
+
+    def make():
+        torch.manual_seed(0)
+        return ODEFunc(H, graphs.to_device(op, dev)).to(dev)
+
+    ya, la, ga = _solve(dev, True, make, x0, ticks, 1e-2, 1e-3, w)
+    yb, lb, gb = _solve(dev, False, make, x0, ticks, 1e-2, 1e-3, w)
+    assert la == lb and torch.equal(ya, yb)
+    steps = [r for r in la if r[0] != 'nfe']
+    assert len(ticks) / max(len(steps), 1) > 7 * 24, (len(steps), 'the case must put > 24 groups into one step')
+    for a, b in zip(ga, gb):
+        assert rel(a, b) < 2e-4, rel(a, b)
+
+
+def test_in_place_edit_of_a_fixed_grid_trajectory_before_backward_is_refused(dev):
+    """the reverse pass re-forms the stages from the returned trajectory: it is saved through autograd (round-5 advisor)"""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    side, H = 24, 256                                                   # (beyond the one-launch solve: _NativeFixedGrid)
+    op = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    f = ODEFunc(H, graphs.to_device(op, dev)).to(dev)
+    x0 = torch.rand(side * side, H, device=dev, requires_grad=True)
+    y = ode.odeint(f, x0, torch.linspace(0., 1., 5, device=dev), method='rk4')
+    assert type(y.grad_fn).__name__.startswith('_NativeFixedGrid')
+    loss = (y * 1.0).sum()
+    with torch.no_grad():
+        y[2].mul_(2.0)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        loss.backward()
 
 
 @pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])

@@ -9,6 +9,7 @@
 #                                bench line (which picks that summary up as roofline.traffic) -> TAG_bench_configs.jsonl
 #   ab "K=V ..." ["K=V ..."]     A/B of environment knobs inside ONE box: ms/step + rocprofv3 per-variant kernel averages
 #   abbuild                      A/B of library builds inside one box: the default build vs every gpurun_in_*.so
+#   abalt ROUNDS [bench flags]   the same, ALTERNATING (A B A B ...): ms/step + per-variant kernel averages per run
 #   timing                       fused3 cycle accounting (needs a -DNDCN_F3_TIMING build)
 #   sq                           SQ issue / stall counters of the fused RHS kernels
 #   power                        power / clock samples while the bench runs
@@ -133,6 +134,19 @@ abbuild)
     for f in gpurun_in_*.so; do [ -f "$f" ] || continue; cp "$f" ndcn_amd/libndcn_hip.so; echo "=== $f"; run "build_$(basename $f .so)"; done
     cp /tmp/default.so ndcn_amd/libndcn_hip.so
   } 2>&1 | tee gpurun_out/exp_ab.log
+  ;;
+abalt)
+  # abalt ROUNDS [bench flags]: ALTERNATING runs of the default build and every gpurun_in_*.so inside one box (A B A B ...), per run
+  # ms/step and the rocprofv3 per-variant kernel averages -> gpurun_out/exp_abalt.log.  Box class: the <1,4> launch's average
+  # (1.52 ms fast class / 1.73 ms slow class).
+  ROUNDS=${1:-3}; shift || true
+  cp ndcn_amd/libndcn_hip.so /tmp/default.so
+  { for r in $(seq 1 $ROUNDS); do
+      cp /tmp/default.so ndcn_amd/libndcn_hip.so; echo "=== round $r default"; kernel_stats "abalt_default_$r" "$@"
+      for f in gpurun_in_*.so; do [ -f "$f" ] || continue; cp "$f" ndcn_amd/libndcn_hip.so; echo "=== round $r $f"; kernel_stats "abalt_$(basename $f .so)_$r" "$@"; done
+    done
+    cp /tmp/default.so ndcn_amd/libndcn_hip.so
+  } 2>&1 | tee gpurun_out/exp_abalt.log
   ;;
 gaps)
   # timeline of one bench run: idle time between consecutive kernels (host round trips of the adaptive controller)
