@@ -129,7 +129,7 @@ struct F3Args {
     const int *rowptr, *colidx;      // direct gather of groups the plan could not stage
     const float *val;
     unsigned long long *dbg_cycles;  // NDCN_FUSED3_TIMING: per (block, wave) {cycles between barriers, cycles inside barriers}
-    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 64 no weight refills
+    int dbg;                         // NDCN_FUSED3_DBG (timing experiments, results wrong): 1 no MFMA, 2 no fold, 4 no epilogue, 8 staged rows from a 1 MiB window, 64 no weight refills
 };
 // the experiment switches exist in timing builds only (in the product they would cost scalar registers and branches)
 __device__ __forceinline__ int f3_dbg(const F3Args &a) { return kF3Timing ? a.dbg : 0; }
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(64 * (f3_producers(MODE, NP) + kF3WM)) void rhs_fus
         for (int k = 0; k < kF3CapD; ++k) {
             const float *base = a.X;
             int c = cc[k];
+            if (f3_dbg(a) & 8) c &= 1023;                        // (timing builds: every staged row out of a 1 MiB window - the launch without its gather's HBM side)
             if (HALO && c >= a.n_own) { base = a.Xh; c -= a.n_own; }
             dma_row(base + (size_t)c * 256, lds_x + (unsigned)(((it % kF3NBuf) * kF3Cap + pw * kF3CapD + k) * 1024), lane_off);
         }

@@ -51,6 +51,7 @@ struct SweepArgs {
     int rows_per_xcd, rpw;
     uint32_t *epoch;            // this pass's launch counter (device memory: a hipGraph replay must see a new tag too)
     int nblk, logb, window;
+    int dbg;                    // NDCN_SWEEP_DBG (timing experiments, results wrong): 1 = the finished rows are not stored
 };
 
 // register map inside the asm (all clobbered):
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void spmm_sweep_kernel(SweepArgs 
         "s_waitcnt vmcnt(0)\n"
         :
         : [voff] "v"(voff), [rsx] "s"(rsx), [rsy] "s"(rsy), [ent] "s"(p), [ngrp] "s"(ngrp), [prog] "s"(prog), [etag] "s"(etag),
-          [nblk] "s"(a.nblk), [slot4] "s"(slot * 4), [nvalid] "s"(nvalid), [logb] "s"(a.logb), [window] "s"(a.window), [wm1] "s"(wm1)
+          [nblk] "s"(a.nblk), [slot4] "s"(slot * 4), [nvalid] "s"((a.dbg & 1) ? 0 : nvalid), [logb] "s"(a.logb), [window] "s"(a.window), [wm1] "s"(wm1)
         : "memory", "vcc", "scc", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", V10(1), V10(2), V10(3), V10(4), V10(5), V10(6),
           V10(7), V10(8), V10(9), V10(10), V10(11), V10(12), V10(13), V10(14), V10(15), V10(16), V10(17), V10(18), V10(19), V10(20), V10(21),
           V10(22), V10(23), "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "s16", "s17", "s18", "s19", S10(2), S10(3),
@@ -255,6 +256,8 @@ int spmm_sweep_f32(const ndcn_csr *A, const float *X, float *Y, hipStream_t st) 
         a.logb = logb;
         a.nblk = (int)((A->n_cols + (1ll << logb) - 1) >> logb);
         a.window = window;
+        static const int dbg_env = [] { const char *e = getenv("NDCN_SWEEP_DBG"); return e ? atoi(e) : 0; }();
+        a.dbg = dbg_env;
         if (a.nblk >= 65536 || a.rpw > kSweepRows) { set_error("spmm_sweep: plan does not fit the kernel"); return NDCN_EINVAL; }
         hipLaunchKernelGGL(spmm_sweep_kernel, dim3(kCus), dim3(kSweepWaves * 64), 0, st, a);
         NDCN_LAUNCH_CHECK();

@@ -633,6 +633,19 @@ def _oracle_gradients(f, A, x0, t, wgt, rtol, atol, log=None):
     return yo.detach(), xc.grad, W.grad, b.grad
 
 
+def _oracle_exact_flow_gradients(f, A, x0, t, wgt, sub=40):
+    """the oracle's autograd through RK4 on a grid `sub` x finer than the ticks (increasing or decreasing): no step-size controller, global
+    error ~1e-9 - the gradient of the exact flow to fp32 rounding"""
+    fine = torch.cat([torch.linspace(float(t[i]), float(t[i + 1]), sub + 1)[:-1] for i in range(len(t) - 1)] + [t[-1:]])
+    W = f.wt.weight.detach().cpu().clone().requires_grad_(True)
+    b = f.wt.bias.detach().cpu().clone().requires_grad_(True)
+    xc = x0.clone().requires_grad_(True)
+    yo = orc.odeint(lambda tt, xx: orc.odefunc_rhs(A, xx, W, b), xc, fine, method='rk4')[::sub]
+    assert yo.shape[0] == len(t)
+    (yo * wgt).sum().backward()
+    return yo.detach(), xc.grad, W.grad, b.grad
+
+
 @pytest.mark.parametrize('side', [12, 16])
 def test_tape_gradients_at_the_fused_width_against_the_oracle(dev, side):
     """The native tape at H = 256 - the fused MFMA launches forward, linear_gs_256_split / linear_wgrad_256_split (split-fp16 MFMA
@@ -654,10 +667,12 @@ def test_tape_gradients_at_the_fused_width_against_the_oracle(dev, side):
 
 
 def test_fused_adjoint_gradients_against_the_oracle(dev):
-    """odeint_adjoint on the fused launches (H = 256, lattice) against the oracle's full-autograd gradient.  The two are different
-    estimators of the same derivative - the adjoint integrates the continuous sensitivity equations (adjoint.py:23-102), autograd
-    differentiates the discrete steps AND the controller - and meet as the tolerance tightens: at rtol 1e-6 / atol 1e-8 they must agree
-    to a few per cent of the gradient's scale, and the forward trajectories to 1e-5."""
+    """odeint_adjoint on the fused launches (H = 256, lattice) DIRECTLY against the oracle (round-5 review, parity hole (b)).  The adjoint
+    integrates the continuous sensitivity equations (adjoint.py:23-102), i.e. it estimates the derivative of the EXACT flow; the oracle's
+    autograd through dopri5 differentiates the discrete steps and the step-size controller and sits 2-9 % away from it even at rtol 1e-6
+    (measured here: x0 2.1 %, W 8.5 %, b 7.5 % of the gradient's scale - the same gap test_odeint_adjoint_on_the_fused_launches... finds
+    against finite differences).  The yardstick without a controller is the oracle's autograd through RK4 on a grid 40 x finer than the
+    ticks (global error ~1e-9: the exact flow's gradient to fp32 rounding)."""
     from ndcn_amd import torchdiffeq as ode
     f, A, x0, t, wgt = _fused_width_case(12, dev)
     x = x0.clone().to(dev).requires_grad_(True)
@@ -669,17 +684,18 @@ def test_fused_adjoint_gradients_against_the_oracle(dev):
     finally:
         f.ndcn_adjoint_step_log = None
     assert len([r for r in log if r[0] != 'nfe']) > 3                 # (the reverse pass ran on the fused stepper: it logs its attempts)
-    yo, gx, gW, gb = _oracle_gradients(f, A, x0, t, wgt, 1e-6, 1e-8)
-    assert float((y.detach().cpu() - yo).abs().max()) < 1e-5 * float(yo.abs().max())
+    yo, gx, gW, gb = _oracle_exact_flow_gradients(f, A, x0, t, wgt)
+    assert float((y.detach().cpu() - yo).abs().max()) < 1e-4 * float(yo.abs().max())
     errs = (rel(x.grad.cpu(), gx), rel(f.wt.weight.grad.cpu(), gW), rel(f.wt.bias.grad.cpu(), gb))
-    print('fused adjoint vs oracle autograd (x0, W, b):', errs)
-    assert max(errs) < 5e-2, errs
+    print('fused adjoint vs oracle autograd through fine-grid RK4 (x0, W, b):', errs)
+    assert max(errs) < 2e-3, errs
 
 
 def test_adjoint_on_a_decreasing_grid_at_the_fused_width(dev):
     """t decreasing: the forward pass goes through odeint's sign flip (misc.py:184-187); the fused reverse stepper integrates in
     tau = -t upwards and does not apply - the gate must hand the intervals to the generic reverse pass (round-5 advisor: 'invalid
-    interpolation' assert).  Same gradients as with the fused stepper switched off, and close to backpropagation through the solver."""
+    interpolation' assert).  Same gradients as with the fused stepper switched off, and - against the oracle - the gradient of the exact
+    flow (autograd through fine-grid RK4 on the same decreasing ticks)."""
     from ndcn_amd import torchdiffeq as ode
     from ndcn_amd.torchdiffeq._impl import adjoint_fused
     f, A, x0, t, wgt = _fused_width_case(12, dev)
@@ -702,10 +718,11 @@ def test_adjoint_on_a_decreasing_grid_at_the_fused_width(dev):
     assert torch.equal(ya, yb)
     for a, b in zip(ga, gb):
         assert torch.equal(a, b)
-    yc, gc = run(ode.odeint, rtol=1e-6, atol=1e-8)
-    assert float((ya - yc).abs().max()) < 1e-5 * float(yc.abs().max())
-    for a, c in zip(ga, gc):
-        assert rel(a.cpu(), c.cpu()) < 5e-2, rel(a.cpu(), c.cpu())
+    yo, gx, gW, gb = _oracle_exact_flow_gradients(f, A, x0, t, wgt)
+    assert float((ya.cpu() - yo).abs().max()) < 1e-4 * float(yo.abs().max())
+    errs = [rel(a.cpu(), c) for a, c in zip(ga, (gx, gW, gb))]
+    print('adjoint on a decreasing grid vs oracle autograd through fine-grid RK4 (x0, W, b):', errs)
+    assert max(errs) < 5e-3, errs
 
 
 def test_kept_solver_follows_the_operator(dev):

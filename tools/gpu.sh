@@ -148,6 +148,21 @@ abalt)
     cp /tmp/default.so ndcn_amd/libndcn_hip.so
   } 2>&1 | tee gpurun_out/exp_abalt.log
   ;;
+c2lab)
+  # what fusing the dense stage into the sweep's tail could save on BASELINE config 2: the sweep without its S store, the dense stage
+  # without the HBM side of its S read (needs gpurun_in_f3timing.so: rhs_fused3.hip built with -DNDCN_F3_TIMING), both
+  cp ndcn_amd/libndcn_hip.so /tmp/default.so
+  { echo "=== default";                          kernel_stats c2lab_default --config C2
+    echo "=== sweep without the S store";        NDCN_SWEEP_DBG=1 kernel_stats c2lab_nostore --config C2
+    cp gpurun_in_f3timing.so ndcn_amd/libndcn_hip.so
+    echo "=== timing build, no switch";          kernel_stats c2lab_tb --config C2
+    echo "=== dense stage: S rows from a 1 MiB window"; NDCN_FUSED3_DBG=8 kernel_stats c2lab_swin --config C2
+    echo "=== dense stage: no MFMA";             NDCN_FUSED3_DBG=1 kernel_stats c2lab_nomfma --config C2
+    echo "=== dense stage: no epilogue";         NDCN_FUSED3_DBG=4 kernel_stats c2lab_noepi --config C2
+    echo "=== dense stage: window + no epilogue"; NDCN_FUSED3_DBG=12 kernel_stats c2lab_swin_noepi --config C2
+    cp /tmp/default.so ndcn_amd/libndcn_hip.so
+  } 2>&1 | tee gpurun_out/exp_c2lab.log
+  ;;
 gaps)
   # timeline of one bench run: idle time between consecutive kernels (host round trips of the adaptive controller)
   (cd /tmp && rm -rf /tmp/p_gaps && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_gaps -o x -- \
