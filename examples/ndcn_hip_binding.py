@@ -5,7 +5,7 @@ import ctypes, torch
 
 import os
 _lib = ctypes.CDLL(os.environ.get('NDCN_HIP_LIB', 'libndcn_hip.so'))   # import torch first: the library binds to torch's HIP runtime
-assert _lib.ndcn_abi_version() == 17
+assert _lib.ndcn_abi_version() == 18
 
 _i64, _p = ctypes.c_int64, ctypes.c_void_p
 

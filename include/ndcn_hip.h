@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NDCN_ABI_VERSION 17
+#define NDCN_ABI_VERSION 18
 #define NDCN_API __attribute__((visibility("default")))
 
 #define NDCN_OK          0
@@ -640,7 +640,18 @@ NDCN_API int ndcn_prof_kinds(void);
 #define NDCN_PATH_REC   32   /* no_control: relu(A X) + the stage algebra in the epilogue of the group-record SpMM (spmm_rec.hip) */
 #define NDCN_PATH_WIDE  64   /* no_control: the same in the epilogue of the row SpMM (spmm.hip: spmm_wide_kernel)                */
 #define NDCN_PATH_SMALL 128  /* H <= 128: the whole ODEFunc + epilogue in one launch (rhs_small.hip)                            */
+#define NDCN_PATH_EXACT32 256 /* H = 256, range guard: the weights' in-row range exceeds what the two-piece fp16 product guarantees
+                               * (four or more non-zero elements more than 2^19 below their row's largest magnitude: csrc/split16.h), found when
+                               * the image was packed - the Linear ran on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; nn.Linear
+                               * in fp32, neural_dynamics.py:33), the stage algebra as kernels of its own.  NDCN_RANGE_GUARD=0
+                               * switches the guard (and the 32-byte read-back per packed image) off                              */
+#define NDCN_PATH_RANGE  512 /* such weights on a launch that exists only fused (x_add / x_mask / s_out): split product, warned once */
 NDCN_API int ndcn_debug_last_rhs_path(void);
+/* The range guard of the H = 256 Linear (NDCN_PATH_EXACT32 above): on = 1 / 0 switches it PROCESS-WIDE at run time, on < 0 returns to the
+ * default (on, unless the environment says NDCN_RANGE_GUARD=0); returns the previous state (1 / 0).  Off, every packed image takes the
+ * split fp16 product whatever its range, and packing does not read back.  Images packed while the guard was off are judged when
+ * they are packed next.                                                                                                            */
+NDCN_API int ndcn_set_range_guard(int on);
 
 /* ---- training through the adaptive solver: the solve that keeps its tape, and its reverse pass ---------------------------------
  * Replaces, for a plain ODEFunc on one state tensor, what the reference's drivers do by autograd through odeint

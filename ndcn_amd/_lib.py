@@ -11,8 +11,8 @@ import torch  # noqa: F401  -- must come first: the library binds to the HIP run
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libndcn_hip.so')
 
-ABI_VERSION = 17
-PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO, PATH_SWEEP, PATH_REC, PATH_WIDE, PATH_SMALL = 1, 2, 4, 8, 16, 32, 64, 128
+ABI_VERSION = 18
+PATH_FUSED2, PATH_FUSED3, PATH_HUB, PATH_HALO, PATH_SWEEP, PATH_REC, PATH_WIDE, PATH_SMALL, PATH_EXACT32, PATH_RANGE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 OK = 0
 EINVAL, EHIP, ENONFINITE, EUNDERFLOW, EMAXSTEPS, ESTATE = -1, -2, -3, -4, -5, -6
@@ -191,6 +191,7 @@ SIGNATURES = {
     'ndcn_prof_read': (_I, [ctypes.POINTER(_D), _I]),
     'ndcn_prof_kinds': (_I, []),
     'ndcn_debug_last_rhs_path': (_I, []),
+    'ndcn_set_range_guard': (_I, [_I]),
 }
 
 _lib = None

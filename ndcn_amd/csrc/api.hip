@@ -43,6 +43,7 @@ extern "C" {
 
 int ndcn_abi_version(void) { return NDCN_ABI_VERSION; }
 int ndcn_debug_last_rhs_path(void) { return g_last_rhs_path; }
+int ndcn_set_range_guard(int on) { return set_range_guard(on); }
 const char *ndcn_last_error(void) { return g_err; }
 
 int64_t ndcn_adjoint_rhs_work_bytes(int64_t n_rows, int H, uint32_t flags) { return adjoint_rhs_work_bytes(n_rows, H, flags); }

@@ -44,6 +44,10 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
                hipStream_t st, const RkOpt *opt = nullptr);
 int rhs_fused_supported(int H, uint32_t flags);
 int pack_weight_256(const float *W, float *Wp, hipStream_t st);
+// the image at Wp was packed from weights whose in-row range exceeds the split product's guarantee (split16.h: kS16GuardBits): the
+// launches that read it take the fp32 matrix-core route (rhs.hip).  False when NDCN_RANGE_GUARD=0.
+bool weights_wide_range(const void *Wp);
+int set_range_guard(int on);                  // ndcn_set_range_guard
 int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st);   // planes of W^T + per-row unscale factors: kS16Bytes + kS16TailBytes
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);
 int rhs_fused2_variant(int mode, int n_prev);

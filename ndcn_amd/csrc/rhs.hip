@@ -1,7 +1,12 @@
 // ODEFunc.forward as one entry point: Y = relu(W (A X) + b)   (neural_dynamics.py:20-39, dropout p = 0).
 // H = 256 runs the fused kernel (rhs_fused.hip); other widths compose the SpMM and the MFMA Linear through a
 // scratch panel.
+#include <stdio.h>
+
+#include <atomic>
+
 #include "kernels.h"
+#include "split16.h"
 
 namespace ndcn {
 
@@ -9,6 +14,8 @@ int rhs_fused_supported(int H, uint32_t flags);
 int64_t rhs_fused_work_bytes(int H);
 int rhs_fused_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *W, const float *b,
                   float *Y, float *work, int H, uint32_t flags, hipStream_t st);
+int rhs_fused_packed_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b, float *Y,
+                         uint32_t flags, hipStream_t st);
 
 __global__ __launch_bounds__(256) void relu_copy_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n,
                                                         int relu) {
@@ -50,6 +57,12 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
                 }
                 int rc = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256(W, work, st);
                 if (rc) return rc;
+                if (weights_wide_range(work)) {
+                    // range guard (split16.h): weights outside the split product's guarantee take the fp32 matrix cores - the
+                    // first-generation fused kernel (v_mfma_f32_32x32x2_f32 over the fp32 image of W in the same scratch)
+                    g_last_rhs_path = NDCN_PATH_EXACT32 | ((Xh && A->n_cols > n_own) ? NDCN_PATH_HALO : 0);
+                    return rhs_fused_packed_f32(A, X, Xh, n_own, work, b, Y, flags, st);
+                }
                 return rhs_fused2_f32(A, X, Xh, n_own, work, b, Y, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f,
                                       0.f, nullptr, nullptr, st);
             }
@@ -93,10 +106,25 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
         if (!work) { set_error("rhs_rk: scratch of ndcn_rhs_work_bytes() bytes required"); return NDCN_EINVAL; }
         int rc = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256(W, work, st);
         if (rc) return rc;
-        return rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
-                              d_out, d_ws, st, opt);
+        const bool wide = weights_wide_range(work);
+        // options that exist only inside the fused launches (input formed on the staged rows, S written on the side) have no composed
+        // form: such a launch stays on the split product and says so (NDCN_PATH_RANGE; the solvers switch the options off instead)
+        const bool fused_only = opt && (opt->xadd || opt->xmask || opt->s_out);
+        if (!wide || fused_only) {
+            rc = rhs_fused2_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol,
+                                d_out, d_ws, st, opt);
+            if (wide) {
+                g_last_rhs_path |= NDCN_PATH_RANGE;
+                static std::atomic<bool> warned{false};
+                if (!warned.exchange(true))
+                    fprintf(stderr, "[ndcn] weights with an in-row range beyond 2^%d on a fused launch that has no fp32 form (x_add / x_mask / "
+                                    "s_out): the split fp16 product's guarantee (csrc/split16.h) does not cover them\n", kS16GuardBits);
+            }
+            return rc;
+        }
+        flags |= NDCN_F_PACKED;                               // composed below: rhs_f32 (fp32 matrix cores) + the stage kernels
     }
-    if (both && rhs_small_supported(A, H, flags)) {
+    else if (both && rhs_small_supported(A, H, flags)) {
         g_last_rhs_path = NDCN_PATH_SMALL;
         return rhs_small_f32(A, X, Xh, n_own, W, b, K, H, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws,
                              st, nullptr, opt);

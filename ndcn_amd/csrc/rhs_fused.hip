@@ -21,6 +21,10 @@
 //              rows in flight on an XCD are ~2048 consecutive rows and their neighbours stay in that XCD's L2.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+#include <unordered_map>
+
 #include "kernels.h"
 #include "split16.h"
 
@@ -212,12 +216,22 @@ int64_t rhs_fused_work_bytes(int H) { return (int64_t)H * H * sizeof(float) + (i
 //   Wh[(((j * 16 + s) * 2 + p) * 64 + lane) * 8 + e] = piece p of B[32 j + (lane & 31)][16 s + 8 (lane >> 5) + e];
 // behind the planes: float unscale[256] = 1 / scale of row n (the consumers multiply output column n back by it).
 // A block packs four k-steps of ONE n-tile j: it needs the maxima of rows 32 j .. 32 j + 31 only (8 threads per row, 32 values each).
+// Range guard (round 6): the two-piece split keeps min(21, 38 - e) bits of an element 2^-e below its row's largest magnitude
+// (split16.h), i.e. elements more than 2^kS16GuardBits below it can - when the rest of the row meets zeros of S - put the output
+// outside 2e-6 sum |s w|.  Behind the scan that forms the row maximum a second one counts the NON-ZERO elements below that mark; a row
+// with kS16GuardCount or more of them (a row that spans decades - not the one or two stragglers every random matrix has: 5 % of the
+// nn.Linear default initialisations and 15 % of Gaussian matrices hold an element 2^-19 below its row's maximum, none holds four in
+// one row) is reported per n-tile in 8 words behind the 256 unscale factors, and pack_weight_256 hands the verdict to the host, which
+// routes such weights to the fp32 matrix-core kernels (rhs.hip: NDCN_PATH_EXACT32; nn.Linear in fp32, neural_dynamics.py:33).
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *__restrict__ W, _Float16 *__restrict__ Wh,
                                                                   float *__restrict__ tail) {
     __shared__ float s_scale[32];
+    __shared__ int s_wide;
     const int idx = blockIdx.x * 256 + threadIdx.x;            // one (j, s, lane): 8 * 16 * 64 = 8192
     const int lane = idx & 63, s = (idx >> 6) & 15, j = idx >> 10;
+    if (threadIdx.x == 0) s_wide = 0;
+    __syncthreads();
     {
         const int r = threadIdx.x >> 3, part = threadIdx.x & 7, n = 32 * j + r;
         unsigned m = 0;
@@ -230,14 +244,27 @@ __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *_
             const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
             m = o > m ? o : m;
         }
+        // (all eight threads of the row hold its maximum now) non-zero elements below the guarantee, exponents compared
+        int below = 0;
+        if (!TRANSPOSED && (blockIdx.x & 3) == 0) {
+            for (int k = 32 * part; k < 32 * part + 32; ++k) {
+                const unsigned b = __builtin_bit_cast(unsigned, W[n * kH + k]) & 0x7fffffffu;
+                below += (b != 0u && (int)(m >> 23) - (int)(b >> 23) > kS16GuardBits) ? 1 : 0;
+            }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) below += __shfl_xor(below, off, 64);
+        }
         if (part == 0) {
             unsigned sb, ub;
             s16_scale_bits(m, sb, ub);
             s_scale[r] = __builtin_bit_cast(float, sb);
             if ((blockIdx.x & 3) == 0) tail[n] = __builtin_bit_cast(float, ub);
+            // finite rows only (a NaN / Inf row is non-finite on every route)
+            if ((m >> 23) != 255u && below >= kS16GuardCount) atomicOr(&s_wide, 1);
         }
     }
     __syncthreads();
+    if (!TRANSPOSED && (blockIdx.x & 3) == 0 && threadIdx.x == 0) reinterpret_cast<int *>(tail)[256 + j] = s_wide;
     const int row = 32 * j + (lane & 31), col = 16 * s + 8 * (lane >> 5);
     const float sc = s_scale[lane & 31];
 #pragma unroll
@@ -250,11 +277,56 @@ __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *_
     }
 }
 
+// ---- which packed images hold wide-range weights: decided when the image is packed, asked at every launch that reads it -----------
+namespace {
+std::mutex g_wide_mu;
+std::unordered_map<const void *, bool> g_wide;          // key: the packed image (a caller's scratch: few, long-lived)
+std::atomic<int> g_guard_override{-1};                  // ndcn_set_range_guard: -1 = the environment's default
+bool range_guard_on() {
+    static const bool dflt = [] { const char *e = getenv("NDCN_RANGE_GUARD"); return !(e && e[0] == '0'); }();
+    const int o = g_guard_override.load(std::memory_order_relaxed);
+    return o < 0 ? dflt : o != 0;
+}
+}  // namespace
+
+int set_range_guard(int on) {
+    const int prev = range_guard_on() ? 1 : 0;
+    g_guard_override.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed);
+    if (!range_guard_on()) {                                 // verdicts of the guarded time do not outlive it
+        std::lock_guard<std::mutex> lk(g_wide_mu);
+        g_wide.clear();
+    }
+    return prev;
+}
+
+bool weights_wide_range(const void *Wp) {
+    if (!range_guard_on()) return false;
+    std::lock_guard<std::mutex> lk(g_wide_mu);
+    auto it = g_wide.find(Wp);
+    return it != g_wide.end() && it->second;
+}
+
 int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
     hipLaunchKernelGGL(pack_weight_256_kernel, dim3(64), dim3(256), 0, st, W, Wp);
     float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(Wp + kH * kH) + kS16Bytes);
     hipLaunchKernelGGL(pack_weight_256_f16_kernel<false>, dim3(32), dim3(256), 0, st, W, reinterpret_cast<_Float16 *>(Wp + kH * kH), tail);
     NDCN_LAUNCH_CHECK();
+    if (range_guard_on()) {
+        // 32 bytes back to the host, once per packed image (a solve packs once; callers that keep the image pass NDCN_F_PACKED).  Not
+        // while the stream is being captured: a captured pack keeps the verdict of the image's last eager pack.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap == hipStreamCaptureStatusNone) {
+            int h[8];
+            NDCN_HIP(hipMemcpyAsync(h, reinterpret_cast<const int *>(tail) + 256, sizeof(h), hipMemcpyDeviceToHost, st));
+            NDCN_HIP(hipStreamSynchronize(st));
+            bool wide = false;
+            for (int q = 0; q < 8; ++q) wide = wide || h[q] != 0;
+            std::lock_guard<std::mutex> lk(g_wide_mu);
+            if (g_wide.size() > 4096) g_wide.clear();            // (images come and go with their solvers: bounded, re-learnt at the next pack)
+            g_wide[Wp] = wide;
+        }
+    }
     return NDCN_OK;
 }
 

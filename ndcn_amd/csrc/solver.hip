@@ -83,6 +83,7 @@ struct ndcn_solver {
     std::vector<std::pair<int64_t, int64_t>> xadd_ranges;
     int xadd_block = -1;           // an interior block whose operator has the XADD kernel (-1: none)
     bool packed = false;           // `work` holds the packed weights of this solve
+    bool exact32 = false;          // ... and they are outside the split product's guarantee (range guard): fp32 matrix cores, composed stage algebra
     double n_mean = 0;             // element count behind the controller's means (global for a shard)
     int n_coef = 0;
     float *h_dt = nullptr;         // pinned ring of step sizes (async H2D source must stay untouched until consumed)
@@ -140,11 +141,13 @@ int rhs_sharded(ndcn_solver *s, const float *x, float *K, int mode, const float 
 int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
     if (s->sharded) return rhs_sharded(s, x, out, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st, nullptr);
     s->n_rhs++;
-    if (s->fused2 && !s->rec_epi)
+    if (s->fused2 && !s->rec_epi && !s->exact32)
         return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, 0, nullptr,
                               nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st);
-    if (s->fused)       // weights were packed once in solver_begin
+    if (s->fused) {     // weights were packed once in solver_begin (exact32: the range guard's route - fp32 matrix cores)
+        if (s->exact32) g_last_rhs_path = NDCN_PATH_EXACT32;
         return rhs_fused_packed_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, st);
+    }
     return rhs_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, out, s->work, s->d.H, s->d.rhs_flags, st);
 }
 
@@ -175,6 +178,9 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
         return spmm_rec_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, 1.f, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next, rtol,
                             atol, d_out, d_ws, st, c_dev, opt);
     }
+    if (s->exact32)     // range guard: the evaluation on the fp32 matrix cores, the stage algebra as kernels of its own (rhs.hip)
+        return rhs_rk_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, K, s->work, s->d.H, s->d.rhs_flags | NDCN_F_PACKED, mode, y0,
+                          kp, cp, n_prev, y_next, rtol, atol, d_out, d_ws, st, opt);
     return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev,
                           y_next, rtol, atol, d_out, d_ws, st, opt);
 }
@@ -261,7 +267,7 @@ int initial_step(ndcn_solver *s, hipStream_t st, double &h_out) {
     // (on the lattice plan the launch that produces f1 forms y0 + h0 f0 on the rows it stages: RkOpt::xadd)
     const bool fuse_d2 = fuse_on && s->fused2 && (s->sharded || s->n_elem > aten_order_max_elems());
     static const bool xadd_on = [] { const char *e = getenv("NDCN_STAGE_XADD"); return !(e && e[0] == '0'); }();
-    const bool xadd = xadd_on && fuse_d2 && !s->sharded && !s->rec_epi && rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 2, 1);
+    const bool xadd = xadd_on && fuse_d2 && !s->sharded && !s->rec_epi && !s->exact32 && rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 2, 1);
     if (!xadd) {
         rc = rk_combine_f32(s->ytmp, s->ycur, kp, cp, 1, s->n_elem, st);
         if (rc) return rc;
@@ -393,7 +399,7 @@ int enqueue_attempt(ndcn_solver *s, hipStream_t st, float dt32, const float *dt_
         // The first stage input y0 + dt beta_21 k1 is a kernel of its own (3 panels) - unless the launch that produces k2 can
         // form it on the rows it stages (RkOpt::xadd: the lattice plan of rhs_fused3.hip, one more gather instead)
         static const bool xadd_on = [] { const char *e = getenv("NDCN_STAGE_XADD"); return !(e && e[0] == '0'); }();
-        const bool xadd = xadd_on && !dt_dev && !s->rec_epi &&
+        const bool xadd = xadd_on && !dt_dev && !s->rec_epi && !s->exact32 &&
                           (s->sharded ? s->xadd_block >= 0 : rhs_xadd_supported(&s->d.A, s->d.H, s->d.rhs_flags, 1, 1));
         dt_coeffs(dt32, kBeta[0], 1, s->k, kp, cp, m);
         const float xadd_c = cp[0];
@@ -875,6 +881,7 @@ int solver_begin(ndcn_solver *s, const float *y0, double t0, hipStream_t st, boo
         int rcp = pack_weight_256(s->d.W, s->work, st);
         if (rcp) return rcp;
         s->packed = true;
+        s->exact32 = weights_wide_range(s->work);
     }
     if (s->d.method == NDCN_M_DOPRI5) {
         // dopri5.py:77-83

@@ -43,7 +43,9 @@ typedef float f32x4_s16 __attribute__((ext_vector_type(4)));
 constexpr int kS16Planes = 2;
 constexpr int kS16Bytes = 8 * 16 * kS16Planes * 1024;         // packed weights: [n-tile 8][k-step 16][plane 2][lane 64][8 fp16]
 // behind the planes: float unscale[256] = 1 / (scale of B-operand row n), i.e. per OUTPUT column of the product
-constexpr int kS16TailBytes = 256 * 4;
+constexpr int kS16TailBytes = 256 * 4;                       // (+ 8 words behind them in the forward image: the range guard's verdict per n-tile)
+constexpr int kS16GuardBits = 19;                              // a non-zero element more than 2^19 below its row's maximum keeps < 19 bits: outside the 2e-6 guarantee
+constexpr int kS16GuardCount = 4;                              // ... and a weight row with this many of them leaves for the fp32 matrix cores (rhs_fused.hip)
 constexpr int kS16Top = 15;                                    // the scale brings a row's largest magnitude into [2^(top-1), 2^top)
 
 // wave-uniform maximum of an unsigned value (|x| bit patterns order like magnitudes; a NaN pattern wins)

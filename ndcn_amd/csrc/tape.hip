@@ -473,6 +473,7 @@ int ndcn_tape_dopri5_f32(const ndcn_csr *A, const ndcn_csr *At, const float *W, 
         if (H == 256 && !no_control && !no_graph) {
             // the packed image of W once per solve (every evaluation reads it: NDCN_F_PACKED)
             if ((rc = pack_weight_256(W, t->work, st))) return rc;
+            if (weights_wide_range(t->work)) t->keep_s = false;       // range guard: the fp32 route has no S output (rhs.hip)
             t->packed = true;
         }
     }

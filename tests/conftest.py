@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'range_guard: tests/test_gpu_split_range.py - run with the range guard of the H = 256 Linear switched on')
 
 
 def load_golden(name):

@@ -23,6 +23,20 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(autouse=True)
+def split_product_only(request):
+    """The tests of this file hold the SPLIT product to its stated guarantee: the range guard (round 6: weights whose rows span more than
+    2^19 leave for the fp32 matrix cores, NDCN_PATH_EXACT32) is switched off around them - except where a test asks for it."""
+    from ndcn_amd import _lib
+    from ndcn_amd.ops import invalidate_packed_weights
+    want = 1 if request.node.get_closest_marker('range_guard') else 0
+    prev = _lib.load().ndcn_set_range_guard(want)
+    invalidate_packed_weights()
+    yield
+    _lib.load().ndcn_set_range_guard(prev)
+    invalidate_packed_weights()
+
+
 def _default_init(seed=0):
     torch.manual_seed(seed)
     lin = torch.nn.Linear(H, H)
@@ -182,3 +196,77 @@ def test_weight_row_scales_are_powers_of_two_per_output_row(dev):
     scaled = W.abs().max(dim=1).values.double().numpy() / tail
     nz = scaled > 0
     assert nz.sum() == H - 1 and (scaled[nz] >= 2.0 ** 14).all() and (scaled[nz] < 2.0 ** 15).all()
+
+
+# ---- the range guard (round 6) ------------------------------------------------------------------------------------------------------
+
+def _wide_range_weights():
+    """default init, except output row 17: one weight of 1.0 against a row 2^-24 below it - and S's channel under that weight is zero,
+    so that the small weights ALONE carry output 17 (the split product would keep 38 - 24 = 14 bits of them: 6e-5 of the magnitudes)"""
+    W, b = _default_init()
+    W[17, :] *= 2.0 ** -24 * 16.0
+    W[17, 33] = 1.0
+    b[17] = 0.0
+    return W.contiguous(), b
+
+
+@pytest.mark.range_guard
+@pytest.mark.parametrize('which', ['fused3', 'fused2', 'sweep'])
+def test_weights_beyond_the_guarantee_take_the_fp32_matrix_cores(dev, which):
+    """nn.Linear is fp32 in the reference (neural_dynamics.py:33).  A weight row spanning 2^24 is found when the image is packed and the
+    launch goes to the fp32 MFMA kernel: within 2e-6 sum |s w| of fp64 where the split product is not; ordinary weights stay on the
+    split product (same path bits as ever)."""
+    from ndcn_amd import hip, _lib
+    L, A = _operator(which, dev)
+    W, b = _wide_range_weights()
+    X = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(5))
+    X[:, 33] = 0.0                                                   # S[:, 33] = 0: the dominant weight meets zeros
+    ratio = _rhs_bound_check(L, A, W, b, X, dev, _lib.PATH_EXACT32)
+    # the same operands on the split product: outside the bound (the reason the guard exists)
+    _lib.load().ndcn_set_range_guard(0)
+    from ndcn_amd.ops import invalidate_packed_weights
+    invalidate_packed_weights()
+    with pytest.raises(AssertionError):
+        _rhs_bound_check(L, A, W, b, X, dev, _want_path(which))
+    _lib.load().ndcn_set_range_guard(1)
+    invalidate_packed_weights()
+    # ordinary weights: the fused kernels, as before
+    W0, b0 = _default_init(seed=3)
+    _rhs_bound_check(L, A, W0, b0, X, dev, _want_path(which))
+    # a launch with an RK epilogue composes: K the same bits as the plain launch, y_next = y0 + c K
+    Wd, bd, Xd = W.to(dev), b.to(dev), X.to(dev)
+    y0 = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(6)).to(dev)
+    K0 = hip.rhs(A, Xd, Wd, bd)
+    K, yn = hip.rhs_rk(A, Xd, Wd, bd, 'combine', y0, [], [0.25])
+    assert int(_lib.load().ndcn_debug_last_rhs_path()) & _lib.PATH_EXACT32
+    assert torch.equal(K, K0)
+    assert float((yn - (y0 + K0 * np.float32(0.25))).abs().max()) == 0.0
+    assert ratio < 2e-6
+
+
+@pytest.mark.range_guard
+@pytest.mark.parametrize('method', ['dopri5', 'rk4'])
+def test_solver_with_weights_beyond_the_guarantee_matches_the_oracle(dev, method):
+    """the device-resident solver learns the verdict when it packs (ndcn_solver_begin) and steps on the fp32 route: the oracle's
+    trajectory and accept / reject sequence"""
+    from ndcn_amd import torchdiffeq as ode, _lib
+    from ndcn_amd.neural_dynamics import ODEFunc
+    L, A = _operator('fused3', dev)
+    W, b = _wide_range_weights()
+    W = W / max(1.0, float(torch.linalg.matrix_norm(W, 2)))
+    f = ODEFunc(H, A).to(dev).eval()
+    f.load_state_dict({'wt.weight': W, 'wt.bias': b})
+    x0 = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(8))
+    x0[:, 33] = 0.0
+    t = torch.tensor([0., 0.5, 1.0])
+    log, lo = [], []
+    kw = dict(rtol=.01, atol=.001) if method == 'dopri5' else {}
+    with torch.no_grad():
+        y = ode.odeint(f, x0.to(dev), t.to(dev), method=method, **(dict(kw, step_log=log) if method == 'dopri5' else {}))
+    assert int(_lib.load().ndcn_debug_last_rhs_path()) & _lib.PATH_EXACT32
+    fo = orc.OracleODEFunc(orc.coo_from_csr(L.indptr, L.indices, L.data, L.shape), W, b)
+    ref = orc.odeint(fo, x0, t, method=method, **(dict(kw, step_log=lo) if method == 'dopri5' else {}))
+    if method == 'dopri5':
+        assert [r[2] for r in log[:-1]] == [r[2] for r in lo]
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((y.cpu() - ref).abs().mean()) < 1e-5 * scale
