@@ -116,6 +116,15 @@ class _AdjointMethod(torch.autograd.Function):
                 def reversed_rhs(tau, y_aug):                    # misc.py:184-187: func(-t, y) negated
                     return tuple(-v for v in native_rhs(-tau, y_aug))
 
+        fused_fixed = None
+        if native is not None and method in ('euler', 'midpoint', 'rk4') and not (options or {}):
+            # fixed grids: one step per interval on the same launches, the method's stage algebra in their epilogues (any width)
+            from . import adjoint_fused
+            th = core.host_grid(t)
+            if bool((th[1:] > th[:-1]).all()) and adjoint_fused.applicable_fixed(native, ans[0]):
+                fused_fixed = adjoint_fused
+                fused_w = adjoint_fused._Weights(native)
+                t_host = th.tolist()
         T = ans[0].shape[0]
         # panels beyond the ATen-order bound are reduced in parallel anyway: let the 65 792-element parameter-gradient vector riding
         # next to them follow (0.6 ms serial per reduction otherwise; include/ndcn_hip.h: ndcn_set_aten_norm_max)
@@ -147,6 +156,12 @@ class _AdjointMethod(torch.autograd.Function):
                         _, a_lo, adj_time, adj_params = fused.integrate_interval(
                             hip, native, fused_w, ans_i[0].contiguous(), adj_y[0].contiguous(), adj_time, adj_params, t[i], t[i - 1],
                             rtol, atol, options, reversed_rhs, step_log=getattr(native, 'ndcn_adjoint_step_log', None))
+                        adj_y = (a_lo,)
+                        aug0 = aug = None
+                    elif fused_fixed is not None:
+                        _, a_lo, adj_time, adj_params = fused_fixed.integrate_interval_fixed(
+                            hip, native, fused_w, ans_i[0].contiguous(), adj_y[0].contiguous(), adj_time, adj_params, t_host[i], t_host[i - 1],
+                            method, None, step_log=getattr(native, 'ndcn_adjoint_step_log', None))
                         adj_y = (a_lo,)
                         aug0 = aug = None
                     else:

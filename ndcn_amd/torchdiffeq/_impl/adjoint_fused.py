@@ -28,8 +28,11 @@ Time runs backwards: the solver integrates in tau = -t (misc.py:184-187 negates 
 rides in the step size of each state tensor's panel algebra (dt * beta * (-K) == (-dt) * beta * K bit for bit):  y uses -dt, a_y and
 a_theta (whose stored panels are +A^T gZ W, +gZ^T S: already the negated derivative) use +dt.
 
-Scope: ODEFunc with H = 256 (the fused kernels' width), graph on, dropout inactive; control on or off.  Everything else keeps the
-generic path.  NDCN_ADJOINT_FUSED=0 switches this off (A/B)."""
+Scope: dopri5 - ODEFunc with H = 256 (the fused kernels' width), graph on, dropout inactive; control on or off.  Fixed grids
+(round 6: euler / midpoint / rk4, `FusedAdjointFixed` below) - any width with the graph on: the same two launches per evaluation with the
+method's stage algebra in their epilogues (`rk4` / `combine` modes of ndcn_rhs_rk_f32; the narrow widths run rhs_small.hip).  Everything
+else - dopri5 on narrow panels, whose accept / reject decisions hang on ATen-order norms of every state tensor - keeps the generic
+path.  NDCN_ADJOINT_FUSED=0 switches this off (A/B)."""
 import math
 import os
 
@@ -246,6 +249,76 @@ class FusedAdjointDopri5:
         out_a = hip.interp_direct(A0, a1_, kA, cmid, dt32, xp)
         out_p = hip.interp_direct(P0, p1, kP, cmid, dt32, xp) if self.has_theta else P0
         return out_y, out_a, self.a_t, out_p
+
+
+def applicable_fixed(f0, y):
+    """the fixed-grid reverse pass: any width, graph on, a square operator over the state's rows"""
+    if not ENABLED or f0.no_graph or y.dtype != torch.float32:
+        return False
+    from ...csr import as_csr
+    A = as_csr(f0.A)
+    return A.shape[0] == A.shape[1] == y.shape[1]
+
+
+class FusedAdjointFixed(FusedAdjointDopri5):
+    """One tick interval of the reverse pass by ONE step of euler / midpoint / rk4 (the reference's fixed grid is the time vector itself:
+    solvers.py:79-99 on [t_i, t_{i-1}], negated by misc.py:184-187), in tau = -t.  The generic path runs `core.integrate_fixed` over the
+    4-tuple with one `ndcn_adjoint_rhs_f32` (4 kernels) and one stage kernel per state tensor per stage; here an evaluation is the two
+    launches of `_evaluate` with the stage algebra of y and a_y in their epilogues (fixed_grid.py:7-29, rk_common.py:72-78: the operator
+    order of ndcn_fixed_stage_f32), the parameter adjoint's by `fixed_stage` on its 65 k-element vector."""
+
+    def __init__(self, hip, f0, weights, y, a, a_t, theta, generic_func):
+        from ...csr import as_csr
+        self.hip = hip
+        self.A = as_csr(f0.A)
+        self.At = self.A.transpose()
+        H = y.shape[1]
+        self.A.ensure_plans(H)
+        self.At.ensure_plans(H)
+        self.w = weights
+        self.generic = generic_func
+        self.Y, self.Aj, self.a_t, self.P = y, a, a_t, theta
+        self.has_theta = theta.numel() > 0 and not self.w.no_control
+        self.n_theta = theta.numel()
+        self.fuse_s = self.fuse_mask = False               # (the masked-input / S-output kernel variants are dopri5's launches)
+        self.nfe = 0
+
+    def step(self, method, dt32):
+        hip = self.hip
+        dty = f32(-dt32)                                   # y's stored panels are +K: the sign of the reversed time rides in dt
+        Y0, A0, P0 = self.Y, self.Aj, self.P
+        if method == 'euler':
+            self.nfe += 1
+            _, y1, _, a1, kp = self._evaluate(Y0, A0, 'combine', Y0, A0, [], [dty], [], [dt32])
+            p1 = hip.fixed_stage(0, P0, kp, dt=dt32) if self.has_theta else P0
+        elif method == 'midpoint':
+            self.nfe += 2
+            _, ym, _, am, _ = self._evaluate(Y0, A0, 'combine', Y0, A0, [], [f32(dty / f32(2))], [], [f32(dt32 / f32(2))])
+            _, y1, _, a1, kp = self._evaluate(ym, am, 'combine', Y0, A0, [], [dty], [], [dt32])
+            p1 = hip.fixed_stage(0, P0, kp, dt=dt32) if self.has_theta else P0
+        else:
+            x, xa, kY, kA, kP = Y0, A0, [], [], []
+            for _ in range(4):
+                self.nfe += 1
+                K, x, KA, xa, kp = self._evaluate(x, xa, 'rk4', Y0, A0, list(kY), [dty], list(kA), [dt32])
+                kY.append(K)
+                kA.append(KA)
+                kP.append(kp)
+            y1, a1 = x, xa
+            p1 = hip.fixed_stage(5, P0, kP[0], kP[1], kP[2], kP[3], dt=dt32) if self.has_theta else P0
+        self.Y, self.Aj, self.P = y1, a1, p1
+        return y1, a1, self.a_t, p1
+
+
+def integrate_interval_fixed(hip, f0, weights, y_i, adj_y, adj_time, adj_params, t_hi, t_lo, method, generic_func, step_log=None):
+    """(y, a_y, a_t, a_theta) at t_hi -> at t_lo < t_hi by one step of `method`; t_hi / t_lo: host scalars of the solve's time vector
+    (the step size is their float32 difference in the negated grid, solvers.py:81)."""
+    s = FusedAdjointFixed(hip, f0, weights, y_i, adj_y, adj_time, adj_params, generic_func)
+    dt32 = f32(f32(-t_lo) - f32(-t_hi))
+    out = s.step(method, dt32)
+    if step_log is not None:
+        step_log.append(('nfe', s.nfe))
+    return out
 
 
 def integrate_interval(hip, f0, weights, y_i, adj_y, adj_time, adj_params, t_hi, t_lo, rtol, atol, options, generic_func, step_log=None):

@@ -752,3 +752,61 @@ def test_kept_solver_follows_the_operator(dev):
         y3 = ode.odeint(f, x0, t, rtol=1e-3, atol=1e-4, method='dopri5')
         g.A = (0.25 * L1).to(dev)
         assert torch.equal(y3, ode.odeint(g, x0, t, rtol=1e-3, atol=1e-4, method='dopri5')) and not torch.equal(y3, y2)
+
+
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'rk4'])
+@pytest.mark.parametrize('shape', ['reference_size', 'no_control', 'fused_width', 'power_law_256'])
+def test_fixed_grid_adjoint_on_the_fused_launches_equals_the_generic_reverse_pass(dev, method, shape):
+    """odeint_adjoint with a fixed-grid method (round 6, adjoint_fused.FusedAdjointFixed): one step per tick interval as two launches
+    per evaluation with the method's stage algebra in their epilogues - any width - against the generic reverse pass (core.integrate_fixed
+    over the 4-tuple on ndcn_adjoint_rhs_f32, which the reference's adjoint_rk4 fixture pins): the same forward solve, gradients equal
+    up to the fp32 rounding of the reordered product A^T (gZ W) = (A^T gZ) W; and against backpropagation through the solver (for a
+    fixed grid the adjoint's discrete error is O(dt^p): a fine grid)."""
+    from ndcn_amd import graphs
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    from ndcn_amd.torchdiffeq._impl import adjoint_fused
+    if shape == 'power_law_256':
+        L, H = graphs.normalized_laplacian(graphs.make_graph('power_law', 2500, seed=4)), 256
+    else:
+        side, H = (24, 256) if shape == 'fused_width' else (20, 20)
+        L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+    N = L.shape[0]
+    torch.manual_seed(5)
+    f = ODEFunc(H, graphs.to_device(L, dev), no_control=shape == 'no_control').to(dev)
+    x_init = torch.rand(N, H, generator=torch.Generator().manual_seed(6)).to(dev)
+    t = torch.linspace(0., 0.8, 33).to(dev)
+    wgt = torch.randn(33, N, H, generator=torch.Generator().manual_seed(7)).to(dev)
+
+    def run(solver, fused):
+        adjoint_fused.ENABLED = fused
+        try:
+            for p in f.parameters():
+                p.grad = None
+            x0 = x_init.clone().requires_grad_(True)
+            log = []
+            f.ndcn_adjoint_step_log = log
+            y = solver(f, x0, t, method=method)
+            (y * wgt).sum().backward()
+            gs = [x0.grad.clone()] + [p.grad.clone() for p in f.parameters() if p.grad is not None]
+            return y.detach(), gs, log
+        finally:
+            adjoint_fused.ENABLED = True
+            f.ndcn_adjoint_step_log = None
+
+    ya, ga, la = run(ode.odeint_adjoint, True)
+    yb, gb, lb = run(ode.odeint_adjoint, False)
+    evals = {'euler': 1, 'midpoint': 2, 'rk4': 4}[method]
+    assert la == [('nfe', evals)] * 32 and lb == []                  # the fused stepper ran (and only where it was asked to)
+    assert torch.equal(ya, yb)
+    assert len(ga) == len(gb)
+    for a, b in zip(ga, gb):
+        # (measured 3e-5 .. 5e-4 over the 32 intervals: the reordered product, and at H = 256 the split-fp16 Linear of the fused launches
+        # against the fp32-MFMA Linear of ndcn_adjoint_rhs_f32; the dopri5 form of this test allows 1e-3 / 5e-3)
+        assert rel(a.cpu(), b.cpu()) < (5e-3 if shape == 'power_law_256' else 1e-3), rel(a.cpu(), b.cpu())
+    _, gc, _ = run(ode.odeint, True)                                 # backpropagation through the same fixed-grid solve
+    # (the adjoint discretises the continuous sensitivity equations backwards, backpropagation differentiates the forward steps: O(dt^p)
+    # apart on smooth dynamics, and the ReLU's kinks cap the order - measured 6e-3 for midpoint, 2.6e-3 for rk4 at dt = 0.025)
+    tol = {'euler': 1e-1, 'midpoint': 2e-2, 'rk4': 1e-2}[method]
+    for a, c in zip(ga, gc):
+        assert rel(a.cpu(), c.cpu()) < tol, (rel(a.cpu(), c.cpu()), tol)
