@@ -179,6 +179,69 @@ class HaloPlan:
         return halo
 
 
+    # ---- training: the exchange's vector-Jacobian product (round 6) ---------------------------------------------------------------
+    def _scatter_operator(self):
+        """P^T: (n_own x rows we send) with a one where packed row j is own row send_idx[j] - the accumulation of the returning
+        gradient rows as an SpMM: a fixed order per own row (an index_add_ with atomics would not be deterministic)"""
+        if getattr(self, '_scatter_op', None) is None:
+            idx = self.send_idx.cpu().numpy().astype(np.int64)
+            m = sp.csr_matrix((np.ones(idx.size, dtype=np.float32), (idx, np.arange(idx.size))), shape=(self.n_own, max(idx.size, 1)))
+            m.sort_indices()
+            self._scatter_op = CsrOperator.from_scipy(m, self.device)
+        return self._scatter_op
+
+    def exchange_grad(self, ops, G):
+        """The backward of `exchange`: G (n_halo x H) is the gradient of the halo panel this rank received; every row goes back to its
+        owner (the same all-to-all-v with the counts swapped) and the owner adds what returns into the rows it had sent.  Returns this
+        rank's (n_own x H) share: the gradient that reaches its own panel THROUGH the other ranks' halos.  Collective: every rank of
+        the group calls it (autograd does: the ranks run the same graph in the same order)."""
+        H = G.shape[1]
+        out_rows = sum(self.send_counts)
+        if self.global_rows_moved == 0:
+            return torch.zeros((self.n_own, H), dtype=G.dtype, device=G.device)
+        back = torch.empty((out_rows, H), dtype=G.dtype, device=G.device)
+        G = G.contiguous()
+        if G.is_cuda and dist.get_backend(self.group) != 'nccl':
+            h = torch.empty((out_rows, H), dtype=G.dtype)
+            dist.all_to_all_single(h, G.cpu(), self.send_counts, self.recv_counts, group=self.group)
+            back.copy_(h)
+        else:
+            dist.all_to_all_single(back, G, self.send_counts, self.recv_counts, group=self.group)
+        if out_rows == 0:
+            return torch.zeros((self.n_own, H), dtype=G.dtype, device=G.device)
+        return ops.spmm(self._scatter_operator(), back)
+
+
+class _HaloExchangeFn(torch.autograd.Function):
+    """halo = exchange(x) as a node of the training graph: backward = the reverse all-to-all-v with accumulation (HaloPlan.exchange_grad)"""
+
+    @staticmethod
+    def forward(ctx, x, plan, ops):
+        ctx.plan, ctx.ops = plan, ops
+        return plan.exchange(ops, x.detach()).clone()        # (the plan may hand out a view of a buffer it re-uses: the graph keeps its own)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.plan.exchange_grad(ctx.ops, g), None, None
+
+
+def allreduce_gradients(params, group=None):
+    """Parameters are replicated, every rank's backward leaves the contribution of ITS rows in `.grad`: the sum over ranks is the
+    gradient of a loss summed over all nodes (call once after loss.backward(); heat_dynamics.py:313-334 on a sharded graph)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        g = p.grad
+        if g.is_cuda and dist.get_backend(group) != 'nccl':
+            h = g.cpu()
+            dist.all_reduce(h, group=group)
+            g.copy_(h)
+        else:
+            dist.all_reduce(g, group=group)
+
+
 class ShardedODEFunc(nn.Module):
     """ODEFunc on one shard: halo exchange, then the local fused RHS over [own | halo]
     (neural_dynamics.py:20-39 semantics on the global graph).
@@ -290,8 +353,34 @@ class ShardedODEFunc(nn.Module):
             return out
         return self._overlapped(x, during, after)
 
+    def _training(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.f.parameters()))
+
+    def _forward_with_grad(self, x):
+        """The evaluation as nodes of an autograd graph (round 6: training on a sharded graph): the exchange is differentiable
+        (_HaloExchangeFn: its backward sends the halo rows' gradients home), the local right-hand side runs on [own | halo] as one
+        panel through the differentiable op set - A^T g in its backward is the local operator's transpose, (n_own + n_halo) rows.
+        One launch form, no overlap: correctness first (the reference trains by plain backpropagation, heat_dynamics.py:313-334)."""
+        f = self.f
+        W, bias = f.wt.weight, f.wt.bias
+        ops = self.ops
+        native = getattr(ops, 'differentiable', False)       # (the CPU test double is plain torch: differentiable as it stands)
+        if f.no_graph:
+            if native:
+                return ops.rhs(None, x, W, bias, no_graph=True, no_control=f.no_control)
+            from .autograd_ops import rhs as rhs_g
+            return rhs_g(None, x, W, bias, True, f.no_control)
+        halo = _HaloExchangeFn.apply(x, self.plan, ops)
+        self.halo_bytes += 2 * self.plan.bytes_per_exchange(x.shape[1])          # (there and, in the backward, back)
+        if native:
+            return ops.rhs(self.plan.local_op, x, W, bias, no_control=f.no_control, X_halo=halo)
+        from .autograd_ops import rhs as rhs_g
+        return rhs_g(self.plan.local_op, torch.cat([x, halo], 0), W, bias, False, f.no_control)
+
     def forward(self, t, x):
         self.nfe += 1
+        if self._training(x):
+            return self._forward_with_grad(x)
         f = self.f
         W, bias = f.wt.weight, f.wt.bias
         if f.no_graph:
@@ -398,6 +487,17 @@ def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, ato
     'one_launch', 'nfe', 'halo_bytes' (sent + received over the solve), 'halo_rows_received_per_rhs'}."""
     from .torchdiffeq._impl import core
     f = ShardedODEFunc(odefunc, plan, ops)
+    training = f._training(x_local)
+    if training:
+        # Training (round 6): every panel operation of the solve is a node of this rank's autograd graph - the differentiable op set
+        # (autograd_ops on the device; the CPU double is torch as it stands), the halo exchange with its reverse exchange as backward.
+        # Fixed grids: the reference's gradient.  dopri5: the step sizes the (globally reduced) controller chose are constants of the
+        # graph - unlike the single-GPU tape, which follows the reference through the controller; stated in DESIGN section 6.
+        # Parameter gradients are per-rank contributions: allreduce_gradients() after backward.
+        if not getattr(ops, 'differentiable', False):
+            from .autograd_ops import autograd_ops
+            ops = autograd_ops
+        fused = False
     dops = DistOps(ops, n_global_rows, x_local.shape[0], group)
     _, func, y0, tt = core.check_inputs(f, x_local, t)
     # A decreasing grid is integrated as -f(-t, y) on -t (misc.py:184-189): the sign flip cannot ride in the ReLU
@@ -409,7 +509,7 @@ def sharded_odeint(ops, odefunc, plan, n_global_rows, x_local, t, rtol=1e-7, ato
     else:
         sol = core.integrate_fixed(dops, func, y0, tt, method, autonomous=True)
     if stats is not None:
-        stats.update(form='row_split' if f.overlap else 'two_phase' if f.two_phase else 'one_launch', nfe=f.nfe,
+        stats.update(form='one_launch+autograd' if training else 'row_split' if f.overlap else 'two_phase' if f.two_phase else 'one_launch', nfe=f.nfe,
                      halo_bytes=f.halo_bytes, halo_rows_received_per_rhs=plan.n_halo)
     return torch.stack([s[0] for s in sol])
 

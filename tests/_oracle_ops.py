@@ -28,6 +28,7 @@ def _bad(x):
 
 class OracleOps:
     name = 'oracle'
+    differentiable = True          # plain torch: the sharded training path differentiates straight through it
 
     @staticmethod
     def _coo(A):

@@ -548,6 +548,56 @@ def test_sharded_path_single_rank_equals_device_solver(dev):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('H', [256, 20])
+def test_sharded_training_single_rank_self_halo_equals_unsharded_training(dev, H):
+    """Training through the sharded path on the device (round 6): the halo exchange and its backward - the reverse all-to-all-v over
+    RCCL, accumulated by the scatter operator - with ONE rank whose self-halo hook routes own rows through the exchange; the local
+    right-hand side on [own | halo] through autograd_ops.  Against training through the unsharded solver (itself pinned to the oracle's
+    gradients in test_gpu_autograd.py): rk4 - the same gradient; dopri5 - the sharded form keeps the controller's step sizes as
+    constants, so it is compared at a tolerance where that choice does not matter (and the forward solve is the same solve)."""
+    import torch.distributed as dist
+    from ndcn_amd import graphs, sharding, hip
+    from ndcn_amd import torchdiffeq as ode
+    from ndcn_amd.neural_dynamics import ODEFunc
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29643', rank=0, world_size=1, device_id=dev)
+    try:
+        side = 24
+        n = side * side
+        L = graphs.normalized_laplacian(graphs.grid_8_neighbor(side))
+        torch.manual_seed(4)
+        f = ODEFunc(H, graphs.to_device(L, dev)).to(dev)
+        x_init = torch.rand(n, H, generator=torch.Generator().manual_seed(5)).to(dev)
+        t = torch.linspace(0., 1., 5).to(dev)
+        wgt = torch.randn(5, n, H, generator=torch.Generator().manual_seed(6)).to(dev)
+        for spec in (2 * side, 'scatter:150'):
+            plan = sharding.HaloPlan(L, [0, n], 0, dev, self_halo=spec)
+            assert plan.n_halo > 0 and sum(plan.send_counts) == plan.n_halo
+            for method, kw, tol in (('rk4', {}, 2e-5), ('dopri5', dict(rtol=1e-6, atol=1e-8), 5e-2)):
+                res = []
+                for sharded in (True, False):
+                    for p_ in f.parameters():
+                        p_.grad = None
+                    x0 = x_init.clone().requires_grad_(True)
+                    if sharded:
+                        st = {}
+                        y = sharding.sharded_odeint(hip, f, plan, n, x0, t, method=method, stats=st, **kw)
+                        assert st['form'] == 'one_launch+autograd'
+                    else:
+                        y = ode.odeint(f, x0, t, method=method, **kw)
+                    (y * wgt).sum().backward()
+                    if sharded:
+                        sharding.allreduce_gradients(f.parameters())
+                    res.append((y.detach(), x0.grad.clone(), f.wt.weight.grad.clone(), f.wt.bias.grad.clone()))
+                (ya, *ga), (yb, *gb) = res
+                assert float((ya - yb).abs().max()) <= 2e-5 * float(yb.abs().max())
+                for a, b in zip(ga, gb):
+                    r = float((a - b).abs().max() / b.abs().max())
+                    assert r < tol, (spec, method, r)
+    finally:
+        dist.destroy_process_group()
+
+
 def _two_rank_graph(case):
     from ndcn_amd import graphs
     if case == 'grid':

@@ -284,3 +284,100 @@ def test_bench_runner_two_ranks_equals_single_process():
     assert np.allclose(np.array(logs)[:, :3], np.array(ret[0]['log'])[:, :3], rtol=1e-4)
     got = np.concatenate([ret[0]['y'], ret[1]['y']], axis=0)
     assert np.abs(got - s.y[0].numpy()).max() < 1e-4
+
+
+def _training_worker(rank, world, port, case, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from ndcn_amd import graphs, sharding
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from _oracle_ops import OracleOps
+        cpu = torch.device('cpu')
+        H = 10
+        if case == 'grid':
+            full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(12, 8))
+            bounds = [(12 * r // world) * 8 for r in range(world + 1)]
+        else:
+            full = graphs.normalized_laplacian(graphs.make_graph('small_world', 140, seed=3))
+            bounds = sharding.even_bounds(140, world)
+        n = full.shape[0]
+        plan = sharding.HaloPlan(full[bounds[rank]:bounds[rank + 1]], bounds, rank, cpu)
+        x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
+        t = torch.linspace(0., 1.2, 5)
+        wgt = torch.randn(5, n, H, generator=torch.Generator().manual_seed(2))
+        out = {}
+        for method in ('euler', 'rk4', 'dopri5'):
+            torch.manual_seed(0)
+            f = ODEFunc(H, None)
+            xl = x[bounds[rank]:bounds[rank + 1]].clone().requires_grad_(True)
+            stats, log = {}, []
+            y = sharding.sharded_odeint(OracleOps, f, plan, n, xl, t, rtol=1e-3, atol=1e-4, method=method, stats=stats, step_log=log)
+            assert y.requires_grad and stats['form'] == 'one_launch+autograd'
+            loss = (y * wgt[:, bounds[rank]:bounds[rank + 1]]).sum()          # this rank's part of a loss summed over all nodes
+            loss.backward()
+            sharding.allreduce_gradients(f.parameters())
+            out[method] = {'y': y.detach().numpy(), 'gx': xl.grad.numpy(), 'gW': f.wt.weight.grad.numpy(), 'gb': f.wt.bias.grad.numpy(),
+                           'log': [r for r in log if r[0] != 'nfe']}
+        out['W'], out['b'] = f.wt.weight.detach().numpy(), f.wt.bias.detach().numpy()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['grid', 'small_world'])
+def test_two_rank_sharded_training_gradients(case):
+    """Training on a node-range sharded graph (round 6; heat_dynamics.py:313-334 on a graph no single device has to hold): autograd
+    through sharded_odeint - the halo exchange's backward is the reverse all-to-all-v with accumulation (HaloPlan.exchange_grad), the
+    local right-hand side's A^T g covers [own | halo] columns, parameter gradients are summed over ranks.  Two gloo ranks against ONE
+    process on the whole graph: fixed grids against the oracle's autograd (the reference's gradient); dopri5 - whose sharded form
+    keeps the controller's step sizes as constants of the graph - against the same stepping (core.integrate_dopri5 over the
+    differentiable op set) unsharded."""
+    world = 2
+    port = 29800 + (os.getpid() % 150) + (0 if case == 'grid' else 1)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_training_worker, args=(world, port, case, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from ndcn_amd import graphs
+    from ndcn_amd.torchdiffeq._impl import core
+    from oracle import ndcn_oracle as orc
+    from _oracle_ops import OracleOps
+    H = 10
+    if case == 'grid':
+        full = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(12, 8))
+    else:
+        full = graphs.normalized_laplacian(graphs.make_graph('small_world', 140, seed=3))
+    n = full.shape[0]
+    A = orc.coo_from_csr(full.indptr, full.indices, full.data, full.shape)
+    x = torch.rand(n, H, generator=torch.Generator().manual_seed(1))
+    t = torch.linspace(0., 1.2, 5)
+    wgt = torch.randn(5, n, H, generator=torch.Generator().manual_seed(2))
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+    for method in ('euler', 'rk4', 'dopri5'):
+        W = torch.from_numpy(ret[0]['W']).clone().requires_grad_(True)
+        b = torch.from_numpy(ret[0]['b']).clone().requires_grad_(True)
+        xc = x.clone().requires_grad_(True)
+        fn = lambda tt, xx: orc.odefunc_rhs(A, xx, W, b)
+        if method == 'dopri5':
+            log = []
+            sol = core.integrate_dopri5(OracleOps, lambda tt, y: (fn(tt, y[0]),), (xc,), t, 1e-3, 1e-4, autonomous=True, step_log=log)
+            yo = torch.stack([s_[0] for s_ in sol])
+            assert [r[2] for r in ret[0][method]['log']] == [r[2] for r in log if r[0] != 'nfe']       # the same attempts
+            assert ret[0][method]['log'] == ret[1][method]['log']
+        else:
+            yo = orc.odeint(fn, xc, t, method=method)
+        (yo * wgt).sum().backward()
+        got_y = np.concatenate([ret[r][method]['y'] for r in range(world)], axis=1)
+        assert np.abs(got_y - yo.detach().numpy()).max() < 5e-6
+        got_gx = np.concatenate([ret[r][method]['gx'] for r in range(world)], axis=0)
+        assert rel(got_gx, xc.grad.numpy()) < 2e-5, (method, rel(got_gx, xc.grad.numpy()))
+        for r in range(world):                                        # every rank holds the summed parameter gradients
+            assert rel(ret[r][method]['gW'], W.grad.numpy()) < 2e-5, (method, rel(ret[r][method]['gW'], W.grad.numpy()))
+            assert rel(ret[r][method]['gb'], b.grad.numpy()) < 2e-5, method
