@@ -573,7 +573,9 @@ def test_sharded_training_single_rank_self_halo_equals_unsharded_training(dev, H
         for spec in (2 * side, 'scatter:150'):
             plan = sharding.HaloPlan(L, [0, n], 0, dev, self_halo=spec)
             assert plan.n_halo > 0 and sum(plan.send_counts) == plan.n_halo
-            for method, kw, tol in (('rk4', {}, 2e-5), ('dopri5', dict(rtol=1e-6, atol=1e-8), 5e-2)):
+            sub = 16
+            fine = torch.cat([torch.linspace(float(t[i]), float(t[i + 1]), sub + 1)[:-1] for i in range(len(t) - 1)] + [t[-1:].cpu()]).to(dev)
+            for method, kw, tol in (('rk4', {}, 2e-5), ('dopri5', dict(rtol=1e-6, atol=1e-8), 1e-2)):      # (dopri5 measured: 3e-3 / 4e-3 of the gradient's scale)
                 res = []
                 for sharded in (True, False):
                     for p_ in f.parameters():
@@ -583,6 +585,10 @@ def test_sharded_training_single_rank_self_halo_equals_unsharded_training(dev, H
                         st = {}
                         y = sharding.sharded_odeint(hip, f, plan, n, x0, t, method=method, stats=st, **kw)
                         assert st['form'] == 'one_launch+autograd'
+                    elif method == 'dopri5':
+                        # the yardstick for the frozen-controller gradient: the exact flow's (RK4 on a 16 x finer grid, unsharded) - the
+                        # unsharded dopri5 tape follows the reference THROUGH the controller and sits several per cent from both
+                        y = ode.odeint(f, x0, fine, method='rk4')[::sub]
                     else:
                         y = ode.odeint(f, x0, t, method=method, **kw)
                     (y * wgt).sum().backward()
@@ -590,7 +596,7 @@ def test_sharded_training_single_rank_self_halo_equals_unsharded_training(dev, H
                         sharding.allreduce_gradients(f.parameters())
                     res.append((y.detach(), x0.grad.clone(), f.wt.weight.grad.clone(), f.wt.bias.grad.clone()))
                 (ya, *ga), (yb, *gb) = res
-                assert float((ya - yb).abs().max()) <= 2e-5 * float(yb.abs().max())
+                assert float((ya - yb).abs().max()) <= (2e-5 if method == 'rk4' else 1e-4) * float(yb.abs().max())
                 for a, b in zip(ga, gb):
                     r = float((a - b).abs().max() / b.abs().max())
                     assert r < tol, (spec, method, r)
