@@ -381,3 +381,62 @@ def test_two_rank_sharded_training_gradients(case):
         for r in range(world):                                        # every rank holds the summed parameter gradients
             assert rel(ret[r][method]['gW'], W.grad.numpy()) < 2e-5, (method, rel(ret[r][method]['gW'], W.grad.numpy()))
             assert rel(ret[r][method]['gb'], b.grad.numpy()) < 2e-5, method
+
+
+def _training_isolated_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import scipy.sparse as sp
+        from ndcn_amd import graphs, sharding
+        from ndcn_amd.neural_dynamics import ODEFunc
+        from _oracle_ops import OracleOps
+        H = 6
+        torch.manual_seed(0)
+        f = ODEFunc(H, None)
+        a = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(5, 6))
+        b = graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(10, 6))
+        full = sp.block_diag([a, b], format='csr')
+        bounds = [0, 30, 60, 90]
+        plan = sharding.HaloPlan(full[bounds[rank]:bounds[rank + 1]], bounds, rank, torch.device('cpu'))
+        x = torch.rand(90, H, generator=torch.Generator().manual_seed(1))
+        wgt = torch.randn(3, 90, H, generator=torch.Generator().manual_seed(2))
+        xl = x[bounds[rank]:bounds[rank + 1]].clone().requires_grad_(True)
+        y = sharding.sharded_odeint(OracleOps, f, plan, 90, xl, torch.linspace(0., 1., 3), method='rk4')
+        (y * wgt[:, bounds[rank]:bounds[rank + 1]]).sum().backward()
+        sharding.allreduce_gradients(f.parameters())
+        ret[rank] = {'gx': xl.grad.numpy(), 'gW': f.wt.weight.grad.numpy(), 'W': f.wt.weight.detach().numpy(), 'b': f.wt.bias.detach().numpy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_rank_without_halo_enters_the_backward_collectives():
+    """Three ranks, rank 0's shard a component of its own: it receives no halo and sends nothing, yet the reverse exchange of the
+    backward pass is a collective its peers enter - it must enter it too (with zero counts), like the forward's; gradients equal the
+    oracle's on the whole graph."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_training_isolated_worker, args=(world, 29760 + os.getpid() % 30, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    from ndcn_amd import graphs
+    from oracle import ndcn_oracle as orc
+    full = sp.block_diag([graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(5, 6)),
+                          graphs.normalized_laplacian(graphs.grid_8_neighbor_rect(10, 6))], format='csr')
+    A = orc.coo_from_csr(full.indptr, full.indices, full.data, full.shape)
+    W = torch.from_numpy(ret[0]['W']).clone().requires_grad_(True)
+    b = torch.from_numpy(ret[0]['b']).clone().requires_grad_(True)
+    x = torch.rand(90, 6, generator=torch.Generator().manual_seed(1)).requires_grad_(True)
+    wgt = torch.randn(3, 90, 6, generator=torch.Generator().manual_seed(2))
+    yo = orc.odeint(lambda tt, xx: orc.odefunc_rhs(A, xx, W, b), x, torch.linspace(0., 1., 3), method='rk4')
+    (yo * wgt).sum().backward()
+    gx = np.concatenate([ret[r]['gx'] for r in range(world)], axis=0)
+    assert np.abs(gx - x.grad.numpy()).max() < 2e-5 * np.abs(x.grad.numpy()).max()
+    for r in range(world):
+        assert np.abs(ret[r]['gW'] - W.grad.numpy()).max() < 2e-5 * np.abs(W.grad.numpy()).max()
