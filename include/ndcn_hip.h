@@ -642,8 +642,8 @@ NDCN_API int ndcn_prof_kinds(void);
 #define NDCN_PATH_SMALL 128  /* H <= 128: the whole ODEFunc + epilogue in one launch (rhs_small.hip)                            */
 #define NDCN_PATH_EXACT32 256 /* H = 256, range guard: the weights' in-row range exceeds what the two-piece fp16 product guarantees
                                * (four or more non-zero elements more than 2^19 below their row's largest magnitude: csrc/split16.h), found when
-                               * the image was packed - the Linear ran on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; nn.Linear
-                               * in fp32, neural_dynamics.py:33), the stage algebra as kernels of its own.  NDCN_RANGE_GUARD=0
+                               * the image was packed - the launch ran with the fp32 matrix cores as its consumer (v_mfma_f32_32x32x2_f32;
+                               * nn.Linear in fp32, neural_dynamics.py:33; csrc/rhs_fused2_exact.hip).  NDCN_RANGE_GUARD=0
                                * switches the guard (and the 32-byte read-back per packed image) off                              */
 #define NDCN_PATH_RANGE  512 /* such weights on a launch that exists only fused (x_add / x_mask / s_out): split product, warned once */
 NDCN_API int ndcn_debug_last_rhs_path(void);

@@ -52,6 +52,11 @@ int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st);   // planes o
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags);
 int rhs_fused2_variant(int mode, int n_prev);
 int64_t rhs_fused2_partials_bytes();
+// rhs_fused2_exact.hip: the same contract with the Linear on the fp32 matrix cores (Wp: the fp32 image at the head of the packed scratch)
+int rhs_fused2_exact_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
+                         float *K, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c,
+                         int n_prev, float *y_next, float rtol, float atol, double *d_out, void *d_ws, hipStream_t st,
+                         const RkOpt *opt = nullptr);
 // mode 0: K only; 1: also y_next = y0 + sum c_m kprev_m + c_new K; 2: also the dopri5 error record into d_out
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
                    float *K, uint32_t flags, int mode, const float *y0, const float *const *h_kprev, const float *h_c,

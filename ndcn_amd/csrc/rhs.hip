@@ -57,12 +57,11 @@ int rhs_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, c
                 }
                 int rc = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256(W, work, st);
                 if (rc) return rc;
-                if (weights_wide_range(work)) {
-                    // range guard (split16.h): weights outside the split product's guarantee take the fp32 matrix cores - the
-                    // first-generation fused kernel (v_mfma_f32_32x32x2_f32 over the fp32 image of W in the same scratch)
-                    g_last_rhs_path = NDCN_PATH_EXACT32 | ((Xh && A->n_cols > n_own) ? NDCN_PATH_HALO : 0);
-                    return rhs_fused_packed_f32(A, X, Xh, n_own, work, b, Y, flags, st);
-                }
+                if (weights_wide_range(work))
+                    // range guard (split16.h): weights outside the split product's guarantee take the fp32 matrix cores - the same
+                    // kernel with the v_mfma_f32_32x32x2_f32 consumer over the fp32 image of W in the same scratch (rhs_fused2_exact.hip)
+                    return rhs_fused2_exact_f32(A, X, Xh, n_own, work, b, Y, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f, 0.f,
+                                                nullptr, nullptr, st);
                 return rhs_fused2_f32(A, X, Xh, n_own, work, b, Y, flags, 0, nullptr, nullptr, nullptr, 0, nullptr, 0.f,
                                       0.f, nullptr, nullptr, st);
             }
@@ -122,7 +121,9 @@ int rhs_rk_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own
             }
             return rc;
         }
-        flags |= NDCN_F_PACKED;                               // composed below: rhs_f32 (fp32 matrix cores) + the stage kernels
+        // the same launch - gather, Linear, RK epilogue - with the fp32 matrix cores as its consumer (rhs_fused2_exact.hip)
+        return rhs_fused2_exact_f32(A, X, Xh, n_own, work, b, K, flags, rk_mode, y0, h_kprev, h_c, n_prev, y_next, rtol, atol, d_out, d_ws,
+                                    st, opt);
     }
     else if (both && rhs_small_supported(A, H, flags)) {
         g_last_rhs_path = NDCN_PATH_SMALL;

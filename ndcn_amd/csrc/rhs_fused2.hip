@@ -53,6 +53,18 @@ constexpr int kTileFloats2 = kTile2 * kLd2;
 // split error-free into two fp16 pieces behind a power-of-two scale, three partial products accumulated in fp32 (split16.h:
 // measured against fp64, 1.9e-7 of sum |s w| vs 2.3e-7 for the fp32-MFMA chain on the same data) at 3/16 of the fp32 MFMA's
 // matrix-pipe time.  NDCN_SPLIT = 0 builds the fp32-MFMA consumer (A/B reference).
+// NDCN_F2_EXACT = 1 (csrc/rhs_fused2_exact.hip includes this file with it): the SAME kernel with the fp32-MFMA consumer under other names -
+// rhs_fused2_exact_kernel / rhs_fused2_exact_f32 - the route of the range guard (rhs.hip: NDCN_PATH_EXACT32): gather, Linear on
+// v_mfma_f32_32x32x2_f32 over the fp32 image of W, RK epilogue, one launch.  The definitions both builds would share stay in the default one.
+#ifndef NDCN_F2_EXACT
+#define NDCN_F2_EXACT 0
+#endif
+#if NDCN_F2_EXACT
+#undef NDCN_SPLIT
+#define NDCN_SPLIT 0
+#define rhs_fused2_kernel rhs_fused2_exact_kernel
+#define rhs_fused2_f32 rhs_fused2_exact_f32
+#endif
 #ifndef NDCN_SPLIT
 #define NDCN_SPLIT 1
 #endif
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(64 * kWaves) void rhs_fused2_kernel(const int *__re
     }
 }
 
+#if !NDCN_F2_EXACT
 // fixed-order sum of the per-producer partials (deterministic accept / reject)
 __global__ __launch_bounds__(256) void fused2_finish_kernel(const double *__restrict__ partial, int n, double *__restrict__ out, int accum) {
     __shared__ double sa[256], sb[256];
@@ -590,12 +603,14 @@ int partials_finish(const double *partials, int n, double *d_out, hipStream_t st
 }
 
 thread_local int g_last_rhs_path = 0;
+#endif
 
 static int env_int3(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
 }
 
+#if !NDCN_F2_EXACT
 int rhs_fused2_supported(const ndcn_csr *A, int H, uint32_t flags) {
     static const int enabled = env_int3("NDCN_RHS_FUSED2", 1);
     if (!enabled || H != kH2 || !A) return 0;
@@ -613,7 +628,8 @@ int rhs_fused2_variant(int mode, int n_prev) {
     return mode == MODE_ERROR && (n_prev == kMaxPrev || n_prev == 1);
 }
 
-int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * kProd * 2 * sizeof(double); }
+int64_t rhs_fused2_partials_bytes() { return (int64_t)kCus * 12 * 2 * sizeof(double); }      // (12: the gather waves of the fp32-MFMA build)
+#endif
 
 // mode: 0 plain; 1 combine (y_next = y0 + sum c_m k_m, new K last); 2 error (d_out[0..1], d_ws scratch)
 int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n_own, const float *Wp, const float *b,
@@ -683,7 +699,7 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
                               d_ws, st, opt);
     }
     if (opt && (opt->xadd || opt->xmask || opt->s_out)) { set_error("rhs_fused2: RkOpt::xadd / xmask / s_out need the rhs_fused3 path (rhs_xadd_supported, rhs_adj_supported)"); return NDCN_EINVAL; }
-    g_last_rhs_path = NDCN_PATH_FUSED2 | path_bits;
+    g_last_rhs_path = (NDCN_F2_EXACT ? NDCN_PATH_EXACT32 : NDCN_PATH_FUSED2) | path_bits;
     if (!rhs_fused2_variant(mode, n_prev)) { set_error("rhs_fused2: no kernel for mode %d with %d previous stages", mode, n_prev); return NDCN_EINVAL; }
     Fused2Args a;
     const int64_t xb = (Xh ? n_own : A->n_cols) * (int64_t)kH2 * 4, xhb = Xh ? (A->n_cols - n_own) * (int64_t)kH2 * 4 : 0;
@@ -745,9 +761,11 @@ int rhs_fused2_f32(const ndcn_csr *A, const float *X, const float *Xh, int64_t n
     else NDCN_F2_DISPATCH(false);
 #undef NDCN_F2_DISPATCH
 #undef NDCN_F2
-    if (mode == MODE_ERROR)
-        hipLaunchKernelGGL(fused2_finish_kernel, dim3(1), dim3(256), 0, st, ea.partials, (int)grid.x * kProd, d_out, (opt && opt->accum) ? 1 : 0);
     NDCN_LAUNCH_CHECK();
+    if (mode == MODE_ERROR) {
+        int rcf = partials_finish(ea.partials, (int)grid.x * kProd, d_out, st, (opt && opt->accum) ? 1 : 0);
+        if (rcf) return rcf;
+    }
     if (timing && timing_prints < timing) {                          // debugging aid: s_memtime accounting of block 0 and 100
         (void)hipStreamSynchronize(st);
         unsigned long long h[2 * kWaves];

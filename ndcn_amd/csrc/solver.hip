@@ -144,8 +144,10 @@ int rhs(ndcn_solver *s, const float *x, float *out, hipStream_t st) {
     if (s->fused2 && !s->rec_epi && !s->exact32)
         return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, 0, nullptr,
                               nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st);
-    if (s->fused) {     // weights were packed once in solver_begin (exact32: the range guard's route - fp32 matrix cores)
-        if (s->exact32) g_last_rhs_path = NDCN_PATH_EXACT32;
+    if (s->fused2 && !s->rec_epi)       // exact32: the range guard's route - the same launch on the fp32 matrix cores
+        return rhs_fused2_exact_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, 0, nullptr,
+                                    nullptr, nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, st);
+    if (s->fused) {     // weights were packed once in solver_begin
         return rhs_fused_packed_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, out, s->d.rhs_flags, st);
     }
     return rhs_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, out, s->work, s->d.H, s->d.rhs_flags, st);
@@ -178,9 +180,9 @@ int rhs_epi(ndcn_solver *s, const float *x, float *K, int mode, const float *y0,
         return spmm_rec_f32(&s->d.A, x, nullptr, s->d.A.n_cols, K, 1.f, s->d.rhs_flags, mode, y0, kp, cp, n_prev, y_next, rtol,
                             atol, d_out, d_ws, st, c_dev, opt);
     }
-    if (s->exact32)     // range guard: the evaluation on the fp32 matrix cores, the stage algebra as kernels of its own (rhs.hip)
-        return rhs_rk_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->d.W, s->d.b, K, s->work, s->d.H, s->d.rhs_flags | NDCN_F_PACKED, mode, y0,
-                          kp, cp, n_prev, y_next, rtol, atol, d_out, d_ws, st, opt);
+    if (s->exact32)     // range guard: the same launch with the fp32 matrix cores as its consumer (rhs_fused2_exact.hip)
+        return rhs_fused2_exact_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev,
+                                    y_next, rtol, atol, d_out, d_ws, st, opt);
     return rhs_fused2_f32(&s->d.A, x, nullptr, s->d.A.n_cols, s->work, s->d.b, K, s->d.rhs_flags, mode, y0, kp, cp, n_prev,
                           y_next, rtol, atol, d_out, d_ws, st, opt);
 }

@@ -221,7 +221,7 @@ def test_weights_beyond_the_guarantee_take_the_fp32_matrix_cores(dev, which):
     W, b = _wide_range_weights()
     X = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(5))
     X[:, 33] = 0.0                                                   # S[:, 33] = 0: the dominant weight meets zeros
-    ratio = _rhs_bound_check(L, A, W, b, X, dev, _lib.PATH_EXACT32)
+    ratio = _rhs_bound_check(L, A, W, b, X, dev, _lib.PATH_EXACT32 | (_lib.PATH_SWEEP if which == 'sweep' else 0))   # (the sweep still forms S)
     # the same operands on the split product: outside the bound (the reason the guard exists)
     _lib.load().ndcn_set_range_guard(0)
     from ndcn_amd.ops import invalidate_packed_weights
