@@ -242,6 +242,23 @@ def test_weights_beyond_the_guarantee_take_the_fp32_matrix_cores(dev, which):
     assert torch.equal(K, K0)
     assert float((yn - (y0 + K0 * np.float32(0.25))).abs().max()) == 0.0
     assert ratio < 2e-6
+    # the other launch modes of the fp32 route against the composed kernels: an RK4 stage, the dopri5 error record (two earlier stages)
+    k1 = torch.rand(L.shape[0], H, generator=torch.Generator().manual_seed(7)).to(dev)
+    K4, y4 = hip.rhs_rk(A, Xd, Wd, bd, 'rk4', y0, [k1], [0.125])
+    assert int(_lib.load().ndcn_debug_last_rhs_path()) & _lib.PATH_EXACT32 and torch.equal(K4, K0)
+    assert torch.equal(y4, hip.fixed_stage(3, y0, k1, K0, dt=0.125))
+    Ke, (se, bade) = hip.rhs_rk(A, Xd, Wd, bd, 'error', y0, [k1], [0.03, -0.02], rtol=1e-2, atol=1e-3)
+    sr, badr = hip.error(y0, Xd, [k1, K0], [0.03, -0.02], 1e-2, 1e-3)
+    assert torch.equal(Ke, K0) and bade == badr == 0 and abs(se - sr) <= 1e-9 * abs(sr)
+    if which == 'fused2':
+        # ... and with a halo panel: the first 2000 rows own, the rest of X arrives as the second panel
+        from ndcn_amd import CsrOperator
+        sub = L[:2000]
+        Ah = CsrOperator.from_scipy(sub, dev)
+        Ah.lattice_hint = (0, 2000)
+        got = hip.rhs(Ah, Xd[:2000].contiguous(), Wd, bd, X_halo=Xd[2000:].contiguous())
+        assert int(_lib.load().ndcn_debug_last_rhs_path()) & _lib.PATH_EXACT32
+        assert torch.equal(got, K0[:2000])
 
 
 @pytest.mark.range_guard
