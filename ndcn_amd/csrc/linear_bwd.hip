@@ -608,7 +608,7 @@ static int64_t wgrad_work_bytes(int64_t n, int Hi, int Ho) {
 
 // partial gW / gb blocks, then (Hi = Ho = 256) the packed fp16 planes of W^T for the gS product
 int64_t linear_bwd_work_bytes(int64_t n, int Hi, int Ho) {
-    return wgrad_work_bytes(n, Hi, Ho) + ((Hi == 256 && Ho == 256) ? (int64_t)kS16Bytes + kS16TailBytes : 0);
+    return wgrad_work_bytes(n, Hi, Ho) + ((Hi == 256 && Ho == 256) ? (int64_t)kS16Bytes + kS16TailBytes + kS16GuardBytes : 0);
 }
 
 int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *W, float *gS, float *gW, float *gb, void *work,
@@ -626,13 +626,19 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
         ProfScope prof(PROF_LINEAR_GS, st, 4.0 * n * (double)(Hi + Ho * (Y ? 2 : 1)) + 4.0 * Hi * Ho, 2.0 * n * (double)Hi * Ho);
         static const bool split_on = [] { const char *e = getenv("NDCN_GS_SPLIT"); return !(e && e[0] == '0'); }();
         const bool a16 = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(gS) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
-        if (small) {
-            hipLaunchKernelGGL(linear_gs_small_kernel, dim3(stream_grid(n * (int64_t)Hi, 256)), dim3(256), 0, st, g, Y, W, gS, n, Hi, Ho);
-        } else if (split_on && Hi == 256 && Ho == 256 && work && a16) {
-            // (a caller without scratch - gS only, older bindings - keeps the fp32 MFMA kernel below)
-            void *Wq = static_cast<char *>(work) + wgrad_work_bytes(n, Hi, Ho);
+        bool split = !small && split_on && Hi == 256 && Ho == 256 && work && a16;
+        void *Wq = split ? static_cast<char *>(work) + wgrad_work_bytes(n, Hi, Ho) : nullptr;
+        if (split) {
             int rcp = (flags & NDCN_F_PACKED) ? NDCN_OK : pack_weight_256_t16(W, Wq, st);
             if (rcp) return rcp;
+            // range guard (split16.h): a COLUMN of W spanning more than the split product guarantees (the rows of the W^T image) sends
+            // gS = gZ W to the fp32 matrix cores below, like the forward's NDCN_PATH_EXACT32
+            if (weights_wide_range(Wq)) split = false;
+        }
+        if (small) {
+            hipLaunchKernelGGL(linear_gs_small_kernel, dim3(stream_grid(n * (int64_t)Hi, 256)), dim3(256), 0, st, g, Y, W, gS, n, Hi, Ho);
+        } else if (split) {
+            // (a caller without scratch - gS only, older bindings - keeps the fp32 MFMA kernel below)
             static const int gs_rows = [] { const char *e = getenv("NDCN_GS_ROWS"); return e ? atoi(e) : 0; }();     // 0: resident weights (default); 32 / 64: the tile kernels
             const int n_tiles = (int)((n + 31) / 32);
             if (gs_rows != 32 && gs_rows != 64)

@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *_
         }
         // (all eight threads of the row hold its maximum now) non-zero elements below the guarantee, exponents compared
         int below = 0;
-        if (!TRANSPOSED && (blockIdx.x & 3) == 0) {
+        if ((blockIdx.x & 3) == 0) {
             for (int k = 32 * part; k < 32 * part + 32; ++k) {
-                const unsigned b = __builtin_bit_cast(unsigned, W[n * kH + k]) & 0x7fffffffu;
+                const unsigned b = __builtin_bit_cast(unsigned, TRANSPOSED ? W[k * kH + n] : W[n * kH + k]) & 0x7fffffffu;
                 below += (b != 0u && (int)(m >> 23) - (int)(b >> 23) > kS16GuardBits) ? 1 : 0;
             }
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void pack_weight_256_f16_kernel(const float *_
         }
     }
     __syncthreads();
-    if (!TRANSPOSED && (blockIdx.x & 3) == 0 && threadIdx.x == 0) reinterpret_cast<int *>(tail)[256 + j] = s_wide;
+    if ((blockIdx.x & 3) == 0 && threadIdx.x == 0) reinterpret_cast<int *>(tail)[256 + j] = s_wide;
     const int row = 32 * j + (lane & 31), col = 16 * s + 8 * (lane >> 5);
     const float sc = s_scale[lane & 31];
 #pragma unroll
@@ -306,36 +306,38 @@ bool weights_wide_range(const void *Wp) {
     return it != g_wide.end() && it->second;
 }
 
+// 32 bytes back to the host, once per packed image (a solve packs once; callers that keep the image pass NDCN_F_PACKED).  Not while the
+// stream is being captured: a captured pack keeps the verdict of the image's last eager pack.
+static int learn_verdict(const void *image, const float *tail, hipStream_t st) {
+    if (!range_guard_on()) return NDCN_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return NDCN_OK;
+    int h[8];
+    NDCN_HIP(hipMemcpyAsync(h, reinterpret_cast<const int *>(tail) + 256, sizeof(h), hipMemcpyDeviceToHost, st));
+    NDCN_HIP(hipStreamSynchronize(st));
+    bool wide = false;
+    for (int q = 0; q < 8; ++q) wide = wide || h[q] != 0;
+    std::lock_guard<std::mutex> lk(g_wide_mu);
+    if (g_wide.size() > 4096) g_wide.clear();                    // (images come and go with their solvers: bounded, re-learnt at the next pack)
+    g_wide[image] = wide;
+    return NDCN_OK;
+}
+
 int pack_weight_256(const float *W, float *Wp, hipStream_t st) {
     hipLaunchKernelGGL(pack_weight_256_kernel, dim3(64), dim3(256), 0, st, W, Wp);
     float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(Wp + kH * kH) + kS16Bytes);
     hipLaunchKernelGGL(pack_weight_256_f16_kernel<false>, dim3(32), dim3(256), 0, st, W, reinterpret_cast<_Float16 *>(Wp + kH * kH), tail);
     NDCN_LAUNCH_CHECK();
-    if (range_guard_on()) {
-        // 32 bytes back to the host, once per packed image (a solve packs once; callers that keep the image pass NDCN_F_PACKED).  Not
-        // while the stream is being captured: a captured pack keeps the verdict of the image's last eager pack.
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-        if (cap == hipStreamCaptureStatusNone) {
-            int h[8];
-            NDCN_HIP(hipMemcpyAsync(h, reinterpret_cast<const int *>(tail) + 256, sizeof(h), hipMemcpyDeviceToHost, st));
-            NDCN_HIP(hipStreamSynchronize(st));
-            bool wide = false;
-            for (int q = 0; q < 8; ++q) wide = wide || h[q] != 0;
-            std::lock_guard<std::mutex> lk(g_wide_mu);
-            if (g_wide.size() > 4096) g_wide.clear();            // (images come and go with their solvers: bounded, re-learnt at the next pack)
-            g_wide[Wp] = wide;
-        }
-    }
-    return NDCN_OK;
+    return learn_verdict(Wp, tail, st);
 }
 
-// Wq <- the fp16 planes of W^T + the 256 per-row unscale factors (kS16Bytes + kS16TailBytes)
+// Wq <- the fp16 planes of W^T + the 256 per-row unscale factors + the range guard's 8 words (kS16Bytes + kS16TailBytes + kS16GuardBytes)
 int pack_weight_256_t16(const float *W, void *Wq, hipStream_t st) {
     float *tail = reinterpret_cast<float *>(static_cast<char *>(Wq) + kS16Bytes);
     hipLaunchKernelGGL(pack_weight_256_f16_kernel<true>, dim3(32), dim3(256), 0, st, W, static_cast<_Float16 *>(Wq), tail);
     NDCN_LAUNCH_CHECK();
-    return NDCN_OK;
+    return learn_verdict(Wq, tail, st);                          // (rows of W^T = columns of W: the backward's gS = gZ W, linear_bwd.hip)
 }
 
 // Wp: packed weights (pack_weight_256).  X, Y, W 16-byte aligned.

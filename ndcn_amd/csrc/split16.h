@@ -46,6 +46,7 @@ constexpr int kS16Bytes = 8 * 16 * kS16Planes * 1024;         // packed weights:
 constexpr int kS16TailBytes = 256 * 4;                       // (+ 8 words behind them in the forward image: the range guard's verdict per n-tile)
 constexpr int kS16GuardBits = 19;                              // a non-zero element more than 2^19 below its row's maximum keeps < 19 bits: outside the 2e-6 guarantee
 constexpr int kS16GuardCount = 4;                              // ... and a weight row with this many of them leaves for the fp32 matrix cores (rhs_fused.hip)
+constexpr int kS16GuardBytes = 32;                             // the guard's verdict per n-tile, behind the unscale factors of a packed image
 constexpr int kS16Top = 15;                                    // the scale brings a row's largest magnitude into [2^(top-1), 2^top)
 
 // wave-uniform maximum of an unsigned value (|x| bit patterns order like magnitudes; a NaN pattern wins)

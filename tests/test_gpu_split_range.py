@@ -287,3 +287,33 @@ def test_solver_with_weights_beyond_the_guarantee_matches_the_oracle(dev, method
         assert [r[2] for r in log[:-1]] == [r[2] for r in lo]
     scale = max(1.0, float(ref.abs().max()))
     assert float((y.cpu() - ref).abs().mean()) < 1e-5 * scale
+
+
+@pytest.mark.range_guard
+def test_backward_product_with_a_weight_column_beyond_the_guarantee(dev):
+    """gS = gZ W reads the planes of W^T: its rows are W's COLUMNS.  A column spanning 2^24 whose dominant weight meets a zero of gZ is
+    outside the split product's guarantee; the guard (the same scan, on the W^T image) sends the launch to the fp32 matrix cores."""
+    from ndcn_amd import hip, _lib
+    from ndcn_amd.ops import invalidate_packed_weights
+    W, b = _default_init()
+    W[:, 33] *= 2.0 ** -24 * 16.0
+    W[17, 33] = 1.0
+    n = 1000
+    gen = torch.Generator().manual_seed(6)
+    g = torch.randn(n, H, generator=gen)
+    g[:, 17] = 0.0                                                   # the dominant weight of column 33 meets zeros
+    Y = torch.rand(n, H, generator=gen) - 0.3
+    gZ = (g * (Y > 0)).double().numpy()
+    ref = gZ @ W.double().numpy()
+    mag = np.abs(gZ) @ np.abs(W.double().numpy())
+
+    def worst():
+        gS, _, _ = hip.linear_bwd(g.to(dev), W.to(dev), S=None, Y=Y.to(dev), need_gS=True, need_gW=False, need_gb=False)
+        return float((np.abs(gS.cpu().double().numpy() - ref) / (mag + 1e-300)).max())
+
+    assert worst() <= 2e-6
+    _lib.load().ndcn_set_range_guard(0)
+    invalidate_packed_weights()
+    assert worst() > 2e-6                                            # the split product on the same operands (why the guard exists)
+    _lib.load().ndcn_set_range_guard(1)
+    invalidate_packed_weights()
