@@ -163,6 +163,21 @@ c2lab)
     cp /tmp/default.so ndcn_amd/libndcn_hip.so
   } 2>&1 | tee gpurun_out/exp_c2lab.log
   ;;
+mlab)
+  # M dopri5 with parts of the lattice kernel switched off (needs gpurun_in_f3timing.so: rhs_fused3.hip built with -DNDCN_F3_TIMING;
+  # results wrong, timing only): where the power-capped step's time goes - rocprofv3 per-variant averages per switch
+  cp ndcn_amd/libndcn_hip.so /tmp/default.so
+  { echo "=== default build";                    kernel_stats mlab_default
+    cp gpurun_in_f3timing.so ndcn_amd/libndcn_hip.so
+    echo "=== timing build, no switch";          kernel_stats mlab_tb
+    echo "=== no MFMA (1)";                      NDCN_FUSED3_DBG=1 kernel_stats mlab_nomfma
+    echo "=== no weight refills (64)";           NDCN_FUSED3_DBG=64 kernel_stats mlab_norefill
+    echo "=== no MFMA, no refills (65)";         NDCN_FUSED3_DBG=65 kernel_stats mlab_nomfma_norefill
+    echo "=== no fold (2)";                      NDCN_FUSED3_DBG=2 kernel_stats mlab_nofold
+    echo "=== no epilogue (4)";                  NDCN_FUSED3_DBG=4 kernel_stats mlab_noepi
+    cp /tmp/default.so ndcn_amd/libndcn_hip.so
+  } 2>&1 | tee gpurun_out/exp_mlab.log
+  ;;
 gaps)
   # timeline of one bench run: idle time between consecutive kernels (host round trips of the adaptive controller)
   (cd /tmp && rm -rf /tmp/p_gaps && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_gaps -o x -- \
