@@ -500,6 +500,8 @@ __global__ __launch_bounds__(256) void linear_gs_256_split_kernel(const float *_
 // addressing of rhs_fused3 (32 x 1040 bytes).  Same pieces, same three products per k-step in the same order: bit-identical to the tile
 // kernels.
 constexpr int kGrLd = 260;                                   // floats per tile row: [256 fp16 high | 256 fp16 low] + 16 bytes
+// MASK: Y is given (gZ = g (.) [Y > 0] formed here); false: g is gZ already (the tape's pull kernel masked it) - no mask registers
+template <bool MASK>
 __global__ __launch_bounds__(512) void linear_gs_256_res_kernel(const float *__restrict__ g, const float *__restrict__ Y,
                                                                 const void *__restrict__ Wq, float *__restrict__ gS, int64_t n,
                                                                 int n_tiles) {
@@ -515,26 +517,41 @@ __global__ __launch_bounds__(512) void linear_gs_256_res_kernel(const float *__r
         for (int pl = 0; pl < 2; ++pl)
             B[ks][pl] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, lane * 16, ((wave * 16 + ks) * 2 + pl) * 1024, 0);
     const float wu = w_unscale[32 * wave + (lane & 31)];
-    f32x4 gv[4], yv[4];
-    auto request = [&](int tile) {                           // this wave's 4 rows of `tile` (rows past n re-read row n - 1, zeroed later)
+    // TWO tiles of requests in flight (round 6): with one, a CU had 32-64 KiB outstanding - 8-16 MB over the chip, below what the HBM's
+    // latency x rate asks for (M: the launch streamed at 4.1 TB/s of its 2 panels); the weights leave 64 registers for the second set
+    struct Rows { f32x4 gv[4], yv[MASK ? 4 : 1]; };
+    Rows ra, rb;
+    // this wave's 4 rows of `tile` - contiguous: through buffer descriptors of the panels (n x 1 KiB < 4 GiB: launcher check) with the
+    // row offset on the scalar unit and the lane offset in ONE register for every request of the kernel; rows past n read as zeros
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g), 0, (int)(unsigned)(n * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MASK ? Y : g), 0, (int)(unsigned)(n * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(gS, 0, (int)(unsigned)(n * 1024), 0x00020000);
+    auto request = [&](int tile, Rows &q) {
+        // (the row offset rides in the VECTOR offset: a raw buffer's range check covers vector + immediate offset, not the scalar one)
+        const int vo = (tile * 32 + 4 * wave) * 1024 + lane * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int64_t gr = (int64_t)tile * 32 + 4 * wave + i;
-            gr = gr < n ? gr : n - 1;
-            gv[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(g + gr * 256) + lane);
-            yv[i] = Y ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Y + gr * 256) + lane) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            q.gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo + 1024 * i, 0, 2));
+            if constexpr (MASK) q.yv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, vo + 1024 * i, 0, 2));
         }
     };
-    auto stage = [&](int tile, int buf) {                    // mask, scale, split, write the pieces
+    auto stage = [&](int tile, int buf, const Rows &q) {     // mask, scale, split, write the pieces
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * wave + i;
             const bool ok = (int64_t)tile * 32 + r < n;
             f32x4 v;
-            v.x = (ok && yv[i].x > 0.f) ? gv[i].x : 0.f;
-            v.y = (ok && yv[i].y > 0.f) ? gv[i].y : 0.f;
-            v.z = (ok && yv[i].z > 0.f) ? gv[i].z : 0.f;
-            v.w = (ok && yv[i].w > 0.f) ? gv[i].w : 0.f;
+            if constexpr (MASK) {
+                v.x = (ok && q.yv[i].x > 0.f) ? q.gv[i].x : 0.f;
+                v.y = (ok && q.yv[i].y > 0.f) ? q.gv[i].y : 0.f;
+                v.z = (ok && q.yv[i].z > 0.f) ? q.gv[i].z : 0.f;
+                v.w = (ok && q.yv[i].w > 0.f) ? q.gv[i].w : 0.f;
+            } else {
+                v.x = ok ? q.gv[i].x : 0.f;
+                v.y = ok ? q.gv[i].y : 0.f;
+                v.z = ok ? q.gv[i].z : 0.f;
+                v.w = ok ? q.gv[i].w : 0.f;
+            }
             unsigned sb, ub;
             s16_scale_bits(s16_wave_umax(s16_row_max_bits(v)), sb, ub);
             u32x2_s16 h0, h1;
@@ -545,12 +562,14 @@ __global__ __launch_bounds__(512) void linear_gs_256_res_kernel(const float *__r
             if (lane == 0) s_un[buf][r] = __builtin_bit_cast(float, ub);
         }
     };
-    int tile = blockIdx.x, buf = 0;
-    if (tile < n_tiles) { request(tile); stage(tile, 0); }
-    __syncthreads();
-    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < n_tiles) request(next);
+    const int G = gridDim.x;
+    // one tile: the products of `tile` out of buffer `buf`, then the pieces of tile + G (in `cur`) into the other buffer; `nxt` receives
+    // the requests of tile + 2 G first (a third set - the unmasked form has the registers - measured no faster: 0.476 vs 0.468 ms at M;
+    // per tile the launch is then at its matrix-pipe + split cycles, which add up on a SIMD like the weight gradient's)
+    constexpr int kAhead = 2;
+    auto one_tile = [&](int tile, int buf, Rows &cur, Rows &nxt) {
+        const int next = tile + G;
+        if (tile + kAhead * G < n_tiles) request(tile + kAhead * G, nxt);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -565,16 +584,25 @@ __global__ __launch_bounds__(512) void linear_gs_256_res_kernel(const float *__r
             if (ks & 1) __builtin_amdgcn_sched_barrier(0);     // (all 32 operand reads hoisted to the top cost 128 registers: spills)
         }
         // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]: column scale, then row scale (both exact)
-        float *tb = gS + (int64_t)tile * 32 * 256;            // wave-uniform base + 32-bit lane offsets (16 address registers, not 32)
-        const unsigned o0 = 32u * wave + (lane & 31) + 1024u * (lane >> 5);
-        const int rows_left = (int)(n - (int64_t)tile * 32 < 32 ? n - (int64_t)tile * 32 : 32);
+        // stores through the output's descriptor: rows past n fall outside its range and are dropped - no branch per store, ONE offset
+        // register (the per-store 64-bit addresses used to spill, and their reloads waited for every request in flight)
+        const int o0 = (tile * 32 + 4 * (lane >> 5)) * 1024 + (32 * wave + (lane & 31)) * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < rows_left) __builtin_nontemporal_store((acc[r] * wu) * s_un[buf][m], tb + (o0 + 256u * ((r & 3) + 8 * (r >> 2))));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (acc[r] * wu) * s_un[buf][m]), rsS, o0 + 1024 * ((r & 3) + 8 * (r >> 2)), 0, 2);
         }
-        if (next < n_tiles) stage(next, buf ^ 1);
+        if (next < n_tiles) stage(next, buf ^ 1, cur);
         __syncthreads();
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) { request(tile, ra); stage(tile, 0, ra); }
+    if (tile + G < n_tiles) request(tile + G, ra);
+    __syncthreads();
+    // (unrolled by two: the register sets alternate with static names)
+    for (; tile < n_tiles; tile += 2 * G) {
+        one_tile(tile, 0, ra, rb);
+        if (tile + G < n_tiles) one_tile(tile + G, 1, rb, ra);
     }
 }
 
@@ -641,9 +669,11 @@ int linear_bwd_f32(const float *g, const float *Y, const float *S, const float *
             // (a caller without scratch - gS only, older bindings - keeps the fp32 MFMA kernel below)
             static const int gs_rows = [] { const char *e = getenv("NDCN_GS_ROWS"); return e ? atoi(e) : 0; }();     // 0: resident weights (default); 32 / 64: the tile kernels
             const int n_tiles = (int)((n + 31) / 32);
-            if (gs_rows != 32 && gs_rows != 64)
-                hipLaunchKernelGGL(linear_gs_256_res_kernel, dim3((unsigned)(n_tiles < kCus ? n_tiles : kCus)), dim3(512), 0, st, g, Y, Wq, gS, n, n_tiles);
-            else if (gs_rows == 64) hipLaunchKernelGGL(linear_gs_256_split_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, g, Y, Wq, gS, n);
+            if (gs_rows != 32 && gs_rows != 64 && n * (int64_t)1024 < (1ll << 32)) {
+                if (Y) hipLaunchKernelGGL(linear_gs_256_res_kernel<true>, dim3((unsigned)(n_tiles < kCus ? n_tiles : kCus)), dim3(512), 0, st, g, Y, Wq, gS, n, n_tiles);
+                else hipLaunchKernelGGL(linear_gs_256_res_kernel<false>, dim3((unsigned)(n_tiles < kCus ? n_tiles : kCus)), dim3(512), 0, st, g, Y, Wq, gS, n, n_tiles);
+            }
+            else if (gs_rows != 32) hipLaunchKernelGGL(linear_gs_256_split_kernel<2>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, g, Y, Wq, gS, n);
             else hipLaunchKernelGGL(linear_gs_256_split_kernel<1>, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, g, Y, Wq, gS, n);
         } else {
             const unsigned gx = (unsigned)((n + kBM2 - 1) / kBM2);
