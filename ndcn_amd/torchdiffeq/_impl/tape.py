@@ -96,7 +96,6 @@ class _TapeDopri5(torch.autograd.Function):
         # backward unless retain_graph - and a reverse pass over a released graph raises autograd's own "second time" error; with
         # retain_graph the record stays and the pass runs again (round-5 advisor: the reference's graph is re-runnable)
         blocks, tape.blocks = tape.blocks, []
-        ctx.n_lead = 3
         ctx.save_for_backward(y0, W, b, *blocks)
         return out
 

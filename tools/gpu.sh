@@ -10,6 +10,9 @@
 #   ab "K=V ..." ["K=V ..."]     A/B of environment knobs inside ONE box: ms/step + rocprofv3 per-variant kernel averages
 #   abbuild                      A/B of library builds inside one box: the default build vs every gpurun_in_*.so
 #   abalt ROUNDS [bench flags]   the same, ALTERNATING (A B A B ...): ms/step + per-variant kernel averages per run
+#   c2lab                        BASELINE config 2 with the sweep's S store / the dense stage's S read, MFMA, epilogue switched off (needs
+#                                gpurun_in_f3timing.so = rhs_fused3.hip built with -DNDCN_F3_TIMING): what a fused tail could save
+#   mlab                         the metric's case with parts of the lattice kernel switched off (same timing build)
 #   timing                       fused3 cycle accounting (needs a -DNDCN_F3_TIMING build)
 #   sq                           SQ issue / stall counters of the fused RHS kernels
 #   power                        power / clock samples while the bench runs
